@@ -1,0 +1,227 @@
+"""ctypes harness for the CPU restatement in oracle/terrarium_oracle.hpp.
+
+TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+and the cpu_baseline leg of bench.py may import this module; nothing under
+terrarium.jl_amd/ does.  It never reads /root/reference at run time.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# field ids (terrarium_oracle.hpp: enum FieldId)
+FIELDS = dict(
+    internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4,
+    hydraulic_conductivity=5, tend_internal_energy=6, tend_saturation_water_ice=7, surface_excess_water=8,
+    tend_surface_excess_water=9, water_table=10, skin_temperature=11, ground_heat_flux=12, surface_shortwave_up=13,
+    surface_longwave_up=14, surface_net_radiation=15, sensible_heat_flux=16, latent_heat_flux=17,
+    evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
+    specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27,
+)
+BC_VARS = dict(internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4)
+BC_KINDS = dict(noflux=0, value=1, flux=2, gradient=3)
+
+
+class ParamsD(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "rho_w rho_i rho_a c_a Lsl Llg Lsg g Tref sigma kappa_vk eps_mw R_a "
+        "k_water k_ice k_air k_mineral k_organic c_water c_ice c_air c_mineral c_organic "
+        "por_mineral por_organic rho_soc rho_org "
+        "K_sat theta_res bc_psi_s bc_lambda vg_alpha vg_n impedance vwc_forcing "
+        "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap").split()] + [
+        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy reserved".split()]
+
+
+def default_params(**overrides):
+    """Reference defaults."""
+    d = dict(
+        rho_w=1000.0, rho_i=916.2, rho_a=1.293, c_a=1005.7, Lsl=3.34e5, Llg=2.257e6, Lsg=2.834e6, g=9.80665,
+        Tref=273.15, sigma=5.6704e-8, kappa_vk=0.4, eps_mw=0.622, R_a=287.058,
+        k_water=0.57, k_ice=2.2, k_air=0.025, k_mineral=3.8, k_organic=0.25,
+        c_water=4.2e6, c_ice=1.9e6, c_air=0.00125e6, c_mineral=2.0e6, c_organic=2.5e6,
+        por_mineral=0.49, por_organic=0.9, rho_soc=0.0, rho_org=1300.0,
+        K_sat=1.0e-5, theta_res=0.0, bc_psi_s=0.01, bc_lambda=0.2, vg_alpha=1.0, vg_n=2.0, impedance=7.0,
+        vwc_forcing=0.0,
+        albedo=0.3, emissivity=0.97, kappa_s=2.0, C_h=1.2e-3, min_windspeed=0.01, tau_r=3600.0, beta_evap=1.0,
+        flow=0, swrc=0, unsat_k=0, seb=0, halo_policy=0, reserved=0,
+    )
+    for k, v in overrides.items():
+        if k not in d:
+            raise KeyError(k)
+        d[k] = v
+    return ParamsD(**d)
+
+
+def build(force=False):
+    """Compile the restatement (gcc only; no reference sources are involved)."""
+    so = os.path.join(_HERE, "build", "libterrarium_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("oracle_capi.cpp", "terrarium_oracle.hpp", "Makefile")]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return so
+
+
+_libs = {}
+
+
+def _lib(omp=False):
+    if omp not in _libs:
+        build()
+        name = "libterrarium_oracle_omp.so" if omp else "libterrarium_oracle.so"
+        lib = C.CDLL(os.path.join(_HERE, "build", name))
+        lib.trm_oracle_create.restype = C.c_void_p
+        lib.trm_oracle_create.argtypes = [C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_double, C.POINTER(ParamsD)]
+        lib.trm_oracle_destroy.argtypes = [C.c_void_p]
+        lib.trm_oracle_field_rows.restype = C.c_long
+        lib.trm_oracle_field_rows.argtypes = [C.c_void_p, C.c_int]
+        lib.trm_oracle_set_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.trm_oracle_get_field.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.trm_oracle_get_halo.restype = C.c_double
+        lib.trm_oracle_get_halo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long]
+        lib.trm_oracle_set_bc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double]
+        lib.trm_oracle_set_land_model.argtypes = [C.c_void_p, C.c_int]
+        lib.trm_oracle_grid.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        for f in ("fill_halo_regions", "initialize", "reset_tendencies", "compute_auxiliary", "compute_tendencies",
+                  "closure", "invclosure", "adjust_saturation_profile", "compute_water_table"):
+            getattr(lib, "trm_oracle_" + f).argtypes = [C.c_void_p]
+        lib.trm_oracle_update_state.argtypes = [C.c_void_p, C.c_int]
+        lib.trm_oracle_explicit_step.argtypes = [C.c_void_p, C.c_double]
+        lib.trm_oracle_timestep.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        lib.trm_oracle_timestep_heun.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        lib.trm_oracle_run.argtypes = [C.c_void_p, C.c_double, C.c_long]
+        lib.trm_oracle_steps.argtypes = [C.c_void_p, C.c_double, C.c_long]
+        lib.trm_oracle_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+        lib.trm_oracle_set_clock.argtypes = [C.c_void_p, C.c_double, C.c_longlong]
+        lib.trm_oracle_status.restype = C.c_uint
+        lib.trm_oracle_status.argtypes = [C.c_void_p]
+        P = C.POINTER(ParamsD)
+        D = C.c_double
+        for name, args in dict(
+            porosity=[P], thermal_conductivity=[P, D, D, D, D], heat_capacity=[P, D, D, D, D],
+            hydraulic_conductivity=[P, D, D, D, D], swrc_theta=[P, D, D], swrc_psi=[P, D, D],
+            energy_to_temperature=[D, D, D], liquid_water_fraction=[D, D], stefan_boltzmann=[P, D, D],
+            net_radiation=[D, D, D, D], longwave_up=[P, D, D, D], saturation_vapor_pressure=[D], pow=[D, D],
+            safediv=[D, D], expmodel=[C.c_int, D, D, D, C.c_int],
+        ).items():
+            fn = getattr(lib, "trm_oracle_" + name)
+            fn.restype = D
+            fn.argtypes = args
+        lib.trm_oracle_volumetric_fractions.argtypes = [D, D, D, D, C.c_void_p]
+        lib.trm_oracle_skin_temperature_iterations.restype = D
+        lib.trm_oracle_skin_temperature_iterations.argtypes = [P] + [D] * 8 + [C.c_int, C.POINTER(D)]
+        _libs[omp] = lib
+    return _libs[omp]
+
+
+def scalar(name, *args):
+    """Call one of the scalar physics entry points (unit known-answer tests)."""
+    lib = _lib()
+    args = [C.byref(a) if isinstance(a, ParamsD) else a for a in args]
+    return getattr(lib, "trm_oracle_" + name)(*args)
+
+
+def volumetric_fractions(por, sat, liq, org=0.0):
+    out = np.zeros(5)
+    _lib().trm_oracle_volumetric_fractions(por, sat, liq, org, out.ctypes.data)
+    return dict(zip(("water", "ice", "air", "mineral", "organic"), out))
+
+
+def skin_temperature_iterations(params, sw_down, lw_down, q_air, pres, T_air, T_ground, windspeed, dz_top, iterations):
+    ts = C.c_double()
+    resid = _lib().trm_oracle_skin_temperature_iterations(C.byref(params), sw_down, lw_down, q_air, pres, T_air,
+                                                          T_ground, windspeed, dz_top, iterations, C.byref(ts))
+    return resid, ts.value
+
+
+class Oracle:
+    """Reference-order CPU driver.  Arrays cross as [rows][Nh], k = 0 bottom."""
+
+    def __init__(self, num_columns, thickness, params=None, dtype=np.float64, dx=0.0, omp=False):
+        self.lib = _lib(omp)
+        self.dtype = np.dtype(dtype)
+        self.Nh = int(num_columns)
+        self.thickness = np.ascontiguousarray(thickness, dtype=np.float64)
+        self.Nz = int(self.thickness.size)
+        self.params = params if params is not None else default_params()
+        prec = 0 if self.dtype == np.float64 else 1
+        self.h = self.lib.trm_oracle_create(prec, self.Nh, self.Nz, self.thickness.ctypes.data, float(dx),
+                                            C.byref(self.params))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.trm_oracle_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # -- fields ---------------------------------------------------------------
+    def rows(self, name):
+        return self.lib.trm_oracle_field_rows(self.h, FIELDS[name])
+
+    def set(self, name, value):
+        rows = self.rows(name)
+        a = np.empty((rows, self.Nh), dtype=self.dtype)
+        a[...] = np.asarray(value, dtype=self.dtype).reshape((-1, 1)) if np.ndim(value) == 1 and np.size(value) == rows and rows != self.Nh else value
+        a = np.ascontiguousarray(a)
+        rc = self.lib.trm_oracle_set_field(self.h, FIELDS[name], a.ctypes.data)
+        assert rc == 0, name
+
+    def get(self, name):
+        rows = self.rows(name)
+        a = np.empty((rows, self.Nh), dtype=self.dtype)
+        rc = self.lib.trm_oracle_get_field(self.h, FIELDS[name], a.ctypes.data)
+        assert rc == 0, name
+        return a[0] if rows == 1 else a
+
+    def halo(self, name, top, i=0):
+        return self.lib.trm_oracle_get_halo(self.h, FIELDS[name], int(top), i)
+
+    def set_bc(self, var, side, kind, value=0.0):
+        top = {"top": 1, "bottom": 0}[side]
+        if np.ndim(value) == 0:
+            ptr, scalar_v = None, float(value)
+        else:
+            arr = np.ascontiguousarray(value, dtype=self.dtype)
+            assert arr.shape == (self.Nh,)
+            ptr, scalar_v = arr.ctypes.data, 0.0
+        rc = self.lib.trm_oracle_set_bc(self.h, BC_VARS[var], top, BC_KINDS[kind], ptr, scalar_v)
+        assert rc == 0
+
+    def set_land_model(self, on=True):
+        self.lib.trm_oracle_set_land_model(self.h, int(on))
+
+    def grid(self):
+        zF, dzf = np.zeros(self.Nz + 1), np.zeros(self.Nz + 1)
+        zC, dzc = np.zeros(self.Nz), np.zeros(self.Nz)
+        self.lib.trm_oracle_grid(self.h, zF.ctypes.data, zC.ctypes.data, dzc.ctypes.data, dzf.ctypes.data)
+        return dict(zF=zF, zC=zC, dzc=dzc, dzf=dzf)
+
+    # -- reference interface --------------------------------------------------
+    def fill_halo_regions(self): self.lib.trm_oracle_fill_halo_regions(self.h)
+    def initialize(self): self.lib.trm_oracle_initialize(self.h)
+    def update_state(self, compute_tendencies=True): self.lib.trm_oracle_update_state(self.h, int(compute_tendencies))
+    def reset_tendencies(self): self.lib.trm_oracle_reset_tendencies(self.h)
+    def compute_auxiliary(self): self.lib.trm_oracle_compute_auxiliary(self.h)
+    def compute_tendencies(self): self.lib.trm_oracle_compute_tendencies(self.h)
+    def explicit_step(self, dt): self.lib.trm_oracle_explicit_step(self.h, float(dt))
+    def closure(self): self.lib.trm_oracle_closure(self.h)
+    def invclosure(self): self.lib.trm_oracle_invclosure(self.h)
+    def adjust_saturation_profile(self): self.lib.trm_oracle_adjust_saturation_profile(self.h)
+    def compute_water_table(self): self.lib.trm_oracle_compute_water_table(self.h)
+    def timestep(self, dt, finalize=True): self.lib.trm_oracle_timestep(self.h, float(dt), int(finalize))
+    def timestep_heun(self, dt, finalize=True): self.lib.trm_oracle_timestep_heun(self.h, float(dt), int(finalize))
+    def run(self, dt, steps): self.lib.trm_oracle_run(self.h, float(dt), int(steps))
+    def steps(self, dt, steps): self.lib.trm_oracle_steps(self.h, float(dt), int(steps))
+
+    def clock(self):
+        t, it = C.c_double(), C.c_longlong()
+        self.lib.trm_oracle_clock(self.h, C.byref(t), C.byref(it))
+        return t.value, it.value
+
+    def status(self):
+        return self.lib.trm_oracle_status(self.h)

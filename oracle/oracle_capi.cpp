@@ -1,0 +1,192 @@
+// oracle/oracle_capi.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+// extern "C" surface of the CPU restatement (terrarium_oracle.hpp) for the
+// ctypes harness in oracle/oracle.py.  Only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg may load the resulting library.
+#include "terrarium_oracle.hpp"
+
+using namespace trm_oracle;
+
+struct OracleHandle {
+    int precision;  // 0 = f64, 1 = f32
+    Oracle<double>* d;
+    Oracle<float>* f;
+};
+
+#define DISPATCH(h, expr)            \
+    do {                             \
+        if ((h)->precision == 0) {   \
+            auto* o = (h)->d;        \
+            expr;                    \
+        } else {                     \
+            auto* o = (h)->f;        \
+            expr;                    \
+        }                            \
+    } while (0)
+
+extern "C" {
+
+OracleHandle* trm_oracle_create(int precision, long nh, int nz, const double* thickness, double dx, const ParamsD* params) {
+    OracleHandle* h = new OracleHandle{precision, nullptr, nullptr};
+    if (precision == 0) h->d = new Oracle<double>(nh, nz, thickness, dx, *params);
+    else h->f = new Oracle<float>(nh, nz, thickness, dx, *params);
+    return h;
+}
+void trm_oracle_destroy(OracleHandle* h) {
+    if (!h) return;
+    delete h->d;
+    delete h->f;
+    delete h;
+}
+long trm_oracle_field_rows(OracleHandle* h, int id) {
+    long r = 0;
+    DISPATCH(h, r = o->field_rows(id));
+    return r;
+}
+int trm_oracle_set_field(OracleHandle* h, int id, const void* src) {
+    if (h->precision == 0) return h->d->set_field(id, (const double*)src);
+    return h->f->set_field(id, (const float*)src);
+}
+int trm_oracle_get_field(OracleHandle* h, int id, void* dst) {
+    if (h->precision == 0) return h->d->get_field(id, (double*)dst);
+    return h->f->get_field(id, (float*)dst);
+}
+double trm_oracle_get_halo(OracleHandle* h, int id, int top, long i) {
+    double r = 0;
+    DISPATCH(h, r = (double)o->get_halo(id, top, i));
+    return r;
+}
+int trm_oracle_set_bc(OracleHandle* h, int var, int top, int kind, const void* values, double scalar) {
+    if (h->precision == 0) return h->d->set_bc(var, top, kind, (const double*)values, scalar);
+    return h->f->set_bc(var, top, kind, (const float*)values, (float)scalar);
+}
+void trm_oracle_set_land_model(OracleHandle* h, int on) { DISPATCH(h, o->land_model = on != 0); }
+void trm_oracle_grid(OracleHandle* h, double* zF /*Nz+1*/, double* zC /*Nz*/, double* dzc /*Nz*/, double* dzf /*Nz+1*/) {
+    DISPATCH(h, {
+        for (int k = 1; k <= o->Nz + 1; ++k) { zF[k - 1] = o->g.zF[k]; dzf[k - 1] = o->g.dzf[k]; }
+        for (int k = 1; k <= o->Nz; ++k) { zC[k - 1] = o->g.zC[k]; dzc[k - 1] = o->g.dzc[k]; }
+    });
+}
+void trm_oracle_fill_halo_regions(OracleHandle* h) { DISPATCH(h, o->fill_halo_regions()); }
+void trm_oracle_initialize(OracleHandle* h) { DISPATCH(h, o->initialize_processes()); }
+void trm_oracle_update_state(OracleHandle* h, int tendencies) { DISPATCH(h, o->update_state(tendencies != 0)); }
+void trm_oracle_reset_tendencies(OracleHandle* h) { DISPATCH(h, o->reset_tendencies()); }
+void trm_oracle_compute_auxiliary(OracleHandle* h) { DISPATCH(h, o->compute_auxiliary()); }
+void trm_oracle_compute_tendencies(OracleHandle* h) { DISPATCH(h, o->compute_tendencies()); }
+void trm_oracle_explicit_step(OracleHandle* h, double dt) {
+    if (h->precision == 0) h->d->explicit_step(dt);
+    else h->f->explicit_step((float)dt);
+}
+void trm_oracle_closure(OracleHandle* h) { DISPATCH(h, o->closure()); }
+void trm_oracle_invclosure(OracleHandle* h) { DISPATCH(h, o->invclosure()); }
+void trm_oracle_adjust_saturation_profile(OracleHandle* h) { DISPATCH(h, o->adjust_saturation_profile()); }
+void trm_oracle_compute_water_table(OracleHandle* h) { DISPATCH(h, o->compute_water_table()); }
+void trm_oracle_timestep(OracleHandle* h, double dt, int finalize) { DISPATCH(h, o->timestep_euler(dt, finalize != 0)); }
+void trm_oracle_timestep_heun(OracleHandle* h, double dt, int finalize) { DISPATCH(h, o->timestep_heun(dt, finalize != 0)); }
+void trm_oracle_run(OracleHandle* h, double dt, long steps) { DISPATCH(h, o->run(dt, steps)); }
+// `steps` Euler steps without the trailing compute_auxiliary (timing leg)
+void trm_oracle_steps(OracleHandle* h, double dt, long steps) {
+    DISPATCH(h, { for (long s = 0; s < steps; ++s) o->timestep_euler(dt, false); });
+}
+void trm_oracle_clock(OracleHandle* h, double* time, long long* iteration) {
+    DISPATCH(h, { *time = o->time; *iteration = o->iteration; });
+}
+void trm_oracle_set_clock(OracleHandle* h, double time, long long iteration) {
+    DISPATCH(h, { o->time = time; o->iteration = iteration; });
+}
+unsigned trm_oracle_status(OracleHandle* h) {
+    unsigned s = 0;
+    DISPATCH(h, s = o->status);
+    return s;
+}
+
+// ---- scalar entry points for the unit known-answer tests --------------------
+double trm_oracle_porosity(const ParamsD* pd) { return porosity(Params<double>(*pd)); }
+double trm_oracle_thermal_conductivity(const ParamsD* pd, double por, double sat, double liq, double org) {
+    Params<double> p(*pd);
+    return thermal_conductivity(p, volumetric_fractions(por, sat, liq, org));
+}
+double trm_oracle_heat_capacity(const ParamsD* pd, double por, double sat, double liq, double org) {
+    Params<double> p(*pd);
+    return heat_capacity(p, volumetric_fractions(por, sat, liq, org));
+}
+void trm_oracle_volumetric_fractions(double por, double sat, double liq, double org, double* out5) {
+    Fractions<double> f = volumetric_fractions(por, sat, liq, org);
+    out5[0] = f.water; out5[1] = f.ice; out5[2] = f.air; out5[3] = f.mineral; out5[4] = f.organic;
+}
+double trm_oracle_hydraulic_conductivity(const ParamsD* pd, double por, double sat, double liq, double org) {
+    Params<double> p(*pd);
+    return hydraulic_conductivity_cell(p, por, liq, volumetric_fractions(por, sat, liq, org));
+}
+double trm_oracle_swrc_theta(const ParamsD* pd, double psi, double theta_sat) { return swrc_theta(Params<double>(*pd), psi, theta_sat); }
+double trm_oracle_swrc_psi(const ParamsD* pd, double theta, double theta_sat) { return swrc_psi(Params<double>(*pd), theta, theta_sat); }
+double trm_oracle_energy_to_temperature(double U, double Ltheta, double C) { return energy_to_temperature(U, Ltheta, C); }
+double trm_oracle_liquid_water_fraction(double U, double Ltheta) { return liquid_water_fraction(U, Ltheta); }
+double trm_oracle_stefan_boltzmann(const ParamsD* pd, double T, double emis) { return stefan_boltzmann(Params<double>(*pd), T, emis); }
+double trm_oracle_net_radiation(double sw_up, double sw_down, double lw_up, double lw_down) { return sw_up - sw_down + lw_up - lw_down; }
+double trm_oracle_longwave_up(const ParamsD* pd, double lw_down, double Ts, double emis) {
+    Params<double> p(*pd);
+    return stefan_boltzmann(p, Ts + p.Tref, emis) + (1.0 - emis) * lw_down;
+}
+double trm_oracle_saturation_vapor_pressure(double T) { return saturation_vapor_pressure(T); }
+double trm_oracle_pow(double x, double y) { return jl_pow(x, y); }
+double trm_oracle_safediv(double x, double y) { return safediv(x, y); }
+
+// Generic explicit integrators on the 0-D model du/dt = u + v used by the
+// reference's time-stepper test (test/timestepping/heun.jl:6-49): restates
+// explicit_step! (abstract_timestepper.jl:113-141) and heun.jl:27-71.
+double trm_oracle_expmodel(int heun, double u, double v, double dt, int steps) {
+    for (int s = 0; s < steps; ++s) {
+        double G = u + v;  // compute_tendencies!
+        if (!heun) {
+            u = u + G * dt;
+        } else {
+            double us = u + G * dt;   // stage Euler step
+            double Gs = us + v;       // tendencies at the stage
+            double Ga = (G + Gs) / 2; // average_tendencies!
+            u = u + Ga * dt;
+        }
+    }
+    return u;
+}
+
+}  // extern "C"
+
+// Standalone surface-energy-balance fixed-point iteration used by the
+// reference's skin-temperature test (test/surface_energy/skin_temperature.jl:
+// 16-47): SurfaceEnergyModel without an ET scheme, so the latent heat flux is
+// diagnosed from the humidity deficit at the skin temperature
+// (turbulent_fluxes.jl:110-126).  Each iteration = fused SEB kernel
+// (fluxes -> T_s -> fluxes, surface_energy_balance.jl:95-110) followed by
+// update_skin_temperature! (skin_temperature.jl:104-109).  Returns the last
+// residual max|T_s - T_s_old| and writes the final skin temperature.
+extern "C" double trm_oracle_skin_temperature_iterations(const trm_oracle::ParamsD* pd, double sw_down, double lw_down,
+                                                          double q_air, double pres, double T_air, double T_ground,
+                                                          double windspeed, double dz_top, int iterations,
+                                                          double* Ts_out) {
+    using namespace trm_oracle;
+    Params<double> p(*pd);
+    double Ts = 0.0, G = 0.0, resid = 0.0;
+    auto fluxes = [&]() {
+        double swu = p.albedo * sw_down;
+        double lwu = stefan_boltzmann(p, Ts + p.Tref, p.emissivity) + (1.0 - p.emissivity) * lw_down;
+        double rnet = swu - sw_down + lwu - lw_down;
+        double V = jl_max(jl_max(windspeed, p.min_windspeed), 1.0e-6);
+        double ra = 1.0 / (p.C_h * V);
+        double Hs = p.c_a * p.rho_a * ((Ts - T_air) / ra);
+        double dq = p.eps_mw * compute_vpd(p, pres, q_air, Ts) / pres;
+        double Hl = p.Llg * p.rho_a * (dq / ra);
+        G = rnet - Hs - Hl;
+    };
+    auto update = [&]() { Ts = T_ground - G * dz_top / (2.0 * p.kappa_s); };
+    double old = Ts;
+    for (int it = 0; it < iterations; ++it) {
+        fluxes();
+        update();
+        fluxes();
+        update();
+        resid = std::fabs(Ts - old);
+        old = Ts;
+    }
+    if (Ts_out) *Ts_out = Ts;
+    return resid;
+}

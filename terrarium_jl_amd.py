@@ -1,0 +1,13 @@
+"""Import shim: the package directory is named `terrarium.jl_amd/` (with a dot,
+after the reference's name), which Python cannot import directly.  `import
+terrarium_jl_amd` loads that directory as a regular package."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "terrarium.jl_amd")
+_spec = importlib.util.spec_from_file_location(__name__, os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)

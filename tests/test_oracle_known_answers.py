@@ -1,0 +1,391 @@
+"""Pin the CPU oracle (oracle/terrarium_oracle.hpp) against the reference's own
+known-answer tests K1..K18.  Each test names the reference
+test file it restates.  CPU only."""
+import math
+
+import numpy as np
+import pytest
+from scipy.special import erfc
+
+import oracle
+from oracle import Oracle, default_params, scalar
+import terrarium_jl_amd as trm
+
+VG = dict(flow=1, swrc=1, unsat_k=1, vg_alpha=2.0, vg_n=2.0)  # soil_hydrology_tests.jl:127-129
+
+
+# K1  test/soil/soil_energy_tests.jl:21-25
+def test_k1_thermal_conductivity_end_members():
+    p = default_params()
+    assert scalar("thermal_conductivity", p, 1.0, 1.0, 1.0, 0.0) == pytest.approx(p.k_water)
+    assert scalar("thermal_conductivity", p, 1.0, 1.0, 0.0, 0.0) == pytest.approx(p.k_ice)
+    assert scalar("thermal_conductivity", p, 1.0, 0.0, 0.0, 0.0) == pytest.approx(p.k_air)
+    assert scalar("thermal_conductivity", p, 0.0, 0.0, 1.0, 0.0) == pytest.approx(p.k_mineral)
+    assert scalar("thermal_conductivity", p, 0.0, 0.0, 1.0, 1.0) == pytest.approx(p.k_organic)
+
+
+# K2  test/soil/soil_energy_tests.jl:28-48
+def test_k2_energy_initialize():
+    o = Oracle(1, trm.ExponentialSpacing().get_spacing())
+    for T0, liq_expected, sign in ((0.0, 1.0, 0), (1.0, 1.0, +1), (-1.0, 0.0, -1)):
+        o.set("temperature", T0)
+        o.initialize()
+        assert np.allclose(o.get("liquid_water_fraction"), liq_expected)
+        U = o.get("internal_energy")
+        if sign == 0:
+            assert np.allclose(U, 0.0)
+        else:
+            assert np.all(np.sign(U) == sign)
+
+
+# "Soil energy: compute_tendencies!"  test/soil/soil_energy_tests.jl:50-60
+def test_energy_tendencies_finite():
+    o = Oracle(1, trm.ExponentialSpacing(N=10).get_spacing())
+    zc = o.grid()["zC"]
+    o.set("temperature", 0.0 - 0.01 * zc)
+    o.initialize()
+    o.update_state(True)
+    assert np.all(np.isfinite(o.get("tend_internal_energy")))
+
+
+# K3  test/soil/soil_energy_tests.jl:63-73
+def test_k3_closure_positive_energy():
+    o = Oracle(1, trm.ExponentialSpacing(N=10).get_spacing())
+    o.set("internal_energy", 1.0e6)
+    o.closure()
+    assert np.all(o.get("temperature") > 0)
+    assert np.allclose(o.get("liquid_water_fraction"), 1.0)
+
+
+# K4  test/soil/soil_energy_tests.jl:89-140
+def test_k4_heat_diffusion_periodic_upper_bc():
+    T0, A, P, k, c = 2.0, 1.0, 24 * 3600.0, 2.0, 1.0e6
+    alpha = k / c
+
+    def T_sol(z, t):
+        d = math.sqrt(math.pi / (alpha * P))
+        return T0 + A * np.exp(-z * d) * np.sin(2 * np.pi * t / P - z * d)
+
+    params = default_params(por_mineral=0.0, rho_soc=0.0, k_mineral=k, c_mineral=c)
+    o = Oracle(1, trm.ExponentialSpacing(dz_min=0.05, dz_max=100.0, N=100).get_spacing(), params)
+    zc = o.grid()["zC"]
+    o.set("temperature", T_sol(-zc, 0.0))
+    o.set("saturation_water_ice", 0.0)
+    o.set_bc("temperature", "top", "value", T0 + A * math.sin(0.0))
+    o.initialize()
+    dt, t, max_rel = 60.0, 0.0, 0.0
+    while t < 2 * P:
+        o.set_bc("temperature", "top", "value", T0 + A * math.sin(2 * math.pi * t / P))  # evaluated at the pre-tick time
+        o.timestep(dt)
+        t = o.clock()[0]
+        Ts = o.get("temperature")[:, 0]
+        target = T_sol(-zc, t)
+        max_rel = max(max_rel, float(np.max(np.abs((Ts - target) / target))))
+    assert t == 2 * P
+    assert max_rel < 0.1
+    assert max_rel < 0.02  # tighter than the reference bound; guards against regressions of the restatement
+
+
+# K5  test/soil/soil_energy_tests.jl:142-190
+def test_k5_step_heat_diffusion():
+    T0, T1 = 1.0, 2.0
+    params = default_params(por_mineral=0.0, rho_soc=0.0)
+    o = Oracle(1, trm.ExponentialSpacing(dz_min=0.01, dz_max=100.0, N=100).get_spacing(), params)
+    zc = o.grid()["zC"]
+    o.set("temperature", T0)
+    o.set("saturation_water_ice", 1.0)  # SaturationWaterTable default => fully saturated (SURVEY C-2)
+    o.set_bc("temperature", "top", "value", T1)
+    o.initialize()
+    alpha = params.k_mineral / params.c_mineral
+    dt, max_rel, last_rel = 10.0, 0.0, None
+    nsteps = int(24 * 3600 / dt)
+    for n in range(nsteps):
+        o.timestep(dt, finalize=False)
+        if n % 60 == 59 or n == nsteps - 1:
+            t = o.clock()[0]
+            Ts = o.get("temperature")[:, 0]
+            target = T0 + (T1 - T0) * erfc(-zc / (2 * math.sqrt(alpha * t)))
+            last_rel = float(np.max(np.abs((Ts - target) / target)))
+            max_rel = max(max_rel, last_rel)
+    assert o.clock() == (24 * 3600.0, nsteps)
+    assert last_rel < 1.0e-3
+    assert max_rel < 0.1
+
+
+# K6  test/soil/soil_composition_tests.jl:31-46 (exact equalities)
+def test_k6_volumetric_fractions_exact():
+    por, sat, liq, org = 0.3, 0.5, 0.5, 0.5
+    f = oracle.volumetric_fractions(por, sat, liq, org)
+    assert f["water"] == por * sat * liq
+    assert f["ice"] == por * sat * (1 - liq)
+    assert f["air"] == por * (1 - sat)
+    assert f["organic"] == (1 - por) * org
+    assert f["mineral"] == (1 - por) * (1 - org)
+
+
+# SoilVolume bounds (soil_composition_tests.jl:20-28) -> status flag instead of AssertionError
+def test_composition_bounds_raise_status_flag():
+    o = Oracle(1, trm.UniformSpacing(dz=0.1, N=4).get_spacing())
+    o.set("saturation_water_ice", 2.0)
+    o.set("liquid_water_fraction", 1.0)
+    o.compute_auxiliary()
+    assert o.status() & 2
+
+
+# K7  test/soil/soil_hydrology_tests.jl:45-91
+@pytest.mark.parametrize("unsat", ["linear", "vg"])
+def test_k7_unsaturated_conductivity_limits(unsat):
+    p = default_params(swrc=1, unsat_k=1) if unsat == "vg" else default_params()
+    por = 0.5  # SoilVolume() default
+    K_sat = p.K_sat
+    assert scalar("hydraulic_conductivity", p, por, 1.0, 1.0, 0.0) == pytest.approx(K_sat)
+    K_half = scalar("hydraulic_conductivity", p, por, 0.5, 1.0, 0.0)
+    assert 0 < K_half < K_sat
+    assert scalar("hydraulic_conductivity", p, por, 0.0, 1.0, 0.0) == 0.0
+    assert scalar("hydraulic_conductivity", p, por, 1.0, 0.0, 0.0) == 0.0
+
+
+# K8  test/soil/soil_hydrology_tests.jl:93-123
+def test_k8_adjust_saturation_profile():
+    o = Oracle(1, trm.UniformSpacing(dz=0.1, N=100).get_spacing(), default_params(**VG))
+    g = o.grid()
+    zc, dz = g["zC"], g["dzc"]
+    # case 1: oversaturation at the surface
+    sat0 = np.maximum(1.1 + zc, 1.0)
+    o.set("saturation_water_ice", sat0)
+    excess = float(np.sum((sat0 - 1.0) * dz))
+    o.adjust_saturation_profile()
+    assert np.allclose(o.get("saturation_water_ice"), 1.0)
+    assert np.allclose(o.get("surface_excess_water"), excess)
+    # case 2: undersaturation at the surface, mass conserved
+    sat0 = np.minimum(-0.1 - zc, 1.0)
+    o.set("saturation_water_ice", sat0)
+    m0 = float(np.sum(sat0 * dz))
+    o.adjust_saturation_profile()
+    sat1 = o.get("saturation_water_ice")[:, 0]
+    assert np.all(sat1 >= 0)
+    assert float(np.sum(sat1 * dz)) - m0 == pytest.approx(0.0, abs=1e-12)
+    # case 3: completely dry with negative saturation near the surface
+    o.set("saturation_water_ice", np.minimum(-0.1 - zc, 0.0))
+    o.adjust_saturation_profile()
+    assert np.allclose(o.get("saturation_water_ice"), 0.0)
+
+
+def _richards_column(sat_fn, **extra):
+    o = Oracle(1, trm.UniformSpacing(dz=0.1, N=100).get_spacing(), default_params(**VG, **extra))
+    zc = o.grid()["zC"]
+    o.set("saturation_water_ice", sat_fn(zc))
+    o.initialize()
+    return o
+
+
+# K9  test/soil/soil_hydrology_tests.jl:125-150
+def test_k9_saturated_steady_state():
+    o = _richards_column(lambda z: np.ones_like(z))
+    assert np.allclose(o.get("water_table"), 0.0, atol=1e-12)
+    assert np.allclose(o.get("pressure_head"), 0.0, atol=1e-12)
+    o.compute_auxiliary()
+    K = o.get("hydraulic_conductivity")
+    assert np.all(np.isfinite(K)) and np.allclose(K, default_params().K_sat)
+    o.update_state(True)
+    assert np.all(o.get("tend_saturation_water_ice") == 0.0)
+    o.timestep(300.0)
+    assert np.allclose(o.get("saturation_water_ice"), 1.0)
+
+
+# K10  test/soil/soil_hydrology_tests.jl:152-188
+def test_k10_variably_saturated_water_table_and_mass_conservation():
+    o = _richards_column(lambda z: np.minimum(1.0, 0.5 - 0.1 * z))
+    dz = o.grid()["dzc"]
+    assert np.allclose(o.get("water_table"), -5.0)
+    assert np.all(o.get("pressure_head") < 0)
+    o.compute_auxiliary()
+    K = o.get("hydraulic_conductivity")
+    assert np.all(np.isfinite(K)) and np.all(K > 0)
+    o.update_state(True)
+    assert np.all(np.isfinite(o.get("tend_saturation_water_ice")))
+    mass = lambda: float(np.sum(o.get("saturation_water_ice")[:, 0] * dz))
+    m0 = mass()
+    o.timestep(60.0)
+    sat = o.get("saturation_water_ice")
+    assert np.all(np.isfinite(sat)) and np.all((0 <= sat) & (sat <= 1))
+    m1 = mass()
+    assert m1 == pytest.approx(m0, rel=1e-8)  # Julia's `≈`: rtol = sqrt(eps)
+    o.run(60.0, 60)
+    sat = o.get("saturation_water_ice")
+    assert np.all(np.isfinite(sat)) and np.all((0 <= sat) & (sat <= 1))
+    assert mass() == pytest.approx(m0, rel=1e-8)
+    assert o.status() == 0
+
+
+# K11  test/soil/soil_hydrology_tests.jl:191-233
+def test_k11_soil_moisture_forcing_sink():
+    Nz, dt, F = 10, 60.0, -1.0e-5
+    p = default_params(**VG, vwc_forcing=F)
+    o = Oracle(1, trm.UniformSpacing(dz=0.1, N=Nz).get_spacing(), p)
+    o.set("temperature", 10.0)
+    o.set("saturation_water_ice", 1.0)
+    o.initialize()
+    o.update_state(True)
+    # dθ/dt at the top cell equals the forcing exactly (no flux divergence at saturation)
+    assert o.get("tend_saturation_water_ice")[Nz - 1, 0] * scalar("porosity", p) == pytest.approx(F, rel=1e-15)
+    assert o.get("tend_saturation_water_ice")[Nz - 1, 0] == F / 0.49
+    o.timestep(dt)
+    assert o.get("saturation_water_ice")[Nz - 1, 0] == pytest.approx(1 + F * dt / 0.49, rel=1e-12)
+
+
+# K12  test/timestepping/heun.jl:26-49 (exact)
+def test_k12_expmodel_euler_heun_exact():
+    dt = 300.0
+    assert scalar("expmodel", 0, 0.0, 0.1, dt, 1) == 0.1 * dt
+    heun = scalar("expmodel", 1, 0.0, 0.1, dt, 1)
+    assert heun == (0.1 * dt + (0.1 * dt + 0.1) * dt) / 2
+    assert heun > 0.1 * dt
+
+
+# K13  test/timestepping/explicit_step.jl:43-53
+def test_k13_explicit_step():
+    o = Oracle(2, trm.ExponentialSpacing(N=10).get_spacing(), default_params(flow=1))
+    dt = 10.0
+    o.set("tend_internal_energy", 0.1)
+    o.set("tend_saturation_water_ice", 0.2)
+    o.explicit_step(dt)
+    assert np.allclose(o.get("internal_energy"), dt * 0.1)
+    assert np.allclose(o.get("saturation_water_ice"), dt * 0.2)
+    assert np.all(o.get("temperature") == 0)  # closure not evaluated by explicit_step!
+
+
+# K14  test/boundary_conditions.jl:16-19 (exact)
+def test_k14_value_bc_halo():
+    o = Oracle(1, trm.UniformSpacing(dz=0.1, N=10).get_spacing())
+    o.set_bc("internal_energy", "top", "value", 1.0)
+    o.set_bc("internal_energy", "bottom", "flux", -0.01)
+    o.set("internal_energy", 0.5)
+    o.fill_halo_regions()
+    assert o.halo("internal_energy", top=True) == 1.5
+    assert o.halo("internal_energy", top=False) == 0.5  # flux BC: halo = edge
+    o.set("internal_energy", 0.0)
+    o.fill_halo_regions()
+    assert o.halo("internal_energy", top=True) == 2.0
+
+
+# K15  test/surface_energy/radiative_fluxes.jl:4-39
+def test_k15_radiative_fluxes():
+    assert scalar("net_radiation", 50.0, 100.0, 5.0, 20.0) == pytest.approx(50.0 - 100.0 + 5.0 - 20.0)
+    p = default_params(albedo=0.5, emissivity=0.9)
+    # skin temperature 0 degC: LW_up = (1-eps) LW_down + eps sigma 273.15^4
+    lw = scalar("longwave_up", p, 20.0, 0.0, 0.9)
+    assert lw == pytest.approx((1 - 0.9) * 20.0 + 0.9 * p.sigma * 273.15 ** 4, rel=1e-14)
+    assert scalar("stefan_boltzmann", p, 273.15, 0.9) == pytest.approx(0.9 * 5.6704e-8 * 273.15 ** 4, rel=1e-14)
+
+
+# K16  test/surface_energy/skin_temperature.jl:16-47
+def test_k16_implicit_skin_temperature_converges():
+    dz_top = trm.ExponentialSpacing(N=10).get_spacing()[0]
+    resid, ts = oracle.skin_temperature_iterations(default_params(), 300.0, 50.0, 0.002, 101325.0, 10.0, 2.0, 1.0,
+                                                   dz_top, 5)
+    assert math.isfinite(ts)
+    assert resid < math.sqrt(np.finfo(float).eps)
+
+
+# K17  test/coupled_models/land_model_tests.jl:6-36
+def test_k17_land_model_one_step():
+    p = default_params(**VG, seb=1)
+    o = Oracle(1, trm.ExponentialSpacing(dz_max=1.0, N=50).get_spacing(), p)
+    g = o.grid()
+    zc = g["zC"]
+    o.set("temperature", 5.0 - 0.02 * zc)
+    o.set("saturation_water_ice", np.minimum(1.0, 0.8 - 0.05 * zc))
+    o.initialize()
+    # flux-BC wiring: +infiltration raises the top-cell saturation tendency, G lowers/raises the energy tendency
+    o.reset_tendencies()
+    o.set("infiltration", 1.0e-8)
+    o.set("ground_heat_flux", 3.0)
+    o.explicit_step(0.0)  # applies compute_z_bcs! then adds G*0
+    o.update_state(False)  # leaves tendencies at zero, recomputes auxiliaries (overwrites infiltration/ground_heat_flux)
+    o.timestep(60.0)
+    for name in ("saturation_water_ice", "internal_energy", "ground_heat_flux", "skin_temperature", "latent_heat_flux"):
+        assert np.all(np.isfinite(o.get(name))), name
+    assert o.status() == 0
+
+
+def test_k17_flux_bc_sign_and_scale():
+    """`-infiltration` is the top Flux BC of saturation (land_model.jl:57-61): a
+    positive infiltration adds I*Az/V = I/dz_top to the top-cell tendency."""
+    p = default_params(**VG, seb=1)
+    o = Oracle(1, trm.ExponentialSpacing(dz_max=1.0, N=50).get_spacing(), p)
+    dz_top = o.grid()["dzc"][-1]
+    o.set("infiltration", 1.0e-8)
+    o.set("ground_heat_flux", 3.0)
+    o.explicit_step(1.0)
+    assert o.get("saturation_water_ice")[-1, 0] == pytest.approx(1.0e-8 / dz_top, rel=1e-14)
+    assert o.get("internal_energy")[-1, 0] == pytest.approx(-3.0 / dz_top, rel=1e-14)
+    assert np.all(o.get("saturation_water_ice")[:-1] == 0)
+
+
+# K18  test/grids.jl:8-19 + SURVEY 8(d) reference tables
+def test_k18_vertical_spacings():
+    assert list(trm.UniformSpacing(dz=0.1, N=1).get_spacing()) == [0.1]
+    assert list(trm.UniformSpacing(dz=0.1, N=10).get_spacing()) == [0.1] * 10
+    assert list(trm.ExponentialSpacing(dz_min=0.1, dz_max=1.0, N=2).get_spacing()) == [0.1, 1.0]
+    s = trm.ExponentialSpacing(dz_min=0.1, dz_max=1.0, N=3, sig=None).get_spacing()
+    assert np.allclose(s, np.exp2(np.linspace(np.log2(0.1), np.log2(1.0), 3)))
+    assert list(trm.PrescribedSpacing(dz=[0.1, 0.2, 0.3]).get_spacing()) == [0.1, 0.2, 0.3]
+    s20 = trm.ExponentialSpacing(N=20).get_spacing()
+    assert list(s20[:6]) == [0.05, 0.0746, 0.111, 0.166, 0.248, 0.37] and list(s20[-2:]) == [67.0, 100.0]
+    assert float(s20.sum()) == pytest.approx(303.1, abs=0.05)
+    s32 = trm.ExponentialSpacing(N=32).get_spacing()
+    assert list(s32[:6]) == [0.05, 0.0639, 0.0816, 0.104, 0.133, 0.17] and list(s32[-2:]) == [78.3, 100.0]
+    assert float(s32.sum()) == pytest.approx(459.7, abs=0.05)
+    s64 = trm.ExponentialSpacing(N=64).get_spacing()
+    assert list(s64[:3]) == [0.05, 0.0564, 0.0636] and list(s64[-2:]) == [88.6, 100.0]
+
+
+# test/grids.jl:21-31 z_domain
+def test_column_grid_z_domain():
+    o = Oracle(2, trm.UniformSpacing(dz=0.1, N=5).get_spacing())
+    zF = o.grid()["zF"]
+    assert (zF[0], zF[-1]) == (-0.5, 0.0)
+    grid = trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=5), 2)
+    assert np.array_equal(grid.z_faces(), zF)
+
+
+# run_simulation.jl:8-27: clock bookkeeping of run!/timestep!
+def test_clock_ticks():
+    o = Oracle(3, trm.ExponentialSpacing(N=50).get_spacing())
+    o.initialize()
+    o.run(300.0, 2)
+    assert o.clock() == (600.0, 2)
+    o.timestep(900.0)
+    assert o.clock() == (1500.0, 3)
+    assert np.all(np.isfinite(o.get("temperature")))
+    o.timestep_heun(300.0)
+    assert o.clock() == (1800.0, 4)
+    assert np.all(np.isfinite(o.get("temperature")))
+
+
+def test_mask_fixture_column_counts():
+    assert int(trm.masks.load_land_mask("N72").sum()) == 14017
+    assert int(trm.masks.load_land_mask("N145").sum()) == 56951
+
+
+def test_swrc_round_trip_and_limits():
+    """FreezeCurves call convention (test/differentiability/soil_hydrology_diff.jl:52-69):
+    sat -> psi -> sat round trip; psi_m(sat = 1) = 0 for van Genuchten."""
+    for kw in (dict(swrc=1, vg_alpha=2.0, vg_n=2.0), dict(swrc=0)):
+        p = default_params(**kw)
+        por = 0.49
+        psi = scalar("swrc_psi", p, 0.5 * por, por)
+        assert psi < 0
+        assert scalar("swrc_theta", p, psi, por) / por == pytest.approx(0.5, rel=1e-12)
+    assert scalar("swrc_psi", default_params(swrc=1), 0.49, 0.49) == 0.0
+    assert scalar("swrc_psi", default_params(swrc=0), 0.49, 0.49) == -0.01
+
+
+def test_julia_integer_power_path():
+    # x^-5.0 goes through Base.Math.pow_body(x, -5): agrees with the correctly rounded power to 1 ulp
+    for x in (0.61, 0.123456789, 0.999, 3.7):
+        v = scalar("pow", x, -5.0)
+        assert v == pytest.approx(x ** -5.0, rel=4e-16)
+    assert scalar("pow", 10.0, -0.0) == 1.0
+    assert scalar("safediv", 1.0, 0.0) == math.inf  # src/utils/utils.jl:25 (test/utils.jl:39 is stale)
