@@ -1,0 +1,230 @@
+/* terrarium_hip.h -- C ABI of libterrarium_hip.so
+ *
+ * MI355X-native (gfx950, hand-written HIP) implementation of ONE hot path of
+ * TUM-PIK-ESM/Terrarium.jl: the explicit time step of SoilModel /
+ * LandModel(vegetation = nothing) over laterally independent soil columns --
+ * heat conduction with freeze/thaw, Richards water transport, bare-ground
+ * surface energy balance, forward-Euler / Heun update and the closures.
+ *
+ * The reference is pure Julia and has NO FFI: its extension surface is multiple
+ * dispatch on (state, model) (src/abstract_model.jl:52-95,175-215) and the
+ * time-stepper hook timestep!(integrator, ::AbstractTimeStepper, dt)
+ * (src/timesteppers/abstract_timestepper.jl:39).  Every entry point below names
+ * the reference method it stands in for; INTEGRATION.md shows the ~200-line
+ * Julia shim (`ccall`) a maintainer would add on the reference side.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a TRM_E* code otherwise; the message
+ *     is available from trm_last_error(ctx).  Nothing throws across the ABI.
+ *   - the context owns all device memory; host pointers are borrowed for the
+ *     duration of a call.  Calls are synchronous on return EXCEPT trm_step /
+ *     trm_step_heun / the compute_* family when TRM_OPT_ASYNC is set.
+ *   - one host thread drives a context; contexts are independent; no globals
+ *     (reference rule AGENTS.md:44).
+ *   - host arrays are [rows][num_columns], x (column) fastest, NO halos, row 0 =
+ *     BOTTOM layer, row Nz-1 = surface layer: exactly `interior(field)` of the
+ *     reference's (Nh, 1, Nz) Fields (src/grids/column_grid.jl:27-32).  Element
+ *     type is double for TRM_F64 contexts and float for TRM_F32.
+ *   - there is no CPU fallback: every entry point that computes needs a GPU.
+ */
+#ifndef TERRARIUM_HIP_H
+#define TERRARIUM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRM_ABI_VERSION 1
+
+typedef struct trm_ctx trm_ctx;
+
+/* ---- status codes ------------------------------------------------------- */
+enum { TRM_OK = 0, TRM_EINVAL = 1, TRM_EHIP = 2, TRM_ENOMEM = 3, TRM_EUNSUPPORTED = 4 };
+
+/* ---- number format NF (every reference struct is parameterised by it) ---- */
+enum { TRM_F64 = 0, TRM_F32 = 1 };
+
+/* ---- configuration enums -------------------------------------------------- */
+enum { TRM_FLOW_NOFLOW = 0, TRM_FLOW_RICHARDS = 1 };        /* soil_hydrology.jl:14, soil_hydrology_rre.jl:18 */
+enum { TRM_SWRC_BROOKS_COREY = 0, TRM_SWRC_VAN_GENUCHTEN = 1 }; /* FreezeCurves.jl SWRCs                     */
+enum { TRM_UNSATK_LINEAR = 0, TRM_UNSATK_VAN_GENUCHTEN = 1 };   /* soil_hydraulic_properties.jl:166,196     */
+/* under NoFlow the reference never fills the z halos of the
+ * auxiliary saturation field (they stay 0); MIRROR copies the edge cell instead. */
+enum { TRM_HALO_REFERENCE_ZERO = 0, TRM_HALO_MIRROR = 1 };
+
+/* Boundary conditions (Oceananigans Value / Flux / Gradient / default NoFlux). */
+enum { TRM_BC_NOFLUX = 0, TRM_BC_VALUE = 1, TRM_BC_FLUX = 2, TRM_BC_GRADIENT = 3 };
+enum { TRM_BOTTOM = 0, TRM_TOP = 1 };
+enum {
+    TRM_BCV_INTERNAL_ENERGY = 0,
+    TRM_BCV_SATURATION_WATER_ICE = 1,
+    TRM_BCV_TEMPERATURE = 2,
+    TRM_BCV_LIQUID_WATER_FRACTION = 3,
+    TRM_BCV_PRESSURE_HEAD = 4,
+    TRM_BCV_COUNT = 5
+};
+
+/* ---- state variables ---------------------------------- */
+enum {
+    /* 3-D, Nz rows */
+    TRM_FIELD_INTERNAL_ENERGY = 0,          /* prognostic, J/m^3   soil_energy.jl:47            */
+    TRM_FIELD_SATURATION_WATER_ICE = 1,     /* prognostic (Richards) / auxiliary (NoFlow)        */
+    TRM_FIELD_TEMPERATURE = 2,              /* closure, degC      soil_energy_closures.jl:23   */
+    TRM_FIELD_LIQUID_WATER_FRACTION = 3,    /* closure             soil_energy_closures.jl:24   */
+    TRM_FIELD_PRESSURE_HEAD = 4,            /* closure, m          soil_hydraulic_closures.jl:15 */
+    TRM_FIELD_HYDRAULIC_CONDUCTIVITY = 5,   /* Face field, Nz+1 rows  soil_hydrology.jl:81      */
+    TRM_FIELD_TEND_INTERNAL_ENERGY = 6,
+    TRM_FIELD_TEND_SATURATION_WATER_ICE = 7,
+    /* 2-D, 1 row */
+    TRM_FIELD_SURFACE_EXCESS_WATER = 8,     /* prognostic, m       soil_hydrology_rre.jl:22     */
+    TRM_FIELD_TEND_SURFACE_EXCESS_WATER = 9,
+    TRM_FIELD_WATER_TABLE = 10,             /* auxiliary, m        soil_hydrology.jl:80         */
+    TRM_FIELD_SKIN_TEMPERATURE = 11,        /* skin_temperature.jl:85                           */
+    TRM_FIELD_GROUND_HEAT_FLUX = 12,        /* skin_temperature.jl:86; top Flux BC of U in LandModel */
+    TRM_FIELD_SURFACE_SHORTWAVE_UP = 13,    /* radiative_fluxes.jl:104-108                      */
+    TRM_FIELD_SURFACE_LONGWAVE_UP = 14,
+    TRM_FIELD_SURFACE_NET_RADIATION = 15,
+    TRM_FIELD_SENSIBLE_HEAT_FLUX = 16,      /* turbulent_fluxes.jl:54-57                        */
+    TRM_FIELD_LATENT_HEAT_FLUX = 17,
+    TRM_FIELD_EVAPORATION_GROUND = 18,      /* bare_ground_evaporation.jl:27                    */
+    TRM_FIELD_INFILTRATION = 19,            /* direct_surface_runoff.jl:65-68; -I = top Flux BC of sat */
+    TRM_FIELD_SURFACE_RUNOFF = 20,
+    /* PrescribedAtmosphere inputs (prescribed_atmosphere.jl:89-99) */
+    TRM_FIELD_AIR_TEMPERATURE = 21,
+    TRM_FIELD_AIR_PRESSURE = 22,
+    TRM_FIELD_WINDSPEED = 23,
+    TRM_FIELD_SPECIFIC_HUMIDITY = 24,
+    TRM_FIELD_RAINFALL = 25,
+    TRM_FIELD_SURFACE_SHORTWAVE_DOWN = 26,
+    TRM_FIELD_SURFACE_LONGWAVE_DOWN = 27,
+    TRM_FIELD_COUNT = 28
+};
+
+/* ---- diagnostics ---------------------------------------------------------- */
+enum { TRM_REDUCE_SUM = 0, TRM_REDUCE_MIN = 1, TRM_REDUCE_MAX = 2, TRM_REDUCE_HASNAN = 3, TRM_REDUCE_VOLUME_INTEGRAL_Z = 4 };
+/* trm_status flag bits: replace the reference's CPU-side @assert / DEBUG NaN scans
+ * (soil_volume.jl:26-28,85; diagnostics/debugging.jl:19-25). */
+enum { TRM_STATUS_NAN = 1u, TRM_STATUS_COMPOSITION_OUT_OF_RANGE = 2u };
+
+/* ---- options (trm_set_option) --------------------------------------------- */
+enum {
+    TRM_OPT_ASYNC = 0,          /* 1: trm_step & co. return after enqueueing on the context stream          */
+    TRM_OPT_STEP_KERNEL = 1,    /* TRM_KERNEL_*: which implementation trm_step uses                          */
+    TRM_OPT_READ_CLOSURE = 2,   /* fused kernel: 0 recompute T/liq/psi from (U, sat) when provably identical, */
+                                /* 1 always read the stored closure fields, 2 read psi only                   */
+    TRM_OPT_WRITE_KF_EVERY_STEP = 3, /* 1 (default): hydraulic_conductivity is stored by every step launch   */
+    TRM_OPT_BLOCK_COLUMNS = 4   /* columns per workgroup of the fused kernel (64, 128 or 256)                */
+};
+enum {
+    TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = column, column state staged in LDS           */
+    TRM_KERNEL_UNFUSED = 1      /* one launch per reference kernel, in the reference's order (A/B comparator) */
+};
+
+/* ---- grid: ColumnGrid(arch, NF, vert, num_columns)  src/grids/column_grid.jl:20-34 */
+typedef struct trm_grid {
+    int32_t precision;        /* TRM_F64 | TRM_F32                                                        */
+    int32_t num_layers;       /* Nz >= 2                                                                   */
+    int64_t num_columns;      /* Nh >= 1 (this device's shard)                                             */
+    const double* thickness;  /* [Nz] get_spacing(vert): index 0 = SURFACE layer (vertical_discretization.jl:20) */
+    double dx;                /* x spacing of the underlying RectilinearGrid; <= 0 selects 1/Nh (x = (0,1)) */
+    int32_t device;           /* HIP device ordinal                                                        */
+    int32_t reserved;
+} trm_grid;
+
+/* ---- parameters: the flat POD of SURVEY 8(a12); defaults = reference defaults -- */
+typedef struct trm_params {
+    /* PhysicalConstants  src/processes/physical_constants.jl:9-51 */
+    double rho_w, rho_i, rho_a, c_a, Lsl, Llg, Lsg, g, Tref, sigma, kappa_vk, eps_mw, R_a;
+    /* SoilThermalConductivities / SoilHeatCapacities  soil_thermal_properties.jl:14-46 */
+    double k_water, k_ice, k_air, k_mineral, k_organic;
+    double c_water, c_ice, c_air, c_mineral, c_organic;
+    /* ConstantSoilPorosity soil_porosity.jl:7-13; ConstantSoilCarbonDensity constant_soil_carbon.jl:10-16 */
+    double por_mineral, por_organic, rho_soc, rho_org;
+    /* ConstantSoilHydraulics / SoilHydraulicsSURFEX + SWRC + UnsatK  soil_hydraulic_properties.jl:66-221 */
+    double K_sat, theta_res, bc_psi_s, bc_lambda, vg_alpha, vg_n, impedance;
+    double vwc_forcing;       /* spatially constant vwc_forcing source/sink [1/s] (soil_hydrology.jl:37-38) */
+    /* ConstantAlbedo, ImplicitSkinTemperature, ConstantAerodynamics, PrescribedAtmosphere,
+     * DirectSurfaceRunoff, ConstantEvaporationResistanceFactor */
+    double albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap;
+    int32_t flow;             /* TRM_FLOW_*                                                               */
+    int32_t swrc;             /* TRM_SWRC_*                                                               */
+    int32_t unsat_k;          /* TRM_UNSATK_*                                                             */
+    int32_t seb;              /* 0: SoilModel; 1: LandModel(vegetation = nothing) coupling (land_model.jl) */
+    int32_t halo_policy;      /* TRM_HALO_*                                                               */
+    int32_t reserved;
+} trm_params;
+
+/* Fill `p` with the reference defaults. */
+int trm_default_params(trm_params* p);
+
+/* initialize(model, timestepper) allocation part (src/state_variables.jl:303-314, 418-430):
+ * creates all state buffers on `g->device`, zero-filled, inputs at their defaults. */
+int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out);
+int trm_destroy(trm_ctx* ctx);
+const char* trm_last_error(const trm_ctx* ctx);
+int trm_abi_version(void);
+
+/* Geometry queries: rows of a field (Nz, Nz+1 or 1), and the grid the library derived
+ * (z of faces [Nz+1] bottom first, z of centres [Nz], dz centre [Nz], dz face [Nz+1]). */
+int trm_field_rows(const trm_ctx* ctx, int field, int64_t* rows);
+int trm_get_grid(const trm_ctx* ctx, double* z_faces, double* z_centers, double* dz_center, double* dz_face);
+
+/* set!(field, array) / Array(interior(field)) */
+int trm_upload(trm_ctx* ctx, int field, const void* host);
+int trm_download(trm_ctx* ctx, int field, void* host);
+/* Device address and row pitch (in elements) of a field, for zero-copy consumers on the same device. */
+int trm_field_device_ptr(trm_ctx* ctx, int field, void** dev, int64_t* pitch_elems);
+
+/* Field boundary conditions (src/models/soil/soil_model_bcs.jl, src/boundary_conditions.jl:25-28):
+ * `values` is a per-column array [Nh] or NULL to broadcast `scalar`. */
+int trm_set_bc(trm_ctx* ctx, int bc_var, int side, int kind, const void* values, double scalar);
+/* update_inputs! (src/state_variables.jl:154-162): same as trm_upload on an input field. */
+int trm_set_forcing(trm_ctx* ctx, int input_field, const void* per_column);
+
+/* initialize!(state, model) process initialisers (soil_coupled.jl:45-54): hydraulics, water table,
+ * sat -> psi, T -> U.  Call after uploading the initial temperature / saturation. */
+int trm_initialize(trm_ctx* ctx);
+/* update_state!(state, model, inputs; compute_tendencies)  src/state_variables.jl:72-80 */
+int trm_update_state(trm_ctx* ctx, int compute_tendencies);
+/* compute_auxiliary!(state, model)  soil_model.jl:39-42 / land_model.jl:79-88 */
+int trm_compute_auxiliary(trm_ctx* ctx);
+/* compute_tendencies!(state, model) soil_model.jl:44-47 (accumulates into the tendency fields) */
+int trm_compute_tendencies(trm_ctx* ctx);
+/* reset_tendencies!(state)  src/state_variables.jl:127-136 */
+int trm_reset_tendencies(trm_ctx* ctx);
+/* explicit_step!(state, grid, timestepper, dt)  abstract_timestepper.jl:65-77 */
+int trm_explicit_step(trm_ctx* ctx, double dt);
+/* closure!/invclosure!(state, model)  soil_coupled.jl:99-122 */
+int trm_closure(trm_ctx* ctx);
+int trm_invclosure(trm_ctx* ctx);
+
+/* `nsteps` x timestep!(integrator, ForwardEuler, dt; finalize = false), then compute_auxiliary! once
+ * if `finalize` (forward_euler.jl:19-31, model_integrator.jl:72-88,124-131).  nsteps = 1, finalize = 1
+ * is the reference's timestep!(integrator, dt); finalize = 1 with nsteps = n is run!(steps = n). */
+int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
+/* Same for Heun (heun.jl:37-71). */
+int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
+/* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
+int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);
+
+int trm_clock(const trm_ctx* ctx, double* time, int64_t* iteration);
+int trm_set_clock(trm_ctx* ctx, double time, int64_t iteration);
+
+/* Local (this device's columns) reduction of a field.  SUM/MIN/MAX/HASNAN give one value per row in
+ * out[rows]; VOLUME_INTEGRAL_Z gives one value (sum over columns of sum_k f*dz).  The host side
+ * combines ranks with one RCCL all-reduce (terrarium.jl_amd/parallel.py). */
+int trm_reduce(trm_ctx* ctx, int field, int op, double* out);
+int trm_status(trm_ctx* ctx, uint32_t* flags);
+
+int trm_set_option(trm_ctx* ctx, int option, int value);
+int trm_get_option(const trm_ctx* ctx, int option, int* value);
+/* Adopt an external hipStream_t (e.g. torch's current stream); NULL restores the context's own. */
+int trm_set_stream(trm_ctx* ctx, void* hip_stream);
+int trm_synchronize(trm_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TERRARIUM_HIP_H */

@@ -10,6 +10,18 @@ include/terrarium_hip.h; there is no CPU fallback.
 from .grids import (AbstractVerticalSpacing, UniformSpacing, ExponentialSpacing, PrescribedSpacing, ColumnGrid,
                     ColumnRingGrid)
 from . import masks
-
-__all__ = ["AbstractVerticalSpacing", "UniformSpacing", "ExponentialSpacing", "PrescribedSpacing", "ColumnGrid",
-           "ColumnRingGrid", "masks"]
+from . import _capi
+from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapacities, SoilThermalProperties,
+                     SoilEnergyBalance, ConstantSoilPorosity, HomogeneousStratigraphy, ConstantSoilCarbonDensity,
+                     BrooksCorey, VanGenuchten, UnsatKLinear, UnsatKVanGenuchten, ConstantSoilHydraulics,
+                     SoilHydraulicsSURFEX, NoFlow, RichardsEq, SoilHydrology, SoilEnergyWaterCarbon, ConstantAlbedo,
+                     ImplicitSkinTemperature, SurfaceEnergyBalance, ConstantAerodynamics, PrescribedAtmosphere,
+                     DirectSurfaceRunoff, BareGroundEvaporation, SurfaceHydrology, DefaultInitializer,
+                     ConstantSoilTemperature, QuasiThermalSteadyState, ConstantSaturation, SaturationWaterTable,
+                     SoilInitializer, SoilModel, LandModel, flatten)
+from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, PrescribedBottomTemperature,
+                         GroundHeatFlux, GeothermalHeatFlux, InfiltrationFlux, ImpermeableBoundary, FreeDrainage,
+                         merge_boundary_conditions, DeviceState, ModelIntegrator, initialize, initialize_integrator,
+                         timestep, run, current_time, compute_auxiliary, compute_tendencies, closure, invclosure,
+                         update_state)
+from ._capi import TerrariumHipError

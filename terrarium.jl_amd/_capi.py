@@ -1,0 +1,120 @@
+"""ctypes binding of libterrarium_hip.so -- exactly the entry points declared in
+include/terrarium_hip.h (the stub a Julia maintainer would write with `ccall`
+is in INTEGRATION.md).  There is no CPU fallback: if the library is missing the
+import of this module's `lib()` raises, and `trm_create` fails without a GPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libterrarium_hip.so")
+
+TRM_F64, TRM_F32 = 0, 1
+FLOW = dict(noflow=0, richards=1)
+SWRC = dict(brooks_corey=0, van_genuchten=1)
+UNSATK = dict(linear=0, van_genuchten=1)
+HALO = dict(reference_zero=0, mirror=1)
+BC_KIND = dict(noflux=0, value=1, flux=2, gradient=3)
+SIDE = dict(bottom=0, top=1)
+BC_VAR = dict(internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4)
+FIELD = dict(
+    internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4,
+    hydraulic_conductivity=5, tend_internal_energy=6, tend_saturation_water_ice=7, surface_excess_water=8,
+    tend_surface_excess_water=9, water_table=10, skin_temperature=11, ground_heat_flux=12, surface_shortwave_up=13,
+    surface_longwave_up=14, surface_net_radiation=15, sensible_heat_flux=16, latent_heat_flux=17,
+    evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
+    specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27,
+)
+INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidity", "rainfall",
+                "surface_shortwave_down", "surface_longwave_down")
+REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
+OPTION = dict(asynchronous=0, step_kernel=1, read_closure=2, write_kf_every_step=3, block_columns=4)
+KERNEL = dict(fused=0, unfused=1)
+STATUS_NAN, STATUS_COMPOSITION = 1, 2
+
+EXPORTS = (
+    "trm_abi_version trm_default_params trm_create trm_destroy trm_last_error trm_field_rows trm_get_grid "
+    "trm_upload trm_download trm_field_device_ptr trm_set_bc trm_set_forcing trm_initialize trm_update_state "
+    "trm_compute_auxiliary trm_compute_tendencies trm_reset_tendencies trm_explicit_step trm_closure trm_invclosure "
+    "trm_step trm_step_heun trm_step_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_option "
+    "trm_get_option trm_set_stream trm_synchronize").split()
+
+
+class TrmGrid(C.Structure):
+    _fields_ = [("precision", C.c_int32), ("num_layers", C.c_int32), ("num_columns", C.c_int64),
+                ("thickness", C.POINTER(C.c_double)), ("dx", C.c_double), ("device", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class TrmParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in (
+        "rho_w rho_i rho_a c_a Lsl Llg Lsg g Tref sigma kappa_vk eps_mw R_a "
+        "k_water k_ice k_air k_mineral k_organic c_water c_ice c_air c_mineral c_organic "
+        "por_mineral por_organic rho_soc rho_org "
+        "K_sat theta_res bc_psi_s bc_lambda vg_alpha vg_n impedance vwc_forcing "
+        "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap").split()] + [
+        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy reserved".split()]
+
+
+class TerrariumHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libterrarium_hip.so; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TerrariumHipError(
+            f"{LIB_PATH} is missing: build it with `make -C terrarium.jl_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
+    L.trm_abi_version.restype = i32
+    L.trm_default_params.argtypes = [C.POINTER(TrmParams)]
+    L.trm_create.argtypes = [C.POINTER(TrmGrid), C.POINTER(TrmParams), C.POINTER(vp)]
+    L.trm_destroy.argtypes = [vp]
+    L.trm_last_error.restype = C.c_char_p
+    L.trm_last_error.argtypes = [vp]
+    L.trm_field_rows.argtypes = [vp, i32, C.POINTER(i64)]
+    L.trm_get_grid.argtypes = [vp, vp, vp, vp, vp]
+    L.trm_upload.argtypes = [vp, i32, vp]
+    L.trm_download.argtypes = [vp, i32, vp]
+    L.trm_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64)]
+    L.trm_set_bc.argtypes = [vp, i32, i32, i32, vp, dbl]
+    L.trm_set_forcing.argtypes = [vp, i32, vp]
+    for name in ("trm_initialize", "trm_compute_auxiliary", "trm_compute_tendencies", "trm_reset_tendencies",
+                 "trm_closure", "trm_invclosure", "trm_synchronize"):
+        getattr(L, name).argtypes = [vp]
+    L.trm_update_state.argtypes = [vp, i32]
+    L.trm_explicit_step.argtypes = [vp, dbl]
+    L.trm_step.argtypes = [vp, dbl, i32, i32]
+    L.trm_step_heun.argtypes = [vp, dbl, i32, i32]
+    L.trm_step_timed.argtypes = [vp, dbl, i32, i32, C.POINTER(C.c_float)]
+    L.trm_clock.argtypes = [vp, C.POINTER(dbl), C.POINTER(i64)]
+    L.trm_set_clock.argtypes = [vp, dbl, i64]
+    L.trm_reduce.argtypes = [vp, i32, i32, vp]
+    L.trm_status.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.trm_set_option.argtypes = [vp, i32, i32]
+    L.trm_get_option.argtypes = [vp, i32, C.POINTER(i32)]
+    L.trm_set_stream.argtypes = [vp, vp]
+    for name in EXPORTS:
+        if name not in ("trm_last_error",):
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def check(ctx, rc, what):
+    if rc != 0:
+        msg = lib().trm_last_error(ctx)
+        raise TerrariumHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def default_params() -> TrmParams:
+    p = TrmParams()
+    check(None, lib().trm_default_params(C.byref(p)), "trm_default_params")
+    return p

@@ -1,0 +1,875 @@
+// terrarium_hip.hip -- context management and the C ABI of libterrarium_hip.so
+// (include/terrarium_hip.h).  gfx950 only; no CPU fallback.
+#include "../../include/terrarium_hip.h"
+#include "trm_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace trm;
+
+namespace {
+
+struct FieldSet {
+    void* f[TRM_FIELD_COUNT];
+};
+
+}  // namespace
+
+struct trm_ctx {
+    int precision = TRM_F64;
+    long Nh = 0, pitch = 0;
+    int Nz = 0, device = 0;
+    size_t esize = 8;
+    trm_params params;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    FieldSet state{}, stage{};
+    bool has_stage = false;
+    void* bc_value[TRM_BCV_COUNT][2] = {};
+    int bc_kind[TRM_BCV_COUNT][2] = {};
+    void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr;
+    std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
+    double dzf_bot = 0, dzf_top = 0, Az = 1, z_ref = 0;
+    uint32_t* d_status = nullptr;
+    double* d_reduce = nullptr;  // scratch for trm_reduce
+    size_t reduce_cap = 0;
+    double time = 0.0;
+    int64_t iteration = 0;
+    int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_read_closure = 0, opt_write_kf = 1, opt_block = 64;
+    bool tl_consistent = false, psi_consistent = false;
+    std::string err;
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(trm_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define TRM_HIP(ctx, call)                                                                               \
+    do {                                                                                                 \
+        hipError_t e__ = (call);                                                                         \
+        if (e__ != hipSuccess)                                                                           \
+            return fail(ctx, TRM_EHIP, std::string(#call) + ": " + hipGetErrorString(e__));             \
+    } while (0)
+
+long field_rows(const trm_ctx* c, int field) {
+    if (field == TRM_FIELD_HYDRAULIC_CONDUCTIVITY) return c->Nz + 1;
+    if (field <= TRM_FIELD_TEND_SATURATION_WATER_ICE) return c->Nz;
+    return 1;
+}
+bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
+
+// ---- grid: ColumnGrid (column_grid.jl:20-34) + Oceananigans' stretched-coordinate recipe --------------
+// thickness[0] is the surface layer.  All derived quantities are formed in NF.
+template <class NF> struct HostGrid {
+    std::vector<NF> zF, zC, dzc, rdzc, rdzf, dzf;  // faces 0..Nz ; centres 0..Nz-1
+    NF dzf_bot, dzf_top;
+    void build(int Nz, const double* thickness) {
+        // z_coords = convert.(NF, vcat(-reverse(cumsum(z_thick)), 0))
+        std::vector<double> cs(Nz);
+        double acc = thickness[0];
+        cs[0] = acc;
+        for (int n = 1; n < Nz; ++n) { acc = acc + thickness[n]; cs[n] = acc; }
+        zF.resize(Nz + 1);
+        for (int f = 0; f < Nz; ++f) zF[f] = (NF)(-cs[Nz - 1 - f]);
+        zF[Nz] = NF(0);
+        // halo faces continue with the boundary cell's spacing (Bounded topology)
+        NF Fm1 = zF[0] - (zF[1] - zF[0]);
+        NF Fp1 = zF[Nz] + (zF[Nz] - zF[Nz - 1]);
+        zC.resize(Nz);
+        dzc.resize(Nz);
+        rdzc.resize(Nz);
+        for (int k = 0; k < Nz; ++k) {
+            zC[k] = (zF[k + 1] + zF[k]) / NF(2);
+            dzc[k] = zF[k + 1] - zF[k];
+            rdzc[k] = NF(1) / dzc[k];
+        }
+        NF Cm1 = (zF[0] + Fm1) / NF(2);
+        NF Cp1 = (Fp1 + zF[Nz]) / NF(2);
+        dzf.resize(Nz + 1);
+        rdzf.resize(Nz + 1);
+        for (int f = 0; f <= Nz; ++f) {
+            NF hi = (f < Nz) ? zC[f] : Cp1;
+            NF lo = (f > 0) ? zC[f - 1] : Cm1;
+            dzf[f] = hi - lo;
+            rdzf[f] = NF(1) / dzf[f];
+        }
+        dzf_bot = dzf[0];
+        dzf_top = dzf[Nz];
+    }
+};
+
+template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
+    DevParams<NF> p;
+    NF rho_soc = (NF)q.rho_soc, rho_org = (NF)q.rho_org, por_m = (NF)q.por_mineral, por_o = (NF)q.por_organic;
+    p.org = rho_soc / ((NF(1) - por_o) * rho_org);               // homogeneous_strat.jl:34-44
+    p.por = (NF(1) - p.org) * por_m + p.org * por_o;             // homogeneous_strat.jl:51-61
+    p.solid_frac = NF(1) - p.por;                                // soil_volume.jl:62
+    p.frac_organic = p.solid_frac * p.org;                       // soil_volume.jl:103-107
+    p.frac_mineral = p.solid_frac * (NF(1) - p.org);
+    p.sk_water = std::sqrt((NF)q.k_water);
+    p.sk_ice = std::sqrt((NF)q.k_ice);
+    p.sk_air = std::sqrt((NF)q.k_air);
+    p.kterm_mineral = std::sqrt((NF)q.k_mineral) * p.frac_mineral;
+    p.kterm_organic = std::sqrt((NF)q.k_organic) * p.frac_organic;
+    p.c_water = (NF)q.c_water;
+    p.c_ice = (NF)q.c_ice;
+    p.c_air = (NF)q.c_air;
+    p.cterm_mineral = (NF)q.c_mineral * p.frac_mineral;
+    p.cterm_organic = (NF)q.c_organic * p.frac_organic;
+    p.L = (NF)q.rho_w * (NF)q.Lsl;
+    p.K_sat = (NF)q.K_sat;
+    p.theta_res = (NF)q.theta_res;
+    p.bc_psi_s = (NF)q.bc_psi_s;
+    p.vg_alpha = (NF)q.vg_alpha;
+    p.impedance = (NF)q.impedance;
+    p.vwc_forcing = (NF)q.vwc_forcing;
+    p.neg_inv_alpha = NF(-1) / p.vg_alpha;
+    NF lam = (NF)q.bc_lambda, n = (NF)q.vg_n;
+    NF m = NF(1) - NF(1) / n;
+    p.bc_lambda = make_pow_spec<NF>(lam);
+    p.bc_neg_inv_lambda = make_pow_spec<NF>(NF(-1) / lam);
+    p.vg_n = make_pow_spec<NF>(n);
+    p.vg_neg_m = make_pow_spec<NF>(-m);
+    p.vg_neg_inv_m = make_pow_spec<NF>(NF(-1) / m);
+    p.vg_inv_n = make_pow_spec<NF>(NF(1) / n);
+    p.vgk_e1 = make_pow_spec<NF>(n / (n + NF(1)));
+    p.vgk_e2 = make_pow_spec<NF>((n - NF(1)) / n);
+    p.albedo = (NF)q.albedo;
+    p.emissivity = (NF)q.emissivity;
+    p.one_minus_emissivity = NF(1) - p.emissivity;
+    p.eps_sigma = p.emissivity * (NF)q.sigma;
+    p.kappa_s2 = NF(2) * (NF)q.kappa_s;
+    p.C_h = (NF)q.C_h;
+    p.min_windspeed = (NF)q.min_windspeed;
+    p.tau_r = (NF)q.tau_r;
+    p.beta_evap = (NF)q.beta_evap;
+    p.Tref = (NF)q.Tref;
+    p.eps_mw = (NF)q.eps_mw;
+    p.one_minus_eps_mw = NF(1) - p.eps_mw;
+    p.ca_rhoa = (NF)q.c_a * (NF)q.rho_a;
+    p.Llg_rhoa = (NF)q.Llg * (NF)q.rho_a;
+    p.flow = q.flow;
+    p.swrc = q.swrc;
+    p.unsat_k = q.unsat_k;
+    p.seb = q.seb;
+    p.halo_policy = q.halo_policy;
+    return p;
+}
+
+template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
+    View<NF> v;
+    v.Nh = c->Nh;
+    v.pitch = c->pitch;
+    v.Nz = c->Nz;
+    auto F = [&](int id) { return (NF*)s.f[id]; };
+    v.U = F(TRM_FIELD_INTERNAL_ENERGY);
+    v.sat = F(TRM_FIELD_SATURATION_WATER_ICE);
+    v.T = F(TRM_FIELD_TEMPERATURE);
+    v.liq = F(TRM_FIELD_LIQUID_WATER_FRACTION);
+    v.psi = F(TRM_FIELD_PRESSURE_HEAD);
+    v.Kf = F(TRM_FIELD_HYDRAULIC_CONDUCTIVITY);
+    v.G_U = F(TRM_FIELD_TEND_INTERNAL_ENERGY);
+    v.G_sat = F(TRM_FIELD_TEND_SATURATION_WATER_ICE);
+    v.S = F(TRM_FIELD_SURFACE_EXCESS_WATER);
+    v.G_S = F(TRM_FIELD_TEND_SURFACE_EXCESS_WATER);
+    v.wt = F(TRM_FIELD_WATER_TABLE);
+    v.Ts = F(TRM_FIELD_SKIN_TEMPERATURE);
+    v.ghf = F(TRM_FIELD_GROUND_HEAT_FLUX);
+    v.swu = F(TRM_FIELD_SURFACE_SHORTWAVE_UP);
+    v.lwu = F(TRM_FIELD_SURFACE_LONGWAVE_UP);
+    v.rnet = F(TRM_FIELD_SURFACE_NET_RADIATION);
+    v.Hs = F(TRM_FIELD_SENSIBLE_HEAT_FLUX);
+    v.Hl = F(TRM_FIELD_LATENT_HEAT_FLUX);
+    v.evap = F(TRM_FIELD_EVAPORATION_GROUND);
+    v.infil = F(TRM_FIELD_INFILTRATION);
+    v.runoff = F(TRM_FIELD_SURFACE_RUNOFF);
+    v.Tair = F(TRM_FIELD_AIR_TEMPERATURE);
+    v.pres = F(TRM_FIELD_AIR_PRESSURE);
+    v.wind = F(TRM_FIELD_WINDSPEED);
+    v.qair = F(TRM_FIELD_SPECIFIC_HUMIDITY);
+    v.rain = F(TRM_FIELD_RAINFALL);
+    v.swd = F(TRM_FIELD_SURFACE_SHORTWAVE_DOWN);
+    v.lwd = F(TRM_FIELD_SURFACE_LONGWAVE_DOWN);
+    v.zC = (const NF*)c->d_zC;
+    v.zF = (const NF*)c->d_zF;
+    v.dzc = (const NF*)c->d_dzc;
+    v.rdzc = (const NF*)c->d_rdzc;
+    v.rdzf = (const NF*)c->d_rdzf;
+    v.dzf_bot = (NF)c->dzf_bot;
+    v.dzf_top = (NF)c->dzf_top;
+    v.Az = (NF)c->Az;
+    v.z_ref = (NF)c->z_ref;
+    v.status = c->d_status;
+    for (int a = 0; a < TRM_BCV_COUNT; ++a)
+        for (int b = 0; b < 2; ++b) {
+            v.bc.kind[a][b] = c->bc_kind[a][b];
+            v.bc.value[a][b] = c->bc_value[a][b];
+        }
+    return v;
+}
+
+dim3 cell_grid(const trm_ctx* c, long rows) { return dim3((unsigned)((c->Nh + 255) / 256), (unsigned)rows, 1); }
+dim3 col_grid(const trm_ctx* c) { return dim3((unsigned)((c->Nh + 255) / 256), 1, 1); }
+
+template <class NF> struct Ops {
+    static bool richards(const trm_ctx* c) { return c->params.flow == TRM_FLOW_RICHARDS; }
+
+    static int hydraulics(trm_ctx* c, const FieldSet& s) {
+        hipLaunchKernelGGL(k_hydraulics<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, make_view<NF>(c, s),
+                           make_dev_params<NF>(c->params));
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int surface(trm_ctx* c, const FieldSet& s) {
+        auto v = make_view<NF>(c, s);
+        auto p = make_dev_params<NF>(c->params);
+        if (richards(c)) hipLaunchKernelGGL((k_surface<NF, true>), col_grid(c), dim3(256), 0, c->stream, v, p);
+        else hipLaunchKernelGGL((k_surface<NF, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int compute_auxiliary(trm_ctx* c, const FieldSet& s) {
+        int rc = hydraulics(c, s);
+        if (rc) return rc;
+        if (c->params.seb) rc = surface(c, s);
+        return rc;
+    }
+    static int compute_tendencies(trm_ctx* c, const FieldSet& s) {
+        auto v = make_view<NF>(c, s);
+        auto p = make_dev_params<NF>(c->params);
+        if (richards(c)) hipLaunchKernelGGL((k_tendencies<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
+        else hipLaunchKernelGGL((k_tendencies<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int reset_tendencies(trm_ctx* c, const FieldSet& s) {
+        size_t row = (size_t)c->pitch * sizeof(NF);
+        TRM_HIP(c, hipMemsetAsync(s.f[TRM_FIELD_TEND_INTERNAL_ENERGY], 0, row * c->Nz, c->stream));
+        TRM_HIP(c, hipMemsetAsync(s.f[TRM_FIELD_TEND_SATURATION_WATER_ICE], 0, row * c->Nz, c->stream));
+        TRM_HIP(c, hipMemsetAsync(s.f[TRM_FIELD_TEND_SURFACE_EXCESS_WATER], 0, row, c->stream));
+        return TRM_OK;
+    }
+    static int update_state(trm_ctx* c, const FieldSet& s, bool tendencies) {
+        int rc = reset_tendencies(c, s);
+        if (!rc) rc = compute_auxiliary(c, s);
+        if (!rc && tendencies) rc = compute_tendencies(c, s);
+        return rc;
+    }
+    static int explicit_step(trm_ctx* c, const FieldSet& s, double dt) {
+        auto v = make_view<NF>(c, s);
+        auto p = make_dev_params<NF>(c->params);
+        if (richards(c)) hipLaunchKernelGGL((k_explicit_step<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
+        else hipLaunchKernelGGL((k_explicit_step<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int closure(trm_ctx* c, const FieldSet& s) {
+        auto v = make_view<NF>(c, s);
+        auto p = make_dev_params<NF>(c->params);
+        if (richards(c)) {
+            hipLaunchKernelGGL((k_closure_hydrology<NF, true>), col_grid(c), dim3(256), 0, c->stream, v, p);
+            TRM_HIP(c, hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_closure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int invclosure(trm_ctx* c, const FieldSet& s) {
+        auto v = make_view<NF>(c, s);
+        auto p = make_dev_params<NF>(c->params);
+        if (richards(c)) {
+            hipLaunchKernelGGL(k_pressure_to_saturation<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
+            hipLaunchKernelGGL((k_closure_hydrology<NF, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
+            TRM_HIP(c, hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_invclosure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int initialize(trm_ctx* c) {
+        auto v = make_view<NF>(c, c->state);
+        auto p = make_dev_params<NF>(c->params);
+        if (richards(c)) {  // soil_hydrology_rre.jl:33-47
+            hipLaunchKernelGGL((k_closure_hydrology<NF, true>), col_grid(c), dim3(256), 0, c->stream, v, p);
+            TRM_HIP(c, hipGetLastError());
+            int rc = hydraulics(c, c->state);
+            if (rc) return rc;
+        } else {  // soil_hydrology.jl:113-117
+            int rc = hydraulics(c, c->state);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_water_table<NF>, col_grid(c), dim3(256), 0, c->stream, v);
+            TRM_HIP(c, hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_invclosure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);  // soil_energy.jl:64-77
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+
+    // ---- fused step ----------------------------------------------------------------------------
+    template <bool RICH, bool RTL, bool RPSI, int BLOCK>
+    static int launch_fused(trm_ctx* c, double dt, int finalize) {
+        auto v = make_view<NF>(c, c->state);
+        auto p = make_dev_params<NF>(c->params);
+        size_t lds = RICH ? (size_t)2 * c->Nz * BLOCK * sizeof(NF) : 0;
+        auto kern = k_step_fused<NF, RICH, RTL, RPSI, BLOCK>;
+        if (lds > 160 * 1024) return fail(c, TRM_EUNSUPPORTED, "fused step: column tile exceeds 160 KiB of LDS");
+        if (lds > 48 * 1024)
+            TRM_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((unsigned)((c->Nh + BLOCK - 1) / BLOCK));
+        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, c->stream, v, p, (NF)dt, finalize, c->opt_write_kf);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    template <bool RICH, bool RTL, bool RPSI> static int fused_block(trm_ctx* c, double dt, int finalize) {
+        switch (c->opt_block) {
+            case 128: return launch_fused<RICH, RTL, RPSI, 128>(c, dt, finalize);
+            case 256: return launch_fused<RICH, RTL, RPSI, 256>(c, dt, finalize);
+            default: return launch_fused<RICH, RTL, RPSI, 64>(c, dt, finalize);
+        }
+    }
+    static int fused_step(trm_ctx* c, double dt, int finalize) {
+        // read the stored closure fields unless they are known to equal closure(U, sat) bit for bit
+        bool rtl = !c->tl_consistent || c->opt_read_closure == 1;
+        bool rpsi = !c->psi_consistent || c->opt_read_closure >= 1;
+        if (richards(c)) {
+            if (rtl && rpsi) return fused_block<true, true, true>(c, dt, finalize);
+            if (rtl) return fused_block<true, true, false>(c, dt, finalize);
+            if (rpsi) return fused_block<true, false, true>(c, dt, finalize);
+            return fused_block<true, false, false>(c, dt, finalize);
+        }
+        if (rtl) return fused_block<false, true, false>(c, dt, finalize);
+        return fused_block<false, false, false>(c, dt, finalize);
+    }
+    static int unfused_step(trm_ctx* c, double dt, int finalize) {
+        int rc = update_state(c, c->state, true);
+        if (!rc) rc = explicit_step(c, c->state, dt);
+        if (!rc) rc = closure(c, c->state);
+        if (!rc && finalize) rc = compute_auxiliary(c, c->state);
+        return rc;
+    }
+    static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
+        for (int n = 0; n < nsteps; ++n) {
+            int fin = (finalize && n == nsteps - 1) ? 1 : 0;
+            int rc = (c->opt_kernel == TRM_KERNEL_FUSED) ? fused_step(c, dt, fin) : unfused_step(c, dt, fin);
+            if (rc) return rc;
+            c->tl_consistent = true;
+            c->psi_consistent = richards(c);
+            c->time += dt;
+            c->iteration += 1;
+        }
+        return TRM_OK;
+    }
+
+    // ---- Heun (heun.jl:37-71), reference-order kernels on a second copy of the state -----------------
+    static int copy_state_to_stage(trm_ctx* c) {
+        for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
+            size_t bytes = (size_t)field_rows(c, f) * c->pitch * sizeof(NF);
+            TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], bytes, hipMemcpyDeviceToDevice, c->stream));
+        }
+        return TRM_OK;
+    }
+    static int average(trm_ctx* c, int field) {
+        long n = field_rows(c, field) * c->pitch;
+        hipLaunchKernelGGL(k_average<NF>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
+                           (NF*)c->state.f[field], (const NF*)c->stage.f[field], n);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int heun_step(trm_ctx* c, double dt, int finalize) {
+        int rc = update_state(c, c->state, true);
+        if (!rc) rc = copy_state_to_stage(c);
+        if (!rc) rc = explicit_step(c, c->stage, dt);
+        if (!rc) rc = closure(c, c->stage);
+        if (!rc) rc = update_state(c, c->stage, true);
+        if (!rc) rc = average(c, TRM_FIELD_TEND_INTERNAL_ENERGY);
+        if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SATURATION_WATER_ICE);
+        if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SURFACE_EXCESS_WATER);
+        if (!rc) rc = explicit_step(c, c->state, dt);
+        if (!rc) rc = closure(c, c->state);
+        if (!rc && finalize) rc = compute_auxiliary(c, c->state);
+        return rc;
+    }
+};
+
+#define DISPATCH(c, expr) ((c)->precision == TRM_F64 ? Ops<double>::expr : Ops<float>::expr)
+
+int finish(trm_ctx* c, int rc) {
+    if (rc) return rc;
+    if (!c->opt_async) TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+
+int alloc_fields(trm_ctx* c, FieldSet& s) {
+    for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
+        size_t bytes = (size_t)field_rows(c, f) * c->pitch * c->esize;
+        TRM_HIP(c, hipMalloc(&s.f[f], bytes));
+        TRM_HIP(c, hipMemset(s.f[f], 0, bytes));
+    }
+    return TRM_OK;
+}
+
+template <class NF> int upload_grid(trm_ctx* c, const double* thickness) {
+    HostGrid<NF> g;
+    g.build(c->Nz, thickness);
+    auto up = [&](void** d, const std::vector<NF>& h) -> int {
+        TRM_HIP(c, hipMalloc(d, h.size() * sizeof(NF)));
+        TRM_HIP(c, hipMemcpy(*d, h.data(), h.size() * sizeof(NF), hipMemcpyHostToDevice));
+        return TRM_OK;
+    };
+    int rc;
+    if ((rc = up(&c->d_zC, g.zC))) return rc;
+    if ((rc = up(&c->d_zF, g.zF))) return rc;
+    if ((rc = up(&c->d_dzc, g.dzc))) return rc;
+    if ((rc = up(&c->d_rdzc, g.rdzc))) return rc;
+    if ((rc = up(&c->d_rdzf, g.rdzf))) return rc;
+    c->h_zF.assign(g.zF.begin(), g.zF.end());
+    c->h_zC.assign(g.zC.begin(), g.zC.end());
+    c->h_dzc.assign(g.dzc.begin(), g.dzc.end());
+    c->h_dzf.assign(g.dzf.begin(), g.dzf.end());
+    c->dzf_bot = g.dzf_bot;
+    c->dzf_top = g.dzf_top;
+    c->z_ref = g.zF[c->Nz];
+    return TRM_OK;
+}
+
+template <class NF> int fill_row(trm_ctx* c, int field, double value) {
+    std::vector<NF> h((size_t)c->pitch, (NF)value);
+    TRM_HIP(c, hipMemcpy(c->state.f[field], h.data(), h.size() * sizeof(NF), hipMemcpyHostToDevice));
+    return TRM_OK;
+}
+
+// ---- reductions ------------------------------------------------------------------------------------
+template <class NF, int OP> __global__ void k_reduce_rows(const NF* f, long Nh, long pitch, const NF* weight, double* partial) {
+    // grid = (nblocks, rows); each block folds a strided slice of one row in double
+    const int row = blockIdx.y;
+    double acc = (OP == TRM_REDUCE_MIN) ? HUGE_VAL : (OP == TRM_REDUCE_MAX ? -HUGE_VAL : 0.0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < Nh; i += (long)gridDim.x * blockDim.x) {
+        double x = (double)f[(long)row * pitch + i];
+        if (OP == TRM_REDUCE_SUM) acc += x;
+        else if (OP == TRM_REDUCE_VOLUME_INTEGRAL_Z) acc += x * (double)weight[row];
+        else if (OP == TRM_REDUCE_MIN) acc = fmin(acc, x);
+        else if (OP == TRM_REDUCE_MAX) acc = fmax(acc, x);
+        else acc += (x != x) ? 1.0 : 0.0;
+    }
+    __shared__ double sm[4];
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_down(acc, off, 64);
+        if (OP == TRM_REDUCE_MIN) acc = fmin(acc, o);
+        else if (OP == TRM_REDUCE_MAX) acc = fmax(acc, o);
+        else acc += o;
+    }
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = sm[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+            if (OP == TRM_REDUCE_MIN) r = fmin(r, sm[w]);
+            else if (OP == TRM_REDUCE_MAX) r = fmax(r, sm[w]);
+            else r += sm[w];
+        }
+        partial[(long)row * gridDim.x + blockIdx.x] = r;
+    }
+}
+
+template <class NF> int reduce_impl(trm_ctx* c, int field, int op, double* out) {
+    const long rows = field_rows(c, field);
+    const int nblocks = (int)std::min<long>(256, (c->Nh + 255) / 256);
+    size_t need = (size_t)rows * nblocks;
+    if (need > c->reduce_cap) {
+        if (c->d_reduce) TRM_HIP(c, hipFree(c->d_reduce));
+        TRM_HIP(c, hipMalloc((void**)&c->d_reduce, need * sizeof(double)));
+        c->reduce_cap = need;
+    }
+    const NF* f = (const NF*)c->state.f[field];
+    const NF* w = (const NF*)c->d_dzc;
+    dim3 grid(nblocks, (unsigned)rows);
+    switch (op) {
+        case TRM_REDUCE_SUM: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_SUM>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
+        case TRM_REDUCE_MIN: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_MIN>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
+        case TRM_REDUCE_MAX: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_MAX>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
+        case TRM_REDUCE_HASNAN: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_HASNAN>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
+        case TRM_REDUCE_VOLUME_INTEGRAL_Z:
+            if (rows != c->Nz) return fail(c, TRM_EINVAL, "VOLUME_INTEGRAL_Z needs a cell-centred 3-D field");
+            hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_VOLUME_INTEGRAL_Z>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce);
+            break;
+        default: return fail(c, TRM_EINVAL, "unknown reduction op");
+    }
+    TRM_HIP(c, hipGetLastError());
+    std::vector<double> part(need);
+    TRM_HIP(c, hipMemcpyAsync(part.data(), c->d_reduce, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    // fixed-order fold of the block partials: deterministic for a given shard size
+    double total = 0.0;
+    for (long r = 0; r < rows; ++r) {
+        double acc = (op == TRM_REDUCE_MIN) ? HUGE_VAL : (op == TRM_REDUCE_MAX ? -HUGE_VAL : 0.0);
+        for (int b = 0; b < nblocks; ++b) {
+            double x = part[(size_t)r * nblocks + b];
+            if (op == TRM_REDUCE_MIN) acc = std::fmin(acc, x);
+            else if (op == TRM_REDUCE_MAX) acc = std::fmax(acc, x);
+            else acc += x;
+        }
+        if (op == TRM_REDUCE_VOLUME_INTEGRAL_Z) total += acc;
+        else if (op == TRM_REDUCE_HASNAN) out[r] = acc > 0.0 ? 1.0 : 0.0;
+        else out[r] = acc;
+    }
+    if (op == TRM_REDUCE_VOLUME_INTEGRAL_Z) out[0] = total;
+    return TRM_OK;
+}
+
+void mark_dirty(trm_ctx* c, int field) {
+    switch (field) {
+        case TRM_FIELD_INTERNAL_ENERGY:
+        case TRM_FIELD_TEMPERATURE:
+        case TRM_FIELD_LIQUID_WATER_FRACTION: c->tl_consistent = false; break;
+        case TRM_FIELD_SATURATION_WATER_ICE: c->tl_consistent = false; c->psi_consistent = false; break;
+        case TRM_FIELD_PRESSURE_HEAD:
+        case TRM_FIELD_WATER_TABLE: c->psi_consistent = false; break;
+        default: break;
+    }
+}
+
+}  // namespace
+
+// ======================================================================================================
+// C ABI
+// ======================================================================================================
+extern "C" {
+
+int trm_abi_version(void) { return TRM_ABI_VERSION; }
+
+int trm_default_params(trm_params* p) {
+    if (!p) return TRM_EINVAL;
+    std::memset(p, 0, sizeof(*p));
+    p->rho_w = 1000.0; p->rho_i = 916.2; p->rho_a = 1.293; p->c_a = 1005.7; p->Lsl = 3.34e5; p->Llg = 2.257e6;
+    p->Lsg = 2.834e6; p->g = 9.80665; p->Tref = 273.15; p->sigma = 5.6704e-8; p->kappa_vk = 0.4; p->eps_mw = 0.622;
+    p->R_a = 287.058;
+    p->k_water = 0.57; p->k_ice = 2.2; p->k_air = 0.025; p->k_mineral = 3.8; p->k_organic = 0.25;
+    p->c_water = 4.2e6; p->c_ice = 1.9e6; p->c_air = 0.00125e6; p->c_mineral = 2.0e6; p->c_organic = 2.5e6;
+    p->por_mineral = 0.49; p->por_organic = 0.9; p->rho_soc = 0.0; p->rho_org = 1300.0;
+    p->K_sat = 1.0e-5; p->theta_res = 0.0; p->bc_psi_s = 0.01; p->bc_lambda = 0.2; p->vg_alpha = 1.0; p->vg_n = 2.0;
+    p->impedance = 7.0; p->vwc_forcing = 0.0;
+    p->albedo = 0.3; p->emissivity = 0.97; p->kappa_s = 2.0; p->C_h = 1.2e-3; p->min_windspeed = 0.01; p->tau_r = 3600.0;
+    p->beta_evap = 1.0;
+    p->flow = TRM_FLOW_NOFLOW; p->swrc = TRM_SWRC_BROOKS_COREY; p->unsat_k = TRM_UNSATK_LINEAR; p->seb = 0;
+    p->halo_policy = TRM_HALO_REFERENCE_ZERO;
+    return TRM_OK;
+}
+
+const char* trm_last_error(const trm_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
+    if (!g || !p || !out) return fail(nullptr, TRM_EINVAL, "trm_create: null argument");
+    if (g->precision != TRM_F64 && g->precision != TRM_F32) return fail(nullptr, TRM_EINVAL, "trm_create: precision");
+    if (g->num_layers < 2) return fail(nullptr, TRM_EINVAL, "trm_create: num_layers must be >= 2");
+    if (g->num_columns < 1 || !g->thickness) return fail(nullptr, TRM_EINVAL, "trm_create: num_columns / thickness");
+    for (int k = 0; k < g->num_layers; ++k)
+        if (!(g->thickness[k] > 0)) return fail(nullptr, TRM_EINVAL, "trm_create: layer thickness must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, TRM_EHIP, "trm_create: no HIP device available (this library has no CPU fallback)");
+    if (g->device < 0 || g->device >= ndev) return fail(nullptr, TRM_EINVAL, "trm_create: device ordinal out of range");
+    trm_ctx* c = new trm_ctx();
+    c->precision = g->precision;
+    c->esize = g->precision == TRM_F64 ? 8 : 4;
+    c->Nh = (long)g->num_columns;
+    c->pitch = ((c->Nh + 63) / 64) * 64;
+    c->Nz = g->num_layers;
+    c->device = g->device;
+    c->params = *p;
+    c->Az = g->dx > 0 ? g->dx : 1.0 / (double)c->Nh;
+    if (c->precision == TRM_F32) c->Az = (double)(float)c->Az;
+    auto bail = [&](int rc) {
+        g_create_error = c->err;
+        trm_destroy(c);
+        return rc;
+    };
+    int rc = TRM_OK;
+    auto hip = [&](hipError_t e, const char* what) {
+        if (e != hipSuccess && rc == TRM_OK) { c->err = std::string(what) + ": " + hipGetErrorString(e); rc = TRM_EHIP; }
+    };
+    hip(hipSetDevice(c->device), "hipSetDevice");
+    hip(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+    c->stream = c->own_stream;
+    hip(hipEventCreate(&c->ev0), "hipEventCreate");
+    hip(hipEventCreate(&c->ev1), "hipEventCreate");
+    hip(hipMalloc((void**)&c->d_status, sizeof(uint32_t)), "hipMalloc(status)");
+    if (rc) return bail(rc);
+    hip(hipMemset(c->d_status, 0, sizeof(uint32_t)), "hipMemset(status)");
+    if ((rc = alloc_fields(c, c->state))) return bail(rc);
+    rc = c->precision == TRM_F64 ? upload_grid<double>(c, g->thickness) : upload_grid<float>(c, g->thickness);
+    if (rc) return bail(rc);
+    // input defaults (prescribed_atmosphere.jl:90-92,148,221-223)
+    const struct { int f; double v; } defaults[] = {
+        {TRM_FIELD_AIR_TEMPERATURE, 10.0}, {TRM_FIELD_AIR_PRESSURE, 101325.0}, {TRM_FIELD_WINDSPEED, 0.1},
+        {TRM_FIELD_SPECIFIC_HUMIDITY, 1.0e-3}, {TRM_FIELD_RAINFALL, 0.0}, {TRM_FIELD_SURFACE_SHORTWAVE_DOWN, 300.0},
+        {TRM_FIELD_SURFACE_LONGWAVE_DOWN, 50.0}};
+    for (auto& d : defaults) {
+        rc = c->precision == TRM_F64 ? fill_row<double>(c, d.f, d.v) : fill_row<float>(c, d.f, d.v);
+        if (rc) return bail(rc);
+    }
+    *out = c;
+    return TRM_OK;
+}
+
+int trm_destroy(trm_ctx* c) {
+    if (!c) return TRM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
+        if (c->state.f[f]) (void)hipFree(c->state.f[f]);
+        if (c->stage.f[f]) (void)hipFree(c->stage.f[f]);
+    }
+    for (int a = 0; a < TRM_BCV_COUNT; ++a)
+        for (int b = 0; b < 2; ++b)
+            if (c->bc_value[a][b]) (void)hipFree(c->bc_value[a][b]);
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, (void*)c->d_status, (void*)c->d_reduce})
+        if (q) (void)hipFree(q);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return TRM_OK;
+}
+
+int trm_field_rows(const trm_ctx* c, int field, int64_t* rows) {
+    if (!c || !rows || !valid_field(field)) return TRM_EINVAL;
+    *rows = field_rows(c, field);
+    return TRM_OK;
+}
+
+int trm_get_grid(const trm_ctx* c, double* z_faces, double* z_centers, double* dz_center, double* dz_face) {
+    if (!c) return TRM_EINVAL;
+    if (z_faces) std::memcpy(z_faces, c->h_zF.data(), sizeof(double) * (c->Nz + 1));
+    if (z_centers) std::memcpy(z_centers, c->h_zC.data(), sizeof(double) * c->Nz);
+    if (dz_center) std::memcpy(dz_center, c->h_dzc.data(), sizeof(double) * c->Nz);
+    if (dz_face) std::memcpy(dz_face, c->h_dzf.data(), sizeof(double) * (c->Nz + 1));
+    return TRM_OK;
+}
+
+int trm_upload(trm_ctx* c, int field, const void* host) {
+    if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_upload: bad argument");
+    TRM_HIP(c, hipSetDevice(c->device));
+    long rows = field_rows(c, field);
+    TRM_HIP(c, hipMemcpy2DAsync(c->state.f[field], c->pitch * c->esize, host, c->Nh * c->esize, c->Nh * c->esize, rows,
+                                hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    mark_dirty(c, field);
+    return TRM_OK;
+}
+
+int trm_download(trm_ctx* c, int field, void* host) {
+    if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_download: bad argument");
+    TRM_HIP(c, hipSetDevice(c->device));
+    long rows = field_rows(c, field);
+    TRM_HIP(c, hipMemcpy2DAsync(host, c->Nh * c->esize, c->state.f[field], c->pitch * c->esize, c->Nh * c->esize, rows,
+                                hipMemcpyDeviceToHost, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+
+int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems) {
+    if (!c || !dev || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_field_device_ptr: bad argument");
+    *dev = c->state.f[field];
+    if (pitch_elems) *pitch_elems = c->pitch;
+    return TRM_OK;
+}
+
+int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, double scalar) {
+    if (!c || var < 0 || var >= TRM_BCV_COUNT || (side != TRM_TOP && side != TRM_BOTTOM) || kind < 0 || kind > TRM_BC_GRADIENT)
+        return fail(c, TRM_EINVAL, "trm_set_bc: bad argument");
+    TRM_HIP(c, hipSetDevice(c->device));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    c->bc_kind[var][side] = kind;
+    if (kind == TRM_BC_NOFLUX) return TRM_OK;
+    size_t bytes = (size_t)c->pitch * c->esize;
+    if (!c->bc_value[var][side]) TRM_HIP(c, hipMalloc(&c->bc_value[var][side], bytes));
+    std::vector<unsigned char> h(bytes, 0);
+    if (values) {
+        std::memcpy(h.data(), values, (size_t)c->Nh * c->esize);
+    } else if (c->precision == TRM_F64) {
+        double* d = (double*)h.data();
+        for (long i = 0; i < c->Nh; ++i) d[i] = scalar;
+    } else {
+        float* d = (float*)h.data();
+        for (long i = 0; i < c->Nh; ++i) d[i] = (float)scalar;
+    }
+    TRM_HIP(c, hipMemcpy(c->bc_value[var][side], h.data(), bytes, hipMemcpyHostToDevice));
+    return TRM_OK;
+}
+
+int trm_set_forcing(trm_ctx* c, int input_field, const void* per_column) {
+    if (!c || input_field < TRM_FIELD_AIR_TEMPERATURE || input_field > TRM_FIELD_SURFACE_LONGWAVE_DOWN)
+        return fail(c, TRM_EINVAL, "trm_set_forcing: not an input field");
+    return trm_upload(c, input_field, per_column);
+}
+
+#define TRM_ENTER(c)                                         \
+    if (!(c)) return TRM_EINVAL;                             \
+    TRM_HIP(c, hipSetDevice((c)->device));
+
+int trm_initialize(trm_ctx* c) {
+    TRM_ENTER(c);
+    int rc = DISPATCH(c, initialize(c));
+    c->tl_consistent = false;
+    c->psi_consistent = c->params.flow == TRM_FLOW_RICHARDS;
+    return finish(c, rc);
+}
+int trm_update_state(trm_ctx* c, int compute_tendencies) {
+    TRM_ENTER(c);
+    return finish(c, DISPATCH(c, update_state(c, c->state, compute_tendencies != 0)));
+}
+int trm_compute_auxiliary(trm_ctx* c) {
+    TRM_ENTER(c);
+    return finish(c, DISPATCH(c, compute_auxiliary(c, c->state)));
+}
+int trm_compute_tendencies(trm_ctx* c) {
+    TRM_ENTER(c);
+    return finish(c, DISPATCH(c, compute_tendencies(c, c->state)));
+}
+int trm_reset_tendencies(trm_ctx* c) {
+    TRM_ENTER(c);
+    return finish(c, DISPATCH(c, reset_tendencies(c, c->state)));
+}
+int trm_explicit_step(trm_ctx* c, double dt) {
+    TRM_ENTER(c);
+    int rc = DISPATCH(c, explicit_step(c, c->state, dt));
+    c->tl_consistent = false;
+    c->psi_consistent = false;
+    return finish(c, rc);
+}
+int trm_closure(trm_ctx* c) {
+    TRM_ENTER(c);
+    int rc = DISPATCH(c, closure(c, c->state));
+    c->tl_consistent = true;
+    c->psi_consistent = c->params.flow == TRM_FLOW_RICHARDS;
+    return finish(c, rc);
+}
+int trm_invclosure(trm_ctx* c) {
+    TRM_ENTER(c);
+    int rc = DISPATCH(c, invclosure(c, c->state));
+    c->tl_consistent = false;
+    c->psi_consistent = false;
+    return finish(c, rc);
+}
+
+int trm_step(trm_ctx* c, double dt, int nsteps, int finalize) {
+    TRM_ENTER(c);
+    if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step: nsteps < 0");
+    return finish(c, DISPATCH(c, step(c, dt, nsteps, finalize)));
+}
+
+int trm_step_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
+    TRM_ENTER(c);
+    if (nsteps < 0 || !ms) return fail(c, TRM_EINVAL, "trm_step_timed: bad argument");
+    TRM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    int rc = DISPATCH(c, step(c, dt, nsteps, finalize));
+    if (rc) return rc;
+    TRM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    TRM_HIP(c, hipEventSynchronize(c->ev1));
+    TRM_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return TRM_OK;
+}
+
+int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
+    TRM_ENTER(c);
+    if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step_heun: nsteps < 0");
+    if (!c->has_stage) {
+        int rc = alloc_fields(c, c->stage);
+        if (rc) return rc;
+        c->has_stage = true;
+    }
+    for (int n = 0; n < nsteps; ++n) {
+        int fin = (finalize && n == nsteps - 1) ? 1 : 0;
+        int rc = DISPATCH(c, heun_step(c, dt, fin));
+        if (rc) return rc;
+        c->tl_consistent = true;
+        c->psi_consistent = c->params.flow == TRM_FLOW_RICHARDS;
+        c->time += dt;
+        c->iteration += 1;
+    }
+    return finish(c, TRM_OK);
+}
+
+int trm_clock(const trm_ctx* c, double* time, int64_t* iteration) {
+    if (!c) return TRM_EINVAL;
+    if (time) *time = c->time;
+    if (iteration) *iteration = c->iteration;
+    return TRM_OK;
+}
+int trm_set_clock(trm_ctx* c, double time, int64_t iteration) {
+    if (!c) return TRM_EINVAL;
+    c->time = time;
+    c->iteration = iteration;
+    return TRM_OK;
+}
+
+int trm_reduce(trm_ctx* c, int field, int op, double* out) {
+    TRM_ENTER(c);
+    if (!out || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_reduce: bad argument");
+    return c->precision == TRM_F64 ? reduce_impl<double>(c, field, op, out) : reduce_impl<float>(c, field, op, out);
+}
+
+int trm_status(trm_ctx* c, uint32_t* flags) {
+    TRM_ENTER(c);
+    if (!flags) return TRM_EINVAL;
+    TRM_HIP(c, hipMemcpyAsync(flags, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+
+int trm_set_option(trm_ctx* c, int option, int value) {
+    if (!c) return TRM_EINVAL;
+    switch (option) {
+        case TRM_OPT_ASYNC: c->opt_async = value != 0; return TRM_OK;
+        case TRM_OPT_STEP_KERNEL:
+            if (value != TRM_KERNEL_FUSED && value != TRM_KERNEL_UNFUSED) break;
+            c->opt_kernel = value;
+            return TRM_OK;
+        case TRM_OPT_READ_CLOSURE:
+            if (value < 0 || value > 2) break;
+            c->opt_read_closure = value;
+            return TRM_OK;
+        case TRM_OPT_WRITE_KF_EVERY_STEP: c->opt_write_kf = value != 0; return TRM_OK;
+        case TRM_OPT_BLOCK_COLUMNS:
+            if (value != 64 && value != 128 && value != 256) break;
+            c->opt_block = value;
+            return TRM_OK;
+        default: break;
+    }
+    return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
+}
+int trm_get_option(const trm_ctx* c, int option, int* value) {
+    if (!c || !value) return TRM_EINVAL;
+    switch (option) {
+        case TRM_OPT_ASYNC: *value = c->opt_async; return TRM_OK;
+        case TRM_OPT_STEP_KERNEL: *value = c->opt_kernel; return TRM_OK;
+        case TRM_OPT_READ_CLOSURE: *value = c->opt_read_closure; return TRM_OK;
+        case TRM_OPT_WRITE_KF_EVERY_STEP: *value = c->opt_write_kf; return TRM_OK;
+        case TRM_OPT_BLOCK_COLUMNS: *value = c->opt_block; return TRM_OK;
+        default: return TRM_EINVAL;
+    }
+}
+
+int trm_set_stream(trm_ctx* c, void* hip_stream) {
+    TRM_ENTER(c);
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return TRM_OK;
+}
+int trm_synchronize(trm_ctx* c) {
+    TRM_ENTER(c);
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+
+}  // extern "C"

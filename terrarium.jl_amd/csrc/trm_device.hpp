@@ -1,0 +1,348 @@
+// trm_device.hpp -- device-side scalar arithmetic of the SoilModel step path.
+//
+// Every function names the reference lines whose arithmetic (operation order
+// included) it carries.  The library is compiled with -ffp-contract=off: Julia
+// never fuses a*b+c on its own, and fma is used only where Julia Base does
+// (the compensated integer power).  Templated on the number format NF.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TRM_DEV __device__ __forceinline__
+#define TRM_HD __host__ __device__ __forceinline__
+
+namespace trm {
+
+// ---------------------------------------------------------------------------
+// Julia Base float semantics the reference relies on
+// ---------------------------------------------------------------------------
+template <class NF> TRM_HD bool is_nan(NF x) { return x != x; }
+template <class NF> TRM_HD bool sign_bit(NF x) { return __builtin_signbit(x); }
+TRM_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+TRM_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+TRM_HD double copysign_(double a, double b) { return __builtin_copysign(a, b); }
+TRM_HD float copysign_(float a, float b) { return __builtin_copysignf(a, b); }
+TRM_HD bool is_finite(double x) { return __builtin_isfinite(x); }
+TRM_HD bool is_finite(float x) { return __builtin_isfinite(x); }
+
+// Base.min / Base.max(x::Float, y::Float): NaN-propagating, signed-zero aware.
+template <class NF> TRM_HD NF jl_min(NF x, NF y) {
+    NF d = x - y;
+    NF a = sign_bit(d) ? x : y;
+    return (is_nan(x) || is_nan(y)) ? d : a;
+}
+template <class NF> TRM_HD NF jl_max(NF x, NF y) {
+    NF d = x - y;
+    NF a = sign_bit(d) ? y : x;
+    return (is_nan(x) || is_nan(y)) ? d : a;
+}
+// Bool * Float: `false` is a strong zero carrying the sign of x.
+template <class NF> TRM_HD NF boolmul(bool b, NF x) { return b ? x : copysign_(NF(0), x); }
+
+template <class NF> struct Limits;
+template <> struct Limits<double> {
+    static TRM_HD double eps() { return 2.220446049250313e-16; }
+    static TRM_HD double inf() { return __builtin_huge_val(); }
+};
+template <> struct Limits<float> {
+    static TRM_HD float eps() { return 1.1920929e-07f; }
+    static TRM_HD float inf() { return __builtin_huge_valf(); }
+};
+
+// src/utils/utils.jl:25
+template <class NF> TRM_HD NF safediv(NF x, NF y) { return (y == NF(0)) ? Limits<NF>::inf() : x / (y + Limits<NF>::eps()); }
+
+// Base.Math.pow_body(x, n::Integer): compensated power by squaring.
+template <class NF> TRM_HD NF pow_int(NF x, int n) {
+    if (n == 0) return NF(1);
+    NF y = NF(1), xnlo = NF(0), ynlo = NF(0);
+    if (n == 3) return x * x * x;
+    if (n < 0) {
+        NF rx = NF(1) / x;
+        if (n == -2) return rx * rx;
+        if (is_finite(x)) xnlo = -fma_(x, rx, NF(-1)) * rx;
+        x = rx;
+        n = -n;
+    }
+    while (n > 1) {
+        if (n & 1) {
+            NF err = fma_(y, xnlo, x * ynlo);
+            NF hi = x * y;
+            NF lo = fma_(x, y, -hi);
+            y = hi;
+            ynlo = lo + err;
+        }
+        NF err = x * NF(2) * xnlo;
+        NF hi = x * x;
+        NF lo = fma_(x, x, -hi);
+        x = hi;
+        xnlo = lo + err;
+        n >>= 1;
+    }
+    NF err = fma_(y, xnlo, x * ynlo);
+    return (is_finite(x) && is_finite(err)) ? fma_(x, y, err) : x * y;
+}
+
+// An exponent that is constant over the launch: Base.:^(x, y) takes the integer
+// path for integer-valued y (decided once on the host), the generic pow otherwise.
+template <class NF> struct PowSpec {
+    NF y;
+    int n;
+    int is_int;
+};
+template <class NF> inline PowSpec<NF> make_pow_spec(NF y) {
+    PowSpec<NF> s;
+    s.y = y;
+    s.n = 0;
+    s.is_int = 0;
+    double yd = (double)y;
+    if (yd > -4096.5 && yd < 24576.5) {
+        long long yi = (long long)yd;
+        if ((double)yi == yd && yi >= -4096 && yi <= 24576) {
+            s.is_int = 1;
+            s.n = (int)yi;
+        }
+    }
+    return s;
+}
+TRM_DEV double pow_generic(double x, double y) { return pow(x, y); }
+TRM_DEV float pow_generic(float x, float y) { return powf(x, y); }
+TRM_DEV double exp_(double x) { return exp(x); }
+TRM_DEV float exp_(float x) { return expf(x); }
+TRM_DEV double sqrt_(double x) { return sqrt(x); }
+TRM_DEV float sqrt_(float x) { return sqrtf(x); }
+TRM_DEV double fabs_(double x) { return fabs(x); }
+TRM_DEV float fabs_(float x) { return fabsf(x); }
+
+template <class NF> TRM_DEV NF jl_pow(NF x, const PowSpec<NF>& s) {
+    if (x == NF(1)) return NF(1);
+    if (s.is_int) return pow_int(x, s.n);
+    return pow_generic(x, s.y);
+}
+
+// ---------------------------------------------------------------------------
+// Device parameter block: trm_params converted to NF plus the sub-expressions
+// that are constant over the grid, evaluated ON THE HOST IN NF with the
+// reference's operation order (IEEE basic ops round identically everywhere).
+// ---------------------------------------------------------------------------
+template <class NF> struct DevParams {
+    // composition (homogeneous_strat.jl:34-61, soil_volume.jl:52-67,103-107)
+    NF org, por, solid_frac, frac_organic, frac_mineral;
+    // thermal (soil_thermal_properties.jl:90-107,119-123)
+    NF sk_water, sk_ice, sk_air;  // sqrt(k_i)
+    NF kterm_mineral, kterm_organic;  // sqrt(k_m)*mineral, sqrt(k_o)*organic
+    NF c_water, c_ice, c_air;
+    NF cterm_mineral, cterm_organic;  // c_m*mineral, c_o*organic
+    NF L;  // rho_w * Lsl (soil_energy_closures.jl:107)
+    // hydrology
+    NF K_sat, theta_res, bc_psi_s, vg_alpha, impedance, vwc_forcing;
+    NF neg_inv_alpha;  // -1/alpha
+    PowSpec<NF> bc_lambda, bc_neg_inv_lambda;       // lambda, -1/lambda
+    PowSpec<NF> vg_n, vg_neg_m, vg_neg_inv_m, vg_inv_n;  // n, -m, -1/m, 1/n
+    PowSpec<NF> vgk_e1, vgk_e2;                     // n/(n+1), (n-1)/n
+    // surface energy balance
+    NF albedo, emissivity, one_minus_emissivity, eps_sigma, kappa_s2, C_h, min_windspeed, tau_r, beta_evap;
+    NF Tref, eps_mw, one_minus_eps_mw, ca_rhoa, Llg_rhoa;
+    int flow, swrc, unsat_k, seb, halo_policy;
+};
+
+template <class NF> struct Frac { NF water, ice, air; };
+
+// volumetric_fractions (soil_volume.jl:52-67); the SoilVolume constructor's
+// @assert bounds (soil_volume.jl:26-28) become a status flag.
+template <class NF> TRM_DEV Frac<NF> fractions(const DevParams<NF>& p, NF sat, NF liq, uint32_t& viol) {
+    bool ok = (NF(0) <= sat && sat <= NF(1)) && (NF(0) <= liq && liq <= NF(1));
+    viol |= ok ? 0u : 2u;
+    Frac<NF> f;
+    NF wi = sat * p.por;
+    f.water = wi * liq;
+    f.ice = wi * (NF(1) - liq);
+    f.air = (NF(1) - sat) * p.por;
+    return f;
+}
+// InverseQuadratic bulk conductivity (soil_thermal_properties.jl:119-123): left fold over
+// (water, ice, air, mineral, organic) of sqrt(k_i)*theta_i, squared.
+template <class NF> TRM_DEV NF conductivity(const DevParams<NF>& p, const Frac<NF>& f) {
+    NF s = p.sk_water * f.water;
+    s = s + p.sk_ice * f.ice;
+    s = s + p.sk_air * f.air;
+    s = s + p.kterm_mineral;
+    s = s + p.kterm_organic;
+    return s * s;
+}
+// heat_capacity (soil_thermal_properties.jl:102-107)
+template <class NF> TRM_DEV NF heat_capacity(const DevParams<NF>& p, const Frac<NF>& f) {
+    NF s = p.c_water * f.water;
+    s = s + p.c_ice * f.ice;
+    s = s + p.c_air * f.air;
+    s = s + p.cterm_mineral;
+    s = s + p.cterm_organic;
+    return s;
+}
+// hydraulic_conductivity at a cell centre (soil_hydraulic_properties.jl:170-181, 203-221)
+template <class NF> TRM_DEV NF conductivity_hydraulic(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
+    if (p.unsat_k == 0) {
+        NF theta_sat = f.water + f.ice + f.air;
+        return p.K_sat * f.water / theta_sat;
+    }
+    // van Genuchten-Mualem with ice impedance.  The reference evaluates this in complex
+    // arithmetic so that illegal states (x outside [0,1]) give a finite magnitude; inside the
+    // legal range the complex evaluation IS the real one.  Outside it we return the magnitude
+    // of the principal-branch result, as the reference does.
+    NF x = f.water / p.por;
+    // I_ice = 10^(-Omega (1 - f)): Base.:^ takes the integer path when the exponent is integer-valued
+    NF y = -p.impedance * (NF(1) - liq);
+    NF yt = (NF)(int)y;
+    NF I_ice = (yt == y && y > NF(-4096) && y < NF(4096)) ? pow_int(NF(10), (int)y) : pow_generic(NF(10), y);
+    if (x >= NF(0) && x <= NF(1)) {
+        NF inner = NF(1) - jl_pow(x, p.vgk_e1);
+        NF t = NF(1) - jl_pow(inner, p.vgk_e2);
+        return fabs_(p.K_sat * I_ice * sqrt_(x) * (t * t));
+    }
+    double e1 = (double)p.vgk_e1.y, e2 = (double)p.vgk_e2.y;
+    double r = fabs((double)x), th = ((double)x < 0.0) ? 3.141592653589793 : 0.0;
+    double rp = pow(r, e1);
+    double ar = rp * cos(e1 * th), ai = rp * sin(e1 * th);
+    double ir = 1.0 - ar, ii = -ai;
+    double r2 = pow(sqrt(ir * ir + ii * ii), e2), th2 = atan2(ii, ir);
+    double br = r2 * cos(e2 * th2), bi = r2 * sin(e2 * th2);
+    double tr = 1.0 - br, ti = -bi;
+    double t2r = tr * tr - ti * ti, t2i = 2.0 * tr * ti;
+    double sr = sqrt(r) * cos(0.5 * th), si = sqrt(r) * sin(0.5 * th);
+    double kk = (double)(p.K_sat * I_ice);
+    double zr = kk * sr * t2r - kk * si * t2i, zi = kk * sr * t2i + kk * si * t2r;
+    return (NF)sqrt(zr * zr + zi * zi);
+}
+
+// Free-water energy closure (soil_energy_closures.jl:99-159): (U, sat) -> (liq, T)
+template <class NF> TRM_DEV void energy_closure(const DevParams<NF>& p, NF U, NF sat, NF& liq, NF& T, uint32_t& viol) {
+    NF Lth = p.L * sat * p.por;
+    liq = (U >= NF(0)) ? NF(1) : boolmul(U >= -Lth, NF(1) - safediv(U, -Lth));
+    NF C = heat_capacity(p, fractions(p, sat, liq, viol));
+    T = (U < -Lth) ? (U + Lth) / C : ((U >= NF(0)) ? U / C : NF(0));
+}
+// inverse (initialisation only, soil_energy_closures.jl:64-97): (T, sat) -> (liq, U)
+template <class NF> TRM_DEV void energy_invclosure(const DevParams<NF>& p, NF T, NF sat, NF& liq, NF& U, uint32_t& viol) {
+    liq = (T >= NF(0)) ? NF(1) : NF(0);
+    NF C = heat_capacity(p, fractions(p, sat, liq, viol));
+    U = T * C - p.L * sat * p.por * (NF(1) - liq);
+}
+
+// FreezeCurves.jl 0.9 SWRCs (restated)
+template <class NF> TRM_DEV NF swrc_psi(const DevParams<NF>& p, NF theta, NF theta_sat) {
+    if (p.swrc == 1) {  // VanGenuchten
+        if (theta < theta_sat) {
+            NF r = (theta - p.theta_res) / (theta_sat - p.theta_res);
+            return p.neg_inv_alpha * jl_pow(jl_pow(r, p.vg_neg_inv_m) - NF(1), p.vg_inv_n);
+        }
+        return NF(0);
+    }
+    if (theta < theta_sat) {  // BrooksCorey
+        NF r = (theta - p.theta_res) / (theta_sat - p.theta_res);
+        return -p.bc_psi_s * jl_pow(r, p.bc_neg_inv_lambda);
+    }
+    return -p.bc_psi_s;
+}
+template <class NF> TRM_DEV NF swrc_theta(const DevParams<NF>& p, NF psi, NF theta_sat) {
+    if (p.swrc == 1) {
+        if (psi <= NF(0))
+            return p.theta_res + (theta_sat - p.theta_res) * jl_pow(NF(1) + jl_pow(-p.vg_alpha * psi, p.vg_n), p.vg_neg_m);
+        return theta_sat;
+    }
+    if (psi < -p.bc_psi_s) return p.theta_res + (theta_sat - p.theta_res) * jl_pow(-p.bc_psi_s / psi, p.bc_lambda);
+    return theta_sat;
+}
+// saturation_to_pressure! (soil_hydraulic_closures.jl:102-129): psi = (psi_h + psi_m) + psi_z
+template <class NF> TRM_DEV NF pressure_head(const DevParams<NF>& p, NF sat, NF z, NF z_ref, NF z0) {
+    NF psim = swrc_psi(p, sat * p.por, p.por);
+    NF psiz = z - z_ref;
+    NF psih = jl_max(NF(0), z0 - z);
+    return psih + psim + psiz;
+}
+
+// ---- surface energy balance ---------------------------
+template <class NF> TRM_DEV NF saturation_vapor_pressure(NF T) {  // physics_utils.jl:54,67-73
+    if (T <= NF(0)) return NF(611.0) * exp_(NF(22.46) * T / (T + NF(272.62)));
+    return NF(611.0) * exp_(NF(17.62) * T / (T + NF(243.12)));
+}
+template <class NF> TRM_DEV NF humidity_vpd(const DevParams<NF>& p, NF pres, NF q_air, NF Ts) {
+    // physical_constants.jl:83-97 compute_vpd; physics_utils.jl:38
+    NF e_sat = saturation_vapor_pressure(Ts);
+    NF e_air = q_air * pres / (p.eps_mw + p.one_minus_eps_mw * q_air);
+    NF vpd = jl_max(e_sat - e_air, NF(0.1));
+    return p.eps_mw * vpd / pres;
+}
+template <class NF> TRM_DEV NF aerodynamic_resistance(const DevParams<NF>& p, NF windspeed) {
+    // prescribed_atmosphere.jl:110-116,137
+    NF V = jl_max(windspeed, p.min_windspeed);
+    NF Va = jl_max(V, NF(1.0e-6));
+    return NF(1) / (p.C_h * Va);
+}
+
+template <class NF> struct SebIn { NF Tair, pres, wind, qair, rain, swd, lwd; };
+template <class NF> struct SebOut { NF Ts, ghf, swu, lwu, rnet, Hs, Hl, evap, infil, runoff; };
+
+template <class NF> TRM_DEV void seb_fluxes(const DevParams<NF>& p, const SebIn<NF>& in, NF ra, SebOut<NF>& o) {
+    // surface_energy_balance.jl:119-144 with the ET-coupled latent heat flux (turbulent_fluxes.jl:130-143)
+    o.swu = p.albedo * in.swd;
+    NF Tk = o.Ts + p.Tref;
+    o.lwu = p.eps_sigma * pow_int(Tk, 4) + p.one_minus_emissivity * in.lwd;
+    o.rnet = o.swu - in.swd + o.lwu - in.lwd;
+    NF Q_T = (o.Ts - in.Tair) / ra;
+    o.Hs = p.ca_rhoa * Q_T;
+    o.Hl = p.Llg_rhoa * o.evap;
+    o.ghf = o.rnet - o.Hs - o.Hl;
+}
+// compute_auxiliary! of the surface processes for one column (land_model.jl:79-88):
+// bare-ground evaporation, direct runoff / infiltration, then the fused SEB kernel twice.
+template <class NF>
+TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF Ts_in, NF T_ground, NF sat_top,
+                               NF Kf_top, NF S, bool richards, NF dz_top, SebOut<NF>& o) {
+    o.Ts = Ts_in;
+    NF ra = aerodynamic_resistance(p, in.wind);
+    // bare_ground_evaporation.jl:49-62
+    o.evap = p.beta_evap * humidity_vpd(p, in.pres, in.qair, o.Ts) / ra;
+    // direct_surface_runoff.jl:87-117
+    NF excess = richards ? S : NF(0);
+    bool unsat = sat_top < NF(1);
+    NF drainage;
+    if (excess > NF(0)) {
+        drainage = jl_max(excess, NF(0)) / p.tau_r;
+        o.infil = boolmul(unsat, jl_min(drainage, Kf_top));
+    } else {
+        drainage = NF(0);
+        o.infil = boolmul(unsat, jl_min(in.rain, Kf_top));
+    }
+    o.runoff = in.rain + drainage - o.infil;
+    // surface_energy_balance.jl:95-110, executed twice (land_model.jl:85-86)
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        seb_fluxes(p, in, ra, o);
+        o.Ts = T_ground - o.ghf * dz_top / p.kappa_s2;  // skin_temperature.jl:62-68
+        seb_fluxes(p, in, ra, o);
+    }
+}
+
+// ---- z halos (Oceananigans fill_halo_regions!) ----------
+struct BcSet {
+    int kind[5][2];          // [bc_var][side]
+    const void* value[5][2]; // per-column arrays (NF), may be null for NOFLUX
+};
+// halo value above the top cell / below the bottom cell of a centre field
+template <class NF> TRM_DEV NF halo_top(int kind, const NF* val, long i, NF c_edge, NF dzf_top) {
+    if (kind == 1) {  // Value: linear extrapolation through the boundary value
+        NF grad = (val[i] - c_edge) / (dzf_top / NF(2));
+        return c_edge + grad * dzf_top;
+    }
+    if (kind == 3) return c_edge + val[i] * dzf_top;  // Gradient
+    return c_edge;                                     // Flux / NoFlux / default
+}
+template <class NF> TRM_DEV NF halo_bottom(int kind, const NF* val, long i, NF c_edge, NF dzf_bot) {
+    if (kind == 1) {
+        NF grad = (c_edge - val[i]) / (dzf_bot / NF(2));
+        return c_edge + grad * (-dzf_bot);
+    }
+    if (kind == 3) return c_edge + val[i] * (-dzf_bot);
+    return c_edge;
+}
+
+}  // namespace trm

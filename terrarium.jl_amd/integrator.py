@@ -1,0 +1,362 @@
+"""Time steppers and the model integrator -- host-side mirror of the reference's
+`src/timesteppers/` (ForwardEuler, Heun, ModelIntegrator, run!, timestep!) and of
+the state-variable interface, driving libterrarium_hip.so through its C ABI.
+
+What stays on the host (as in the reference, where the host issues launches):
+evaluation of time-dependent boundary-condition / forcing *functions* to
+per-column arrays once per step (the library then reads arrays), bookkeeping,
+and sharding.  All field arithmetic runs on the GPU.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional
+
+import numpy as np
+
+from . import _capi
+from . import models as M
+from .grids import ColumnGrid
+
+
+# ---- time steppers ------------------------------------------------------------
+@dataclass
+class ForwardEuler:
+    """src/timesteppers/forward_euler.jl:6-9"""
+    dt: float = 300.0
+
+
+@dataclass
+class Heun:
+    """src/timesteppers/heun.jl:8-14"""
+    dt: float = 300.0
+
+
+# ---- boundary-condition aliases (src/models/soil/soil_model_bcs.jl) -----------
+def _bc(var, side, kind, value):
+    return {(var, side): (kind, value)}
+
+
+def PrescribedSurfaceTemperature(name, value):
+    """ValueBoundaryCondition on top `temperature` (soil_model_bcs.jl:17)."""
+    return _bc("temperature", "top", "value", value)
+
+
+def PrescribedBottomTemperature(name, value):
+    return _bc("temperature", "bottom", "value", value)
+
+
+def GroundHeatFlux(value):
+    """FluxBoundaryCondition on top `internal_energy` (soil_model_bcs.jl:6)."""
+    return _bc("internal_energy", "top", "flux", value)
+
+
+def GeothermalHeatFlux(value):
+    return _bc("internal_energy", "bottom", "flux", value)
+
+
+def InfiltrationFlux(value):
+    """FluxBoundaryCondition on top `saturation_water_ice` (soil_model_bcs.jl:29); positive = upward."""
+    return _bc("saturation_water_ice", "top", "flux", value)
+
+
+def ImpermeableBoundary():
+    return _bc("saturation_water_ice", "bottom", "noflux", 0.0)
+
+
+def FreeDrainage():
+    """GradientBoundaryCondition(0) on bottom `pressure_head` (soil_model_bcs.jl:40)."""
+    return _bc("pressure_head", "bottom", "gradient", 0.0)
+
+
+def merge_boundary_conditions(*bcs):
+    """src/boundary_conditions.jl:19"""
+    out = {}
+    for b in bcs:
+        out.update(b or {})
+    return out
+
+
+# ---- device context -------------------------------------------------------------
+class DeviceState:
+    """Owns one `trm_ctx` (one device's shard of columns) and exposes the state
+    variables by the reference's names; reading an attribute downloads the field
+    as an array [rows][Nh] (row 0 = bottom layer) -- `Array(interior(field))`."""
+
+    def __init__(self, grid: ColumnGrid, params: "_capi.TrmParams"):
+        object.__setattr__(self, "_ctx", None)
+        self._lib = _capi.lib()
+        self.grid = grid
+        self.dtype = grid.dtype
+        self.params = params
+        th = np.ascontiguousarray(grid.thickness, dtype=np.float64)
+        g = _capi.TrmGrid(_capi.TRM_F64 if grid.dtype == np.float64 else _capi.TRM_F32, grid.Nz, grid.Nh,
+                          th.ctypes.data_as(C.POINTER(C.c_double)), float(grid.dx), int(grid.device), 0)
+        h = C.c_void_p()
+        rc = self._lib.trm_create(C.byref(g), C.byref(params), C.byref(h))
+        if rc != 0:
+            raise _capi.TerrariumHipError(f"trm_create failed (code {rc}): {self._lib.trm_last_error(None).decode()}")
+        self._ctx = h
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.trm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        _capi.check(self._ctx, rc, what)
+
+    # -- fields -----------------------------------------------------------------
+    def rows(self, name):
+        r = C.c_int64()
+        self._check(self._lib.trm_field_rows(self._ctx, _capi.FIELD[name], C.byref(r)), "trm_field_rows")
+        return int(r.value)
+
+    def get(self, name) -> np.ndarray:
+        if name == "ground_temperature":  # view of the top soil layer (soil_energy.jl:52-57)
+            return self.get("temperature")[-1]
+        if name == "rainfall_ground":  # alias of rainfall (canopy_interception.jl:11-15)
+            name = "rainfall"
+        rows = self.rows(name)
+        a = np.empty((rows, self.grid.Nh), dtype=self.dtype)
+        self._check(self._lib.trm_download(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_download")
+        return a[0] if rows == 1 else a
+
+    def set(self, name, value):
+        """set!(field, number | array | function(x, z))"""
+        rows = self.rows(name)
+        Nh = self.grid.Nh
+        if callable(value):
+            zc = self.z_centers() if rows == self.grid.Nz else self.z_faces()
+            x = np.arange(1, Nh + 1, dtype=np.float64)
+            value = np.array([[value(x[i], zc[k]) for i in range(Nh)] for k in range(rows)], dtype=np.float64) \
+                if rows > 1 else np.array([value(x[i]) for i in range(Nh)], dtype=np.float64)
+        a = np.empty((rows, Nh), dtype=self.dtype)
+        v = np.asarray(value)
+        if v.ndim == 1 and rows > 1 and v.size == rows and rows != Nh:
+            v = v.reshape(rows, 1)  # a vertical profile shared by every column
+        a[...] = v
+        self._check(self._lib.trm_upload(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_upload")
+
+    def __getattr__(self, name):
+        if name in _capi.FIELD or name in ("ground_temperature", "rainfall_ground"):
+            return self.get(name)
+        raise AttributeError(name)
+
+    def set_bc(self, var, side, kind, value=0.0):
+        if np.ndim(value) == 0:
+            ptr, scalar = None, float(value)
+        else:
+            arr = np.ascontiguousarray(value, dtype=self.dtype)
+            assert arr.shape == (self.grid.Nh,), arr.shape
+            ptr, scalar = arr.ctypes.data, 0.0
+        self._check(self._lib.trm_set_bc(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], _capi.BC_KIND[kind], ptr,
+                                         scalar), "trm_set_bc")
+
+    def set_forcing(self, name, value):
+        a = np.empty(self.grid.Nh, dtype=self.dtype)
+        a[...] = value
+        self._check(self._lib.trm_set_forcing(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_set_forcing")
+
+    # -- grid ---------------------------------------------------------------------
+    def _grid_arrays(self):
+        Nz = self.grid.Nz
+        zf, dzf = np.zeros(Nz + 1), np.zeros(Nz + 1)
+        zc, dzc = np.zeros(Nz), np.zeros(Nz)
+        self._check(self._lib.trm_get_grid(self._ctx, zf.ctypes.data, zc.ctypes.data, dzc.ctypes.data, dzf.ctypes.data),
+                    "trm_get_grid")
+        return dict(zF=zf, zC=zc, dzc=dzc, dzf=dzf)
+
+    def z_centers(self):
+        return self._grid_arrays()["zC"]
+
+    def z_faces(self):
+        return self._grid_arrays()["zF"]
+
+    # -- reference process interface (abstract_model.jl:52-95,175-215) -------------
+    def initialize(self): self._check(self._lib.trm_initialize(self._ctx), "trm_initialize")
+    def update_state(self, compute_tendencies=True):
+        self._check(self._lib.trm_update_state(self._ctx, int(compute_tendencies)), "trm_update_state")
+    def compute_auxiliary(self): self._check(self._lib.trm_compute_auxiliary(self._ctx), "trm_compute_auxiliary")
+    def compute_tendencies(self): self._check(self._lib.trm_compute_tendencies(self._ctx), "trm_compute_tendencies")
+    def reset_tendencies(self): self._check(self._lib.trm_reset_tendencies(self._ctx), "trm_reset_tendencies")
+    def explicit_step(self, dt): self._check(self._lib.trm_explicit_step(self._ctx, float(dt)), "trm_explicit_step")
+    def closure(self): self._check(self._lib.trm_closure(self._ctx), "trm_closure")
+    def invclosure(self): self._check(self._lib.trm_invclosure(self._ctx), "trm_invclosure")
+
+    def step(self, dt, nsteps=1, finalize=True):
+        self._check(self._lib.trm_step(self._ctx, float(dt), int(nsteps), int(finalize)), "trm_step")
+
+    def step_heun(self, dt, nsteps=1, finalize=True):
+        self._check(self._lib.trm_step_heun(self._ctx, float(dt), int(nsteps), int(finalize)), "trm_step_heun")
+
+    def step_timed(self, dt, nsteps=1, finalize=False) -> float:
+        ms = C.c_float()
+        self._check(self._lib.trm_step_timed(self._ctx, float(dt), int(nsteps), int(finalize), C.byref(ms)),
+                    "trm_step_timed")
+        return float(ms.value)
+
+    def clock(self):
+        t, it = C.c_double(), C.c_int64()
+        self._check(self._lib.trm_clock(self._ctx, C.byref(t), C.byref(it)), "trm_clock")
+        return t.value, int(it.value)
+
+    def set_clock(self, time, iteration):
+        self._check(self._lib.trm_set_clock(self._ctx, float(time), int(iteration)), "trm_set_clock")
+
+    def reduce(self, name, op) -> np.ndarray:
+        rows = 1 if op == "volume_integral_z" else self.rows(name)
+        out = np.zeros(rows, dtype=np.float64)
+        self._check(self._lib.trm_reduce(self._ctx, _capi.FIELD[name], _capi.REDUCE[op], out.ctypes.data), "trm_reduce")
+        return out
+
+    def status(self) -> int:
+        f = C.c_uint32()
+        self._check(self._lib.trm_status(self._ctx, C.byref(f)), "trm_status")
+        return int(f.value)
+
+    def set_option(self, option, value):
+        if option == "step_kernel" and isinstance(value, str):
+            value = _capi.KERNEL[value]
+        self._check(self._lib.trm_set_option(self._ctx, _capi.OPTION[option], int(value)), "trm_set_option")
+
+    def set_stream(self, hip_stream_handle):
+        self._check(self._lib.trm_set_stream(self._ctx, C.c_void_p(hip_stream_handle)), "trm_set_stream")
+
+    def synchronize(self):
+        self._check(self._lib.trm_synchronize(self._ctx), "trm_synchronize")
+
+
+# ---- integrator -------------------------------------------------------------------
+class ModelIntegrator:
+    """src/timesteppers/model_integrator.jl:10-37"""
+
+    def __init__(self, model, timestepper, state: DeviceState, boundary_conditions, initializers, inputs):
+        self.model = model
+        self.timestepper = timestepper
+        self.state = state
+        self.boundary_conditions = boundary_conditions
+        self.initializers = initializers
+        self.inputs = inputs  # name -> number | array | f(t) returning an array/number
+
+    @property
+    def clock(self):
+        return self.state.clock()
+
+    def _apply_time_dependent(self, t):
+        """update_inputs! + BC functions, evaluated at the pre-tick time (the reference fills halos
+        before tick!, forward_euler.jl:19-31)."""
+        dyn = False
+        for (var, side), (kind, value) in self.boundary_conditions.items():
+            if callable(value):
+                self.state.set_bc(var, side, kind, value(t))
+                dyn = True
+        for name, value in self.inputs.items():
+            if callable(value):
+                self.state.set_forcing(name, value(t))
+                dyn = True
+        return dyn
+
+    def _has_time_dependence(self):
+        return any(callable(v) for _, v in self.boundary_conditions.values()) or \
+            any(callable(v) for v in self.inputs.values())
+
+
+def current_time(integrator: ModelIntegrator) -> float:
+    return integrator.state.clock()[0]
+
+
+def _apply_model_initializer(state: DeviceState, model):
+    init = model.initializer
+    if isinstance(init, M.DefaultInitializer) or init is None:
+        return
+    zc = state.z_centers()
+    hyd = init.hydrology if isinstance(init, M.SoilInitializer) else None
+    en = init.energy if isinstance(init, M.SoilInitializer) else init
+    if isinstance(hyd, M.ConstantSaturation):
+        state.set("saturation_water_ice", hyd.sat)
+    elif isinstance(hyd, M.SaturationWaterTable):
+        # soil_model_init.jl:149-152 compares z <= +depth, i.e. always true (SURVEY C-2): reproduced
+        state.set("saturation_water_ice", np.where(zc <= hyd.water_table_depth, 1.0, hyd.vadose_zone_saturation))
+    if isinstance(en, M.ConstantSoilTemperature):
+        state.set("temperature", en.T0)
+    elif isinstance(en, M.QuasiThermalSteadyState):
+        state.set("temperature", en.T0 - en.Qgeo / en.k_eff * zc)
+
+
+def initialize(model, timestepper=None, boundary_conditions=None, initializers=None, inputs=None) -> ModelIntegrator:
+    """initialize(model, timestepper; boundary_conditions, initializers) (model_integrator.jl:145-161).
+
+    `boundary_conditions`: dict {(variable, side): (kind, value)} as built by the aliases above; a value may
+    be a number, a per-column array, or a function of time returning one of those.
+    `initializers`: dict {field name: number | array | function(x, z)} (`set!` arguments).
+    `inputs`: dict {input field: number | array | function(t)} (InputSource stand-in)."""
+    timestepper = timestepper or ForwardEuler()
+    bcs = dict(boundary_conditions or {})
+    inits = dict(initializers or {})
+    inputs = dict(inputs or {})
+    state = DeviceState(model.grid, M.flatten(model))
+    integ = ModelIntegrator(model, timestepper, state, bcs, inits, inputs)
+    initialize_integrator(integ)
+    return integ
+
+
+def initialize_integrator(integ: ModelIntegrator):
+    """initialize!(integrator) (model_integrator.jl:96-109): reset, inputs, user initializers,
+    model initializer, process initializers."""
+    st = integ.state
+    st.set_clock(0.0, 0)
+    for (var, side), (kind, value) in integ.boundary_conditions.items():
+        st.set_bc(var, side, kind, value(0.0) if callable(value) else value)
+    for name, value in integ.inputs.items():
+        st.set_forcing(name, value(0.0) if callable(value) else value)
+    for name, value in integ.initializers.items():
+        st.set(name, value)
+    _apply_model_initializer(st, integ.model)
+    st.initialize()
+    return integ
+
+
+def timestep(integ: ModelIntegrator, dt: Optional[float] = None, finalize: bool = True):
+    """timestep!(integrator, dt; finalize) (model_integrator.jl:124-131)"""
+    dt = integ.timestepper.dt if dt is None else float(dt)
+    integ._apply_time_dependent(current_time(integ))
+    if isinstance(integ.timestepper, Heun):
+        integ.state.step_heun(dt, 1, finalize)
+    else:
+        integ.state.step(dt, 1, finalize)
+
+
+def run(integ: ModelIntegrator, steps: Optional[int] = None, period: Optional[float] = None, dt: Optional[float] = None):
+    """run!(integrator; steps, period, dt) (model_integrator.jl:72-88); `period` in seconds."""
+    dt = integ.timestepper.dt if dt is None else float(dt)
+    if steps is None and period is None:
+        raise ValueError("either `steps` or `period` must be specified")
+    if steps is not None and period is not None:
+        raise ValueError("both `steps` and `period` cannot be specified")
+    if steps is None:
+        steps = int(period // dt)
+    heun = isinstance(integ.timestepper, Heun)
+    stepper = integ.state.step_heun if heun else integ.state.step
+    if integ._has_time_dependence():
+        for n in range(steps):
+            integ._apply_time_dependent(current_time(integ))
+            stepper(dt, 1, finalize=(n == steps - 1))
+    elif steps > 0:
+        stepper(dt, steps, finalize=True)
+    if steps == 0:
+        integ.state.compute_auxiliary()  # run! always ends with compute_auxiliary! (model_integrator.jl:85-86)
+    return integ
+
+
+# reference-named process interface on an integrator's state
+def compute_auxiliary(state: DeviceState, model=None): state.compute_auxiliary()
+def compute_tendencies(state: DeviceState, model=None): state.compute_tendencies()
+def closure(state: DeviceState, model=None): state.closure()
+def invclosure(state: DeviceState, model=None): state.invclosure()
+def update_state(integ: ModelIntegrator, compute_tendencies=True): integ.state.update_state(compute_tendencies)

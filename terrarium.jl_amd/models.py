@@ -1,0 +1,322 @@
+"""Model configuration structs -- host-side mirror of the reference's immutable
+`@kwdef` parameter structs on the SoilModel hot path.  They
+hold no arrays; `flatten()` turns a model into the flat `trm_params` POD of
+include/terrarium_hip.h.  Names and defaults follow the reference."""
+from dataclasses import dataclass, field
+from typing import Optional, Union
+
+from . import _capi
+from .grids import ColumnGrid
+
+
+# ---- src/processes/physical_constants.jl:9-51 -------------------------------
+@dataclass
+class PhysicalConstants:
+    rho_w: float = 1000.0
+    rho_i: float = 916.2
+    rho_a: float = 1.293
+    c_a: float = 1005.7
+    Lsl: float = 3.34e5
+    Llg: float = 2.257e6
+    Lsg: float = 2.834e6
+    g: float = 9.80665
+    Tref: float = 273.15
+    sigma: float = 5.6704e-8
+    kappa: float = 0.4
+    epsilon: float = 0.622
+    R_a: float = 287.058
+
+
+# ---- src/processes/soil/energy/soil_thermal_properties.jl:14-46 -------------
+@dataclass
+class SoilThermalConductivities:
+    water: float = 0.57
+    ice: float = 2.2
+    air: float = 0.025
+    mineral: float = 3.8
+    organic: float = 0.25
+
+
+@dataclass
+class SoilHeatCapacities:
+    water: float = 4.2e6
+    ice: float = 1.9e6
+    air: float = 0.00125e6
+    mineral: float = 2.0e6
+    organic: float = 2.5e6
+
+
+@dataclass
+class SoilThermalProperties:
+    """Bulk conductivity = InverseQuadratic, freeze curve = FreeWater (the only
+    ones the reference implements, soil_thermal_properties.jl:80-83,119-123)."""
+    conductivities: SoilThermalConductivities = field(default_factory=SoilThermalConductivities)
+    heat_capacities: SoilHeatCapacities = field(default_factory=SoilHeatCapacities)
+
+
+@dataclass
+class SoilEnergyBalance:
+    """src/processes/soil/energy/soil_energy.jl:22-43 (ExplicitTwoPhaseHeatConduction,
+    SoilEnergyTemperatureClosure)."""
+    thermal_properties: SoilThermalProperties = field(default_factory=SoilThermalProperties)
+
+
+# ---- stratigraphy / biogeochemistry -----------------------------------------
+@dataclass
+class ConstantSoilPorosity:
+    """soil_porosity.jl:7-13"""
+    mineral_porosity: float = 0.49
+    organic_porosity: float = 0.9
+
+
+@dataclass
+class HomogeneousStratigraphy:
+    """homogeneous_strat.jl:9-15 (texture only matters to SURFEX hydraulics, off-path)."""
+    porosity: ConstantSoilPorosity = field(default_factory=ConstantSoilPorosity)
+
+
+@dataclass
+class ConstantSoilCarbonDensity:
+    """constant_soil_carbon.jl:10-16"""
+    rho_soc: float = 0.0
+    rho_org: float = 1300.0
+
+
+# ---- hydrology ---------------------------------------------------------------
+@dataclass
+class BrooksCorey:
+    """FreezeCurves.BrooksCorey(psi_s = 0.01 m, lambda = 0.2); theta_res = 0."""
+    psi_s: float = 0.01
+    lam: float = 0.2
+    theta_res: float = 0.0
+
+
+@dataclass
+class VanGenuchten:
+    """FreezeCurves.VanGenuchten(alpha = 1/m, n = 2); theta_res = 0."""
+    alpha: float = 1.0
+    n: float = 2.0
+    theta_res: float = 0.0
+
+
+@dataclass
+class UnsatKLinear:
+    """soil_hydraulic_properties.jl:166-181"""
+
+
+@dataclass
+class UnsatKVanGenuchten:
+    """soil_hydraulic_properties.jl:196-221"""
+    impedance: float = 7.0
+
+
+@dataclass
+class ConstantSoilHydraulics:
+    """soil_hydraulic_properties.jl:66-97 (SoilHydraulicsSURFEX shares every quantity the step uses)."""
+    swrc: Union[BrooksCorey, VanGenuchten] = field(default_factory=BrooksCorey)
+    unsat_hydraulic_cond: Union[UnsatKLinear, UnsatKVanGenuchten] = field(default_factory=UnsatKLinear)
+    sat_hydraulic_cond: float = 1.0e-5
+
+
+SoilHydraulicsSURFEX = ConstantSoilHydraulics
+
+
+@dataclass
+class NoFlow:
+    """soil_hydrology.jl:14"""
+
+
+@dataclass
+class RichardsEq:
+    """soil_hydrology_rre.jl:18"""
+
+
+@dataclass
+class SoilHydrology:
+    """soil_hydrology.jl:21-53.  `vwc_forcing` is a spatially constant source/sink
+    [1/s]; general Oceananigans `Forcing` callbacks do not cross the C ABI."""
+    vertical_flow: Union[NoFlow, RichardsEq] = field(default_factory=NoFlow)
+    hydraulic_properties: ConstantSoilHydraulics = field(default_factory=ConstantSoilHydraulics)
+    vwc_forcing: Optional[float] = None
+
+
+@dataclass
+class SoilEnergyWaterCarbon:
+    """soil_coupled.jl:7-39"""
+    strat: HomogeneousStratigraphy = field(default_factory=HomogeneousStratigraphy)
+    energy: SoilEnergyBalance = field(default_factory=SoilEnergyBalance)
+    hydrology: SoilHydrology = field(default_factory=SoilHydrology)
+    biogeochem: ConstantSoilCarbonDensity = field(default_factory=ConstantSoilCarbonDensity)
+
+
+# ---- surface energy balance / atmosphere / surface hydrology -----------------
+@dataclass
+class ConstantAlbedo:
+    """albedo.jl:22-28"""
+    albedo: float = 0.3
+    emissivity: float = 0.97
+
+
+@dataclass
+class ImplicitSkinTemperature:
+    """skin_temperature.jl:49-52"""
+    kappa_s: float = 2.0
+
+
+@dataclass
+class SurfaceEnergyBalance:
+    """surface_energy_balance.jl:9-37 (DiagnosedRadiativeFluxes, DiagnosedTurbulentFluxes)."""
+    skin_temperature: ImplicitSkinTemperature = field(default_factory=ImplicitSkinTemperature)
+    albedo: ConstantAlbedo = field(default_factory=ConstantAlbedo)
+
+
+@dataclass
+class ConstantAerodynamics:
+    """aerodynamics.jl:6-9"""
+    C_h: float = 1.2e-3
+
+
+@dataclass
+class PrescribedAtmosphere:
+    """prescribed_atmosphere.jl:45-99"""
+    altitude: float = 10.0
+    min_windspeed: float = 0.01
+    aerodynamics: ConstantAerodynamics = field(default_factory=ConstantAerodynamics)
+
+
+@dataclass
+class DirectSurfaceRunoff:
+    """direct_surface_runoff.jl:15-18"""
+    tau_r: float = 3600.0
+
+
+@dataclass
+class BareGroundEvaporation:
+    """bare_ground_evaporation.jl:12-24 with ConstantEvaporationResistanceFactor"""
+    factor: float = 1.0
+
+
+@dataclass
+class SurfaceHydrology:
+    """surface_hydrology.jl:10-34 in the `vegetation = nothing` configuration
+    (land_model.jl:119-125): BareGroundEvaporation + NoCanopyInterception."""
+    evapotranspiration: BareGroundEvaporation = field(default_factory=BareGroundEvaporation)
+    surface_runoff: DirectSurfaceRunoff = field(default_factory=DirectSurfaceRunoff)
+
+
+# ---- initialisers (src/models/soil/soil_model_init.jl) ------------------------
+@dataclass
+class DefaultInitializer:
+    """initializers.jl:29-34: leave every Field at its default (zero)."""
+
+
+@dataclass
+class ConstantSoilTemperature:
+    T0: float = 0.0
+
+
+@dataclass
+class QuasiThermalSteadyState:
+    T0: float = 0.0
+    Qgeo: float = 0.02
+    k_eff: float = 1.0
+
+
+@dataclass
+class ConstantSaturation:
+    sat: float = 1.0
+
+
+@dataclass
+class SaturationWaterTable:
+    vadose_zone_saturation: float = 0.5
+    water_table_depth: float = 5.0
+
+
+@dataclass
+class SoilInitializer:
+    energy: object = field(default_factory=QuasiThermalSteadyState)
+    hydrology: object = field(default_factory=SaturationWaterTable)
+
+
+# ---- models -------------------------------------------------------------------
+@dataclass
+class SoilModel:
+    """src/models/soil/soil_model.jl:9-27"""
+    grid: ColumnGrid
+    soil: SoilEnergyWaterCarbon = field(default_factory=SoilEnergyWaterCarbon)
+    constants: PhysicalConstants = field(default_factory=PhysicalConstants)
+    initializer: object = field(default_factory=DefaultInitializer)
+    halo_policy: str = "reference_zero"
+
+    coupled_surface = False
+
+
+@dataclass
+class LandModel:
+    """src/models/coupled/land_model.jl:10-44 with `vegetation = nothing`: soil +
+    surface energy balance + bare-ground surface hydrology + PrescribedAtmosphere,
+    ground_heat_flux / -infiltration wired as the soil's top flux BCs (:46-66)."""
+    grid: ColumnGrid
+    soil: SoilEnergyWaterCarbon = field(default_factory=SoilEnergyWaterCarbon)
+    surface_energy_balance: SurfaceEnergyBalance = field(default_factory=SurfaceEnergyBalance)
+    surface_hydrology: SurfaceHydrology = field(default_factory=SurfaceHydrology)
+    atmosphere: PrescribedAtmosphere = field(default_factory=PrescribedAtmosphere)
+    constants: PhysicalConstants = field(default_factory=PhysicalConstants)
+    initializer: object = field(default_factory=DefaultInitializer)
+    halo_policy: str = "reference_zero"
+    vegetation: None = None
+
+    coupled_surface = True
+
+
+def flatten(model) -> "_capi.TrmParams":
+    """Model structs -> trm_params (include/terrarium_hip.h)."""
+    p = _capi.TrmParams()
+    c = model.constants
+    p.rho_w, p.rho_i, p.rho_a, p.c_a = c.rho_w, c.rho_i, c.rho_a, c.c_a
+    p.Lsl, p.Llg, p.Lsg, p.g, p.Tref, p.sigma = c.Lsl, c.Llg, c.Lsg, c.g, c.Tref, c.sigma
+    p.kappa_vk, p.eps_mw, p.R_a = c.kappa, c.epsilon, c.R_a
+    soil = model.soil
+    k, h = soil.energy.thermal_properties.conductivities, soil.energy.thermal_properties.heat_capacities
+    p.k_water, p.k_ice, p.k_air, p.k_mineral, p.k_organic = k.water, k.ice, k.air, k.mineral, k.organic
+    p.c_water, p.c_ice, p.c_air, p.c_mineral, p.c_organic = h.water, h.ice, h.air, h.mineral, h.organic
+    p.por_mineral = soil.strat.porosity.mineral_porosity
+    p.por_organic = soil.strat.porosity.organic_porosity
+    p.rho_soc, p.rho_org = soil.biogeochem.rho_soc, soil.biogeochem.rho_org
+    hyd = soil.hydrology
+    hp = hyd.hydraulic_properties
+    p.K_sat = hp.sat_hydraulic_cond
+    # defaults of the unused SWRC keep the struct fully defined
+    p.bc_psi_s, p.bc_lambda, p.vg_alpha, p.vg_n, p.theta_res = 0.01, 0.2, 1.0, 2.0, 0.0
+    if isinstance(hp.swrc, VanGenuchten):
+        p.swrc = _capi.SWRC["van_genuchten"]
+        p.vg_alpha, p.vg_n, p.theta_res = hp.swrc.alpha, hp.swrc.n, hp.swrc.theta_res
+    else:
+        p.swrc = _capi.SWRC["brooks_corey"]
+        p.bc_psi_s, p.bc_lambda, p.theta_res = hp.swrc.psi_s, hp.swrc.lam, hp.swrc.theta_res
+    p.impedance = 7.0
+    if isinstance(hp.unsat_hydraulic_cond, UnsatKVanGenuchten):
+        if not isinstance(hp.swrc, VanGenuchten):
+            raise ValueError("UnsatKVanGenuchten requires a VanGenuchten SWRC (soil_hydraulic_properties.jl:203-206)")
+        p.unsat_k = _capi.UNSATK["van_genuchten"]
+        p.impedance = hp.unsat_hydraulic_cond.impedance
+    else:
+        p.unsat_k = _capi.UNSATK["linear"]
+    p.flow = _capi.FLOW["richards"] if isinstance(hyd.vertical_flow, RichardsEq) else _capi.FLOW["noflow"]
+    p.vwc_forcing = 0.0 if hyd.vwc_forcing is None else float(hyd.vwc_forcing)
+    # surface defaults (used only when seb = 1)
+    p.albedo, p.emissivity, p.kappa_s, p.C_h = 0.3, 0.97, 2.0, 1.2e-3
+    p.min_windspeed, p.tau_r, p.beta_evap = 0.01, 3600.0, 1.0
+    p.seb = 0
+    if getattr(model, "coupled_surface", False):
+        p.seb = 1
+        seb = model.surface_energy_balance
+        p.albedo, p.emissivity = seb.albedo.albedo, seb.albedo.emissivity
+        p.kappa_s = seb.skin_temperature.kappa_s
+        p.C_h = model.atmosphere.aerodynamics.C_h
+        p.min_windspeed = model.atmosphere.min_windspeed
+        p.tau_r = model.surface_hydrology.surface_runoff.tau_r
+        p.beta_evap = model.surface_hydrology.evapotranspiration.factor
+    p.halo_policy = _capi.HALO[model.halo_policy]
+    return p

@@ -1,0 +1,312 @@
+"""GPU parity: the HIP library (through its C ABI) against the CPU oracle on the
+same seeded inputs.  Bars: paths made only of + - * / sqrt fma are
+BIT-EXACT (heat-only; Richards with the reference-default BrooksCorey + linear K,
+whose powers Julia evaluates by compensated squaring); paths through generic
+pow / exp (van Genuchten, surface energy balance) agree to 1e-10 * max(1, |x|)
+in fp64 after the stated number of steps; fp32 to 1e-4 relative."""
+import numpy as np
+import pytest
+
+import workloads as W
+import terrarium_jl_amd as trm
+
+pytestmark = pytest.mark.gpu
+
+TOL64 = 1.0e-10   # fp64 tolerance for pow/exp paths, relative to max(1, |x|)
+TOL32 = 1.0e-4    # fp32 tolerance
+
+
+def small_columns(n, name="N72"):
+    lat, lon = W.columns_from_mask(name)
+    sel = np.linspace(0, lat.size - 1, n).astype(int)
+    return lat[sel], lon[sel]
+
+
+def assert_fields_match(dev, orc, names, exact, tol, label=""):
+    for n in names:
+        a, b = dev.get(n), orc.get(n)
+        assert a.shape == b.shape, n
+        if exact:
+            assert np.array_equal(a, b, equal_nan=True), (
+                f"{label}{n}: max abs diff {np.nanmax(np.abs(a.astype(np.float64) - b.astype(np.float64)))}")
+        else:
+            a64, b64 = a.astype(np.float64), b.astype(np.float64)
+            scale = np.maximum(1.0, np.abs(b64))
+            err = np.abs(a64 - b64) / scale
+            assert np.all(np.isfinite(a64) == np.isfinite(b64)), n
+            assert np.nanmax(err) <= tol, f"{label}{n}: max scaled err {np.nanmax(err):.3e} > {tol}"
+
+
+def bit_exact_config(config, hydraulics, dtype):
+    return np.dtype(dtype) == np.float64 and config in ("heat", "richards") and hydraulics == "default"
+
+
+CASES = [
+    ("heat", "default", np.float64, 20, 100),
+    ("heat", "default", np.float64, 30, 100),
+    ("richards", "default", np.float64, 32, 100),
+    ("richards", "vg", np.float64, 32, 100),
+    ("land", "default", np.float64, 32, 50),
+    ("land", "vg", np.float64, 32, 50),
+    ("heat", "default", np.float32, 20, 100),
+    ("richards", "default", np.float32, 64, 100),
+    ("land", "vg", np.float32, 64, 50),
+]
+
+
+@pytest.mark.parametrize("kernel", ["fused", "unfused"])
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz,nsteps", CASES)
+def test_step_parity(config, hydraulics, dtype, Nz, nsteps, kernel):
+    lat, lon = small_columns(333)  # ragged: not a multiple of the 64-column tile
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    orc = W.setup_oracle(w)
+    dev = W.setup_device(w)
+    dev.set_option("step_kernel", kernel)
+    names = W.compared_fields(w)
+    exact = bit_exact_config(config, hydraulics, dtype)
+    tol = TOL64 if np.dtype(dtype) == np.float64 else TOL32
+    # initial state (process initialisers) must already agree
+    assert_fields_match(dev, orc, names, exact, tol, "init ")
+    # one reference timestep!(integrator, dt) with finalize, then a run!(steps)
+    orc.timestep(w["dt"], finalize=True)
+    dev.step(w["dt"], 1, finalize=True)
+    assert_fields_match(dev, orc, names, exact, tol, "step1 ")
+    orc.run(w["dt"], nsteps - 1)
+    dev.step(w["dt"], nsteps - 1, finalize=True)
+    assert dev.clock() == orc.clock()
+    assert_fields_match(dev, orc, names, exact, tol, f"step{nsteps} ")
+    assert dev.status() == orc.status() == 0
+
+
+@pytest.mark.parametrize("config,hydraulics", [("heat", "default"), ("richards", "default"), ("richards", "vg"),
+                                                ("land", "vg")])
+def test_fused_equals_unfused_bitwise(config, hydraulics):
+    """Both implementations share the device arithmetic, so they must agree bit for bit on every path."""
+    lat, lon = small_columns(500)
+    w = W.make_workload(config, lat, lon, 32, hydraulics=hydraulics)
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("step_kernel", "unfused")
+    for nsteps, fin in ((1, True), (7, False), (12, True)):
+        a.step(w["dt"], nsteps, finalize=fin)
+        b.step(w["dt"], nsteps, finalize=fin)
+        # without finalize the auxiliaries hold the values of the last compute_auxiliary! (pre-update state)
+        for n in W.compared_fields(w):
+            assert np.array_equal(a.get(n), b.get(n), equal_nan=True), (config, n, nsteps, fin)
+
+
+@pytest.mark.parametrize("config", ["heat", "richards", "land"])
+def test_read_closure_variants_bitwise(config):
+    """Re-deriving temperature / liquid fraction / pressure head from (U, sat) instead of reading the
+    stored closure fields must not change a single bit."""
+    lat, lon = small_columns(200)
+    w = W.make_workload(config, lat, lon, 32, hydraulics="vg" if config == "land" else "default")
+    ref = None
+    for mode in (1, 2, 0):
+        d = W.setup_device(w)
+        d.set_option("read_closure", mode)
+        d.step(w["dt"], 20, finalize=True)
+        out = {n: d.get(n) for n in W.compared_fields(w)}
+        if ref is None:
+            ref = out
+        else:
+            for n in out:
+                assert np.array_equal(out[n], ref[n], equal_nan=True), (config, mode, n)
+
+
+@pytest.mark.parametrize("block", [64, 128, 256])
+def test_block_sizes_bitwise(block):
+    lat, lon = small_columns(700)
+    w = W.make_workload("richards", lat, lon, 32)
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("block_columns", block)
+    a.step(w["dt"], 10, True)
+    b.step(w["dt"], 10, True)
+    for n in W.compared_fields(w):
+        assert np.array_equal(a.get(n), b.get(n)), n
+
+
+def test_process_interface_parity():
+    """Stand-alone compute_auxiliary! / compute_tendencies! / explicit_step! / closure! / invclosure!"""
+    lat, lon = small_columns(130)
+    for hydraulics, exact in (("default", True), ("vg", False)):
+        w = W.make_workload("richards", lat, lon, 32, hydraulics=hydraulics)
+        orc, dev = W.setup_oracle(w), W.setup_device(w)
+        orc.update_state(True)
+        dev.update_state(True)
+        names = ["hydraulic_conductivity", "tend_internal_energy", "tend_saturation_water_ice",
+                 "tend_surface_excess_water"]
+        assert_fields_match(dev, orc, names, exact, TOL64, "update_state ")
+        orc.explicit_step(w["dt"])
+        dev.explicit_step(w["dt"])
+        assert_fields_match(dev, orc, ["internal_energy", "saturation_water_ice", "surface_excess_water",
+                                       "tend_internal_energy"], exact, TOL64, "explicit_step ")
+        orc.closure()
+        dev.closure()
+        assert_fields_match(dev, orc, W.compared_fields(w), exact, TOL64, "closure ")
+        orc.invclosure()
+        dev.invclosure()
+        assert_fields_match(dev, orc, ["internal_energy", "saturation_water_ice", "liquid_water_fraction",
+                                       "water_table"], exact, TOL64, "invclosure ")
+
+
+def test_land_process_interface_parity():
+    lat, lon = small_columns(130)
+    w = W.make_workload("land", lat, lon, 32, hydraulics="vg")
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    orc.compute_auxiliary()
+    dev.compute_auxiliary()
+    assert_fields_match(dev, orc, W.FIELDS_SEB + ("hydraulic_conductivity",), False, TOL64, "compute_auxiliary ")
+
+
+@pytest.mark.parametrize("config,hydraulics", [("heat", "default"), ("richards", "default"), ("land", "vg")])
+def test_heun_parity(config, hydraulics):
+    lat, lon = small_columns(97)
+    w = W.make_workload(config, lat, lon, 20, hydraulics=hydraulics)
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    for _ in range(5):
+        orc.timestep_heun(w["dt"], finalize=True)
+    dev.step_heun(w["dt"], 5, finalize=True)
+    # the library finalizes once after the last step, the loop above after every step: identical for
+    # SoilModel (auxiliaries do not feed back) but not for LandModel's in-place skin temperature
+    if config == "land":
+        orc = W.setup_oracle(w)
+        for n in range(5):
+            orc.timestep_heun(w["dt"], finalize=(n == 4))
+    exact = bit_exact_config(config, hydraulics, np.float64)
+    assert_fields_match(dev, orc, W.compared_fields(w), exact, TOL64, "heun ")
+    assert dev.clock() == orc.clock()
+
+
+def test_halo_policy_mirror():
+    lat, lon = small_columns(70)
+    w = W.make_workload("heat", lat, lon, 20, halo_policy="mirror")
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    orc.run(w["dt"], 30)
+    dev.step(w["dt"], 30, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, "mirror ")
+    w0 = W.make_workload("heat", lat, lon, 20)
+    d0 = W.setup_device(w0)
+    d0.step(w0["dt"], 30, True)
+    assert not np.array_equal(d0.temperature, dev.temperature)  # the policy matters (SURVEY C-1)
+
+
+@pytest.mark.parametrize("Nh", [1, 63, 64, 65, 129])
+@pytest.mark.parametrize("Nz", [2, 3, 5])
+def test_ragged_and_tiny_shapes(Nh, Nz):
+    lat, lon = small_columns(max(Nh, 2))
+    w = W.make_workload("richards", lat[:Nh], lon[:Nh], Nz)
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    orc.run(w["dt"], 10)
+    dev.step(w["dt"], 10, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, f"Nh={Nh} Nz={Nz} ")
+
+
+def test_bc_kinds_parity():
+    """Value / Flux / Gradient boundary conditions on every variable that carries them."""
+    lat, lon = small_columns(80)
+    w = W.make_workload("richards", lat, lon, 16)
+    rng = np.random.default_rng(7)
+    w["bcs"] = {
+        ("temperature", "top"): ("value", w["T0"] + 3.0),
+        ("temperature", "bottom"): ("value", w["T0"] - 1.0),
+        ("internal_energy", "bottom"): ("flux", np.full(80, 0.05)),            # geothermal heat flux
+        ("saturation_water_ice", "top"): ("flux", -1.0e-8 * rng.random(80)),   # infiltration (negative = downward)
+        ("pressure_head", "bottom"): ("gradient", 0.0),                        # FreeDrainage()
+        ("liquid_water_fraction", "top"): ("gradient", 0.1),
+    }
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    orc.run(w["dt"], 40)
+    dev.step(w["dt"], 40, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, "bcs ")
+    # and through the unfused kernels
+    dev2 = W.setup_device(w)
+    dev2.set_option("step_kernel", "unfused")
+    dev2.step(w["dt"], 40, True)
+    assert_fields_match(dev2, orc, W.compared_fields(w), True, 0.0, "bcs unfused ")
+
+
+def test_saturation_repair_cases_on_device():
+    """K8 (test/soil/soil_hydrology_tests.jl:93-123) through trm_closure, against the oracle."""
+    import oracle
+    thickness = trm.UniformSpacing(dz=0.1, N=100).get_spacing()
+    p = trm._capi.default_params()
+    p.flow, p.swrc, p.unsat_k, p.vg_alpha, p.vg_n = 1, 1, 1, 2.0, 2.0
+    grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(thickness)), 3)
+    dev = trm.DeviceState(grid, p)
+    orc = oracle.Oracle(3, thickness, oracle.default_params(flow=1, swrc=1, unsat_k=1, vg_alpha=2.0, vg_n=2.0))
+    zc = dev.z_centers()
+    cases = np.stack([np.maximum(1.1 + zc, 1.0), np.minimum(-0.1 - zc, 1.0), np.minimum(-0.1 - zc, 0.0)], axis=1)
+    dev.set("saturation_water_ice", cases)
+    orc.set("saturation_water_ice", cases)
+    dev.closure()
+    orc.closure()
+    for n in ("saturation_water_ice", "surface_excess_water", "water_table"):
+        assert np.array_equal(dev.get(n), orc.get(n)), n
+    sat = dev.saturation_water_ice
+    assert np.allclose(sat[:, 0], 1.0) and np.all(sat[:, 1] >= 0) and np.allclose(sat[:, 2], 0.0)
+    # the same repair inside the fused step: start from the broken profiles and take one step
+    dev.set("saturation_water_ice", cases)
+    orc.set("saturation_water_ice", cases)
+    dev.set("surface_excess_water", 0.0)
+    orc.set("surface_excess_water", 0.0)
+    dev.initialize()
+    orc.initialize()
+    dev.set("saturation_water_ice", cases)   # re-break after the initial closure
+    orc.set("saturation_water_ice", cases)
+    dev.step(60.0, 1, True)
+    orc.timestep(60.0, True)
+    assert_fields_match(dev, orc, ["saturation_water_ice", "surface_excess_water", "water_table"], False, TOL64,
+                        "repair-in-step ")
+
+
+def test_zero_steps_and_clock():
+    lat, lon = small_columns(10)
+    w = W.make_workload("heat", lat, lon, 20)
+    dev = W.setup_device(w)
+    before = dev.temperature
+    dev.step(300.0, 0, False)
+    assert dev.clock() == (0.0, 0)
+    assert np.array_equal(before, dev.temperature)
+    dev.step(300.0, 2, True)
+    dev.step(900.0, 1, True)
+    assert dev.clock() == (1500.0, 3)
+
+
+def test_status_flags_replace_asserts():
+    """SoilVolume's @assert bounds (soil_volume.jl:26-28) -> TRM_STATUS_COMPOSITION_OUT_OF_RANGE."""
+    lat, lon = small_columns(10)
+    w = W.make_workload("heat", lat, lon, 20)
+    dev = W.setup_device(w)
+    assert dev.status() == 0
+    dev.set("saturation_water_ice", 2.0)
+    dev.compute_auxiliary()
+    assert dev.status() & trm._capi.STATUS_COMPOSITION
+    dev2 = W.setup_device(w)
+    bad = w["fields"]["temperature"].copy()
+    dev2.set("internal_energy", np.full_like(bad, np.nan))
+    dev2.step(300.0, 1, True)
+    assert dev2.status() & trm._capi.STATUS_NAN
+
+
+def test_reductions_match_numpy():
+    lat, lon = small_columns(1000)
+    w = W.make_workload("richards", lat, lon, 32)
+    dev = W.setup_device(w)
+    dev.step(w["dt"], 5, True)
+    T = dev.temperature.astype(np.float64)
+    assert np.allclose(dev.reduce("temperature", "sum"), T.sum(axis=1), rtol=1e-12)
+    assert np.array_equal(dev.reduce("temperature", "min"), T.min(axis=1))
+    assert np.array_equal(dev.reduce("temperature", "max"), T.max(axis=1))
+    assert np.all(dev.reduce("temperature", "hasnan") == 0)
+    g = dev._grid_arrays()
+    sat = dev.saturation_water_ice.astype(np.float64)
+    assert np.allclose(dev.reduce("saturation_water_ice", "volume_integral_z")[0], (sat * g["dzc"][:, None]).sum(),
+                       rtol=1e-12)
+    assert np.allclose(dev.reduce("water_table", "sum")[0], dev.water_table.sum(), rtol=1e-12)
+
+
+def test_missing_gpu_path_is_loud():
+    """No silent fallback: an invalid device ordinal fails with an error, never computes on the host."""
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10), 4, device=99)
+    with pytest.raises(trm.TerrariumHipError):
+        trm.DeviceState(grid, trm._capi.default_params())

@@ -1,0 +1,171 @@
+"""The reference's own integration tests, re-run on the GPU through the host-side
+mirror of its API (terrarium.jl_amd) -- each test names the reference test it follows."""
+import math
+
+import numpy as np
+import pytest
+from scipy.special import erfc
+
+import terrarium_jl_amd as trm
+
+pytestmark = pytest.mark.gpu
+
+
+def vg_hydrology(**kw):
+    hp = trm.ConstantSoilHydraulics(swrc=trm.VanGenuchten(alpha=2.0, n=2.0), unsat_hydraulic_cond=trm.UnsatKVanGenuchten())
+    return trm.SoilHydrology(vertical_flow=trm.RichardsEq(), hydraulic_properties=hp, **kw)
+
+
+# test/soil/soil_energy_tests.jl:28-48
+def test_soil_energy_initialize():
+    grid = trm.ColumnGrid(trm.ExponentialSpacing())
+    for T0, liq, sign in ((0.0, 1.0, 0), (1.0, 1.0, 1), (-1.0, 0.0, -1)):
+        integ = trm.initialize(trm.SoilModel(grid), initializers=dict(temperature=T0))
+        assert np.allclose(integ.state.liquid_water_fraction, liq)
+        U = integ.state.internal_energy
+        assert np.allclose(U, 0.0) if sign == 0 else np.all(np.sign(U) == sign)
+
+
+# test/soil/soil_energy_tests.jl:63-73
+def test_soil_energy_closure():
+    integ = trm.initialize(trm.SoilModel(trm.ColumnGrid(trm.ExponentialSpacing(N=10))))
+    integ.state.set("internal_energy", 1.0e6)
+    trm.closure(integ.state)
+    assert np.all(integ.state.temperature > 0)
+    assert np.allclose(integ.state.liquid_water_fraction, 1.0)
+
+
+# test/soil/soil_energy_tests.jl:89-140
+def test_heat_diffusion_periodic_upper_bc():
+    T0, A, P, k, c = 2.0, 1.0, 24 * 3600.0, 2.0, 1.0e6
+    alpha = k / c
+    d = math.sqrt(math.pi / (alpha * P))
+    T_sol = lambda z, t: T0 + A * np.exp(-z * d) * np.sin(2 * np.pi * t / P - z * d)
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(dz_min=0.05, dz_max=100.0, N=100))
+    thermal = trm.SoilThermalProperties(conductivities=trm.SoilThermalConductivities(mineral=k),
+                                        heat_capacities=trm.SoilHeatCapacities(mineral=c))
+    soil = trm.SoilEnergyWaterCarbon(energy=trm.SoilEnergyBalance(thermal_properties=thermal),
+                                     strat=trm.HomogeneousStratigraphy(porosity=trm.ConstantSoilPorosity(mineral_porosity=0.0)),
+                                     biogeochem=trm.ConstantSoilCarbonDensity(rho_soc=0.0))
+    model = trm.SoilModel(grid, soil=soil)
+    bcs = trm.PrescribedSurfaceTemperature("Tsurf", lambda t: T0 + A * math.sin(2 * math.pi * t / P))
+    inits = dict(temperature=lambda x, z: T_sol(-z, 0.0), saturation_water_ice=0.0)
+    integ = trm.initialize(model, trm.ForwardEuler(), boundary_conditions=bcs, initializers=inits)
+    zc = integ.state.z_centers()
+    max_rel = 0.0
+    while trm.current_time(integ) < 2 * P:
+        trm.timestep(integ, 60.0)
+        t = trm.current_time(integ)
+        Ts = integ.state.temperature[:, 0]
+        target = T_sol(-zc, t)
+        max_rel = max(max_rel, float(np.max(np.abs((Ts - target) / target))))
+    assert max_rel < 0.1
+
+
+# test/soil/soil_energy_tests.jl:142-190
+def test_step_heat_diffusion():
+    T0, T1 = 1.0, 2.0
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(dz_min=0.01, dz_max=100.0, N=100))
+    soil = trm.SoilEnergyWaterCarbon(strat=trm.HomogeneousStratigraphy(porosity=trm.ConstantSoilPorosity(mineral_porosity=0.0)),
+                                     biogeochem=trm.ConstantSoilCarbonDensity(rho_soc=0.0))
+    model = trm.SoilModel(grid, soil=soil, initializer=trm.SoilInitializer(energy=trm.ConstantSoilTemperature(T0)))
+    integ = trm.initialize(model, trm.ForwardEuler(), boundary_conditions={("temperature", "top"): ("value", T1)})
+    trm.run(integ, period=24 * 3600.0, dt=10.0)
+    alpha = 3.8 / 2.0e6
+    zc = integ.state.z_centers()
+    t = trm.current_time(integ)
+    assert t == 24 * 3600.0
+    target = T0 + (T1 - T0) * erfc(-zc / (2 * math.sqrt(alpha * t)))
+    rel = np.abs((integ.state.temperature[:, 0] - target) / target)
+    assert rel.max() < 1.0e-3
+
+
+# test/soil/soil_hydrology_tests.jl:125-150
+def test_richards_saturated_steady_state():
+    grid = trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=100))
+    model = trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=vg_hydrology()))
+    integ = trm.initialize(model, trm.ForwardEuler(), initializers=dict(saturation_water_ice=lambda x, z: 1.0))
+    st = integ.state
+    assert np.allclose(st.water_table, 0.0, atol=1e-12)
+    assert np.allclose(st.pressure_head, 0.0, atol=1e-12)
+    trm.compute_auxiliary(st, model)
+    K = st.hydraulic_conductivity
+    assert np.all(np.isfinite(K)) and np.allclose(K, 1.0e-5)
+    st.reset_tendencies()
+    trm.compute_tendencies(st, model)
+    assert np.all(st.tend_saturation_water_ice == 0)
+    trm.timestep(integ)
+    assert np.allclose(st.saturation_water_ice, 1.0)
+
+
+# test/soil/soil_hydrology_tests.jl:152-188
+def test_richards_variably_saturated():
+    grid = trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=100))
+    model = trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=vg_hydrology()))
+    integ = trm.initialize(model, trm.ForwardEuler(),
+                           initializers=dict(saturation_water_ice=lambda x, z: min(1.0, 0.5 - 0.1 * z)))
+    st = integ.state
+    assert np.allclose(st.water_table, -5.0)
+    assert np.all(st.pressure_head < 0)
+    trm.compute_auxiliary(st, model)
+    K = st.hydraulic_conductivity
+    assert np.all(np.isfinite(K)) and np.all(K > 0)
+    mass = lambda: st.reduce("saturation_water_ice", "volume_integral_z")[0]
+    m0 = mass()
+    trm.timestep(integ, 60.0)
+    sat = st.saturation_water_ice
+    assert np.all(np.isfinite(sat)) and np.all((0 <= sat) & (sat <= 1))
+    assert mass() == pytest.approx(m0, rel=1e-8)
+    trm.run(integ, period=3600.0, dt=60.0)
+    sat = st.saturation_water_ice
+    assert np.all(np.isfinite(sat)) and np.all((0 <= sat) & (sat <= 1))
+    assert mass() == pytest.approx(m0, rel=1e-8)
+
+
+# test/soil/soil_hydrology_tests.jl:191-233
+def test_soil_moisture_forcing_sink():
+    Nz, dt, F = 10, 60.0, -1.0e-5
+    grid = trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=Nz))
+    model = trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=vg_hydrology(vwc_forcing=F)))
+    integ = trm.initialize(model, trm.ForwardEuler(), initializers=dict(temperature=10.0, saturation_water_ice=1.0))
+    trm.timestep(integ, dt)
+    assert integ.state.saturation_water_ice[Nz - 1, 0] == pytest.approx(1 + F * dt / 0.49, rel=1e-12)
+
+
+# test/coupled_models/land_model_tests.jl:6-36
+def test_land_model_soil_no_vegetation():
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(dz_max=1.0, N=50))
+    land = trm.LandModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=vg_hydrology()))
+    assert isinstance(land.surface_hydrology.evapotranspiration, trm.BareGroundEvaporation)
+    inits = dict(temperature=lambda x, z: 5.0 - 0.02 * z, saturation_water_ice=lambda x, z: min(1.0, 0.8 - 0.05 * z))
+    integ = trm.initialize(land, trm.ForwardEuler(), initializers=inits)
+    st = integ.state
+    # infiltration / ground heat flux are wired as top flux BCs: +I raises, +G lowers the top-cell tendency
+    dz_top = st._grid_arrays()["dzc"][-1]
+    st.reset_tendencies()
+    st.set("infiltration", 1.0e-8)
+    st.set("ground_heat_flux", 3.0)
+    sat0, U0 = st.saturation_water_ice, st.internal_energy
+    st.explicit_step(1.0)
+    assert st.saturation_water_ice[-1, 0] - sat0[-1, 0] == pytest.approx(1.0e-8 / dz_top, rel=1e-6)
+    assert st.internal_energy[-1, 0] - U0[-1, 0] == pytest.approx(-3.0 / dz_top, rel=1e-6)
+    integ = trm.initialize(land, trm.ForwardEuler(), initializers=inits)
+    trm.timestep(integ, 60.0)
+    for name in ("saturation_water_ice", "internal_energy", "ground_heat_flux"):
+        assert np.all(np.isfinite(integ.state.get(name))), name
+
+
+# test/timestepping/run_simulation.jl:8-43
+@pytest.mark.parametrize("stepper", [trm.ForwardEuler, trm.Heun])
+def test_run_soil_model(stepper):
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=50), 3072)  # FullHEALPixGrid(16) has 3072 points
+    integ = trm.initialize(trm.SoilModel(grid), stepper())
+    trm.run(integ, steps=2)
+    assert np.all(np.isfinite(integ.state.temperature))
+    trm.run(integ, period=3600.0)
+    assert np.all(np.isfinite(integ.state.temperature))
+    assert trm.current_time(integ) == 600.0 + 3600.0
+    with pytest.raises(ValueError):
+        trm.run(integ, steps=2, period=3600.0)
+    with pytest.raises(ValueError):
+        trm.run(integ)

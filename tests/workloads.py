@@ -1,0 +1,111 @@
+"""Seeded synthetic workloads shared by the parity tests, the golden-fixture
+generator, __graft_entry__.smoke() and bench.py.  Pure
+numpy: describes inputs only; it computes nothing of the model."""
+import numpy as np
+
+import terrarium_jl_amd as trm
+
+SEED = 20260424
+DAY = 86400.0
+
+
+def columns_from_mask(name):
+    mask = trm.masks.load_land_mask(name)
+    lat, lon = trm.masks.masked_latlon(mask)
+    return lat, lon
+
+
+def synthetic_columns(num_columns):
+    return trm.masks.synthetic_latlon(num_columns)
+
+
+def make_workload(config, lat, lon, Nz, dtype=np.float64, hydraulics="default", halo_policy="reference_zero", t=0.0):
+    """config in {"heat", "richards", "land"}; lat/lon in radians, one per column.
+    Returns a dict: thickness, params overrides, initial fields, BCs, forcing inputs, dt."""
+    Nh = lat.size
+    rng = np.random.Generator(np.random.PCG64(SEED))
+    u = rng.uniform(-1.0, 1.0, size=Nh)
+    thickness = trm.ExponentialSpacing(dz_min=0.05, dz_max=100.0, N=Nz, sig=3).get_spacing()
+    grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(thickness)), Nh, dtype=dtype)
+    zc = grid.z_centers().astype(np.float64)
+    T0 = 20.0 - np.abs(40.0 * np.sin(lat))                       # soil_heat_global.jl:51
+    T_init = T0[None, :] - 0.05 * zc[:, None]                     # soil_heat_global.jl:59-64
+    w = dict(config=config, Nh=Nh, Nz=Nz, dtype=np.dtype(dtype), thickness=thickness, lat=lat, lon=lon, T0=T0, u=u)
+    params = dict(halo_policy={"reference_zero": 0, "mirror": 1}[halo_policy])
+    fields = dict(temperature=T_init)
+    bcs = {}
+    inputs = {}
+    if config == "heat":
+        fields["saturation_water_ice"] = np.ones((Nz, Nh))        # soil_heat_column.jl:19-22
+        bcs[("temperature", "top")] = ("value", T0 + 10.0 * np.sin(2 * np.pi * t / DAY - lon))
+        dt = 300.0
+    else:
+        sat = np.minimum(1.0, 0.8 - 0.05 * zc)[:, None] * (1.0 + 0.05 * u)[None, :]   # land_model_tests.jl:19
+        fields["saturation_water_ice"] = np.clip(sat, 0.05, 1.0)
+        params["flow"] = 1
+        if hydraulics == "vg":                                     # soil_hydrology_tests.jl:127-129
+            params.update(swrc=1, unsat_k=1, vg_alpha=2.0, vg_n=2.0)
+        dt = 60.0
+        if config == "richards":
+            bcs[("temperature", "top")] = ("value", T0 + 10.0 * np.sin(2 * np.pi * t / DAY - lon))
+        else:
+            params["seb"] = 1
+            phase = 2 * np.pi * t / DAY - lon
+            inputs = dict(
+                air_temperature=T0 + 5.0 * np.sin(phase), air_pressure=np.full(Nh, 101325.0),
+                windspeed=1.0 + 2.0 * np.abs(u), specific_humidity=np.full(Nh, 2.0e-3),
+                surface_shortwave_down=np.maximum(0.0, 600.0 * np.sin(phase)),
+                surface_longwave_down=np.full(Nh, 300.0), rainfall=1.0e-8 * (u > 0.5))
+            fields["skin_temperature"] = T_init[-1].copy()
+    w.update(params=params, fields=fields, bcs=bcs, inputs=inputs, dt=dt)
+    return w
+
+
+FIELDS_3D = ("internal_energy", "temperature", "liquid_water_fraction")
+FIELDS_RICHARDS = ("saturation_water_ice", "pressure_head", "hydraulic_conductivity", "surface_excess_water",
+                   "water_table")
+FIELDS_SEB = ("skin_temperature", "ground_heat_flux", "surface_shortwave_up", "surface_longwave_up",
+              "surface_net_radiation", "sensible_heat_flux", "latent_heat_flux", "evaporation_ground", "infiltration",
+              "surface_runoff")
+
+
+def compared_fields(w):
+    names = list(FIELDS_3D)
+    if w["config"] != "heat":
+        names += list(FIELDS_RICHARDS)
+    else:
+        names += ["hydraulic_conductivity"]
+    if w["config"] == "land":
+        names += list(FIELDS_SEB)
+    return names
+
+
+# ---- set-up on either side --------------------------------------------------------
+def setup_oracle(w, omp=False):
+    import oracle
+    p = oracle.default_params(**w["params"])
+    o = oracle.Oracle(w["Nh"], w["thickness"], p, dtype=w["dtype"], omp=omp)
+    for name, v in w["fields"].items():
+        o.set(name, v)
+    for (var, side), (kind, value) in w["bcs"].items():
+        o.set_bc(var, side, kind, value)
+    for name, v in w["inputs"].items():
+        o.set(name, v)
+    o.initialize()
+    return o
+
+
+def setup_device(w, device=0):
+    p = trm._capi.default_params()
+    for k, v in w["params"].items():
+        setattr(p, k, v)
+    grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(w["thickness"])), w["Nh"], dtype=w["dtype"], device=device)
+    d = trm.DeviceState(grid, p)
+    for name, v in w["fields"].items():
+        d.set(name, v)
+    for (var, side), (kind, value) in w["bcs"].items():
+        d.set_bc(var, side, kind, value)
+    for name, v in w["inputs"].items():
+        d.set_forcing(name, v)
+    d.initialize()
+    return d
