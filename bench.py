@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the fused SoilModel step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (update_state! + explicit_step! + closure!,
+forward_euler.jl:19-31) over every column of the workload: ONE launch of the fused
+HIP kernel, reading and writing the whole state through HBM -- no temporal
+blocking, state is not kept resident across steps.  The headline workload (N=1)
+is BASELINE.json config C3: global N145 ERA5-land mask (56 951 columns) x 32 soil
+levels, coupled heat + Richards water transport, fp64.  With --gpus N every rank
+holds a full N145-sized shard (weak scaling: columns are independent, there is no
+collective on the step path).  Rank 0 prints ONE JSON line.
+
+The CPU oracle is used here ONLY for the `cpu_baseline` leg (a timed, bounded
+sample of the same workload on the host cores) -- never for the measured path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+WORKLOADS = {
+    # name: (description, config, hydraulics, mask/columns, Nz, dtype)
+    "c2": ("C2: N72 ERA5-land mask (14017 columns) x 30 levels, soil heat conduction only, fp64", "heat", "default", "N72", 30, "f64"),
+    "c3": ("C3: N145 ERA5-land mask (56951 columns) x 32 levels, coupled heat + Richards (BrooksCorey SWRC, linear K), fp64", "richards", "default", "N145", 32, "f64"),
+    "c3vg": ("C3-VG: N145 mask x 32 levels, heat + Richards (VanGenuchten SWRC + Mualem K with ice impedance), fp64", "richards", "vg", "N145", 32, "f64"),
+    "c4": ("C4: N145 mask x 32 levels, full bare-ground LandModel (heat + Richards + surface energy balance, PrescribedAtmosphere), fp64", "land", "vg", "N145", 32, "f64"),
+    "c5": ("C5: synthetic 0.1-degree grid, 812500 columns per GPU x 64 levels, heat + Richards + SEB, fp32", "land", "vg", 812500, 64, "f32"),
+}
+
+
+def algorithmic_bytes_per_column_step(config, Nz, wordsize):
+    """compulsory reads + reference-visible writes per column per step."""
+    if config == "heat":
+        return wordsize * (5 * Nz + 1)          # U,sat read; U,T,liq written; T_ub
+    b = wordsize * (8 * Nz + 4)                 # U,sat read; U,sat,T,liq,psi,K written; S r+w, water_table, K top face
+    if config == "land":
+        b += wordsize * 18                      # 7 forcing reads, T_s r+w, 9 flux/diagnostic writes
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
+    ap.add_argument("--read-closure", type=int, default=None, help="fused kernel: 0 recompute, 1 read T/liq/psi, 2 read psi")
+    ap.add_argument("--block", type=int, default=None, help="columns per workgroup (64/128/256)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+
+    import workloads as W
+    import terrarium_jl_amd as trm
+    from terrarium_jl_amd import parallel
+
+    desc, config, hydraulics, columns, Nz, dt_name = WORKLOADS[args.workload]
+    dtype = np.float64 if dt_name == "f64" else np.float32
+    if isinstance(columns, str):
+        lat, lon = W.columns_from_mask(columns)
+    else:
+        lat, lon = W.synthetic_columns(columns)
+    if args.scaling == "strong" and world > 1:
+        lo, hi = parallel.shard_range(lat.size, world, rank)
+        lat, lon = lat[lo:hi], lon[lo:hi]
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    Nh = w["Nh"]
+
+    dev = W.setup_device(w, device=local_rank)
+    dev.set_option("step_kernel", args.kernel)
+    if args.read_closure is not None:
+        dev.set_option("read_closure", args.read_closure)
+    if args.block is not None:
+        dev.set_option("block_columns", args.block)
+    dt = w["dt"]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warmup (untimed)
+    if args.warmup > 0:
+        dev.step(dt, args.warmup, finalize=False)
+    barrier()
+    t0 = time.perf_counter()
+    ms = dev.step_timed(dt, args.steps, finalize=False)  # exactly K steps = K launches, HIP events on the library's stream
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    status = dev.status()
+
+    # max over ranks, total columns over ranks
+    stats = torch.tensor([elapsed, ms, float(Nh)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        mx = stats.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        sm = stats.clone()
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        elapsed, ms, total_columns = float(mx[0]), float(mx[1]), float(sm[2])
+        nan_flag = parallel.global_status(status)
+    else:
+        total_columns = float(Nh)
+        nan_flag = status
+    wordsize = 8 if dtype == np.float64 else 4
+    bytes_per_colstep = algorithmic_bytes_per_column_step(config, Nz, wordsize)
+    kernel_s = ms * 1e-3 / max(args.steps, 1)            # average duration of one step launch on this GPU
+    achieved_gbs = bytes_per_colstep * Nh / kernel_s / 1e9
+    value = total_columns * args.steps / elapsed
+
+    out = {
+        "metric": "column-steps/sec",
+        "value": value,
+        "unit": "column-steps/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed * 1e3 / max(args.steps, 1),
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": dt_name,
+        "data": "synthetic forcing and initial state on the reference's ERA5-land mask columns (SURVEY 8(d)); seeded",
+        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": dt, "kernel": args.kernel,
+                   "parallelism": f"columns block-sharded over {n_gpus} GPU(s), no data-path collective",
+                   "status_flags": int(nan_flag)},
+        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_step_fused" if args.kernel == "fused" else "unfused sequence",
+                     "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_column_step": bytes_per_colstep},
+    }
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(W, w, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(W, w, target_seconds):
+    """CPU restatement of the reference path (oracle/, OpenMP over columns, reference kernel order) timed on
+    this box's host cores on the same workload: whole column set, bounded number of steps."""
+    import oracle
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    chunk, done, spent = 10, 0, 0.0
+    orc = W.setup_oracle(w, omp=True)
+    orc.steps(w["dt"], 2)  # touch pages / spin up the thread pool
+    orc = W.setup_oracle(w, omp=True)
+    while spent < target_seconds and done < 100:
+        t0 = time.perf_counter()
+        orc.steps(w["dt"], chunk)
+        spent += time.perf_counter() - t0
+        done += chunk
+    return {"value": w["Nh"] * done / spent, "unit": "column-steps/s", "cores": cores, "kind": "port",
+            "sample": f"all {w['Nh']} columns x {done} steps of the same workload, OpenMP over columns, "
+                      f"reference kernel order (one pass per reference kernel); {spent:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@ include/terrarium_hip.h; there is no CPU fallback.
 from .grids import (AbstractVerticalSpacing, UniformSpacing, ExponentialSpacing, PrescribedSpacing, ColumnGrid,
                     ColumnRingGrid)
 from . import masks
+from . import parallel
 from . import _capi
 from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapacities, SoilThermalProperties,
                      SoilEnergyBalance, ConstantSoilPorosity, HomogeneousStratigraphy, ConstantSoilCarbonDensity,

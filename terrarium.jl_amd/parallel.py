@@ -1,0 +1,93 @@
+"""Multi-GPU: block-sharding of the laterally independent columns over the
+ranks of one node (one process per GPU, `torch.distributed`; backend "nccl" is
+RCCL over xGMI on ROCm), and the global diagnostic reductions.
+
+There is NO collective on the step path: columns never exchange data (the
+reference's only cross-column code is the x-periodic halo copy, which nothing
+reads).  Collectives appear only where the path has a real
+exchange: diagnostics.  Each `global_reduce` packs its per-row partials into one
+small tensor and issues ONE all-reduce; the messages are a few hundred bytes, so
+they are latency-bound and ring/link bandwidth is irrelevant.
+"""
+from typing import Tuple
+
+import numpy as np
+
+
+def shard_range(num_columns: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of the ring-ordered columns owned by `rank`:
+    blocks of B = ceil(Nh / P) columns, device d owns [d*B, min((d+1)*B, Nh))."""
+    assert 0 <= rank < world_size
+    block = -(-num_columns // world_size)
+    lo = min(rank * block, num_columns)
+    hi = min(lo + block, num_columns)
+    return lo, hi
+
+
+def shard_columns(array: np.ndarray, world_size: int, rank: int) -> np.ndarray:
+    """Slice the trailing (column) axis of a host array to this rank's block."""
+    lo, hi = shard_range(array.shape[-1], world_size, rank)
+    return array[..., lo:hi]
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist if dist.is_available() and dist.is_initialized() else None
+
+
+def _device():
+    import torch
+    dist = _dist()
+    if dist is not None and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+_OPS = {"sum": "SUM", "min": "MIN", "max": "MAX", "hasnan": "MAX", "volume_integral_z": "SUM"}
+
+
+def combine(local: np.ndarray, op: str) -> np.ndarray:
+    """All-reduce per-rank partial results (`DeviceState.reduce` output) across ranks."""
+    import torch
+    dist = _dist()
+    local = np.asarray(local, dtype=np.float64)
+    if dist is None or dist.get_world_size() == 1:
+        return local
+    t = torch.from_numpy(local.copy()).to(_device())
+    dist.all_reduce(t, op=getattr(dist.ReduceOp, _OPS[op]))
+    return t.cpu().numpy()
+
+
+def global_reduce(state, field: str, op: str) -> np.ndarray:
+    """Global diagnostic over all ranks' columns: local GPU reduction (trm_reduce) + one all-reduce."""
+    return combine(state.reduce(field, op), op)
+
+
+def global_status(local_flags: int) -> int:
+    """OR of the status flag words of all ranks (NaN seen / composition out of range)."""
+    import torch
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return int(local_flags)
+    bits = torch.tensor([(local_flags >> b) & 1 for b in range(8)], dtype=torch.int32, device=_device())
+    dist.all_reduce(bits, op=dist.ReduceOp.MAX)
+    return int(sum(int(v) << b for b, v in enumerate(bits.cpu().tolist())))
+
+
+def gather_columns(local: np.ndarray, num_columns: int) -> np.ndarray:
+    """Gather a column-sharded host array [..., Nh_local] to the full ring-ordered array on every rank
+    (output path only; e.g. a 2-D field at N145 is 0.46 MB)."""
+    import torch
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return np.asarray(local)
+    world = dist.get_world_size()
+    block = -(-num_columns // world)
+    lead = local.shape[:-1]
+    padded = np.zeros(lead + (block,), dtype=local.dtype)
+    padded[..., : local.shape[-1]] = local
+    t = torch.from_numpy(padded).to(_device())
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    full = np.concatenate([p.cpu().numpy() for p in parts], axis=-1)
+    return full[..., :num_columns]

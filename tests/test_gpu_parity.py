@@ -145,8 +145,9 @@ def test_process_interface_parity():
         assert_fields_match(dev, orc, W.compared_fields(w), exact, TOL64, "closure ")
         orc.invclosure()
         dev.invclosure()
+        # pressure -> saturation evaluates theta(psi) = (-psi_s/psi)^lambda with a non-integer lambda: generic pow
         assert_fields_match(dev, orc, ["internal_energy", "saturation_water_ice", "liquid_water_fraction",
-                                       "water_table"], exact, TOL64, "invclosure ")
+                                       "water_table"], False, TOL64, "invclosure ")
 
 
 def test_land_process_interface_parity():
