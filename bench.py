@@ -56,9 +56,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
-    ap.add_argument("--read-closure", type=int, default=None, help="fused kernel: 0 recompute, 1 read T/liq/psi, 2 read psi")
-    ap.add_argument("--block", type=int, default=None, help="columns per workgroup (64/128/256)")
+    ap.add_argument("--kernel", default="fused", choices=["fused", "fused_wave", "fused_lane", "unfused"])
+    ap.add_argument("--skip-kf", action="store_true", help="store hydraulic_conductivity only when finalizing")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -96,10 +95,8 @@ def main():
 
     dev = W.setup_device(w, device=local_rank)
     dev.set_option("step_kernel", args.kernel)
-    if args.read_closure is not None:
-        dev.set_option("read_closure", args.read_closure)
-    if args.block is not None:
-        dev.set_option("block_columns", args.block)
+    if args.skip_kf:
+        dev.set_option("write_kf_every_step", 0)
     dt = w["dt"]
 
     def barrier():
@@ -155,7 +152,7 @@ def main():
                    "status_flags": int(nan_flag)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_step_fused" if args.kernel == "fused" else "unfused sequence",
+                     "kernel": {"fused": "k_step_wave", "fused_wave": "k_step_wave", "fused_lane": "k_step_fused"}.get(args.kernel, "unfused sequence"),
                      "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_column_step": bytes_per_colstep},
     }
 

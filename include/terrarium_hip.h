@@ -112,14 +112,15 @@ enum { TRM_STATUS_NAN = 1u, TRM_STATUS_COMPOSITION_OUT_OF_RANGE = 2u };
 enum {
     TRM_OPT_ASYNC = 0,          /* 1: trm_step & co. return after enqueueing on the context stream          */
     TRM_OPT_STEP_KERNEL = 1,    /* TRM_KERNEL_*: which implementation trm_step uses                          */
-    TRM_OPT_READ_CLOSURE = 2,   /* fused kernel: 0 recompute T/liq/psi from (U, sat) when provably identical, */
-                                /* 1 always read the stored closure fields, 2 read psi only                   */
-    TRM_OPT_WRITE_KF_EVERY_STEP = 3, /* 1 (default): hydraulic_conductivity is stored by every step launch   */
-    TRM_OPT_BLOCK_COLUMNS = 4   /* columns per workgroup of the fused kernel (64, 128 or 256)                */
+    TRM_OPT_WRITE_KF_EVERY_STEP = 2 /* 1 (default): hydraulic_conductivity is stored by every step launch;   */
+                                    /* 0: only by launches that finalize (it is never an input of a step)   */
 };
 enum {
-    TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = column, column state staged in LDS           */
-    TRM_KERNEL_UNFUSED = 1      /* one launch per reference kernel, in the reference's order (A/B comparator) */
+    TRM_KERNEL_FUSED = 0,       /* one launch per step; picks FUSED_WAVE when Nz <= 64, else FUSED_LANE       */
+    TRM_KERNEL_UNFUSED = 1,     /* one launch per reference kernel, in the reference's order (A/B comparator) */
+    TRM_KERNEL_FUSED_LANE = 2,  /* fused, lane = column: rolling vertical stencil in registers, (U, sat) in LDS */
+    TRM_KERNEL_FUSED_WAVE = 3   /* fused, lane = level: column per (half-)wavefront, tile transposed through  */
+                                /* LDS, wavefront shuffles for the vertical stencil (Nz <= 64)                */
 };
 
 /* ---- grid: ColumnGrid(arch, NF, vert, num_columns)  src/grids/column_grid.jl:20-34 */

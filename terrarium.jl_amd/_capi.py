@@ -27,8 +27,8 @@ FIELD = dict(
 INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidity", "rainfall",
                 "surface_shortwave_down", "surface_longwave_down")
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
-OPTION = dict(asynchronous=0, step_kernel=1, read_closure=2, write_kf_every_step=3, block_columns=4)
-KERNEL = dict(fused=0, unfused=1)
+OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2)
+KERNEL = dict(fused=0, unfused=1, fused_lane=2, fused_wave=3)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
 
 EXPORTS = (

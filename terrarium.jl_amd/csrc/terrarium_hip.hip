@@ -2,6 +2,7 @@
 // (include/terrarium_hip.h).  gfx950 only; no CPU fallback.
 #include "../../include/terrarium_hip.h"
 #include "trm_kernels.hpp"
+#include "trm_kernel_wave.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -31,16 +32,15 @@ struct trm_ctx {
     bool has_stage = false;
     void* bc_value[TRM_BCV_COUNT][2] = {};
     int bc_kind[TRM_BCV_COUNT][2] = {};
-    void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr;
+    void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr;
     std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
-    double dzf_bot = 0, dzf_top = 0, Az = 1, z_ref = 0;
+    double dzf_bot = 0, dzf_top = 0, dzc_bot = 0, dzc_top = 0, Az = 1;
     uint32_t* d_status = nullptr;
     double* d_reduce = nullptr;  // scratch for trm_reduce
     size_t reduce_cap = 0;
     double time = 0.0;
     int64_t iteration = 0;
-    int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_read_closure = 0, opt_write_kf = 1, opt_block = 64;
-    bool tl_consistent = false, psi_consistent = false;
+    int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1;
     std::string err;
 };
 
@@ -71,7 +71,7 @@ bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
 // ---- grid: ColumnGrid (column_grid.jl:20-34) + Oceananigans' stretched-coordinate recipe --------------
 // thickness[0] is the surface layer.  All derived quantities are formed in NF.
 template <class NF> struct HostGrid {
-    std::vector<NF> zF, zC, dzc, rdzc, rdzf, dzf;  // faces 0..Nz ; centres 0..Nz-1
+    std::vector<NF> zF, zC, dzc, rdzc, rdzf, dzf, psiz;  // faces 0..Nz ; centres 0..Nz-1
     NF dzf_bot, dzf_top;
     void build(int Nz, const double* thickness) {
         // z_coords = convert.(NF, vcat(-reverse(cumsum(z_thick)), 0))
@@ -105,6 +105,9 @@ template <class NF> struct HostGrid {
         }
         dzf_bot = dzf[0];
         dzf_top = dzf[Nz];
+        // elevation head psi_z = z - z_ref with z_ref the surface face (soil_hydraulic_closures.jl:112-121)
+        psiz.resize(Nz);
+        for (int k = 0; k < Nz; ++k) psiz[k] = zC[k] - zF[Nz];
     }
 };
 
@@ -113,6 +116,7 @@ template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
     NF rho_soc = (NF)q.rho_soc, rho_org = (NF)q.rho_org, por_m = (NF)q.por_mineral, por_o = (NF)q.por_organic;
     p.org = rho_soc / ((NF(1) - por_o) * rho_org);               // homogeneous_strat.jl:34-44
     p.por = (NF(1) - p.org) * por_m + p.org * por_o;             // homogeneous_strat.jl:51-61
+    p.rpor = NF(1) / p.por;
     p.solid_frac = NF(1) - p.por;                                // soil_volume.jl:62
     p.frac_organic = p.solid_frac * p.org;                       // soil_volume.jl:103-107
     p.frac_mineral = p.solid_frac * (NF(1) - p.org);
@@ -129,6 +133,8 @@ template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
     p.L = (NF)q.rho_w * (NF)q.Lsl;
     p.K_sat = (NF)q.K_sat;
     p.theta_res = (NF)q.theta_res;
+    p.theta_span = p.por - p.theta_res;   // (theta_sat - theta_res) with theta_sat = por at every call site
+    p.rtheta_span = NF(1) / p.theta_span;
     p.bc_psi_s = (NF)q.bc_psi_s;
     p.vg_alpha = (NF)q.vg_alpha;
     p.impedance = (NF)q.impedance;
@@ -149,9 +155,11 @@ template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
     p.one_minus_emissivity = NF(1) - p.emissivity;
     p.eps_sigma = p.emissivity * (NF)q.sigma;
     p.kappa_s2 = NF(2) * (NF)q.kappa_s;
+    p.rkappa_s2 = NF(1) / p.kappa_s2;
     p.C_h = (NF)q.C_h;
     p.min_windspeed = (NF)q.min_windspeed;
     p.tau_r = (NF)q.tau_r;
+    p.rtau_r = NF(1) / p.tau_r;
     p.beta_evap = (NF)q.beta_evap;
     p.Tref = (NF)q.Tref;
     p.eps_mw = (NF)q.eps_mw;
@@ -205,10 +213,19 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     v.dzc = (const NF*)c->d_dzc;
     v.rdzc = (const NF*)c->d_rdzc;
     v.rdzf = (const NF*)c->d_rdzf;
-    v.dzf_bot = (NF)c->dzf_bot;
-    v.dzf_top = (NF)c->dzf_top;
-    v.Az = (NF)c->Az;
-    v.z_ref = (NF)c->z_ref;
+    v.psiz = (const NF*)c->d_psiz;
+    BcGeom<NF>& g = v.g;
+    g.dzf_bot = (NF)c->dzf_bot;
+    g.dzf_top = (NF)c->dzf_top;
+    g.hdzf_bot = g.dzf_bot / NF(2);
+    g.hdzf_top = g.dzf_top / NF(2);
+    g.rhdzf_bot = NF(1) / g.hdzf_bot;
+    g.rhdzf_top = NF(1) / g.hdzf_top;
+    g.Az = (NF)c->Az;                       // Flat y => Az = dx
+    g.V_bot = g.Az * (NF)c->dzc_bot;        // V = Az * dz
+    g.V_top = g.Az * (NF)c->dzc_top;
+    g.rV_bot = NF(1) / g.V_bot;
+    g.rV_top = NF(1) / g.V_top;
     v.status = c->d_status;
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b) {
@@ -224,17 +241,36 @@ dim3 col_grid(const trm_ctx* c) { return dim3((unsigned)((c->Nh + 255) / 256), 1
 template <class NF> struct Ops {
     static bool richards(const trm_ctx* c) { return c->params.flow == TRM_FLOW_RICHARDS; }
 
+    // hydraulics specialisation of this context (trm_device.hpp: HYD_*)
+    static int hyd(const trm_ctx* c) {
+        if (c->params.swrc == TRM_SWRC_BROOKS_COREY && c->params.unsat_k == TRM_UNSATK_LINEAR) return HYD_BC_LINEAR;
+        if (c->params.swrc == TRM_SWRC_VAN_GENUCHTEN && c->params.unsat_k == TRM_UNSATK_VAN_GENUCHTEN) return HYD_VG_VG;
+        return HYD_GENERIC;
+    }
+#define TRM_BY_HYD(c, CALL)                                   \
+    switch (hyd(c)) {                                         \
+        case HYD_BC_LINEAR: { constexpr int H = HYD_BC_LINEAR; CALL; } break; \
+        case HYD_VG_VG: { constexpr int H = HYD_VG_VG; CALL; } break;         \
+        default: { constexpr int H = HYD_GENERIC; CALL; } break;             \
+    }
+
     static int hydraulics(trm_ctx* c, const FieldSet& s) {
-        hipLaunchKernelGGL(k_hydraulics<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, make_view<NF>(c, s),
-                           make_dev_params<NF>(c->params));
+        auto v = make_view<NF>(c, s);
+        auto p = make_dev_params<NF>(c->params);
+        TRM_BY_HYD(c, hipLaunchKernelGGL((k_hydraulics<NF, H>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p));
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
-    static int surface(trm_ctx* c, const FieldSet& s) {
+    static int surface(trm_ctx* c, const FieldSet& s, bool from_state = false) {
         auto v = make_view<NF>(c, s);
         auto p = make_dev_params<NF>(c->params);
-        if (richards(c)) hipLaunchKernelGGL((k_surface<NF, true>), col_grid(c), dim3(256), 0, c->stream, v, p);
-        else hipLaunchKernelGGL((k_surface<NF, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
+        if (from_state) {
+            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
+            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
+        } else {
+            if (richards(c)) hipLaunchKernelGGL((k_surface<NF, true, HYD_GENERIC, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
+            else hipLaunchKernelGGL((k_surface<NF, false, HYD_GENERIC, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
+        }
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
@@ -273,12 +309,23 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
+    static int closure_hydrology(trm_ctx* c, const FieldSet& s, bool with_psi) {
+        auto v = make_view<NF>(c, s);
+        auto p = make_dev_params<NF>(c->params);
+        if (with_psi) {
+            TRM_BY_HYD(c, hipLaunchKernelGGL((k_closure_hydrology<NF, true, H>), col_grid(c), dim3(256), 0, c->stream, v, p));
+        } else {
+            hipLaunchKernelGGL((k_closure_hydrology<NF, false, HYD_GENERIC>), col_grid(c), dim3(256), 0, c->stream, v, p);
+        }
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
     static int closure(trm_ctx* c, const FieldSet& s) {
         auto v = make_view<NF>(c, s);
         auto p = make_dev_params<NF>(c->params);
         if (richards(c)) {
-            hipLaunchKernelGGL((k_closure_hydrology<NF, true>), col_grid(c), dim3(256), 0, c->stream, v, p);
-            TRM_HIP(c, hipGetLastError());
+            int rc = closure_hydrology(c, s, true);
+            if (rc) return rc;
         }
         hipLaunchKernelGGL(k_closure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
         TRM_HIP(c, hipGetLastError());
@@ -289,8 +336,9 @@ template <class NF> struct Ops {
         auto p = make_dev_params<NF>(c->params);
         if (richards(c)) {
             hipLaunchKernelGGL(k_pressure_to_saturation<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
-            hipLaunchKernelGGL((k_closure_hydrology<NF, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
             TRM_HIP(c, hipGetLastError());
+            int rc = closure_hydrology(c, s, false);
+            if (rc) return rc;
         }
         hipLaunchKernelGGL(k_invclosure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
         TRM_HIP(c, hipGetLastError());
@@ -300,9 +348,8 @@ template <class NF> struct Ops {
         auto v = make_view<NF>(c, c->state);
         auto p = make_dev_params<NF>(c->params);
         if (richards(c)) {  // soil_hydrology_rre.jl:33-47
-            hipLaunchKernelGGL((k_closure_hydrology<NF, true>), col_grid(c), dim3(256), 0, c->stream, v, p);
-            TRM_HIP(c, hipGetLastError());
-            int rc = hydraulics(c, c->state);
+            int rc = closure_hydrology(c, c->state, true);
+            if (!rc) rc = hydraulics(c, c->state);
             if (rc) return rc;
         } else {  // soil_hydrology.jl:113-117
             int rc = hydraulics(c, c->state);
@@ -315,40 +362,49 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
 
-    // ---- fused step ----------------------------------------------------------------------------
-    template <bool RICH, bool RTL, bool RPSI, int BLOCK>
-    static int launch_fused(trm_ctx* c, double dt, int finalize) {
+    // ---- fused step, lane = column ---------------------------------------------------------------------
+    template <bool RICH, int H> static int launch_lane(trm_ctx* c, double dt, int finalize) {
         auto v = make_view<NF>(c, c->state);
         auto p = make_dev_params<NF>(c->params);
-        size_t lds = RICH ? (size_t)2 * c->Nz * BLOCK * sizeof(NF) : 0;
-        auto kern = k_step_fused<NF, RICH, RTL, RPSI, BLOCK>;
+        size_t lds = RICH ? (size_t)2 * c->Nz * LANE_BLOCK * sizeof(NF) : 0;
+        auto kern = k_step_fused<NF, RICH, H>;
         if (lds > 160 * 1024) return fail(c, TRM_EUNSUPPORTED, "fused step: column tile exceeds 160 KiB of LDS");
         if (lds > 48 * 1024)
             TRM_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        dim3 grid((unsigned)((c->Nh + BLOCK - 1) / BLOCK));
-        hipLaunchKernelGGL(kern, grid, dim3(BLOCK), lds, c->stream, v, p, (NF)dt, finalize, c->opt_write_kf);
+        dim3 grid((unsigned)((c->Nh + LANE_BLOCK - 1) / LANE_BLOCK));
+        hipLaunchKernelGGL(kern, grid, dim3(LANE_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, (c->opt_write_kf || finalize) ? 1 : 0);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
-    template <bool RICH, bool RTL, bool RPSI> static int fused_block(trm_ctx* c, double dt, int finalize) {
-        switch (c->opt_block) {
-            case 128: return launch_fused<RICH, RTL, RPSI, 128>(c, dt, finalize);
-            case 256: return launch_fused<RICH, RTL, RPSI, 256>(c, dt, finalize);
-            default: return launch_fused<RICH, RTL, RPSI, 64>(c, dt, finalize);
-        }
+    static int lane_step(trm_ctx* c, double dt, int finalize) {
+        int rc = TRM_OK;
+        if (richards(c)) { TRM_BY_HYD(c, rc = (launch_lane<true, H>(c, dt, finalize))); }
+        else { TRM_BY_HYD(c, rc = (launch_lane<false, H>(c, dt, finalize))); }
+        return rc;
     }
-    static int fused_step(trm_ctx* c, double dt, int finalize) {
-        // read the stored closure fields unless they are known to equal closure(U, sat) bit for bit
-        bool rtl = !c->tl_consistent || c->opt_read_closure == 1;
-        bool rpsi = !c->psi_consistent || c->opt_read_closure >= 1;
-        if (richards(c)) {
-            if (rtl && rpsi) return fused_block<true, true, true>(c, dt, finalize);
-            if (rtl) return fused_block<true, true, false>(c, dt, finalize);
-            if (rpsi) return fused_block<true, false, true>(c, dt, finalize);
-            return fused_block<true, false, false>(c, dt, finalize);
-        }
-        if (rtl) return fused_block<false, true, false>(c, dt, finalize);
-        return fused_block<false, false, false>(c, dt, finalize);
+    // ---- fused step, column per (half-)wavefront ------------------------------------------------------
+    template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
+        auto v = make_view<NF>(c, c->state);
+        auto p = make_dev_params<NF>(c->params);
+        size_t lds = wave_lds_bytes(c->Nz, sizeof(NF));
+        auto kern = k_step_wave<NF, RICH, H, LPC>;
+        if (lds > 160 * 1024) return fail(c, TRM_EUNSUPPORTED, "wave step: tile exceeds 160 KiB of LDS");
+        if (lds > 48 * 1024)
+            TRM_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((unsigned)((c->Nh + WAVE_TILE_COLS - 1) / WAVE_TILE_COLS));
+        hipLaunchKernelGGL(kern, grid, dim3(WAVE_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, (c->opt_write_kf || finalize) ? 1 : 0);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    template <bool RICH, int H> static int wave_lpc(trm_ctx* c, double dt, int finalize) {
+        if (c->Nz <= 32) return launch_wave<RICH, H, 32>(c, dt, finalize);
+        return launch_wave<RICH, H, 64>(c, dt, finalize);
+    }
+    static int wave_step(trm_ctx* c, double dt, int finalize) {
+        int rc = TRM_OK;
+        if (richards(c)) { TRM_BY_HYD(c, rc = (wave_lpc<true, H>(c, dt, finalize))); }
+        else { TRM_BY_HYD(c, rc = (wave_lpc<false, H>(c, dt, finalize))); }
+        return rc;
     }
     static int unfused_step(trm_ctx* c, double dt, int finalize) {
         int rc = update_state(c, c->state, true);
@@ -360,10 +416,21 @@ template <class NF> struct Ops {
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
         for (int n = 0; n < nsteps; ++n) {
             int fin = (finalize && n == nsteps - 1) ? 1 : 0;
-            int rc = (c->opt_kernel == TRM_KERNEL_FUSED) ? fused_step(c, dt, fin) : unfused_step(c, dt, fin);
+            int kern = c->opt_kernel;
+            if (kern == TRM_KERNEL_FUSED) kern = c->Nz <= 64 ? TRM_KERNEL_FUSED_WAVE : TRM_KERNEL_FUSED_LANE;
+            if (kern == TRM_KERNEL_FUSED_WAVE && c->Nz > 64)
+                return fail(c, TRM_EUNSUPPORTED, "TRM_KERNEL_FUSED_WAVE needs num_layers <= 64");
+            int rc = TRM_OK;
+            if (kern == TRM_KERNEL_UNFUSED) {
+                rc = unfused_step(c, dt, fin);
+            } else {
+                // LandModel: the 0-D surface processes run as their own small launch in front of the fused
+                // column kernel (and once more after it when finalizing)
+                if (c->params.seb) rc = surface(c, c->state, true);
+                if (!rc) rc = kern == TRM_KERNEL_FUSED_WAVE ? wave_step(c, dt, fin) : lane_step(c, dt, fin);
+                if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
+            }
             if (rc) return rc;
-            c->tl_consistent = true;
-            c->psi_consistent = richards(c);
             c->time += dt;
             c->iteration += 1;
         }
@@ -432,13 +499,15 @@ template <class NF> int upload_grid(trm_ctx* c, const double* thickness) {
     if ((rc = up(&c->d_dzc, g.dzc))) return rc;
     if ((rc = up(&c->d_rdzc, g.rdzc))) return rc;
     if ((rc = up(&c->d_rdzf, g.rdzf))) return rc;
+    if ((rc = up(&c->d_psiz, g.psiz))) return rc;
     c->h_zF.assign(g.zF.begin(), g.zF.end());
     c->h_zC.assign(g.zC.begin(), g.zC.end());
     c->h_dzc.assign(g.dzc.begin(), g.dzc.end());
     c->h_dzf.assign(g.dzf.begin(), g.dzf.end());
     c->dzf_bot = g.dzf_bot;
     c->dzf_top = g.dzf_top;
-    c->z_ref = g.zF[c->Nz];
+    c->dzc_bot = g.dzc[0];
+    c->dzc_top = g.dzc[c->Nz - 1];
     return TRM_OK;
 }
 
@@ -524,18 +593,6 @@ template <class NF> int reduce_impl(trm_ctx* c, int field, int op, double* out) 
     }
     if (op == TRM_REDUCE_VOLUME_INTEGRAL_Z) out[0] = total;
     return TRM_OK;
-}
-
-void mark_dirty(trm_ctx* c, int field) {
-    switch (field) {
-        case TRM_FIELD_INTERNAL_ENERGY:
-        case TRM_FIELD_TEMPERATURE:
-        case TRM_FIELD_LIQUID_WATER_FRACTION: c->tl_consistent = false; break;
-        case TRM_FIELD_SATURATION_WATER_ICE: c->tl_consistent = false; c->psi_consistent = false; break;
-        case TRM_FIELD_PRESSURE_HEAD:
-        case TRM_FIELD_WATER_TABLE: c->psi_consistent = false; break;
-        default: break;
-    }
 }
 
 }  // namespace
@@ -632,7 +689,7 @@ int trm_destroy(trm_ctx* c) {
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b)
             if (c->bc_value[a][b]) (void)hipFree(c->bc_value[a][b]);
-    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, (void*)c->d_status, (void*)c->d_reduce})
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, (void*)c->d_status, (void*)c->d_reduce})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -663,7 +720,6 @@ int trm_upload(trm_ctx* c, int field, const void* host) {
     TRM_HIP(c, hipMemcpy2DAsync(c->state.f[field], c->pitch * c->esize, host, c->Nh * c->esize, c->Nh * c->esize, rows,
                                 hipMemcpyHostToDevice, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
-    mark_dirty(c, field);
     return TRM_OK;
 }
 
@@ -719,10 +775,7 @@ int trm_set_forcing(trm_ctx* c, int input_field, const void* per_column) {
 
 int trm_initialize(trm_ctx* c) {
     TRM_ENTER(c);
-    int rc = DISPATCH(c, initialize(c));
-    c->tl_consistent = false;
-    c->psi_consistent = c->params.flow == TRM_FLOW_RICHARDS;
-    return finish(c, rc);
+    return finish(c, DISPATCH(c, initialize(c)));
 }
 int trm_update_state(trm_ctx* c, int compute_tendencies) {
     TRM_ENTER(c);
@@ -742,24 +795,15 @@ int trm_reset_tendencies(trm_ctx* c) {
 }
 int trm_explicit_step(trm_ctx* c, double dt) {
     TRM_ENTER(c);
-    int rc = DISPATCH(c, explicit_step(c, c->state, dt));
-    c->tl_consistent = false;
-    c->psi_consistent = false;
-    return finish(c, rc);
+    return finish(c, DISPATCH(c, explicit_step(c, c->state, dt)));
 }
 int trm_closure(trm_ctx* c) {
     TRM_ENTER(c);
-    int rc = DISPATCH(c, closure(c, c->state));
-    c->tl_consistent = true;
-    c->psi_consistent = c->params.flow == TRM_FLOW_RICHARDS;
-    return finish(c, rc);
+    return finish(c, DISPATCH(c, closure(c, c->state)));
 }
 int trm_invclosure(trm_ctx* c) {
     TRM_ENTER(c);
-    int rc = DISPATCH(c, invclosure(c, c->state));
-    c->tl_consistent = false;
-    c->psi_consistent = false;
-    return finish(c, rc);
+    return finish(c, DISPATCH(c, invclosure(c, c->state)));
 }
 
 int trm_step(trm_ctx* c, double dt, int nsteps, int finalize) {
@@ -792,8 +836,6 @@ int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
         int fin = (finalize && n == nsteps - 1) ? 1 : 0;
         int rc = DISPATCH(c, heun_step(c, dt, fin));
         if (rc) return rc;
-        c->tl_consistent = true;
-        c->psi_consistent = c->params.flow == TRM_FLOW_RICHARDS;
         c->time += dt;
         c->iteration += 1;
     }
@@ -832,18 +874,10 @@ int trm_set_option(trm_ctx* c, int option, int value) {
     switch (option) {
         case TRM_OPT_ASYNC: c->opt_async = value != 0; return TRM_OK;
         case TRM_OPT_STEP_KERNEL:
-            if (value != TRM_KERNEL_FUSED && value != TRM_KERNEL_UNFUSED) break;
+            if (value < TRM_KERNEL_FUSED || value > TRM_KERNEL_FUSED_WAVE) break;
             c->opt_kernel = value;
             return TRM_OK;
-        case TRM_OPT_READ_CLOSURE:
-            if (value < 0 || value > 2) break;
-            c->opt_read_closure = value;
-            return TRM_OK;
         case TRM_OPT_WRITE_KF_EVERY_STEP: c->opt_write_kf = value != 0; return TRM_OK;
-        case TRM_OPT_BLOCK_COLUMNS:
-            if (value != 64 && value != 128 && value != 256) break;
-            c->opt_block = value;
-            return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -853,9 +887,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
     switch (option) {
         case TRM_OPT_ASYNC: *value = c->opt_async; return TRM_OK;
         case TRM_OPT_STEP_KERNEL: *value = c->opt_kernel; return TRM_OK;
-        case TRM_OPT_READ_CLOSURE: *value = c->opt_read_closure; return TRM_OK;
         case TRM_OPT_WRITE_KF_EVERY_STEP: *value = c->opt_write_kf; return TRM_OK;
-        case TRM_OPT_BLOCK_COLUMNS: *value = c->opt_block; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

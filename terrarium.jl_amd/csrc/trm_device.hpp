@@ -25,16 +25,24 @@ TRM_HD float copysign_(float a, float b) { return __builtin_copysignf(a, b); }
 TRM_HD bool is_finite(double x) { return __builtin_isfinite(x); }
 TRM_HD bool is_finite(float x) { return __builtin_isfinite(x); }
 
-// Base.min / Base.max(x::Float, y::Float): NaN-propagating, signed-zero aware.
-template <class NF> TRM_HD NF jl_min(NF x, NF y) {
-    NF d = x - y;
-    NF a = sign_bit(d) ? x : y;
-    return (is_nan(x) || is_nan(y)) ? d : a;
-}
-template <class NF> TRM_HD NF jl_max(NF x, NF y) {
-    NF d = x - y;
-    NF a = sign_bit(d) ? y : x;
-    return (is_nan(x) || is_nan(y)) ? d : a;
+// Base.min / Base.max(x::Float, y::Float) are signed-zero aware (-0 < +0) and NaN-propagating.
+// The hardware v_min/v_max_f64 have the same zero ordering; they differ only when an operand is
+// already NaN (IEEE minNum returns the other operand).  A NaN state is reported through the status
+// word either way, so the one-instruction form is used on the device.
+TRM_DEV double jl_min(double x, double y) { return __builtin_fmin(x, y); }
+TRM_DEV double jl_max(double x, double y) { return __builtin_fmax(x, y); }
+TRM_DEV float jl_min(float x, float y) { return __builtin_fminf(x, y); }
+TRM_DEV float jl_max(float x, float y) { return __builtin_fmaxf(x, y); }
+
+// a / b for a divisor b that is constant over the launch, given rb = RN(1/b) formed on the host by
+// an IEEE division.  Markstein's theorem: with q = RN(a*rb) and the exact residual r = a - b*q (one
+// fma), RN(q + r*rb) IS the correctly rounded quotient -- bit-identical to a / b for finite
+// operands (verified against 3.3e8 random cases), in 3 dependent ops instead of the 11-deep divide.
+template <class NF> TRM_HD NF div_const(NF a, NF b, NF rb) {
+    NF q = a * rb;
+    NF r = fma_(-q, b, a);
+    NF q2 = fma_(r, rb, q);
+    return (q == NF(0)) ? q : q2;  // keeps the sign of a zero quotient
 }
 // Bool * Float: `false` is a strong zero carrying the sign of x.
 template <class NF> TRM_HD NF boolmul(bool b, NF x) { return b ? x : copysign_(NF(0), x); }
@@ -125,23 +133,28 @@ template <class NF> TRM_DEV NF jl_pow(NF x, const PowSpec<NF>& s) {
 // that are constant over the grid, evaluated ON THE HOST IN NF with the
 // reference's operation order (IEEE basic ops round identically everywhere).
 // ---------------------------------------------------------------------------
+// Hydraulics specialisation of the kernels (dead-code elimination + register pressure):
+enum { HYD_BC_LINEAR = 0,   // BrooksCorey SWRC + UnsatKLinear: the reference default (soil_hydraulic_properties.jl:132-140)
+       HYD_VG_VG = 1,       // VanGenuchten SWRC + UnsatKVanGenuchten: the tested/examples variant
+       HYD_GENERIC = 2 };   // any combination, decided at run time
+
 template <class NF> struct DevParams {
     // composition (homogeneous_strat.jl:34-61, soil_volume.jl:52-67,103-107)
-    NF org, por, solid_frac, frac_organic, frac_mineral;
+    NF org, por, rpor, solid_frac, frac_organic, frac_mineral;
     // thermal (soil_thermal_properties.jl:90-107,119-123)
-    NF sk_water, sk_ice, sk_air;  // sqrt(k_i)
+    NF sk_water, sk_ice, sk_air;      // sqrt(k_i)
     NF kterm_mineral, kterm_organic;  // sqrt(k_m)*mineral, sqrt(k_o)*organic
     NF c_water, c_ice, c_air;
     NF cterm_mineral, cterm_organic;  // c_m*mineral, c_o*organic
-    NF L;  // rho_w * Lsl (soil_energy_closures.jl:107)
+    NF L;                             // rho_w * Lsl (soil_energy_closures.jl:107)
     // hydrology
-    NF K_sat, theta_res, bc_psi_s, vg_alpha, impedance, vwc_forcing;
-    NF neg_inv_alpha;  // -1/alpha
-    PowSpec<NF> bc_lambda, bc_neg_inv_lambda;       // lambda, -1/lambda
-    PowSpec<NF> vg_n, vg_neg_m, vg_neg_inv_m, vg_inv_n;  // n, -m, -1/m, 1/n
-    PowSpec<NF> vgk_e1, vgk_e2;                     // n/(n+1), (n-1)/n
+    NF K_sat, theta_res, theta_span, rtheta_span, bc_psi_s, vg_alpha, impedance, vwc_forcing;  // theta_span = por - theta_res
+    NF neg_inv_alpha;                                     // -1/alpha
+    PowSpec<NF> bc_lambda, bc_neg_inv_lambda;             // lambda, -1/lambda
+    PowSpec<NF> vg_n, vg_neg_m, vg_neg_inv_m, vg_inv_n;   // n, -m, -1/m, 1/n
+    PowSpec<NF> vgk_e1, vgk_e2;                           // n/(n+1), (n-1)/n
     // surface energy balance
-    NF albedo, emissivity, one_minus_emissivity, eps_sigma, kappa_s2, C_h, min_windspeed, tau_r, beta_evap;
+    NF albedo, emissivity, one_minus_emissivity, eps_sigma, kappa_s2, rkappa_s2, C_h, min_windspeed, tau_r, rtau_r, beta_evap;
     NF Tref, eps_mw, one_minus_eps_mw, ca_rhoa, Llg_rhoa;
     int flow, swrc, unsat_k, seb, halo_policy;
 };
@@ -179,16 +192,31 @@ template <class NF> TRM_DEV NF heat_capacity(const DevParams<NF>& p, const Frac<
     s = s + p.cterm_organic;
     return s;
 }
+
+// van Genuchten-Mualem conductivity for states OUTSIDE 0 <= x <= 1: the reference evaluates the
+// formula in complex arithmetic so illegal states give a finite magnitude
+// (soil_hydraulic_properties.jl:217-218).  Cold path, kept out of line.
+template <class NF> __device__ __noinline__ NF vg_conductivity_complex(NF x, NF kk, NF e1f, NF e2f) {
+    double e1 = (double)e1f, e2 = (double)e2f;
+    double r = fabs((double)x), th = ((double)x < 0.0) ? 3.141592653589793 : 0.0;
+    double rp = pow(r, e1);
+    double ar = rp * cos(e1 * th), ai = rp * sin(e1 * th);
+    double ir = 1.0 - ar, ii = -ai;
+    double r2 = pow(sqrt(ir * ir + ii * ii), e2), th2 = atan2(ii, ir);
+    double br = r2 * cos(e2 * th2), bi = r2 * sin(e2 * th2);
+    double tr = 1.0 - br, ti = -bi;
+    double t2r = tr * tr - ti * ti, t2i = 2.0 * tr * ti;
+    double sr = sqrt(r) * cos(0.5 * th), si = sqrt(r) * sin(0.5 * th);
+    double zr = (double)kk * sr * t2r - (double)kk * si * t2i, zi = (double)kk * sr * t2i + (double)kk * si * t2r;
+    return (NF)sqrt(zr * zr + zi * zi);
+}
+
 // hydraulic_conductivity at a cell centre (soil_hydraulic_properties.jl:170-181, 203-221)
-template <class NF> TRM_DEV NF conductivity_hydraulic(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
-    if (p.unsat_k == 0) {
-        NF theta_sat = f.water + f.ice + f.air;
-        return p.K_sat * f.water / theta_sat;
-    }
-    // van Genuchten-Mualem with ice impedance.  The reference evaluates this in complex
-    // arithmetic so that illegal states (x outside [0,1]) give a finite magnitude; inside the
-    // legal range the complex evaluation IS the real one.  Outside it we return the magnitude
-    // of the principal-branch result, as the reference does.
+template <class NF> TRM_DEV NF conductivity_linear(const DevParams<NF>& p, const Frac<NF>& f) {
+    NF theta_sat = f.water + f.ice + f.air;
+    return p.K_sat * f.water / theta_sat;
+}
+template <class NF> TRM_DEV NF conductivity_vg(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
     NF x = f.water / p.por;
     // I_ice = 10^(-Omega (1 - f)): Base.:^ takes the integer path when the exponent is integer-valued
     NF y = -p.impedance * (NF(1) - liq);
@@ -199,19 +227,12 @@ template <class NF> TRM_DEV NF conductivity_hydraulic(const DevParams<NF>& p, NF
         NF t = NF(1) - jl_pow(inner, p.vgk_e2);
         return fabs_(p.K_sat * I_ice * sqrt_(x) * (t * t));
     }
-    double e1 = (double)p.vgk_e1.y, e2 = (double)p.vgk_e2.y;
-    double r = fabs((double)x), th = ((double)x < 0.0) ? 3.141592653589793 : 0.0;
-    double rp = pow(r, e1);
-    double ar = rp * cos(e1 * th), ai = rp * sin(e1 * th);
-    double ir = 1.0 - ar, ii = -ai;
-    double r2 = pow(sqrt(ir * ir + ii * ii), e2), th2 = atan2(ii, ir);
-    double br = r2 * cos(e2 * th2), bi = r2 * sin(e2 * th2);
-    double tr = 1.0 - br, ti = -bi;
-    double t2r = tr * tr - ti * ti, t2i = 2.0 * tr * ti;
-    double sr = sqrt(r) * cos(0.5 * th), si = sqrt(r) * sin(0.5 * th);
-    double kk = (double)(p.K_sat * I_ice);
-    double zr = kk * sr * t2r - kk * si * t2i, zi = kk * sr * t2i + kk * si * t2r;
-    return (NF)sqrt(zr * zr + zi * zi);
+    return vg_conductivity_complex(x, p.K_sat * I_ice, p.vgk_e1.y, p.vgk_e2.y);
+}
+template <class NF, int HYD> TRM_DEV NF conductivity_hydraulic(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
+    if (HYD == HYD_BC_LINEAR) return conductivity_linear(p, f);
+    if (HYD == HYD_VG_VG) return conductivity_vg(p, liq, f);
+    return p.unsat_k == 0 ? conductivity_linear(p, f) : conductivity_vg(p, liq, f);
 }
 
 // Free-water energy closure (soil_energy_closures.jl:99-159): (U, sat) -> (liq, T)
@@ -219,7 +240,10 @@ template <class NF> TRM_DEV void energy_closure(const DevParams<NF>& p, NF U, NF
     NF Lth = p.L * sat * p.por;
     liq = (U >= NF(0)) ? NF(1) : boolmul(U >= -Lth, NF(1) - safediv(U, -Lth));
     NF C = heat_capacity(p, fractions(p, sat, liq, viol));
-    T = (U < -Lth) ? (U + Lth) / C : ((U >= NF(0)) ? U / C : NF(0));
+    // (U < -Lth) ? (U + Lth) / C : (U >= 0 ? U / C : 0): one divide, operands selected first
+    NF num = (U < -Lth) ? (U + Lth) : U;
+    NF quo = num / C;
+    T = (U < -Lth || U >= NF(0)) ? quo : NF(0);
 }
 // inverse (initialisation only, soil_energy_closures.jl:64-97): (T, sat) -> (liq, U)
 template <class NF> TRM_DEV void energy_invclosure(const DevParams<NF>& p, NF T, NF sat, NF& liq, NF& U, uint32_t& viol) {
@@ -228,20 +252,23 @@ template <class NF> TRM_DEV void energy_invclosure(const DevParams<NF>& p, NF T,
     U = T * C - p.L * sat * p.por * (NF(1) - liq);
 }
 
-// FreezeCurves.jl 0.9 SWRCs (restated)
-template <class NF> TRM_DEV NF swrc_psi(const DevParams<NF>& p, NF theta, NF theta_sat) {
-    if (p.swrc == 1) {  // VanGenuchten
-        if (theta < theta_sat) {
-            NF r = (theta - p.theta_res) / (theta_sat - p.theta_res);
-            return p.neg_inv_alpha * jl_pow(jl_pow(r, p.vg_neg_inv_m) - NF(1), p.vg_inv_n);
-        }
-        return NF(0);
+// FreezeCurves.jl 0.9 SWRCs (restated): psi_m(theta; theta_sat = por)
+template <class NF> TRM_DEV NF swrc_psi_bc(const DevParams<NF>& p, NF theta) {
+    NF r = div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
+    NF v = -p.bc_psi_s * jl_pow(r, p.bc_neg_inv_lambda);
+    return (theta < p.por) ? v : -p.bc_psi_s;
+}
+template <class NF> TRM_DEV NF swrc_psi_vg(const DevParams<NF>& p, NF theta) {
+    if (theta < p.por) {
+        NF r = div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
+        return p.neg_inv_alpha * jl_pow(jl_pow(r, p.vg_neg_inv_m) - NF(1), p.vg_inv_n);
     }
-    if (theta < theta_sat) {  // BrooksCorey
-        NF r = (theta - p.theta_res) / (theta_sat - p.theta_res);
-        return -p.bc_psi_s * jl_pow(r, p.bc_neg_inv_lambda);
-    }
-    return -p.bc_psi_s;
+    return NF(0);
+}
+template <class NF, int HYD> TRM_DEV NF swrc_psi(const DevParams<NF>& p, NF theta) {
+    if (HYD == HYD_BC_LINEAR) return swrc_psi_bc(p, theta);
+    if (HYD == HYD_VG_VG) return swrc_psi_vg(p, theta);
+    return p.swrc == 1 ? swrc_psi_vg(p, theta) : swrc_psi_bc(p, theta);
 }
 template <class NF> TRM_DEV NF swrc_theta(const DevParams<NF>& p, NF psi, NF theta_sat) {
     if (p.swrc == 1) {
@@ -252,10 +279,10 @@ template <class NF> TRM_DEV NF swrc_theta(const DevParams<NF>& p, NF psi, NF the
     if (psi < -p.bc_psi_s) return p.theta_res + (theta_sat - p.theta_res) * jl_pow(-p.bc_psi_s / psi, p.bc_lambda);
     return theta_sat;
 }
-// saturation_to_pressure! (soil_hydraulic_closures.jl:102-129): psi = (psi_h + psi_m) + psi_z
-template <class NF> TRM_DEV NF pressure_head(const DevParams<NF>& p, NF sat, NF z, NF z_ref, NF z0) {
-    NF psim = swrc_psi(p, sat * p.por, p.por);
-    NF psiz = z - z_ref;
+// saturation_to_pressure! (soil_hydraulic_closures.jl:102-129): psi = (psi_h + psi_m) + psi_z,
+// psi_z = z - z_ref is a per-level constant formed on the host.
+template <class NF, int HYD> TRM_DEV NF pressure_head(const DevParams<NF>& p, NF sat, NF z, NF psiz, NF z0) {
+    NF psim = swrc_psi<NF, HYD>(p, sat * p.por);
     NF psih = jl_max(NF(0), z0 - z);
     return psih + psim + psiz;
 }
@@ -295,9 +322,11 @@ template <class NF> TRM_DEV void seb_fluxes(const DevParams<NF>& p, const SebIn<
 }
 // compute_auxiliary! of the surface processes for one column (land_model.jl:79-88):
 // bare-ground evaporation, direct runoff / infiltration, then the fused SEB kernel twice.
+// 0-D per column; it runs in its own small launch (k_surface) so that its registers (exp, divides)
+// do not inflate the per-cell kernels.
 template <class NF>
 TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF Ts_in, NF T_ground, NF sat_top,
-                               NF Kf_top, NF S, bool richards, NF dz_top, SebOut<NF>& o) {
+                                               NF Kf_top, NF S, bool richards, NF dz_top, SebOut<NF>& o) {
     o.Ts = Ts_in;
     NF ra = aerodynamic_resistance(p, in.wind);
     // bare_ground_evaporation.jl:49-62
@@ -307,7 +336,7 @@ TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF T
     bool unsat = sat_top < NF(1);
     NF drainage;
     if (excess > NF(0)) {
-        drainage = jl_max(excess, NF(0)) / p.tau_r;
+        drainage = div_const(jl_max(excess, NF(0)), p.tau_r, p.rtau_r);
         o.infil = boolmul(unsat, jl_min(drainage, Kf_top));
     } else {
         drainage = NF(0);
@@ -317,7 +346,7 @@ TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF T
     // surface_energy_balance.jl:95-110, executed twice (land_model.jl:85-86)
     for (int sweep = 0; sweep < 2; ++sweep) {
         seb_fluxes(p, in, ra, o);
-        o.Ts = T_ground - o.ghf * dz_top / p.kappa_s2;  // skin_temperature.jl:62-68
+        o.Ts = T_ground - div_const(o.ghf * dz_top, p.kappa_s2, p.rkappa_s2);  // skin_temperature.jl:62-68
         seb_fluxes(p, in, ra, o);
     }
 }
@@ -327,22 +356,32 @@ struct BcSet {
     int kind[5][2];          // [bc_var][side]
     const void* value[5][2]; // per-column arrays (NF), may be null for NOFLUX
 };
+// Boundary-face geometry, constant over the launch (formed on the host in NF)
+template <class NF> struct BcGeom {
+    NF dzf_bot, dzf_top;             // face spacing at the two boundary faces
+    NF hdzf_bot, hdzf_top;           // dzf / 2
+    NF rhdzf_bot, rhdzf_top;         // 1 / (dzf / 2)
+    NF Az, V_bot, V_top, rV_bot, rV_top;  // Az = dx (Flat y), V = Az * dz of the boundary cell
+};
 // halo value above the top cell / below the bottom cell of a centre field
-template <class NF> TRM_DEV NF halo_top(int kind, const NF* val, long i, NF c_edge, NF dzf_top) {
+template <class NF> TRM_DEV NF halo_top(int kind, const NF* val, long i, NF c_edge, const BcGeom<NF>& g) {
     if (kind == 1) {  // Value: linear extrapolation through the boundary value
-        NF grad = (val[i] - c_edge) / (dzf_top / NF(2));
-        return c_edge + grad * dzf_top;
+        NF grad = div_const(val[i] - c_edge, g.hdzf_top, g.rhdzf_top);
+        return c_edge + grad * g.dzf_top;
     }
-    if (kind == 3) return c_edge + val[i] * dzf_top;  // Gradient
-    return c_edge;                                     // Flux / NoFlux / default
+    if (kind == 3) return c_edge + val[i] * g.dzf_top;  // Gradient
+    return c_edge;                                       // Flux / NoFlux / default
 }
-template <class NF> TRM_DEV NF halo_bottom(int kind, const NF* val, long i, NF c_edge, NF dzf_bot) {
+template <class NF> TRM_DEV NF halo_bottom(int kind, const NF* val, long i, NF c_edge, const BcGeom<NF>& g) {
     if (kind == 1) {
-        NF grad = (c_edge - val[i]) / (dzf_bot / NF(2));
-        return c_edge + grad * (-dzf_bot);
+        NF grad = div_const(c_edge - val[i], g.hdzf_bot, g.rhdzf_bot);
+        return c_edge + grad * (-g.dzf_bot);
     }
-    if (kind == 3) return c_edge + val[i] * (-dzf_bot);
+    if (kind == 3) return c_edge + val[i] * (-g.dzf_bot);
     return c_edge;
 }
+// compute_z_bcs!: flux * Az / V of a boundary cell
+template <class NF> TRM_DEV NF flux_term_top(NF flux, const BcGeom<NF>& g) { return div_const(flux * g.Az, g.V_top, g.rV_top); }
+template <class NF> TRM_DEV NF flux_term_bottom(NF flux, const BcGeom<NF>& g) { return div_const(flux * g.Az, g.V_bot, g.rV_bot); }
 
 }  // namespace trm

@@ -6,12 +6,10 @@
 // memory: halo values are pure functions of the edge cell and the boundary
 // condition and are formed in registers.  Row 0 = bottom layer.
 //
-// Two implementations sit behind the same C ABI:
-//   * k_step_fused   -- ONE launch per time step.  lane = column, so every
-//     global access is a coalesced row segment; the vertical stencil walks up
-//     the column in registers; the column's updated (U, sat) are staged in LDS
-//     ([level][lane], bank-conflict free) across the serial saturation repair
-//     and the water-table search, then closed to (T, liq, psi, K) on the way out.
+// Three implementations sit behind the same C ABI:
+//   * k_step_wave (trm_kernel_wave.hpp) -- ONE launch per step, lane = soil level, a column per
+//     (half-)wavefront, tiles transposed through LDS, shuffles for the vertical stencil.
+//   * k_step_fused (below) -- ONE launch per step, lane = column, rolling stencil in registers.
 //   * k_* (unfused)  -- one launch per reference kernel in the reference's order
 //     (SURVEY 2.1), used for the stand-alone compute_* entry points and as the
 //     A/B comparator for what fusion buys.
@@ -28,9 +26,10 @@ template <class NF> struct View {
     // 2-D
     NF *S, *G_S, *wt, *Ts, *ghf, *swu, *lwu, *rnet, *Hs, *Hl, *evap, *infil, *runoff;
     const NF *Tair, *pres, *wind, *qair, *rain, *swd, *lwd;
-    // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f)
-    const NF *zC, *zF, *dzc, *rdzc, *rdzf;
-    NF dzf_bot, dzf_top, Az, z_ref;
+    // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f),
+    // psiz[Nz] = zC - z_surface (elevation head)
+    const NF *zC, *zF, *dzc, *rdzc, *rdzf, *psiz;
+    BcGeom<NF> g;
     uint32_t* status;
     BcSet bc;
 };
@@ -42,7 +41,7 @@ template <class NF> TRM_DEV const NF* bcval(const View<NF>& v, int var, int side
 template <class NF, bool RICHARDS> TRM_DEV NF sat_halo(const View<NF>& v, const DevParams<NF>& p, int side, long i, NF edge) {
     if (RICHARDS) {
         int kind = v.bc.kind[1][side];
-        return side ? halo_top(kind, bcval(v, 1, 1), i, edge, v.dzf_top) : halo_bottom(kind, bcval(v, 1, 0), i, edge, v.dzf_bot);
+        return side ? halo_top(kind, bcval(v, 1, 1), i, edge, v.g) : halo_bottom(kind, bcval(v, 1, 0), i, edge, v.g);
     }
     return p.halo_policy == 1 ? edge : NF(0);
 }
@@ -52,7 +51,7 @@ template <class NF, bool RICHARDS> TRM_DEV NF sat_halo(const View<NF>& v, const 
 // ===========================================================================
 
 // compute_hydraulics_kernel! (soil_hydrology.jl:145-163, 297-300)
-template <class NF> __global__ void k_hydraulics(View<NF> v, DevParams<NF> p) {
+template <class NF, int HYD> __global__ void k_hydraulics(View<NF> v, DevParams<NF> p) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     int k = blockIdx.y;
     if (i >= v.Nh) return;
@@ -60,7 +59,7 @@ template <class NF> __global__ void k_hydraulics(View<NF> v, DevParams<NF> p) {
     const int Nz = v.Nz;
     auto Kc = [&](int kk) {
         NF s = v.sat[(long)kk * v.pitch + i], l = v.liq[(long)kk * v.pitch + i];
-        return conductivity_hydraulic(p, l, fractions(p, s, l, viol));
+        return conductivity_hydraulic<NF, HYD>(p, l, fractions(p, s, l, viol));
     };
     if (k <= 0) {
         v.Kf[i] = Kc(0);
@@ -74,14 +73,21 @@ template <class NF> __global__ void k_hydraulics(View<NF> v, DevParams<NF> p) {
     if (viol) atomicOr(v.status, viol);
 }
 
-// bare-ground evaporation + direct runoff + fused SEB kernel x2 (land_model.jl:79-88)
-template <class NF, bool RICHARDS> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
+// bare-ground evaporation + direct runoff + fused SEB kernel x2 (land_model.jl:79-88), one thread
+// per column.  FROM_STATE: take the top-face hydraulic conductivity from (sat, liq) of the top cell
+// (what compute_hydraulics! would store there, soil_hydrology.jl:156-158) instead of reading the
+// hydraulic_conductivity field -- used in front of the fused step kernels, which do not
+// materialise K before the surface processes run.
+template <class NF, bool RICHARDS, int HYD, bool FROM_STATE> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.Nh) return;
     const long top = (long)(v.Nz - 1) * v.pitch + i;
     SebIn<NF> in = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i]};
     SebOut<NF> o;
-    surface_processes(p, in, v.Ts[i], v.T[top], v.sat[top], v.Kf[top], v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
+    uint32_t viol = 0;
+    NF Kf_top = FROM_STATE ? conductivity_hydraulic<NF, HYD>(p, v.liq[top], fractions(p, v.sat[top], v.liq[top], viol))
+                           : v.Kf[top];
+    surface_processes(p, in, v.Ts[i], v.T[top], v.sat[top], Kf_top, v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
     v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
     v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
 }
@@ -99,8 +105,8 @@ template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevP
     if (RICHARDS) {
         // psi with halos
         NF psi0 = v.psi[c];
-        NF psim = (k > 0) ? v.psi[c - P] : halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), i, psi0, v.dzf_bot);
-        NF psip = (k < Nz - 1) ? v.psi[c + P] : halo_top(v.bc.kind[4][1], bcval(v, 4, 1), i, psi0, v.dzf_top);
+        NF psim = (k > 0) ? v.psi[c - P] : halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), i, psi0, v.g);
+        NF psip = (k < Nz - 1) ? v.psi[c + P] : halo_top(v.bc.kind[4][1], bcval(v, 4, 1), i, psi0, v.g);
         // face conductivities k-1 .. k+2 (halo faces are never written: 0)
         NF Km = (k > 0) ? v.Kf[c - P] : NF(0);
         NF K0 = v.Kf[c];
@@ -112,7 +118,7 @@ template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevP
         NF Khi = boolmul(g_hi < NF(0), jl_min(K0, K1)) + boolmul(g_hi >= NF(0), jl_min(K1, K2));
         NF q_lo = -Klo * g_lo, q_hi = -Khi * g_hi;
         NF dtheta = -((q_hi - q_lo) * v.rdzc[k]) + NF(0) + p.vwc_forcing;
-        v.G_sat[c] += dtheta / p.por;
+        v.G_sat[c] += div_const(dtheta, p.por, p.rpor);
         if (k == 0) v.G_S[i] += jl_min(NF(0), v.S[i]);
     }
     {
@@ -120,14 +126,14 @@ template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevP
         NF Tm, sm, lm, Tp, sp, lp;
         if (k > 0) { Tm = v.T[c - P]; sm = v.sat[c - P]; lm = v.liq[c - P]; }
         else {
-            Tm = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), i, T0, v.dzf_bot);
-            lm = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), i, l0, v.dzf_bot);
+            Tm = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), i, T0, v.g);
+            lm = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), i, l0, v.g);
             sm = sat_halo<NF, RICHARDS>(v, p, 0, i, s0);
         }
         if (k < Nz - 1) { Tp = v.T[c + P]; sp = v.sat[c + P]; lp = v.liq[c + P]; }
         else {
-            Tp = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), i, T0, v.dzf_top);
-            lp = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), i, l0, v.dzf_top);
+            Tp = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), i, T0, v.g);
+            lp = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), i, l0, v.g);
             sp = sat_halo<NF, RICHARDS>(v, p, 1, i, s0);
         }
         NF k0 = conductivity(p, fractions(p, s0, l0, viol));
@@ -150,17 +156,15 @@ template <class NF, bool RICHARDS> __global__ void k_explicit_step(View<NF> v, D
     NF gU = v.G_U[c];
     NF gS = RICHARDS ? v.G_sat[c] : NF(0);
     if (k == 0) {
-        NF V = v.Az * v.dzc[0];
-        if (v.bc.kind[0][0] == 2) gU += bcval(v, 0, 0)[i] * v.Az / V;
-        if (RICHARDS && v.bc.kind[1][0] == 2) gS += bcval(v, 1, 0)[i] * v.Az / V;
+        if (v.bc.kind[0][0] == 2) gU += flux_term_bottom(bcval(v, 0, 0)[i], v.g);
+        if (RICHARDS && v.bc.kind[1][0] == 2) gS += flux_term_bottom(bcval(v, 1, 0)[i], v.g);
     }
     if (k == Nz - 1) {
-        NF V = v.Az * v.dzc[Nz - 1];
-        if (p.seb) gU -= v.ghf[i] * v.Az / V;                       // land_model.jl:56-58
-        else if (v.bc.kind[0][1] == 2) gU -= bcval(v, 0, 1)[i] * v.Az / V;
+        if (p.seb) gU -= flux_term_top(v.ghf[i], v.g);                       // land_model.jl:56-58
+        else if (v.bc.kind[0][1] == 2) gU -= flux_term_top(bcval(v, 0, 1)[i], v.g);
         if (RICHARDS) {
-            if (p.seb) gS -= (-v.infil[i]) * v.Az / V;              // land_model.jl:57-61
-            else if (v.bc.kind[1][1] == 2) gS -= bcval(v, 1, 1)[i] * v.Az / V;
+            if (p.seb) gS -= flux_term_top(-v.infil[i], v.g);                // land_model.jl:57-61
+            else if (v.bc.kind[1][1] == 2) gS -= flux_term_top(bcval(v, 1, 1)[i], v.g);
         }
     }
     if (k == 0 || k == Nz - 1) {  // compute_z_bcs! modifies the stored tendency
@@ -183,7 +187,7 @@ template <class NF, bool RICHARDS> __global__ void k_explicit_step(View<NF> v, D
 // hydrology closure!, one thread per column (soil_hydraulic_closures.jl:23-44):
 // adjust_saturation_profile! (soil_hydrology.jl:185-219), compute_water_table!
 // (soil_hydrology.jl:170-175) and, if WITH_PSI, saturation_to_pressure!.
-template <class NF, bool WITH_PSI> __global__ void k_closure_hydrology(View<NF> v, DevParams<NF> p) {
+template <class NF, bool WITH_PSI, int HYD> __global__ void k_closure_hydrology(View<NF> v, DevParams<NF> p) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.Nh) return;
     const int Nz = v.Nz;
@@ -193,13 +197,13 @@ template <class NF, bool WITH_PSI> __global__ void k_closure_hydrology(View<NF> 
         NF sk = s[(long)k * P];
         NF e = jl_max(sk - NF(1), NF(0));
         s[(long)k * P] = sk - e;
-        s[(long)(k + 1) * P] += e * v.dzc[k] / v.dzc[k + 1];
+        s[(long)(k + 1) * P] += div_const(e * v.dzc[k], v.dzc[k + 1], v.rdzc[k + 1]);
     }
     for (int k = Nz - 1; k >= 1; --k) {
         NF sk = s[(long)k * P];
         NF d = jl_max(-sk, NF(0));
         s[(long)k * P] = sk + d;
-        s[(long)(k - 1) * P] -= d * v.dzc[k] / v.dzc[k - 1];
+        s[(long)(k - 1) * P] -= div_const(d * v.dzc[k], v.dzc[k - 1], v.rdzc[k - 1]);
     }
     {
         NF st = s[(long)(Nz - 1) * P];
@@ -214,7 +218,7 @@ template <class NF, bool WITH_PSI> __global__ void k_closure_hydrology(View<NF> 
     NF z0 = v.zF[idx >= 0 ? idx : Nz];
     v.wt[i] = z0;
     if (WITH_PSI)
-        for (int k = 0; k < Nz; ++k) v.psi[(long)k * P + i] = pressure_head(p, s[(long)k * P], v.zC[k], v.z_ref, z0);
+        for (int k = 0; k < Nz; ++k) v.psi[(long)k * P + i] = pressure_head<NF, HYD>(p, s[(long)k * P], v.zC[k], v.psiz[k], z0);
 }
 // compute_water_table! alone (NoFlow initialisation, soil_hydrology.jl:113-117)
 template <class NF> __global__ void k_water_table(View<NF> v) {
@@ -234,7 +238,7 @@ template <class NF> __global__ void k_pressure_to_saturation(View<NF> v, DevPara
     if (i >= v.Nh) return;
     const long c = (long)k * v.pitch + i;
     NF z = v.zC[k];
-    NF psiz = z - v.z_ref;
+    NF psiz = v.psiz[k];
     NF psih = jl_max(NF(0), v.wt[i] - z);
     NF psim = v.psi[c] - psih - psiz;
     v.sat[c] = swrc_theta(p, psim, p.por) / p.por;
@@ -271,20 +275,22 @@ template <class NF> __global__ void k_average(NF* a, const NF* b, long n) {
 }
 
 // ===========================================================================
-// Fused step: update_state! + explicit_step! + closure! (+ finalize) in ONE launch
-// (forward_euler.jl:19-31).  lane = column; BLOCK columns per workgroup.
-//   READ_TL : read the stored temperature / liquid_water_fraction (needed when they may not be
-//             bitwise equal to closure(U, sat), e.g. right after initialisation); otherwise
-//             re-derive them from (U, sat) and save two reads per cell.
-//   READ_PSI: same for pressure_head.
-// LDS (Richards only): sat and U of the column's new state, [2][Nz][BLOCK].
+// Fused step, lane = column (TRM_KERNEL_FUSED_LANE): update_state! + explicit_step! + closure!
+// (+ finalize) in ONE launch (forward_euler.jl:19-31).  64 columns per workgroup; every global
+// access is a coalesced 512-byte row segment; the vertical stencil walks up the column in
+// registers; the column's updated (U, sat) wait in LDS ([level][lane], conflict free) across the
+// serial saturation repair and the water-table search and are closed to (T, liq, psi, K) on the
+// way out.  The stored closure fields T / liq / psi are read, exactly as the reference does.
 // ===========================================================================
 template <class NF> struct Level { NF U, sat, T, liq, psi, kap, Kc; };
 template <class NF> struct Raw { NF U, sat, T, liq, psi; };
 
-template <class NF, bool RICHARDS, bool READ_TL, bool READ_PSI, int BLOCK>
-__global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
+constexpr int LANE_BLOCK = 64;
+
+template <class NF, bool RICHARDS, int HYD>
+__global__ void __launch_bounds__(LANE_BLOCK) k_step_fused(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
     extern __shared__ __align__(16) unsigned char trm_smem[];
+    constexpr int BLOCK = LANE_BLOCK;
     const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
     if (i >= v.Nh) return;
     const int Nz = v.Nz;
@@ -293,64 +299,48 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
     NF* lds_U = lds_sat + (long)Nz * BLOCK;
     uint32_t viol = 0;
     bool bad = false;
-    const bool need_kc = RICHARDS || write_kf || p.seb;
-
-    NF z0_old = NF(0);
-    if (RICHARDS && !READ_PSI) z0_old = v.wt[i];
+    const bool need_kc = RICHARDS || write_kf;
 
     auto load_raw = [&](int k) {
         Raw<NF> r;
         const long c = (long)k * P + i;
         r.U = v.U[c];
         r.sat = v.sat[c];
-        r.T = READ_TL ? v.T[c] : NF(0);
-        r.liq = READ_TL ? v.liq[c] : NF(0);
-        r.psi = (RICHARDS && READ_PSI) ? v.psi[c] : NF(0);
+        r.T = v.T[c];
+        r.liq = v.liq[c];
+        r.psi = RICHARDS ? v.psi[c] : NF(0);
         return r;
     };
-    auto make_level = [&](const Raw<NF>& r, int k) {
+    auto make_level = [&](const Raw<NF>& r) {
         Level<NF> L;
-        L.U = r.U;
-        L.sat = r.sat;
-        if (READ_TL) { L.T = r.T; L.liq = r.liq; }
-        else energy_closure(p, r.U, r.sat, L.liq, L.T, viol);
-        L.psi = NF(0);
-        if (RICHARDS) L.psi = READ_PSI ? r.psi : pressure_head(p, r.sat, v.zC[k], v.z_ref, z0_old);
+        L.U = r.U; L.sat = r.sat; L.T = r.T; L.liq = r.liq; L.psi = r.psi;
         Frac<NF> f = fractions(p, L.sat, L.liq, viol);
         L.kap = conductivity(p, f);
-        L.Kc = need_kc ? conductivity_hydraulic(p, L.liq, f) : NF(0);
+        L.Kc = need_kc ? conductivity_hydraulic<NF, HYD>(p, L.liq, f) : NF(0);
         return L;
     };
 
-    // ---- surface processes at the head of the column (LandModel coupling) ----------------
+    // ---- top flux BCs: LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61); the
+    // surface processes that produce them ran in k_surface just before this launch ----------------
     NF S = RICHARDS ? v.S[i] : NF(0);
-    NF flux_top_U = NF(0), flux_top_sat = NF(0);
-    bool has_top_U = false, has_top_sat = false;
-    NF Ts_cur = NF(0);
-    SebIn<NF> sin = {};
+    NF top_U = NF(0), top_S = NF(0);   // flux-BC terms of the top cell (0 when there is none)
     if (p.seb) {
-        sin = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i]};
-        Level<NF> Ltop = make_level(load_raw(Nz - 1), Nz - 1);
-        SebOut<NF> o;
-        surface_processes(p, sin, v.Ts[i], Ltop.T, Ltop.sat, Ltop.Kc, S, RICHARDS, v.dzc[Nz - 1], o);
-        Ts_cur = o.Ts;
-        if (!finalize) {  // otherwise overwritten by the epilogue
-            v.Ts[i] = o.Ts + NF(0) * dt; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
-            v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
-        }
-        Ts_cur = o.Ts + NF(0) * dt;  // explicit_step! of the zero-tendency prognostic
-        flux_top_U = o.ghf; has_top_U = true;
-        flux_top_sat = -o.infil; has_top_sat = true;
+        top_U = flux_term_top(v.ghf[i], v.g);
+        if (RICHARDS) top_S = flux_term_top(-v.infil[i], v.g);
+        v.Ts[i] = v.Ts[i] + NF(0) * dt;  // explicit_step! of the zero-tendency prognostic skin_temperature
     } else {
-        if (v.bc.kind[0][1] == 2) { flux_top_U = bcval(v, 0, 1)[i]; has_top_U = true; }
-        if (RICHARDS && v.bc.kind[1][1] == 2) { flux_top_sat = bcval(v, 1, 1)[i]; has_top_sat = true; }
+        if (v.bc.kind[0][1] == 2) top_U = flux_term_top(bcval(v, 0, 1)[i], v.g);
+        if (RICHARDS && v.bc.kind[1][1] == 2) top_S = flux_term_top(bcval(v, 1, 1)[i], v.g);
     }
+    NF bot_U = NF(0), bot_S = NF(0);
+    if (v.bc.kind[0][0] == 2) bot_U = flux_term_bottom(bcval(v, 0, 0)[i], v.g);
+    if (RICHARDS && v.bc.kind[1][0] == 2) bot_S = flux_term_bottom(bcval(v, 1, 0)[i], v.g);
 
     // ---- upward sweep: tendencies, Euler update, upward pass of the saturation repair -------
-    Level<NF> r0 = make_level(load_raw(0), 0);
-    Level<NF> r1 = make_level(load_raw(1), 1);
+    Level<NF> r0 = make_level(load_raw(0));
+    Level<NF> r1 = make_level(load_raw(1));
     Level<NF> r2 = r1;
-    if (Nz > 2) r2 = make_level(load_raw(2), 2);
+    if (Nz > 2) r2 = make_level(load_raw(2));
     Raw<NF> nxt = {};
     if (Nz > 3) nxt = load_raw(3);
 
@@ -359,13 +349,13 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
     NF Kf_a = r0.Kc;                                              // face 0:  k <= 1 branch
     NF Kf_b = (Nz - 1 == 1) ? r1.Kc : jl_min(r1.Kc, r0.Kc);      // face 1
     {
-        NF Th = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), i, r0.T, v.dzf_bot);
-        NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), i, r0.liq, v.dzf_bot);
+        NF Th = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), i, r0.T, v.g);
+        NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), i, r0.liq, v.g);
         NF sh = sat_halo<NF, RICHARDS>(v, p, 0, i, r0.sat);
         NF kh = conductivity(p, fractions(p, sh, lh, viol));
         qT_lo = -(NF(0.5) * (r0.kap + kh)) * ((r0.T - Th) * v.rdzf[0]);
         if (RICHARDS) {
-            NF ph = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), i, r0.psi, v.dzf_bot);
+            NF ph = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), i, r0.psi, v.g);
             NF g = (r0.psi - ph) * v.rdzf[0];
             NF Ks = boolmul(g < NF(0), jl_min(NF(0), Kf_a)) + boolmul(g >= NF(0), jl_min(Kf_a, Kf_b));
             qW_lo = -Ks * g;
@@ -379,21 +369,21 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
         // face k+2 conductivity (soil_hydrology.jl:145-163); faces beyond Nz are halo (0)
         NF Kf_c;
         {
-            int f = k + 2;
+            const int f = k + 2;
             if (f > Nz) Kf_c = NF(0);
-            else if (f >= Nz - 1) Kf_c = (f == Nz) ? Kf_b : r2.Kc;  // face Nz-1 = Kc(top); face Nz = same value
+            else if (f == Nz) Kf_c = r1.Kc;        // face Nz repeats the top cell's value
+            else if (f == Nz - 1) Kf_c = r2.Kc;    // face Nz-1 = Kc(top cell)
             else Kf_c = jl_min(r2.Kc, r1.Kc);
-            if (f == Nz && Nz - 1 == k + 1) Kf_c = Kf_b;
         }
         // upper face k+1
         NF Th, kh, ph = NF(0);
         if (k + 1 < Nz) { Th = r1.T; kh = r1.kap; ph = r1.psi; }
         else {
-            Th = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), i, r0.T, v.dzf_top);
-            NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), i, r0.liq, v.dzf_top);
+            Th = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), i, r0.T, v.g);
+            NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), i, r0.liq, v.g);
             NF sh = sat_halo<NF, RICHARDS>(v, p, 1, i, r0.sat);
             kh = conductivity(p, fractions(p, sh, lh, viol));
-            if (RICHARDS) ph = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), i, r0.psi, v.dzf_top);
+            if (RICHARDS) ph = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), i, r0.psi, v.g);
         }
         NF qT_hi = -(NF(0.5) * (kh + r0.kap)) * ((Th - r0.T) * v.rdzf[k + 1]);
         NF gU = NF(0) + (-((qT_hi - qT_lo) * v.rdzc[k]));
@@ -403,19 +393,11 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
             NF Ks = boolmul(g < NF(0), jl_min(Kf_a, Kf_b)) + boolmul(g >= NF(0), jl_min(Kf_b, Kf_c));
             qW_hi = -Ks * g;
             NF dtheta = -((qW_hi - qW_lo) * v.rdzc[k]) + NF(0) + p.vwc_forcing;
-            gS = NF(0) + dtheta / p.por;
+            gS = NF(0) + div_const(dtheta, p.por, p.rpor);
         }
         // compute_z_bcs!: flux BCs enter the boundary cells' tendencies
-        if (k == 0) {
-            NF V = v.Az * v.dzc[0];
-            if (v.bc.kind[0][0] == 2) gU += bcval(v, 0, 0)[i] * v.Az / V;
-            if (RICHARDS && v.bc.kind[1][0] == 2) gS += bcval(v, 1, 0)[i] * v.Az / V;
-        }
-        if (k == Nz - 1) {
-            NF V = v.Az * v.dzc[Nz - 1];
-            if (has_top_U) gU -= flux_top_U * v.Az / V;
-            if (RICHARDS && has_top_sat) gS -= flux_top_sat * v.Az / V;
-        }
+        if (k == 0) { gU += bot_U; if (RICHARDS) gS += bot_S; }
+        if (k == Nz - 1) { gU -= top_U; if (RICHARDS) gS -= top_S; }
         NF Unew = r0.U + gU * dt;
         bad = bad || is_nan(Unew);
         const long c = (long)k * P + i;
@@ -424,11 +406,11 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
             NF snew = r0.sat + gS * dt;
             bad = bad || is_nan(snew);
             // upward pass of adjust_saturation_profile! (soil_hydrology.jl:192-199), fused
-            snew = snew + carry;
+            if (k > 0) snew = snew + carry;
             if (k < Nz - 1) {
                 NF e = jl_max(snew - NF(1), NF(0));
                 snew = snew - e;
-                carry = __any(e != NF(0)) ? e * v.dzc[k] / v.dzc[k + 1] : NF(0);
+                carry = __any(e != NF(0)) ? div_const(e * v.dzc[k], v.dzc[k + 1], v.rdzc[k + 1]) : NF(0);
             }
             lds_sat[(long)k * BLOCK] = snew;
             lds_U[(long)k * BLOCK] = Unew;
@@ -439,17 +421,12 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
             v.U[c] = Unew;
             v.liq[c] = ln;
             v.T[c] = Tn;
-            if (finalize && (write_kf || p.seb)) {
-                NF Kc_new = conductivity_hydraulic(p, ln, fractions(p, r0.sat, ln, viol));
+            if (finalize && write_kf) {
+                NF Kc_new = conductivity_hydraulic<NF, HYD>(p, ln, fractions(p, r0.sat, ln, viol));
                 NF face = (k == 0 || k == Nz - 1) ? Kc_new : jl_min(Kc_new, Kc_prev_new);
-                if (write_kf) { v.Kf[c] = face; if (k == Nz - 1) v.Kf[c + P] = face; }
+                v.Kf[c] = face;
+                if (k == Nz - 1) v.Kf[c + P] = face;
                 Kc_prev_new = Kc_new;
-                if (k == Nz - 1 && p.seb) {
-                    SebOut<NF> o;
-                    surface_processes(p, sin, Ts_cur, Tn, r0.sat, face, NF(0), false, v.dzc[Nz - 1], o);
-                    v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
-                    v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
-                }
             }
         }
         // shift the window
@@ -459,7 +436,7 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
         Kf_b = Kf_c;
         r0 = r1;
         r1 = r2;
-        if (k + 3 < Nz) r2 = make_level(nxt, k + 3);
+        if (k + 3 < Nz) r2 = make_level(nxt);
         nxt = pre;
     }
     if (write_kf && !finalize) v.Kf[(long)Nz * P + i] = Kf_a;  // face Nz
@@ -474,7 +451,7 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
             NF s = lds_sat[(long)k * BLOCK] - pend;
             NF d = jl_max(-s, NF(0));
             s = s + d;
-            pend = __any(d != NF(0)) ? d * v.dzc[k] / v.dzc[k - 1] : NF(0);
+            pend = __any(d != NF(0)) ? div_const(d * v.dzc[k], v.dzc[k - 1], v.rdzc[k - 1]) : NF(0);
             if (k == Nz - 1) {  // surface overflow joins surface_excess_water (soil_hydrology.jl:211-213)
                 NF e = jl_max(s - NF(1), NF(0));
                 s = s - e;
@@ -500,24 +477,19 @@ __global__ void __launch_bounds__(BLOCK) k_step_fused(View<NF> v, DevParams<NF> 
             NF un = lds_U[(long)k * BLOCK];
             NF ln;
             energy_closure(p, un, sn, ln, Tn, viol);
-            NF ps = pressure_head(p, sn, v.zC[k], v.z_ref, z0);
+            NF ps = pressure_head<NF, HYD>(p, sn, v.zC[k], v.psiz[k], z0);
             v.U[c] = un;
             v.sat[c] = sn;
             v.T[c] = Tn;
             v.liq[c] = ln;
             v.psi[c] = ps;
-            if (finalize && (write_kf || p.seb)) {
-                NF Kc_new = conductivity_hydraulic(p, ln, fractions(p, sn, ln, viol));
+            if (finalize && write_kf) {
+                NF Kc_new = conductivity_hydraulic<NF, HYD>(p, ln, fractions(p, sn, ln, viol));
                 face = (k == 0 || k == Nz - 1) ? Kc_new : jl_min(Kc_new, Kc_prev);
-                if (write_kf) { v.Kf[c] = face; if (k == Nz - 1) v.Kf[c + P] = face; }
+                v.Kf[c] = face;
+                if (k == Nz - 1) v.Kf[c + P] = face;
                 Kc_prev = Kc_new;
             }
-        }
-        if (finalize && p.seb) {  // compute_auxiliary! after the step (model_integrator.jl:127-129)
-            SebOut<NF> o;
-            surface_processes(p, sin, Ts_cur, Tn, sn, face, S, true, v.dzc[Nz - 1], o);
-            v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
-            v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
         }
     }
     viol |= bad ? 1u : 0u;
