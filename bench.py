@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--kernel", default="fused", choices=["fused", "fused_wave", "fused_lane", "unfused"])
+    ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--skip-kf", action="store_true", help="store hydraulic_conductivity only when finalizing")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -152,7 +152,7 @@ def main():
                    "status_flags": int(nan_flag)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": {"fused": "k_step_wave", "fused_wave": "k_step_wave", "fused_lane": "k_step_fused"}.get(args.kernel, "unfused sequence"),
+                     "kernel": "k_step_wave" if args.kernel == "fused" else "unfused sequence",
                      "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_column_step": bytes_per_colstep},
     }
 

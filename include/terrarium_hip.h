@@ -116,11 +116,10 @@ enum {
                                     /* 0: only by launches that finalize (it is never an input of a step)   */
 };
 enum {
-    TRM_KERNEL_FUSED = 0,       /* one launch per step; picks FUSED_WAVE when Nz <= 64, else FUSED_LANE       */
-    TRM_KERNEL_UNFUSED = 1,     /* one launch per reference kernel, in the reference's order (A/B comparator) */
-    TRM_KERNEL_FUSED_LANE = 2,  /* fused, lane = column: rolling vertical stencil in registers, (U, sat) in LDS */
-    TRM_KERNEL_FUSED_WAVE = 3   /* fused, lane = level: column per (half-)wavefront, tile transposed through  */
-                                /* LDS, wavefront shuffles for the vertical stencil (Nz <= 64)                */
+    TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
+                                /* wavefront shuffles for the vertical stencil (Nz <= 64; deeper columns take */
+                                /* the unfused kernels)                                                       */
+    TRM_KERNEL_UNFUSED = 1      /* one launch per reference kernel, in the reference's order (A/B comparator) */
 };
 
 /* ---- grid: ColumnGrid(arch, NF, vert, num_columns)  src/grids/column_grid.jl:20-34 */
@@ -175,7 +174,10 @@ int trm_get_grid(const trm_ctx* ctx, double* z_faces, double* z_centers, double*
 /* set!(field, array) / Array(interior(field)) */
 int trm_upload(trm_ctx* ctx, int field, const void* host);
 int trm_download(trm_ctx* ctx, int field, void* host);
-/* Device address and row pitch (in elements) of a field, for zero-copy consumers on the same device. */
+/* Device address of a field, for zero-copy consumers on the same device.  The device layout is z-fastest:
+ * element (column i, level k) of a 3-D field is at dev[i * pitch_elems + k] (pitch 32 for Nz <= 32, 64 for
+ * Nz <= 64); 2-D fields are dev[i] (pitch 1).  The top face of hydraulic_conductivity is not part of this
+ * buffer (use trm_download). */
 int trm_field_device_ptr(trm_ctx* ctx, int field, void** dev, int64_t* pitch_elems);
 
 /* Field boundary conditions (src/models/soil/soil_model_bcs.jl, src/boundary_conditions.jl:25-28):

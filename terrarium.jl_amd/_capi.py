@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libterrarium_hip.so")
+LIB_PATH = os.environ.get("TRM_LIBRARY", os.path.join(_HERE, "libterrarium_hip.so"))  # override: kernel-tuning experiments
 
 TRM_F64, TRM_F32 = 0, 1
 FLOW = dict(noflow=0, richards=1)
@@ -28,7 +28,7 @@ INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidi
                 "surface_shortwave_down", "surface_longwave_down")
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2)
-KERNEL = dict(fused=0, unfused=1, fused_lane=2, fused_wave=3)
+KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
 
 EXPORTS = (

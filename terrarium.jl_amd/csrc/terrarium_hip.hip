@@ -2,7 +2,6 @@
 // (include/terrarium_hip.h).  gfx950 only; no CPU fallback.
 #include "../../include/terrarium_hip.h"
 #include "trm_kernels.hpp"
-#include "trm_kernel_wave.hpp"
 
 #include <cmath>
 #include <cstdio>
@@ -16,14 +15,15 @@ namespace {
 
 struct FieldSet {
     void* f[TRM_FIELD_COUNT];
+    void* kf_top;  // top face (face Nz) of the hydraulic_conductivity Face field, [Nh]
 };
 
 }  // namespace
 
 struct trm_ctx {
     int precision = TRM_F64;
-    long Nh = 0, pitch = 0;
-    int Nz = 0, device = 0;
+    long Nh = 0;
+    int Nz = 0, Nzp = 0, device = 0;  // Nzp: level pitch of the z-fastest device layout
     size_t esize = 8;
     trm_params params;
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -67,6 +67,9 @@ long field_rows(const trm_ctx* c, int field) {
     return 1;
 }
 bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
+bool is_3d(int field) { return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE; }
+// elements of the device buffer of a field: [Nh][Nzp] for 3-D fields, [Nh] for 2-D fields
+size_t field_elems(const trm_ctx* c, int field) { return is_3d(field) ? (size_t)c->Nh * c->Nzp : (size_t)c->Nh; }
 
 // ---- grid: ColumnGrid (column_grid.jl:20-34) + Oceananigans' stretched-coordinate recipe --------------
 // thickness[0] is the surface layer.  All derived quantities are formed in NF.
@@ -177,8 +180,8 @@ template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
 template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     View<NF> v;
     v.Nh = c->Nh;
-    v.pitch = c->pitch;
     v.Nz = c->Nz;
+    v.Nzp = c->Nzp;
     auto F = [&](int id) { return (NF*)s.f[id]; };
     v.U = F(TRM_FIELD_INTERNAL_ENERGY);
     v.sat = F(TRM_FIELD_SATURATION_WATER_ICE);
@@ -186,6 +189,7 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     v.liq = F(TRM_FIELD_LIQUID_WATER_FRACTION);
     v.psi = F(TRM_FIELD_PRESSURE_HEAD);
     v.Kf = F(TRM_FIELD_HYDRAULIC_CONDUCTIVITY);
+    v.Kf_top = (NF*)s.kf_top;
     v.G_U = F(TRM_FIELD_TEND_INTERNAL_ENERGY);
     v.G_sat = F(TRM_FIELD_TEND_SATURATION_WATER_ICE);
     v.S = F(TRM_FIELD_SURFACE_EXCESS_WATER);
@@ -235,8 +239,13 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     return v;
 }
 
-dim3 cell_grid(const trm_ctx* c, long rows) { return dim3((unsigned)((c->Nh + 255) / 256), (unsigned)rows, 1); }
+dim3 cell_grid(const trm_ctx* c, long /*rows*/ = 0) { return dim3((unsigned)(((size_t)c->Nh * c->Nzp + 255) / 256), 1, 1); }
 dim3 col_grid(const trm_ctx* c) { return dim3((unsigned)((c->Nh + 255) / 256), 1, 1); }
+// lane = level kernels: one column per LPC lanes, 4 waves per workgroup
+dim3 wave_grid(const trm_ctx* c, int lpc) {
+    long waves = (c->Nh + (64 / lpc) - 1) / (64 / lpc);
+    return dim3((unsigned)((waves + 3) / 4), 1, 1);
+}
 
 template <class NF> struct Ops {
     static bool richards(const trm_ctx* c) { return c->params.flow == TRM_FLOW_RICHARDS; }
@@ -289,10 +298,8 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     static int reset_tendencies(trm_ctx* c, const FieldSet& s) {
-        size_t row = (size_t)c->pitch * sizeof(NF);
-        TRM_HIP(c, hipMemsetAsync(s.f[TRM_FIELD_TEND_INTERNAL_ENERGY], 0, row * c->Nz, c->stream));
-        TRM_HIP(c, hipMemsetAsync(s.f[TRM_FIELD_TEND_SATURATION_WATER_ICE], 0, row * c->Nz, c->stream));
-        TRM_HIP(c, hipMemsetAsync(s.f[TRM_FIELD_TEND_SURFACE_EXCESS_WATER], 0, row, c->stream));
+        for (int f : {TRM_FIELD_TEND_INTERNAL_ENERGY, TRM_FIELD_TEND_SATURATION_WATER_ICE, TRM_FIELD_TEND_SURFACE_EXCESS_WATER})
+            TRM_HIP(c, hipMemsetAsync(s.f[f], 0, field_elems(c, f) * sizeof(NF), c->stream));
         return TRM_OK;
     }
     static int update_state(trm_ctx* c, const FieldSet& s, bool tendencies) {
@@ -309,13 +316,21 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
-    static int closure_hydrology(trm_ctx* c, const FieldSet& s, bool with_psi) {
+    // hydrology closure: adjust_saturation_profile! + compute_water_table! (+ saturation_to_pressure!)
+    template <bool PSI, bool ADJ, int H> static void launch_closure_hydrology(trm_ctx* c, View<NF> v, DevParams<NF> p) {
+        if (c->Nz <= 32) hipLaunchKernelGGL((k_closure_hydrology_wave<NF, PSI, H, ADJ, 32>), wave_grid(c, 32), dim3(256), 0, c->stream, v, p);
+        else if (c->Nz <= 64) hipLaunchKernelGGL((k_closure_hydrology_wave<NF, PSI, H, ADJ, 64>), wave_grid(c, 64), dim3(256), 0, c->stream, v, p);
+        else hipLaunchKernelGGL((k_closure_hydrology_seq<NF, PSI, H, ADJ>), col_grid(c), dim3(256), 0, c->stream, v, p);
+    }
+    static int closure_hydrology(trm_ctx* c, const FieldSet& s, bool with_psi, bool with_adjust = true) {
         auto v = make_view<NF>(c, s);
         auto p = make_dev_params<NF>(c->params);
         if (with_psi) {
-            TRM_BY_HYD(c, hipLaunchKernelGGL((k_closure_hydrology<NF, true, H>), col_grid(c), dim3(256), 0, c->stream, v, p));
+            TRM_BY_HYD(c, (launch_closure_hydrology<true, true, H>(c, v, p)));
+        } else if (with_adjust) {
+            launch_closure_hydrology<false, true, HYD_GENERIC>(c, v, p);
         } else {
-            hipLaunchKernelGGL((k_closure_hydrology<NF, false, HYD_GENERIC>), col_grid(c), dim3(256), 0, c->stream, v, p);
+            launch_closure_hydrology<false, false, HYD_GENERIC>(c, v, p);
         }
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
@@ -354,45 +369,20 @@ template <class NF> struct Ops {
         } else {  // soil_hydrology.jl:113-117
             int rc = hydraulics(c, c->state);
             if (rc) return rc;
-            hipLaunchKernelGGL(k_water_table<NF>, col_grid(c), dim3(256), 0, c->stream, v);
-            TRM_HIP(c, hipGetLastError());
+            rc = closure_hydrology(c, c->state, false, false);  // compute_water_table! only
+            if (rc) return rc;
         }
         hipLaunchKernelGGL(k_invclosure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);  // soil_energy.jl:64-77
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
 
-    // ---- fused step, lane = column ---------------------------------------------------------------------
-    template <bool RICH, int H> static int launch_lane(trm_ctx* c, double dt, int finalize) {
-        auto v = make_view<NF>(c, c->state);
-        auto p = make_dev_params<NF>(c->params);
-        size_t lds = RICH ? (size_t)2 * c->Nz * LANE_BLOCK * sizeof(NF) : 0;
-        auto kern = k_step_fused<NF, RICH, H>;
-        if (lds > 160 * 1024) return fail(c, TRM_EUNSUPPORTED, "fused step: column tile exceeds 160 KiB of LDS");
-        if (lds > 48 * 1024)
-            TRM_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        dim3 grid((unsigned)((c->Nh + LANE_BLOCK - 1) / LANE_BLOCK));
-        hipLaunchKernelGGL(kern, grid, dim3(LANE_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, (c->opt_write_kf || finalize) ? 1 : 0);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    static int lane_step(trm_ctx* c, double dt, int finalize) {
-        int rc = TRM_OK;
-        if (richards(c)) { TRM_BY_HYD(c, rc = (launch_lane<true, H>(c, dt, finalize))); }
-        else { TRM_BY_HYD(c, rc = (launch_lane<false, H>(c, dt, finalize))); }
-        return rc;
-    }
     // ---- fused step, column per (half-)wavefront ------------------------------------------------------
     template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
         auto v = make_view<NF>(c, c->state);
         auto p = make_dev_params<NF>(c->params);
-        size_t lds = wave_lds_bytes(c->Nz, sizeof(NF));
-        auto kern = k_step_wave<NF, RICH, H, LPC>;
-        if (lds > 160 * 1024) return fail(c, TRM_EUNSUPPORTED, "wave step: tile exceeds 160 KiB of LDS");
-        if (lds > 48 * 1024)
-            TRM_HIP(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        dim3 grid((unsigned)((c->Nh + WAVE_TILE_COLS - 1) / WAVE_TILE_COLS));
-        hipLaunchKernelGGL(kern, grid, dim3(WAVE_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, (c->opt_write_kf || finalize) ? 1 : 0);
+        hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), wave_grid(c, LPC), dim3(256), 0, c->stream, v, p, (NF)dt, finalize,
+                           (c->opt_write_kf || finalize) ? 1 : 0);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
@@ -416,18 +406,17 @@ template <class NF> struct Ops {
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
         for (int n = 0; n < nsteps; ++n) {
             int fin = (finalize && n == nsteps - 1) ? 1 : 0;
-            int kern = c->opt_kernel;
-            if (kern == TRM_KERNEL_FUSED) kern = c->Nz <= 64 ? TRM_KERNEL_FUSED_WAVE : TRM_KERNEL_FUSED_LANE;
-            if (kern == TRM_KERNEL_FUSED_WAVE && c->Nz > 64)
-                return fail(c, TRM_EUNSUPPORTED, "TRM_KERNEL_FUSED_WAVE needs num_layers <= 64");
+            // the fused kernel maps one soil level to one lane: columns deeper than 64 levels take the
+            // reference-order kernels
+            const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
             int rc = TRM_OK;
-            if (kern == TRM_KERNEL_UNFUSED) {
+            if (!fused) {
                 rc = unfused_step(c, dt, fin);
             } else {
                 // LandModel: the 0-D surface processes run as their own small launch in front of the fused
                 // column kernel (and once more after it when finalizing)
                 if (c->params.seb) rc = surface(c, c->state, true);
-                if (!rc) rc = kern == TRM_KERNEL_FUSED_WAVE ? wave_step(c, dt, fin) : lane_step(c, dt, fin);
+                if (!rc) rc = wave_step(c, dt, fin);
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             }
             if (rc) return rc;
@@ -439,14 +428,13 @@ template <class NF> struct Ops {
 
     // ---- Heun (heun.jl:37-71), reference-order kernels on a second copy of the state -----------------
     static int copy_state_to_stage(trm_ctx* c) {
-        for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
-            size_t bytes = (size_t)field_rows(c, f) * c->pitch * sizeof(NF);
-            TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], bytes, hipMemcpyDeviceToDevice, c->stream));
-        }
+        for (int f = 0; f < TRM_FIELD_COUNT; ++f)
+            TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], field_elems(c, f) * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+        TRM_HIP(c, hipMemcpyAsync(c->stage.kf_top, c->state.kf_top, (size_t)c->Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
         return TRM_OK;
     }
     static int average(trm_ctx* c, int field) {
-        long n = field_rows(c, field) * c->pitch;
+        long n = (long)field_elems(c, field);
         hipLaunchKernelGGL(k_average<NF>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
                            (NF*)c->state.f[field], (const NF*)c->stage.f[field], n);
         TRM_HIP(c, hipGetLastError());
@@ -478,10 +466,12 @@ int finish(trm_ctx* c, int rc) {
 
 int alloc_fields(trm_ctx* c, FieldSet& s) {
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
-        size_t bytes = (size_t)field_rows(c, f) * c->pitch * c->esize;
+        size_t bytes = field_elems(c, f) * c->esize;
         TRM_HIP(c, hipMalloc(&s.f[f], bytes));
         TRM_HIP(c, hipMemset(s.f[f], 0, bytes));
     }
+    TRM_HIP(c, hipMalloc(&s.kf_top, (size_t)c->Nh * c->esize));
+    TRM_HIP(c, hipMemset(s.kf_top, 0, (size_t)c->Nh * c->esize));
     return TRM_OK;
 }
 
@@ -512,18 +502,21 @@ template <class NF> int upload_grid(trm_ctx* c, const double* thickness) {
 }
 
 template <class NF> int fill_row(trm_ctx* c, int field, double value) {
-    std::vector<NF> h((size_t)c->pitch, (NF)value);
+    std::vector<NF> h((size_t)c->Nh, (NF)value);
     TRM_HIP(c, hipMemcpy(c->state.f[field], h.data(), h.size() * sizeof(NF), hipMemcpyHostToDevice));
     return TRM_OK;
 }
 
 // ---- reductions ------------------------------------------------------------------------------------
-template <class NF, int OP> __global__ void k_reduce_rows(const NF* f, long Nh, long pitch, const NF* weight, double* partial) {
-    // grid = (nblocks, rows); each block folds a strided slice of one row in double
+// element (row r, column i) of a field sits at base[r] + i * stride[r]
+template <class NF, int OP> __global__ void k_reduce_rows(const NF* f3, const NF* ftop, long Nh, int Nzp, int Nz, int is3d,
+                                                          const NF* weight, double* partial) {
     const int row = blockIdx.y;
+    const NF* base = is3d ? ((row == Nz && ftop) ? ftop : f3 + row) : f3;
+    const long stride = (is3d && !(row == Nz && ftop)) ? Nzp : 1;
     double acc = (OP == TRM_REDUCE_MIN) ? HUGE_VAL : (OP == TRM_REDUCE_MAX ? -HUGE_VAL : 0.0);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < Nh; i += (long)gridDim.x * blockDim.x) {
-        double x = (double)f[(long)row * pitch + i];
+        double x = (double)base[i * stride];
         if (OP == TRM_REDUCE_SUM) acc += x;
         else if (OP == TRM_REDUCE_VOLUME_INTEGRAL_Z) acc += x * (double)weight[row];
         else if (OP == TRM_REDUCE_MIN) acc = fmin(acc, x);
@@ -560,19 +553,23 @@ template <class NF> int reduce_impl(trm_ctx* c, int field, int op, double* out) 
         c->reduce_cap = need;
     }
     const NF* f = (const NF*)c->state.f[field];
+    const NF* ftop = field == TRM_FIELD_HYDRAULIC_CONDUCTIVITY ? (const NF*)c->state.kf_top : nullptr;
     const NF* w = (const NF*)c->d_dzc;
+    const int d3 = is_3d(field) ? 1 : 0;
     dim3 grid(nblocks, (unsigned)rows);
+#define TRM_REDUCE_LAUNCH(OP) hipLaunchKernelGGL((k_reduce_rows<NF, OP>), grid, dim3(256), 0, c->stream, f, ftop, c->Nh, c->Nzp, c->Nz, d3, w, c->d_reduce)
     switch (op) {
-        case TRM_REDUCE_SUM: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_SUM>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
-        case TRM_REDUCE_MIN: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_MIN>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
-        case TRM_REDUCE_MAX: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_MAX>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
-        case TRM_REDUCE_HASNAN: hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_HASNAN>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce); break;
+        case TRM_REDUCE_SUM: TRM_REDUCE_LAUNCH(TRM_REDUCE_SUM); break;
+        case TRM_REDUCE_MIN: TRM_REDUCE_LAUNCH(TRM_REDUCE_MIN); break;
+        case TRM_REDUCE_MAX: TRM_REDUCE_LAUNCH(TRM_REDUCE_MAX); break;
+        case TRM_REDUCE_HASNAN: TRM_REDUCE_LAUNCH(TRM_REDUCE_HASNAN); break;
         case TRM_REDUCE_VOLUME_INTEGRAL_Z:
             if (rows != c->Nz) return fail(c, TRM_EINVAL, "VOLUME_INTEGRAL_Z needs a cell-centred 3-D field");
-            hipLaunchKernelGGL((k_reduce_rows<NF, TRM_REDUCE_VOLUME_INTEGRAL_Z>), grid, dim3(256), 0, c->stream, f, c->Nh, c->pitch, w, c->d_reduce);
+            TRM_REDUCE_LAUNCH(TRM_REDUCE_VOLUME_INTEGRAL_Z);
             break;
         default: return fail(c, TRM_EINVAL, "unknown reduction op");
     }
+#undef TRM_REDUCE_LAUNCH
     TRM_HIP(c, hipGetLastError());
     std::vector<double> part(need);
     TRM_HIP(c, hipMemcpyAsync(part.data(), c->d_reduce, need * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -592,6 +589,41 @@ template <class NF> int reduce_impl(trm_ctx* c, int field, int op, double* out) 
         else out[r] = acc;
     }
     if (op == TRM_REDUCE_VOLUME_INTEGRAL_Z) out[0] = total;
+    return TRM_OK;
+}
+
+// Host arrays are the reference's interior layout [rows][Nh] (column fastest); the device keeps 3-D fields
+// z-fastest [Nh][Nzp].  The transposition happens here, on the host, off the hot path.
+template <class NF> int upload_impl(trm_ctx* c, int field, const NF* host) {
+    const long Nh = c->Nh, rows = field_rows(c, field);
+    if (!is_3d(field)) {
+        TRM_HIP(c, hipMemcpyAsync(c->state.f[field], host, (size_t)Nh * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        return TRM_OK;
+    }
+    std::vector<NF> tmp((size_t)Nh * c->Nzp, NF(0));
+    for (int k = 0; k < c->Nz; ++k)
+        for (long i = 0; i < Nh; ++i) tmp[(size_t)i * c->Nzp + k] = host[(size_t)k * Nh + i];
+    TRM_HIP(c, hipMemcpyAsync(c->state.f[field], tmp.data(), tmp.size() * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+    if (rows == c->Nz + 1)  // Face field: the top face lives in its own [Nh] buffer
+        TRM_HIP(c, hipMemcpyAsync(c->state.kf_top, host + (size_t)c->Nz * Nh, (size_t)Nh * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+template <class NF> int download_impl(trm_ctx* c, int field, NF* host) {
+    const long Nh = c->Nh, rows = field_rows(c, field);
+    if (!is_3d(field)) {
+        TRM_HIP(c, hipMemcpyAsync(host, c->state.f[field], (size_t)Nh * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        return TRM_OK;
+    }
+    std::vector<NF> tmp((size_t)Nh * c->Nzp);
+    TRM_HIP(c, hipMemcpyAsync(tmp.data(), c->state.f[field], tmp.size() * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
+    if (rows == c->Nz + 1)
+        TRM_HIP(c, hipMemcpyAsync(host + (size_t)c->Nz * Nh, c->state.kf_top, (size_t)Nh * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < c->Nz; ++k)
+        for (long i = 0; i < Nh; ++i) host[(size_t)k * Nh + i] = tmp[(size_t)i * c->Nzp + k];
     return TRM_OK;
 }
 
@@ -639,8 +671,8 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     c->precision = g->precision;
     c->esize = g->precision == TRM_F64 ? 8 : 4;
     c->Nh = (long)g->num_columns;
-    c->pitch = ((c->Nh + 63) / 64) * 64;
     c->Nz = g->num_layers;
+    c->Nzp = c->Nz <= 32 ? 32 : (c->Nz <= 64 ? 64 : ((c->Nz + 31) / 32) * 32);
     c->device = g->device;
     c->params = *p;
     c->Az = g->dx > 0 ? g->dx : 1.0 / (double)c->Nh;
@@ -686,6 +718,8 @@ int trm_destroy(trm_ctx* c) {
         if (c->state.f[f]) (void)hipFree(c->state.f[f]);
         if (c->stage.f[f]) (void)hipFree(c->stage.f[f]);
     }
+    if (c->state.kf_top) (void)hipFree(c->state.kf_top);
+    if (c->stage.kf_top) (void)hipFree(c->stage.kf_top);
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b)
             if (c->bc_value[a][b]) (void)hipFree(c->bc_value[a][b]);
@@ -716,27 +750,19 @@ int trm_get_grid(const trm_ctx* c, double* z_faces, double* z_centers, double* d
 int trm_upload(trm_ctx* c, int field, const void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_upload: bad argument");
     TRM_HIP(c, hipSetDevice(c->device));
-    long rows = field_rows(c, field);
-    TRM_HIP(c, hipMemcpy2DAsync(c->state.f[field], c->pitch * c->esize, host, c->Nh * c->esize, c->Nh * c->esize, rows,
-                                hipMemcpyHostToDevice, c->stream));
-    TRM_HIP(c, hipStreamSynchronize(c->stream));
-    return TRM_OK;
+    return c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
 }
 
 int trm_download(trm_ctx* c, int field, void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_download: bad argument");
     TRM_HIP(c, hipSetDevice(c->device));
-    long rows = field_rows(c, field);
-    TRM_HIP(c, hipMemcpy2DAsync(host, c->Nh * c->esize, c->state.f[field], c->pitch * c->esize, c->Nh * c->esize, rows,
-                                hipMemcpyDeviceToHost, c->stream));
-    TRM_HIP(c, hipStreamSynchronize(c->stream));
-    return TRM_OK;
+    return c->precision == TRM_F64 ? download_impl<double>(c, field, (double*)host) : download_impl<float>(c, field, (float*)host);
 }
 
 int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems) {
     if (!c || !dev || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_field_device_ptr: bad argument");
     *dev = c->state.f[field];
-    if (pitch_elems) *pitch_elems = c->pitch;
+    if (pitch_elems) *pitch_elems = is_3d(field) ? c->Nzp : 1;
     return TRM_OK;
 }
 
@@ -747,7 +773,7 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
     TRM_HIP(c, hipStreamSynchronize(c->stream));
     c->bc_kind[var][side] = kind;
     if (kind == TRM_BC_NOFLUX) return TRM_OK;
-    size_t bytes = (size_t)c->pitch * c->esize;
+    size_t bytes = (size_t)c->Nh * c->esize;
     if (!c->bc_value[var][side]) TRM_HIP(c, hipMalloc(&c->bc_value[var][side], bytes));
     std::vector<unsigned char> h(bytes, 0);
     if (values) {

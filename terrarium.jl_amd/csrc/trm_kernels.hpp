@@ -1,29 +1,40 @@
 // trm_kernels.hpp -- HIP kernels of the SoilModel / LandModel(bare ground) step.
 //
-// Data layout (HBM): one plain buffer per variable, [rows][pitch] with the
-// column index fastest (SoA over columns); pitch = Nh rounded up to 64 so every
-// level of every wavefront starts on a 512-byte (f64) boundary.  No halos in
-// memory: halo values are pure functions of the edge cell and the boundary
-// condition and are formed in registers.  Row 0 = bottom layer.
+// Data layout (HBM): one plain buffer per variable (SoA), stored COLUMN-MAJOR IN z:
+// element (column i, level k) lives at i * Nzp + k, k = 0 the bottom layer, Nzp the level
+// pitch (32 for Nz <= 32, 64 for Nz <= 64, otherwise Nz rounded up to 32).  A soil column is
+// therefore one contiguous, 256/512-byte aligned segment, and the mapping "lane = soil level"
+// reads and writes it with a single fully coalesced access per variable: two columns per
+// wavefront at Nz <= 32, one at Nz <= 64.  No halos in memory: halo values are pure functions
+// of the edge cell and the boundary condition and are formed in registers.  The C ABI
+// (trm_upload / trm_download) converts from / to the reference's x-fastest interior layout.
 //
-// Three implementations sit behind the same C ABI:
-//   * k_step_wave (trm_kernel_wave.hpp) -- ONE launch per step, lane = soil level, a column per
-//     (half-)wavefront, tiles transposed through LDS, shuffles for the vertical stencil.
-//   * k_step_fused (below) -- ONE launch per step, lane = column, rolling stencil in registers.
-//   * k_* (unfused)  -- one launch per reference kernel in the reference's order
-//     (SURVEY 2.1), used for the stand-alone compute_* entry points and as the
-//     A/B comparator for what fusion buys.
+// Why lane = level: the global N145 grid has only 56 951 columns.  One lane per column gives
+// 890 wavefronts for 1024 SIMDs, and the step is bound by dependent fp64 arithmetic (about
+// 300 instructions and 6 divides per cell), not by HBM: measured 64 us per step with a rolling
+// register stencil.  Spreading the vertical axis over the lanes gives 28 000+ independent
+// waves, the vertical stencil becomes wavefront shuffles, the water table a ballot, and the
+// sequential saturation repair a ballot-guarded lane-serial loop.  (An intermediate version kept
+// the x-fastest layout and transposed 32-column tiles through LDS: 57-82 us, limited by the
+// load -> barrier -> compute -> barrier -> store phases at one workgroup per CU.  See DESIGN.md.)
+//
+// Two implementations sit behind the same C ABI:
+//   * k_step_wave -- ONE launch per time step (update_state! + explicit_step! + closure!).
+//   * k_* (unfused) -- one launch per reference kernel in the reference's order:
+//     the stand-alone compute_* / closure entry points, Heun, Nz > 64, and the A/B comparator
+//     for what fusion buys.
 #pragma once
 #include "trm_device.hpp"
 
 namespace trm {
 
 template <class NF> struct View {
-    long Nh, pitch;
-    int Nz;
-    // 3-D
+    long Nh;
+    int Nz, Nzp;
+    // 3-D, [Nh][Nzp]
     NF *U, *sat, *T, *liq, *psi, *Kf, *G_U, *G_sat;
-    // 2-D
+    // 2-D, [Nh]
+    NF *Kf_top;  // hydraulic conductivity of the top face (face Nz)
     NF *S, *G_S, *wt, *Ts, *ghf, *swu, *lwu, *rnet, *Hs, *Hl, *evap, *infil, *runoff;
     const NF *Tair, *pres, *wind, *qair, *rain, *swd, *lwd;
     // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f),
@@ -46,29 +57,35 @@ template <class NF, bool RICHARDS> TRM_DEV NF sat_halo(const View<NF>& v, const 
     return p.halo_policy == 1 ? edge : NF(0);
 }
 
+// cell index of the one-thread-per-cell kernels (level fastest => coalesced)
+#define TRM_CELL_INDEX(v)                                                  \
+    const long gid__ = (long)blockIdx.x * blockDim.x + threadIdx.x;       \
+    const long i = gid__ / (v).Nzp;                                        \
+    const int k = (int)(gid__ % (v).Nzp);                                  \
+    if (i >= (v).Nh || k >= (v).Nz) return;                                \
+    const long c = gid__;
+
 // ===========================================================================
-// Unfused kernels: one per reference kernel (grid = (ceil(Nh/256), rows))
+// Unfused kernels: one per reference kernel
 // ===========================================================================
 
 // compute_hydraulics_kernel! (soil_hydrology.jl:145-163, 297-300)
 template <class NF, int HYD> __global__ void k_hydraulics(View<NF> v, DevParams<NF> p) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (i >= v.Nh) return;
+    TRM_CELL_INDEX(v);
     uint32_t viol = 0;
     const int Nz = v.Nz;
-    auto Kc = [&](int kk) {
-        NF s = v.sat[(long)kk * v.pitch + i], l = v.liq[(long)kk * v.pitch + i];
+    auto Kc = [&](long cc) {
+        NF s = v.sat[cc], l = v.liq[cc];
         return conductivity_hydraulic<NF, HYD>(p, l, fractions(p, s, l, viol));
     };
     if (k <= 0) {
-        v.Kf[i] = Kc(0);
+        v.Kf[c] = Kc(c);
     } else if (k >= Nz - 1) {
-        NF val = Kc(Nz - 1);
-        v.Kf[(long)k * v.pitch + i] = val;
-        v.Kf[(long)(k + 1) * v.pitch + i] = val;
+        NF val = Kc(c);
+        v.Kf[c] = val;
+        v.Kf_top[i] = val;
     } else {
-        v.Kf[(long)k * v.pitch + i] = jl_min(Kc(k), Kc(k - 1));
+        v.Kf[c] = jl_min(Kc(c), Kc(c - 1));
     }
     if (viol) atomicOr(v.status, viol);
 }
@@ -76,12 +93,12 @@ template <class NF, int HYD> __global__ void k_hydraulics(View<NF> v, DevParams<
 // bare-ground evaporation + direct runoff + fused SEB kernel x2 (land_model.jl:79-88), one thread
 // per column.  FROM_STATE: take the top-face hydraulic conductivity from (sat, liq) of the top cell
 // (what compute_hydraulics! would store there, soil_hydrology.jl:156-158) instead of reading the
-// hydraulic_conductivity field -- used in front of the fused step kernels, which do not
+// hydraulic_conductivity field -- used in front of the fused step kernel, which does not
 // materialise K before the surface processes run.
 template <class NF, bool RICHARDS, int HYD, bool FROM_STATE> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.Nh) return;
-    const long top = (long)(v.Nz - 1) * v.pitch + i;
+    const long top = i * v.Nzp + (v.Nz - 1);
     SebIn<NF> in = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i]};
     SebOut<NF> o;
     uint32_t viol = 0;
@@ -95,23 +112,16 @@ template <class NF, bool RICHARDS, int HYD, bool FROM_STATE> __global__ void k_s
 // compute_tendencies_kernel! for SoilHydrology{RichardsEq} (soil_hydrology_rre.jl:150-162) and
 // SoilEnergyBalance (soil_energy.jl:153-156), hydrology first (soil_coupled.jl:80-90).
 template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevParams<NF> p) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (i >= v.Nh) return;
+    TRM_CELL_INDEX(v);
     const int Nz = v.Nz;
-    const long P = v.pitch;
     uint32_t viol = 0;
-    const long c = (long)k * P + i;
     if (RICHARDS) {
-        // psi with halos
         NF psi0 = v.psi[c];
-        NF psim = (k > 0) ? v.psi[c - P] : halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), i, psi0, v.g);
-        NF psip = (k < Nz - 1) ? v.psi[c + P] : halo_top(v.bc.kind[4][1], bcval(v, 4, 1), i, psi0, v.g);
-        // face conductivities k-1 .. k+2 (halo faces are never written: 0)
-        NF Km = (k > 0) ? v.Kf[c - P] : NF(0);
-        NF K0 = v.Kf[c];
-        NF K1 = v.Kf[c + P];
-        NF K2 = (k + 2 <= Nz) ? v.Kf[c + 2 * P] : NF(0);
+        NF psim = (k > 0) ? v.psi[c - 1] : halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), i, psi0, v.g);
+        NF psip = (k < Nz - 1) ? v.psi[c + 1] : halo_top(v.bc.kind[4][1], bcval(v, 4, 1), i, psi0, v.g);
+        // face conductivities k-1 .. k+2 (halo faces are never written: 0; face Nz lives in Kf_top)
+        auto face = [&](int f) { return f < 0 || f > Nz ? NF(0) : (f == Nz ? v.Kf_top[i] : v.Kf[i * v.Nzp + f]); };
+        NF Km = face(k - 1), K0 = face(k), K1 = face(k + 1), K2 = face(k + 2);
         NF g_lo = (psi0 - psim) * v.rdzf[k];
         NF g_hi = (psip - psi0) * v.rdzf[k + 1];
         NF Klo = boolmul(g_lo < NF(0), jl_min(Km, K0)) + boolmul(g_lo >= NF(0), jl_min(K0, K1));
@@ -124,13 +134,13 @@ template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevP
     {
         NF T0 = v.T[c], s0 = v.sat[c], l0 = v.liq[c];
         NF Tm, sm, lm, Tp, sp, lp;
-        if (k > 0) { Tm = v.T[c - P]; sm = v.sat[c - P]; lm = v.liq[c - P]; }
+        if (k > 0) { Tm = v.T[c - 1]; sm = v.sat[c - 1]; lm = v.liq[c - 1]; }
         else {
             Tm = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), i, T0, v.g);
             lm = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), i, l0, v.g);
             sm = sat_halo<NF, RICHARDS>(v, p, 0, i, s0);
         }
-        if (k < Nz - 1) { Tp = v.T[c + P]; sp = v.sat[c + P]; lp = v.liq[c + P]; }
+        if (k < Nz - 1) { Tp = v.T[c + 1]; sp = v.sat[c + 1]; lp = v.liq[c + 1]; }
         else {
             Tp = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), i, T0, v.g);
             lp = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), i, l0, v.g);
@@ -148,11 +158,8 @@ template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevP
 
 // compute_z_bcs! + explicit_step_*_kernel! (abstract_timestepper.jl:65-141)
 template <class NF, bool RICHARDS> __global__ void k_explicit_step(View<NF> v, DevParams<NF> p, NF dt) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (i >= v.Nh) return;
+    TRM_CELL_INDEX(v);
     const int Nz = v.Nz;
-    const long c = (long)k * v.pitch + i;
     NF gU = v.G_U[c];
     NF gS = RICHARDS ? v.G_sat[c] : NF(0);
     if (k == 0) {
@@ -184,59 +191,9 @@ template <class NF, bool RICHARDS> __global__ void k_explicit_step(View<NF> v, D
     if (bad) atomicOr(v.status, 1u);
 }
 
-// hydrology closure!, one thread per column (soil_hydraulic_closures.jl:23-44):
-// adjust_saturation_profile! (soil_hydrology.jl:185-219), compute_water_table!
-// (soil_hydrology.jl:170-175) and, if WITH_PSI, saturation_to_pressure!.
-template <class NF, bool WITH_PSI, int HYD> __global__ void k_closure_hydrology(View<NF> v, DevParams<NF> p) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= v.Nh) return;
-    const int Nz = v.Nz;
-    const long P = v.pitch;
-    NF* s = v.sat + i;
-    for (int k = 0; k <= Nz - 2; ++k) {
-        NF sk = s[(long)k * P];
-        NF e = jl_max(sk - NF(1), NF(0));
-        s[(long)k * P] = sk - e;
-        s[(long)(k + 1) * P] += div_const(e * v.dzc[k], v.dzc[k + 1], v.rdzc[k + 1]);
-    }
-    for (int k = Nz - 1; k >= 1; --k) {
-        NF sk = s[(long)k * P];
-        NF d = jl_max(-sk, NF(0));
-        s[(long)k * P] = sk + d;
-        s[(long)(k - 1) * P] -= div_const(d * v.dzc[k], v.dzc[k - 1], v.rdzc[k - 1]);
-    }
-    {
-        NF st = s[(long)(Nz - 1) * P];
-        NF e = jl_max(st - NF(1), NF(0));
-        s[(long)(Nz - 1) * P] = st - e;
-        v.S[i] += e * v.dzc[Nz - 1];
-        s[0] = jl_max(s[0], NF(0));
-    }
-    int idx = -1;
-    for (int k = 0; k < Nz; ++k)
-        if (idx < 0 && s[(long)k * P] < NF(1)) idx = k;
-    NF z0 = v.zF[idx >= 0 ? idx : Nz];
-    v.wt[i] = z0;
-    if (WITH_PSI)
-        for (int k = 0; k < Nz; ++k) v.psi[(long)k * P + i] = pressure_head<NF, HYD>(p, s[(long)k * P], v.zC[k], v.psiz[k], z0);
-}
-// compute_water_table! alone (NoFlow initialisation, soil_hydrology.jl:113-117)
-template <class NF> __global__ void k_water_table(View<NF> v) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= v.Nh) return;
-    int idx = -1;
-    for (int k = 0; k < v.Nz; ++k)
-        if (idx < 0 && v.sat[(long)k * v.pitch + i] < NF(1)) idx = k;
-    // the reference scan also visits the (never filled => 0) halo above the top cell, which
-    // maps to the same surface node as "not found"
-    v.wt[i] = v.zF[idx >= 0 ? idx : v.Nz];
-}
 // pressure_to_saturation_kernel! (soil_hydraulic_closures.jl:74-100)
 template <class NF> __global__ void k_pressure_to_saturation(View<NF> v, DevParams<NF> p) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (i >= v.Nh) return;
-    const long c = (long)k * v.pitch + i;
+    TRM_CELL_INDEX(v);
     NF z = v.zC[k];
     NF psiz = v.psiz[k];
     NF psih = jl_max(NF(0), v.wt[i] - z);
@@ -245,10 +202,8 @@ template <class NF> __global__ void k_pressure_to_saturation(View<NF> v, DevPara
 }
 // energy_to_temperature_kernel! / temperature_to_energy_kernel! (soil_energy_closures.jl:163-171)
 template <class NF> __global__ void k_closure_energy(View<NF> v, DevParams<NF> p) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (i >= v.Nh) return;
-    const long c = (long)k * v.pitch + i;
+    TRM_CELL_INDEX(v);
+    (void)i; (void)k;
     uint32_t viol = 0;
     NF l, t;
     energy_closure(p, v.U[c], v.sat[c], l, t, viol);
@@ -257,10 +212,8 @@ template <class NF> __global__ void k_closure_energy(View<NF> v, DevParams<NF> p
     if (viol) atomicOr(v.status, viol);
 }
 template <class NF> __global__ void k_invclosure_energy(View<NF> v, DevParams<NF> p) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int k = blockIdx.y;
-    if (i >= v.Nh) return;
-    const long c = (long)k * v.pitch + i;
+    TRM_CELL_INDEX(v);
+    (void)i; (void)k;
     uint32_t viol = 0;
     NF l, u;
     energy_invclosure(p, v.T[c], v.sat[c], l, u, viol);
@@ -274,226 +227,296 @@ template <class NF> __global__ void k_average(NF* a, const NF* b, long n) {
     if (i < n) a[i] = (a[i] + b[i]) / NF(2);
 }
 
-// ===========================================================================
-// Fused step, lane = column (TRM_KERNEL_FUSED_LANE): update_state! + explicit_step! + closure!
-// (+ finalize) in ONE launch (forward_euler.jl:19-31).  64 columns per workgroup; every global
-// access is a coalesced 512-byte row segment; the vertical stencil walks up the column in
-// registers; the column's updated (U, sat) wait in LDS ([level][lane], conflict free) across the
-// serial saturation repair and the water-table search and are closed to (T, liq, psi, K) on the
-// way out.  The stored closure fields T / liq / psi are read, exactly as the reference does.
-// ===========================================================================
-template <class NF> struct Level { NF U, sat, T, liq, psi, kap, Kc; };
-template <class NF> struct Raw { NF U, sat, T, liq, psi; };
-
-constexpr int LANE_BLOCK = 64;
-
-template <class NF, bool RICHARDS, int HYD>
-__global__ void __launch_bounds__(LANE_BLOCK) k_step_fused(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
-    extern __shared__ __align__(16) unsigned char trm_smem[];
-    constexpr int BLOCK = LANE_BLOCK;
-    const long i = (long)blockIdx.x * BLOCK + threadIdx.x;
+// hydrology closure!, generic fallback with one thread per column and a sequential walk in z
+// (any Nz; used when Nz > 64): adjust_saturation_profile! (soil_hydrology.jl:185-219),
+// compute_water_table! (soil_hydrology.jl:170-175) and, if WITH_PSI, saturation_to_pressure!.
+template <class NF, bool WITH_PSI, int HYD, bool WITH_ADJUST> __global__ void k_closure_hydrology_seq(View<NF> v, DevParams<NF> p) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.Nh) return;
     const int Nz = v.Nz;
-    const long P = v.pitch;
-    NF* lds_sat = reinterpret_cast<NF*>(trm_smem) + threadIdx.x;
-    NF* lds_U = lds_sat + (long)Nz * BLOCK;
-    uint32_t viol = 0;
-    bool bad = false;
-    const bool need_kc = RICHARDS || write_kf;
-
-    auto load_raw = [&](int k) {
-        Raw<NF> r;
-        const long c = (long)k * P + i;
-        r.U = v.U[c];
-        r.sat = v.sat[c];
-        r.T = v.T[c];
-        r.liq = v.liq[c];
-        r.psi = RICHARDS ? v.psi[c] : NF(0);
-        return r;
-    };
-    auto make_level = [&](const Raw<NF>& r) {
-        Level<NF> L;
-        L.U = r.U; L.sat = r.sat; L.T = r.T; L.liq = r.liq; L.psi = r.psi;
-        Frac<NF> f = fractions(p, L.sat, L.liq, viol);
-        L.kap = conductivity(p, f);
-        L.Kc = need_kc ? conductivity_hydraulic<NF, HYD>(p, L.liq, f) : NF(0);
-        return L;
-    };
-
-    // ---- top flux BCs: LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61); the
-    // surface processes that produce them ran in k_surface just before this launch ----------------
-    NF S = RICHARDS ? v.S[i] : NF(0);
-    NF top_U = NF(0), top_S = NF(0);   // flux-BC terms of the top cell (0 when there is none)
-    if (p.seb) {
-        top_U = flux_term_top(v.ghf[i], v.g);
-        if (RICHARDS) top_S = flux_term_top(-v.infil[i], v.g);
-        v.Ts[i] = v.Ts[i] + NF(0) * dt;  // explicit_step! of the zero-tendency prognostic skin_temperature
-    } else {
-        if (v.bc.kind[0][1] == 2) top_U = flux_term_top(bcval(v, 0, 1)[i], v.g);
-        if (RICHARDS && v.bc.kind[1][1] == 2) top_S = flux_term_top(bcval(v, 1, 1)[i], v.g);
-    }
-    NF bot_U = NF(0), bot_S = NF(0);
-    if (v.bc.kind[0][0] == 2) bot_U = flux_term_bottom(bcval(v, 0, 0)[i], v.g);
-    if (RICHARDS && v.bc.kind[1][0] == 2) bot_S = flux_term_bottom(bcval(v, 1, 0)[i], v.g);
-
-    // ---- upward sweep: tendencies, Euler update, upward pass of the saturation repair -------
-    Level<NF> r0 = make_level(load_raw(0));
-    Level<NF> r1 = make_level(load_raw(1));
-    Level<NF> r2 = r1;
-    if (Nz > 2) r2 = make_level(load_raw(2));
-    Raw<NF> nxt = {};
-    if (Nz > 3) nxt = load_raw(3);
-
-    // face 0 (bottom boundary): halo cell from the BCs with level 0 as the edge
-    NF qT_lo, qW_lo = NF(0);
-    NF Kf_a = r0.Kc;                                              // face 0:  k <= 1 branch
-    NF Kf_b = (Nz - 1 == 1) ? r1.Kc : jl_min(r1.Kc, r0.Kc);      // face 1
-    {
-        NF Th = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), i, r0.T, v.g);
-        NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), i, r0.liq, v.g);
-        NF sh = sat_halo<NF, RICHARDS>(v, p, 0, i, r0.sat);
-        NF kh = conductivity(p, fractions(p, sh, lh, viol));
-        qT_lo = -(NF(0.5) * (r0.kap + kh)) * ((r0.T - Th) * v.rdzf[0]);
-        if (RICHARDS) {
-            NF ph = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), i, r0.psi, v.g);
-            NF g = (r0.psi - ph) * v.rdzf[0];
-            NF Ks = boolmul(g < NF(0), jl_min(NF(0), Kf_a)) + boolmul(g >= NF(0), jl_min(Kf_a, Kf_b));
-            qW_lo = -Ks * g;
+    NF* s = v.sat + i * v.Nzp;
+    if (WITH_ADJUST) {
+        for (int k = 0; k <= Nz - 2; ++k) {
+            NF sk = s[k];
+            NF e = jl_max(sk - NF(1), NF(0));
+            s[k] = sk - e;
+            s[k + 1] += div_const(e * v.dzc[k], v.dzc[k + 1], v.rdzc[k + 1]);
         }
-    }
-    NF carry = NF(0);
-    NF Kc_prev_new = NF(0);  // NoFlow + finalize: rolling new-state cell conductivity
-    for (int k = 0; k < Nz; ++k) {
-        Raw<NF> pre = {};
-        if (k + 4 < Nz) pre = load_raw(k + 4);
-        // face k+2 conductivity (soil_hydrology.jl:145-163); faces beyond Nz are halo (0)
-        NF Kf_c;
-        {
-            const int f = k + 2;
-            if (f > Nz) Kf_c = NF(0);
-            else if (f == Nz) Kf_c = r1.Kc;        // face Nz repeats the top cell's value
-            else if (f == Nz - 1) Kf_c = r2.Kc;    // face Nz-1 = Kc(top cell)
-            else Kf_c = jl_min(r2.Kc, r1.Kc);
-        }
-        // upper face k+1
-        NF Th, kh, ph = NF(0);
-        if (k + 1 < Nz) { Th = r1.T; kh = r1.kap; ph = r1.psi; }
-        else {
-            Th = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), i, r0.T, v.g);
-            NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), i, r0.liq, v.g);
-            NF sh = sat_halo<NF, RICHARDS>(v, p, 1, i, r0.sat);
-            kh = conductivity(p, fractions(p, sh, lh, viol));
-            if (RICHARDS) ph = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), i, r0.psi, v.g);
-        }
-        NF qT_hi = -(NF(0.5) * (kh + r0.kap)) * ((Th - r0.T) * v.rdzf[k + 1]);
-        NF gU = NF(0) + (-((qT_hi - qT_lo) * v.rdzc[k]));
-        NF gS = NF(0), qW_hi = NF(0);
-        if (RICHARDS) {
-            NF g = (ph - r0.psi) * v.rdzf[k + 1];
-            NF Ks = boolmul(g < NF(0), jl_min(Kf_a, Kf_b)) + boolmul(g >= NF(0), jl_min(Kf_b, Kf_c));
-            qW_hi = -Ks * g;
-            NF dtheta = -((qW_hi - qW_lo) * v.rdzc[k]) + NF(0) + p.vwc_forcing;
-            gS = NF(0) + div_const(dtheta, p.por, p.rpor);
-        }
-        // compute_z_bcs!: flux BCs enter the boundary cells' tendencies
-        if (k == 0) { gU += bot_U; if (RICHARDS) gS += bot_S; }
-        if (k == Nz - 1) { gU -= top_U; if (RICHARDS) gS -= top_S; }
-        NF Unew = r0.U + gU * dt;
-        bad = bad || is_nan(Unew);
-        const long c = (long)k * P + i;
-        if (write_kf && !finalize) v.Kf[c] = Kf_a;
-        if (RICHARDS) {
-            NF snew = r0.sat + gS * dt;
-            bad = bad || is_nan(snew);
-            // upward pass of adjust_saturation_profile! (soil_hydrology.jl:192-199), fused
-            if (k > 0) snew = snew + carry;
-            if (k < Nz - 1) {
-                NF e = jl_max(snew - NF(1), NF(0));
-                snew = snew - e;
-                carry = __any(e != NF(0)) ? div_const(e * v.dzc[k], v.dzc[k + 1], v.rdzc[k + 1]) : NF(0);
-            }
-            lds_sat[(long)k * BLOCK] = snew;
-            lds_U[(long)k * BLOCK] = Unew;
-        } else {
-            // NoFlow: saturation is static, the column closes immediately
-            NF ln, Tn;
-            energy_closure(p, Unew, r0.sat, ln, Tn, viol);
-            v.U[c] = Unew;
-            v.liq[c] = ln;
-            v.T[c] = Tn;
-            if (finalize && write_kf) {
-                NF Kc_new = conductivity_hydraulic<NF, HYD>(p, ln, fractions(p, r0.sat, ln, viol));
-                NF face = (k == 0 || k == Nz - 1) ? Kc_new : jl_min(Kc_new, Kc_prev_new);
-                v.Kf[c] = face;
-                if (k == Nz - 1) v.Kf[c + P] = face;
-                Kc_prev_new = Kc_new;
-            }
-        }
-        // shift the window
-        qT_lo = qT_hi;
-        qW_lo = qW_hi;
-        Kf_a = Kf_b;
-        Kf_b = Kf_c;
-        r0 = r1;
-        r1 = r2;
-        if (k + 3 < Nz) r2 = make_level(nxt);
-        nxt = pre;
-    }
-    if (write_kf && !finalize) v.Kf[(long)Nz * P + i] = Kf_a;  // face Nz
-
-    if (RICHARDS) {
-        // surface_excess_water: tendency min(0, S) evaluated once per column (SURVEY C-3), Euler update
-        S = S + (NF(0) + jl_min(NF(0), S)) * dt;
-        // ---- downward pass of the repair (soil_hydrology.jl:202-208) + top overflow + water table
-        NF pend = NF(0);
-        int idx = -1;
         for (int k = Nz - 1; k >= 1; --k) {
-            NF s = lds_sat[(long)k * BLOCK] - pend;
-            NF d = jl_max(-s, NF(0));
-            s = s + d;
-            pend = __any(d != NF(0)) ? div_const(d * v.dzc[k], v.dzc[k - 1], v.rdzc[k - 1]) : NF(0);
-            if (k == Nz - 1) {  // surface overflow joins surface_excess_water (soil_hydrology.jl:211-213)
-                NF e = jl_max(s - NF(1), NF(0));
-                s = s - e;
-                S = S + e * v.dzc[Nz - 1];
-            }
-            lds_sat[(long)k * BLOCK] = s;
-            if (s < NF(1)) idx = k;
+            NF sk = s[k];
+            NF d = jl_max(-sk, NF(0));
+            s[k] = sk + d;
+            s[k - 1] -= div_const(d * v.dzc[k], v.dzc[k - 1], v.rdzc[k - 1]);
         }
-        {
-            NF s = lds_sat[0] - pend;
-            s = jl_max(s, NF(0));
-            lds_sat[0] = s;
-            if (s < NF(1)) idx = 0;
-        }
-        const NF z0 = v.zF[idx >= 0 ? idx : Nz];
-        v.wt[i] = z0;
-        v.S[i] = S;
-        // ---- closing sweep: (U, sat) -> (T, liq, psi [, K]) and the stores ---------------------
-        NF Kc_prev = NF(0), Tn = NF(0), face = NF(0), sn = NF(0);
-        for (int k = 0; k < Nz; ++k) {
-            const long c = (long)k * P + i;
-            sn = lds_sat[(long)k * BLOCK];
-            NF un = lds_U[(long)k * BLOCK];
-            NF ln;
-            energy_closure(p, un, sn, ln, Tn, viol);
-            NF ps = pressure_head<NF, HYD>(p, sn, v.zC[k], v.psiz[k], z0);
-            v.U[c] = un;
-            v.sat[c] = sn;
-            v.T[c] = Tn;
-            v.liq[c] = ln;
-            v.psi[c] = ps;
-            if (finalize && write_kf) {
-                NF Kc_new = conductivity_hydraulic<NF, HYD>(p, ln, fractions(p, sn, ln, viol));
-                face = (k == 0 || k == Nz - 1) ? Kc_new : jl_min(Kc_new, Kc_prev);
-                v.Kf[c] = face;
-                if (k == Nz - 1) v.Kf[c + P] = face;
-                Kc_prev = Kc_new;
+        NF st = s[Nz - 1];
+        NF e = jl_max(st - NF(1), NF(0));
+        s[Nz - 1] = st - e;
+        v.S[i] += e * v.dzc[Nz - 1];
+        s[0] = jl_max(s[0], NF(0));
+    }
+    int idx = -1;
+    for (int k = 0; k < Nz; ++k)
+        if (idx < 0 && s[k] < NF(1)) idx = k;
+    // (the reference scan also visits the halo above the top cell, which maps to the same surface node
+    // as "not found")
+    NF z0 = v.zF[idx >= 0 ? idx : Nz];
+    v.wt[i] = z0;
+    if (WITH_PSI)
+        for (int k = 0; k < Nz; ++k) v.psi[i * v.Nzp + k] = pressure_head<NF, HYD>(p, s[k], v.zC[k], v.psiz[k], z0);
+}
+
+// ===========================================================================
+// lane = level machinery
+// ===========================================================================
+template <class NF, int LPC> TRM_DEV NF shfl_from(NF x, int src_k) { return __shfl(x, src_k, LPC); }
+template <class NF, int LPC> TRM_DEV NF shfl_up1(NF x) { return __shfl_up(x, 1, LPC); }
+template <class NF, int LPC> TRM_DEV NF shfl_dn1(NF x) { return __shfl_down(x, 1, LPC); }
+template <int LPC> TRM_DEV unsigned long long group_mask(int lane) {
+    if (LPC == 64) return ~0ull;
+    return (lane & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+}
+
+// per-lane grid constants of level k (fixed for the whole kernel: lane <-> level)
+template <class NF> struct LevelGeom {
+    NF zC, psiz, zFlo, dzc, rdzc, rdzf_lo, rdzf_hi, dzc_up, rdzc_up, dzc_dn, rdzc_dn, zF_top, dzc_top;
+};
+template <class NF> TRM_DEV LevelGeom<NF> level_geom(const View<NF>& v, int k) {
+    const int Nz = v.Nz;
+    const int kk = k < Nz ? k : Nz - 1;
+    const int ku = kk + 1 < Nz ? kk + 1 : kk, kd = kk > 0 ? kk - 1 : 0;
+    LevelGeom<NF> L;
+    L.zC = v.zC[kk]; L.psiz = v.psiz[kk]; L.zFlo = v.zF[kk]; L.dzc = v.dzc[kk]; L.rdzc = v.rdzc[kk];
+    L.rdzf_lo = v.rdzf[kk]; L.rdzf_hi = v.rdzf[kk + 1];
+    L.dzc_up = v.dzc[ku]; L.rdzc_up = v.rdzc[ku]; L.dzc_dn = v.dzc[kd]; L.rdzc_dn = v.rdzc[kd];
+    L.zF_top = v.zF[Nz]; L.dzc_top = v.dzc[Nz - 1];
+    return L;
+}
+
+// adjust_saturation_profile! (soil_hydrology.jl:185-219) on a column held one level per lane.
+// Both passes are sequential in z; the lane-serial loops run only when a ballot finds a cell that
+// actually needs repair, otherwise the pass reduces to the `+ 0` the reference applies.
+// Returns the column's surface overflow (excess * dz_top), uniform over the column's lanes.
+template <class NF, int LPC>
+TRM_DEV NF repair_saturation(NF& snew, int k, int Nz, bool act, bool is_bot, bool is_top, const LevelGeom<NF>& L) {
+    {   // upward pass
+        const bool over = act && !is_top && !(jl_max(snew - NF(1), NF(0)) == NF(0));
+        if (__ballot(over) == 0ull) {
+            if (!is_bot) snew = snew + NF(0);  // sat[k+1] += 0 * dz[k] / dz[k+1]
+        } else {
+            NF carry = NF(0);
+            for (int q = 0; q < Nz - 1; ++q) {
+                NF cout = NF(0);
+                if (k == q) {
+                    if (q > 0) snew = snew + carry;
+                    NF e = jl_max(snew - NF(1), NF(0));
+                    snew = snew - e;
+                    cout = div_const(e * L.dzc, L.dzc_up, L.rdzc_up);
+                }
+                carry = shfl_from<NF, LPC>(cout, q);
             }
+            if (is_top) snew = snew + carry;
         }
     }
-    viol |= bad ? 1u : 0u;
-    if (viol) atomicOr(v.status, viol);
+    {   // downward pass
+        const bool under = act && !is_bot && !(jl_max(-snew, NF(0)) == NF(0));
+        if (__ballot(under) == 0ull) {
+            if (!is_bot) snew = snew + NF(0);  // sat[k] += deficit (= 0)
+        } else {
+            NF pend = NF(0);
+            for (int q = Nz - 1; q >= 1; --q) {
+                NF pout = NF(0);
+                if (k == q) {
+                    snew = snew - pend;
+                    NF d = jl_max(-snew, NF(0));
+                    snew = snew + d;
+                    pout = div_const(d * L.dzc, L.dzc_dn, L.rdzc_dn);
+                }
+                pend = shfl_from<NF, LPC>(pout, q);
+            }
+            if (is_bot) snew = snew - pend;
+        }
+    }
+    // surface overflow joins surface_excess_water; bottom clamp
+    NF e_top = NF(0);
+    if (is_top) {
+        e_top = jl_max(snew - NF(1), NF(0));
+        snew = snew - e_top;
+    }
+    e_top = shfl_from<NF, LPC>(e_top, Nz - 1);
+    if (is_bot) snew = jl_max(snew, NF(0));
+    return e_top * L.dzc_top;
+}
+// compute_water_table! (soil_hydrology.jl:170-175, kernel_utils.jl:7-16): lower face of the first
+// unsaturated cell from the bottom, the surface if there is none.
+template <class NF, int LPC> TRM_DEV NF water_table(NF sat, bool act, int lane, const LevelGeom<NF>& L) {
+    const unsigned long long unsat = __ballot(act && sat < NF(1)) & group_mask<LPC>(lane);
+    const int first = unsat ? (__ffsll((long long)unsat) - 1) % LPC : -1;
+    const NF z_first = shfl_from<NF, LPC>(L.zFlo, first >= 0 ? first : 0);
+    return first >= 0 ? z_first : L.zF_top;
+}
+
+// hydrology closure! with lane = level (Nz <= 64): grid = ceil(Nh / (64 / LPC)) waves
+template <class NF, bool WITH_PSI, int HYD, bool WITH_ADJUST, int LPC>
+__global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
+    constexpr int CPW = 64 / LPC;
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int k = lane % LPC, sub = lane / LPC;
+    const long i = wave * CPW + sub;
+    const int Nz = v.Nz;
+    const bool act = i < v.Nh && k < Nz;
+    const bool is_bot = k == 0, is_top = k == Nz - 1;
+    const LevelGeom<NF> L = level_geom(v, k);
+    const long c = (i < v.Nh ? i : v.Nh - 1) * v.Nzp + (k < Nz ? k : Nz - 1);
+    NF s = v.sat[c];
+    if (WITH_ADJUST) {
+        NF over = repair_saturation<NF, LPC>(s, k, Nz, act, is_bot, is_top, L);
+        if (act) {
+            v.sat[c] = s;
+            if (is_bot) v.S[i] += over;
+        }
+    }
+    NF z0 = water_table<NF, LPC>(s, act, lane, L);
+    if (act) {
+        if (is_bot) v.wt[i] = z0;
+        if (WITH_PSI) v.psi[c] = pressure_head<NF, HYD>(p, s, L.zC, L.psiz, z0);
+    }
+}
+
+// ===========================================================================
+// Fused step (TRM_KERNEL_FUSED): update_state! + explicit_step! + closure! (+ the K of
+// compute_auxiliary! when finalizing) in ONE launch, forward_euler.jl:19-31.
+// lane = level, one column per LPC lanes; every wave is independent (no LDS, no barrier):
+// 5 coalesced loads, ~300 fp64 instructions, 6 coalesced stores per cell.
+// ===========================================================================
+template <class NF, bool RICHARDS, int HYD, int LPC>
+__global__ void __launch_bounds__(256) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
+    constexpr int CPW = 64 / LPC;
+    const int lane = threadIdx.x & 63;
+    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int k = lane % LPC, sub = lane / LPC;
+    const long i = wave * CPW + sub;
+    const int Nz = v.Nz;
+    const bool colok = i < v.Nh;            // uniform within the column's lanes
+    const bool act = colok && k < Nz;
+    const bool is_bot = k == 0, is_top = k == Nz - 1;
+    const long ii = colok ? i : v.Nh - 1;   // safe index for per-column reads
+    const long c = ii * v.Nzp + (k < Nz ? k : Nz - 1);
+    const LevelGeom<NF> L = level_geom(v, k);
+    const bool need_kc = RICHARDS || write_kf;
+    uint32_t viol = 0;
+
+    const NF U = v.U[c], sat = v.sat[c], T = v.T[c], liq = v.liq[c];
+    const NF psi = RICHARDS ? v.psi[c] : NF(0);
+
+    const Frac<NF> f = fractions(p, sat, liq, viol);
+    const NF kap = conductivity(p, f);
+    const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD>(p, liq, f) : NF(0);
+
+    // ---- neighbours by shuffle (executed by all lanes, never inside a divergent select) -----------
+    const NF T_sh = shfl_up1<NF, LPC>(T), kap_sh = shfl_up1<NF, LPC>(kap);
+    // halo cells below the bottom / above the top cell, formed by the boundary lanes only
+    NF T_m = T_sh, kap_m = kap_sh, T_h = NF(0), kap_h = NF(0), psi_hb = NF(0), psi_ht = NF(0);
+    NF flux_U = NF(0), flux_S = NF(0);  // compute_z_bcs! term of this lane's cell (0 in the interior)
+    if (is_bot) {
+        T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
+        NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq, v.g);
+        NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat);
+        kap_m = conductivity(p, fractions(p, sh, lh, viol));
+        if (RICHARDS) psi_hb = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), ii, psi, v.g);
+        if (v.bc.kind[0][0] == 2) flux_U = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
+        if (RICHARDS && v.bc.kind[1][0] == 2) flux_S = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
+    }
+    if (is_top) {
+        T_h = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), ii, T, v.g);
+        NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, liq, v.g);
+        NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sat);
+        kap_h = conductivity(p, fractions(p, sh, lh, viol));
+        if (RICHARDS) psi_ht = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), ii, psi, v.g);
+        // top flux BCs enter with a minus sign; LandModel wires ground_heat_flux / -infiltration
+        // (land_model.jl:56-61), produced by k_surface just before this launch
+        if (p.seb) {
+            flux_U = -flux_term_top(v.ghf[ii], v.g);
+            if (RICHARDS) flux_S = -flux_term_top(-v.infil[ii], v.g);
+        } else {
+            if (v.bc.kind[0][1] == 2) flux_U = -flux_term_top(bcval(v, 0, 1)[ii], v.g);
+            if (RICHARDS && v.bc.kind[1][1] == 2) flux_S = -flux_term_top(bcval(v, 1, 1)[ii], v.g);
+        }
+    }
+    // ---- heat: every lane forms its lower face, the top lane also the boundary face -------------------
+    const NF qT_lo = -(NF(0.5) * (kap + kap_m)) * ((T - T_m) * L.rdzf_lo);
+    const NF qT_sh = shfl_dn1<NF, LPC>(qT_lo);
+    const NF qT_hi = is_top ? -(NF(0.5) * (kap_h + kap)) * ((T_h - T) * L.rdzf_hi) : qT_sh;
+    NF gU = NF(0) + (-((qT_hi - qT_lo) * L.rdzc));
+
+    // ---- Richards: face conductivities (soil_hydrology.jl:145-163) and Darcy fluxes -------------------
+    NF gS = NF(0), Kf_lo = NF(0);
+    if (need_kc) {
+        const NF Kc_m = shfl_up1<NF, LPC>(Kc);
+        Kf_lo = (is_bot || is_top) ? Kc : jl_min(Kc, Kc_m);
+    }
+    if (RICHARDS) {
+        const NF Kf_up = shfl_up1<NF, LPC>(Kf_lo), Kf_dn = shfl_dn1<NF, LPC>(Kf_lo), psi_sh = shfl_up1<NF, LPC>(psi);
+        const NF Kf_m = is_bot ? NF(0) : Kf_up;   // halo face below: never written (0)
+        const NF Kf_p = is_top ? Kc : Kf_dn;      // face Nz repeats the top cell's value
+        const NF psi_m = is_bot ? psi_hb : psi_sh;
+        const NF g_lo = (psi - psi_m) * L.rdzf_lo;
+        const NF Ks_lo = boolmul(g_lo < NF(0), jl_min(Kf_m, Kf_lo)) + boolmul(g_lo >= NF(0), jl_min(Kf_lo, Kf_p));
+        const NF qW_lo = -Ks_lo * g_lo;
+        const NF qW_sh = shfl_dn1<NF, LPC>(qW_lo);
+        NF qW_hi = qW_sh;
+        if (is_top) {  // boundary face above the top cell
+            const NF g_t = (psi_ht - psi) * L.rdzf_hi;
+            const NF Ks_t = boolmul(g_t < NF(0), jl_min(Kf_lo, Kc)) + boolmul(g_t >= NF(0), jl_min(Kc, NF(0)));
+            qW_hi = -Ks_t * g_t;
+        }
+        const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
+        gS = NF(0) + div_const(dtheta, p.por, p.rpor);
+    }
+    // ---- compute_z_bcs!: flux BCs into the boundary cells (x + 0 is exact for the interior lanes) -------
+    gU += flux_U;
+    if (RICHARDS) gS += flux_S;
+    // ---- explicit Euler update ------------------------------------------------------------------------------------
+    const NF Unew = U + gU * dt;
+    bool bad = act && is_nan(Unew);
+    NF snew = sat, z0 = NF(0);
+    if (RICHARDS) {
+        snew = sat + gS * dt;
+        bad = bad || (act && is_nan(snew));
+        const NF over = repair_saturation<NF, LPC>(snew, k, Nz, act, is_bot, is_top, L);
+        z0 = water_table<NF, LPC>(snew, act, lane, L);
+        if (act && is_bot) {
+            // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler update, overflow
+            NF S = v.S[i];
+            S = S + (NF(0) + jl_min(NF(0), S)) * dt;
+            v.S[i] = S + over;
+            v.wt[i] = z0;
+        }
+    }
+    if (act && is_top && p.seb) v.Ts[i] = v.Ts[i] + NF(0) * dt;  // zero-tendency prognostic skin_temperature
+    // ---- closures: (U, sat) -> (T, liq, psi) ------------------------------------------------------------------
+    NF ln, Tn;
+    energy_closure(p, Unew, snew, ln, Tn, viol);
+    const NF psin = RICHARDS ? pressure_head<NF, HYD>(p, snew, L.zC, L.psiz, z0) : NF(0);
+    NF Kf_out = Kf_lo, Kf_out_top = Kc;
+    if (finalize && write_kf) {
+        const NF Kc_new = conductivity_hydraulic<NF, HYD>(p, ln, fractions(p, snew, ln, viol));
+        const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
+        Kf_out = (is_bot || is_top) ? Kc_new : jl_min(Kc_new, Kc_new_m);
+        Kf_out_top = Kc_new;
+    }
+    if (act) {
+        v.U[c] = Unew;
+        v.T[c] = Tn;
+        v.liq[c] = ln;
+        if (RICHARDS) { v.sat[c] = snew; v.psi[c] = psin; }
+        if (write_kf) {
+            v.Kf[c] = Kf_out;
+            if (is_top) v.Kf_top[i] = Kf_out_top;
+        }
+        viol |= bad ? 1u : 0u;
+        if (viol) atomicOr(v.status, viol);
+    }
 }
 
 }  // namespace trm

@@ -54,7 +54,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("kernel", ["fused_wave", "fused_lane", "unfused"])
+@pytest.mark.parametrize("kernel", ["fused", "unfused"])
 @pytest.mark.parametrize("config,hydraulics,dtype,Nz,nsteps", CASES)
 def test_step_parity(config, hydraulics, dtype, Nz, nsteps, kernel):
     lat, lon = small_columns(333)  # ragged: not a multiple of the 64-column tile
@@ -80,14 +80,12 @@ def test_step_parity(config, hydraulics, dtype, Nz, nsteps, kernel):
 
 @pytest.mark.parametrize("config,hydraulics", [("heat", "default"), ("richards", "default"), ("richards", "vg"),
                                                 ("land", "vg")])
-@pytest.mark.parametrize("fused", ["fused_wave", "fused_lane"])
 @pytest.mark.parametrize("Nz", [32, 20, 64])
-def test_fused_equals_unfused_bitwise(config, hydraulics, fused, Nz):
+def test_fused_equals_unfused_bitwise(config, hydraulics, Nz):
     """All implementations share the device arithmetic, so they must agree bit for bit on every path."""
     lat, lon = small_columns(500)
     w = W.make_workload(config, lat, lon, Nz, hydraulics=hydraulics)
     a, b = W.setup_device(w), W.setup_device(w)
-    a.set_option("step_kernel", fused)
     b.set_option("step_kernel", "unfused")
     for nsteps, fin in ((1, True), (7, False), (12, True)):
         a.step(w["dt"], nsteps, finalize=fin)
@@ -97,7 +95,7 @@ def test_fused_equals_unfused_bitwise(config, hydraulics, fused, Nz):
             assert np.array_equal(a.get(n), b.get(n), equal_nan=True), (config, n, nsteps, fin)
 
 
-@pytest.mark.parametrize("kernel", ["fused_wave", "fused_lane", "unfused"])
+@pytest.mark.parametrize("kernel", ["fused", "unfused"])
 def test_skipping_intermediate_conductivity_stores(kernel):
     """TRM_OPT_WRITE_KF_EVERY_STEP = 0: hydraulic_conductivity is never an input of a step, so storing it only
     when finalizing must leave every field -- including the final K -- unchanged."""
@@ -181,7 +179,7 @@ def test_halo_policy_mirror():
 
 @pytest.mark.parametrize("Nh", [1, 63, 64, 65, 129])
 @pytest.mark.parametrize("Nz", [2, 3, 5])
-@pytest.mark.parametrize("kernel", ["fused_wave", "fused_lane"])
+@pytest.mark.parametrize("kernel", ["fused", "unfused"])
 def test_ragged_and_tiny_shapes(Nh, Nz, kernel):
     lat, lon = small_columns(max(Nh, 2))
     w = W.make_workload("richards", lat[:Nh], lon[:Nh], Nz)
@@ -210,7 +208,7 @@ def test_bc_kinds_parity():
     dev.step(w["dt"], 40, True)
     assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, "bcs ")
     # and through the unfused kernels
-    for kern in ("unfused", "fused_lane"):
+    for kern in ("unfused",):
         dev2 = W.setup_device(w)
         dev2.set_option("step_kernel", kern)
         dev2.step(w["dt"], 40, True)
@@ -238,7 +236,7 @@ def test_saturation_repair_cases_on_device():
     assert np.allclose(sat[:, 0], 1.0) and np.all(sat[:, 1] >= 0) and np.allclose(sat[:, 2], 0.0)
 
 
-@pytest.mark.parametrize("kernel", ["fused_wave", "fused_lane", "unfused"])
+@pytest.mark.parametrize("kernel", ["fused", "unfused"])
 def test_saturation_repair_inside_step(kernel):
     """Drive the serial repair from legal states: a strong infiltration flux oversaturates the top cells; the
     excess is pushed upward cell by cell and overflows into surface_excess_water.  (The deficit pass is
@@ -309,3 +307,13 @@ def test_missing_gpu_path_is_loud():
     grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10), 4, device=99)
     with pytest.raises(trm.TerrariumHipError):
         trm.DeviceState(grid, trm._capi.default_params())
+
+
+def test_deep_columns_take_the_unfused_kernels():
+    """Nz > 64 does not fit the lane = level mapping: trm_step transparently uses the reference-order kernels."""
+    lat, lon = small_columns(40)
+    w = W.make_workload("richards", lat, lon, 100)
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    orc.run(w["dt"], 20)
+    dev.step(w["dt"], 20, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, "Nz=100 ")
