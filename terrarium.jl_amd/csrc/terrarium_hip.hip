@@ -900,7 +900,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
     switch (option) {
         case TRM_OPT_ASYNC: c->opt_async = value != 0; return TRM_OK;
         case TRM_OPT_STEP_KERNEL:
-            if (value < TRM_KERNEL_FUSED || value > TRM_KERNEL_FUSED_WAVE) break;
+            if (value != TRM_KERNEL_FUSED && value != TRM_KERNEL_UNFUSED) break;
             c->opt_kernel = value;
             return TRM_OK;
         case TRM_OPT_WRITE_KF_EVERY_STEP: c->opt_write_kf = value != 0; return TRM_OK;

@@ -269,8 +269,31 @@ template <class NF, bool WITH_PSI, int HYD, bool WITH_ADJUST> __global__ void k_
 // lane = level machinery
 // ===========================================================================
 template <class NF, int LPC> TRM_DEV NF shfl_from(NF x, int src_k) { return __shfl(x, src_k, LPC); }
-template <class NF, int LPC> TRM_DEV NF shfl_up1(NF x) { return __shfl_up(x, 1, LPC); }
-template <class NF, int LPC> TRM_DEV NF shfl_dn1(NF x) { return __shfl_down(x, 1, LPC); }
+// Neighbour exchange k-1 / k+1 as DPP whole-wave shifts (wave_shr:1 / wave_shl:1, gfx9 family): a VALU
+// move per dword instead of a round trip through the LDS crossbar (ds_bpermute).  The shift runs over
+// the whole wavefront, so with two columns per wave the lanes at a column edge receive the
+// neighbouring column's value -- exactly the lanes (bottom / top level) whose input is replaced by
+// the halo / boundary-face value anyway.
+TRM_DEV int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
+TRM_DEV int dpp_shl1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, false); }
+TRM_DEV double shift_up(double x) {  // lane l receives lane l-1 (level k-1)
+    union { double d; int w[2]; } u;
+    u.d = x;
+    u.w[0] = dpp_shr1(u.w[0]);
+    u.w[1] = dpp_shr1(u.w[1]);
+    return u.d;
+}
+TRM_DEV double shift_dn(double x) {  // lane l receives lane l+1 (level k+1)
+    union { double d; int w[2]; } u;
+    u.d = x;
+    u.w[0] = dpp_shl1(u.w[0]);
+    u.w[1] = dpp_shl1(u.w[1]);
+    return u.d;
+}
+TRM_DEV float shift_up(float x) { return __builtin_bit_cast(float, dpp_shr1(__builtin_bit_cast(int, x))); }
+TRM_DEV float shift_dn(float x) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(int, x))); }
+template <class NF, int LPC> TRM_DEV NF shfl_up1(NF x) { return shift_up(x); }
+template <class NF, int LPC> TRM_DEV NF shfl_dn1(NF x) { return shift_dn(x); }
 template <int LPC> TRM_DEV unsigned long long group_mask(int lane) {
     if (LPC == 64) return ~0ull;
     return (lane & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
@@ -418,20 +441,32 @@ __global__ void __launch_bounds__(256) k_step_wave(View<NF> v, DevParams<NF> p, 
     // halo cells below the bottom / above the top cell, formed by the boundary lanes only
     NF T_m = T_sh, kap_m = kap_sh, T_h = NF(0), kap_h = NF(0), psi_hb = NF(0), psi_ht = NF(0);
     NF flux_U = NF(0), flux_S = NF(0);  // compute_z_bcs! term of this lane's cell (0 in the interior)
+    // With the default (no-flux) conditions on liquid fraction and saturation the halo cell has the edge
+    // cell's composition, hence bit for bit its conductivity: nothing to recompute.
+    const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 &&
+                          (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
+    const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 &&
+                          (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
     if (is_bot) {
         T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
-        NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq, v.g);
-        NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat);
-        kap_m = conductivity(p, fractions(p, sh, lh, viol));
+        kap_m = kap;
+        if (!same_bot) {
+            NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq, v.g);
+            NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat);
+            kap_m = conductivity(p, fractions(p, sh, lh, viol));
+        }
         if (RICHARDS) psi_hb = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), ii, psi, v.g);
         if (v.bc.kind[0][0] == 2) flux_U = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
         if (RICHARDS && v.bc.kind[1][0] == 2) flux_S = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
     }
     if (is_top) {
         T_h = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), ii, T, v.g);
-        NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, liq, v.g);
-        NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sat);
-        kap_h = conductivity(p, fractions(p, sh, lh, viol));
+        kap_h = kap;
+        if (!same_top) {
+            NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, liq, v.g);
+            NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sat);
+            kap_h = conductivity(p, fractions(p, sh, lh, viol));
+        }
         if (RICHARDS) psi_ht = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), ii, psi, v.g);
         // top flux BCs enter with a minus sign; LandModel wires ground_heat_flux / -infiltration
         // (land_model.jl:56-61), produced by k_surface just before this launch
