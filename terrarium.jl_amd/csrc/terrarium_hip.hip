@@ -5,7 +5,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -41,6 +43,7 @@ struct trm_ctx {
     double time = 0.0;
     int64_t iteration = 0;
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1;
+    int max_step_blocks = 256 * 5;  // resident workgroups of the persistent fused step kernel
     std::string err;
 };
 
@@ -381,7 +384,15 @@ template <class NF> struct Ops {
     template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
         auto v = make_view<NF>(c, c->state);
         auto p = make_dev_params<NF>(c->params);
-        hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), wave_grid(c, LPC), dim3(256), 0, c->stream, v, p, (NF)dt, finalize,
+        // persistent waves: at most 8 workgroups (32 waves) per CU's worth of the 256 CUs
+        dim3 grid = wave_grid(c, LPC);
+        grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
+        if (TRM_STEP_PERSISTENT) {
+            if (grid.x > (unsigned)c->max_step_blocks) grid.x = (unsigned)c->max_step_blocks;
+        } else {
+            grid.x = (grid.x + TRM_STEP_GROUPS - 1) / TRM_STEP_GROUPS;  // each wave takes TRM_STEP_GROUPS column groups
+        }
+        hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize,
                            (c->opt_write_kf || finalize) ? 1 : 0);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
@@ -667,6 +678,11 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
         return fail(nullptr, TRM_EHIP, "trm_create: no HIP device available (this library has no CPU fallback)");
     if (g->device < 0 || g->device >= ndev) return fail(nullptr, TRM_EINVAL, "trm_create: device ordinal out of range");
+    {
+        long nzp = g->num_layers <= 32 ? 32 : (g->num_layers <= 64 ? 64 : ((g->num_layers + 31) / 32) * 32);
+        if ((double)g->num_columns * (double)nzp >= 2147483648.0)
+            return fail(nullptr, TRM_EINVAL, "trm_create: num_columns * level pitch must stay below 2^31 per device");
+    }
     trm_ctx* c = new trm_ctx();
     c->precision = g->precision;
     c->esize = g->precision == TRM_F64 ? 8 : 4;
@@ -675,6 +691,7 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     c->Nzp = c->Nz <= 32 ? 32 : (c->Nz <= 64 ? 64 : ((c->Nz + 31) / 32) * 32);
     c->device = g->device;
     c->params = *p;
+    if (const char* e = getenv("TRM_STEP_BLOCKS")) c->max_step_blocks = std::max(1, atoi(e));  // tuning knob
     c->Az = g->dx > 0 ? g->dx : 1.0 / (double)c->Nh;
     if (c->precision == TRM_F32) c->Az = (double)(float)c->Az;
     auto bail = [&](int rc) {

@@ -412,25 +412,110 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 // lane = level, one column per LPC lanes; every wave is independent (no LDS, no barrier):
 // 5 coalesced loads, ~300 fp64 instructions, 6 coalesced stores per cell.
 // ===========================================================================
+template <class NF> struct RawCell { NF U, sat, T, liq, psi; };
+
+#ifndef TRM_STEP_MIN_WAVES
+#define TRM_STEP_MIN_WAVES 1
+#endif
+#ifndef TRM_STEP_PERSISTENT
+#define TRM_STEP_PERSISTENT 0
+#endif
+#ifndef TRM_STEP_GROUPS
+#define TRM_STEP_GROUPS 1
+#endif
+#ifndef TRM_STEP_BLOCK
+#define TRM_STEP_BLOCK 256
+#endif
+
 template <class NF, bool RICHARDS, int HYD, int LPC>
-__global__ void __launch_bounds__(256) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
+__global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
     constexpr int CPW = 64 / LPC;
+    constexpr bool PERSIST = TRM_STEP_PERSISTENT != 0;
+#ifdef TRM_EXP_EMPTY_WAVES   // tuning experiment: same register footprint, waves exit at once => pure launch throughput
+    if (finalize != 12345) return;
+#endif
     const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const long ngroups = (v.Nh + CPW - 1) / CPW;   // column groups (CPW columns each), one per wave visit
     const int k = lane % LPC, sub = lane / LPC;
-    const long i = wave * CPW + sub;
     const int Nz = v.Nz;
+    const bool is_bot = k == 0, is_top = k == Nz - 1;
+#if TRM_STEP_PERSISTENT
+    // Persistent build: the per-level grid constants live in LDS and are re-read per column group, so that
+    // they do not stay in 26 VGPRs across the whole loop.
+    __shared__ LevelGeom<NF> geom_lds[LPC];
+    if (threadIdx.x < LPC) geom_lds[threadIdx.x] = level_geom(v, (int)threadIdx.x);
+    __syncthreads();
+#else
+    const LevelGeom<NF> L = level_geom(v, k);
+#endif
+    const bool need_kc = RICHARDS || write_kf;
+    // With the default (no-flux) conditions on liquid fraction and saturation the halo cell has the edge
+    // cell's composition, hence bit for bit its conductivity: nothing to recompute.
+    const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 &&
+                          (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
+    const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 &&
+                          (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
+    uint32_t viol_all = 0;
+
+    // 32-bit element offsets (Nh * Nzp < 2^31 is checked at trm_create): the loads and stores then use
+    // the scalar-base + 32-bit vector-offset addressing form instead of 64-bit vector address arithmetic
+    auto cell_index = [&](long group) {
+        const int i = (int)(group * CPW) + sub;
+        const int ii = i < (int)v.Nh ? i : (int)v.Nh - 1;
+        return (unsigned)(ii * v.Nzp + (k < Nz ? k : Nz - 1));
+    };
+    auto load_cell = [&](long group) {
+        const unsigned c = cell_index(group);
+        RawCell<NF> r;
+#ifdef TRM_EXP_COMPUTE_ONLY   // tuning experiment: plausible register inputs, no global loads
+        r.U = NF(1.0e6) + NF(c) * NF(3.0); r.sat = NF(0.5) + NF(c & 31) * NF(0.01); r.T = NF(2) + NF(c & 7);
+        r.liq = NF(1); r.psi = NF(-1) - NF(c & 15) * NF(0.1);
+        return r;
+#endif
+#ifdef TRM_EXP_RECOMPUTE_TL   // tuning experiment: derive T / liq from (U, sat) instead of reading them
+        r.U = v.U[c]; r.sat = v.sat[c];
+        { uint32_t vv = 0; energy_closure(p, r.U, r.sat, r.liq, r.T, vv); }
+        r.psi = RICHARDS ? v.psi[c] : NF(0);
+        return r;
+#endif
+        r.U = v.U[c]; r.sat = v.sat[c]; r.T = v.T[c]; r.liq = v.liq[c];
+        r.psi = RICHARDS ? v.psi[c] : NF(0);
+        return r;
+    };
+
+#ifdef TRM_EXP_STAGGER
+    // tuning experiment: de-phase the first generation of waves by their SIMD slot so that not every
+    // wave of the chip loads (then computes) at the same time
+    if (blockIdx.x < 256u * 6u) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 0xf;  // HW_ID.wave_id
+        for (unsigned j = 0; j < slot; ++j) __builtin_amdgcn_s_sleep(TRM_EXP_STAGGER);
+    }
+#endif
+    // One column group (CPW columns) per call.
+    auto process = [&](long group, const RawCell<NF>& cur) {
+#if TRM_STEP_PERSISTENT
+    int kopaque = k;
+    asm volatile("" : "+v"(kopaque));   // keeps the LDS reads inside the loop (no hoisting into long-lived VGPRs)
+    const LevelGeom<NF> L = geom_lds[kopaque];
+#endif
+    const long i = group * CPW + sub;
     const bool colok = i < v.Nh;            // uniform within the column's lanes
     const bool act = colok && k < Nz;
-    const bool is_bot = k == 0, is_top = k == Nz - 1;
     const long ii = colok ? i : v.Nh - 1;   // safe index for per-column reads
-    const long c = ii * v.Nzp + (k < Nz ? k : Nz - 1);
-    const LevelGeom<NF> L = level_geom(v, k);
-    const bool need_kc = RICHARDS || write_kf;
+    const unsigned c = cell_index(group);
     uint32_t viol = 0;
 
-    const NF U = v.U[c], sat = v.sat[c], T = v.T[c], liq = v.liq[c];
-    const NF psi = RICHARDS ? v.psi[c] : NF(0);
+    const NF U = cur.U, sat = cur.sat, T = cur.T, liq = cur.liq, psi = cur.psi;
+#ifdef TRM_EXP_MEMORY_ONLY   // tuning experiment: same traffic, no arithmetic
+    if (act) {
+        v.U[c] = U + dt; v.T[c] = T + dt; v.liq[c] = liq + dt;
+        if (RICHARDS) { v.sat[c] = sat + dt; v.psi[c] = psi + dt; }
+        if (write_kf) v.Kf[c] = U + sat;
+    }
+    return;
+#endif
 
     const Frac<NF> f = fractions(p, sat, liq, viol);
     const NF kap = conductivity(p, f);
@@ -441,12 +526,6 @@ __global__ void __launch_bounds__(256) k_step_wave(View<NF> v, DevParams<NF> p, 
     // halo cells below the bottom / above the top cell, formed by the boundary lanes only
     NF T_m = T_sh, kap_m = kap_sh, T_h = NF(0), kap_h = NF(0), psi_hb = NF(0), psi_ht = NF(0);
     NF flux_U = NF(0), flux_S = NF(0);  // compute_z_bcs! term of this lane's cell (0 in the interior)
-    // With the default (no-flux) conditions on liquid fraction and saturation the halo cell has the edge
-    // cell's composition, hence bit for bit its conductivity: nothing to recompute.
-    const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 &&
-                          (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
-    const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 &&
-                          (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
     if (is_bot) {
         T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
         kap_m = kap;
@@ -540,7 +619,11 @@ __global__ void __launch_bounds__(256) k_step_wave(View<NF> v, DevParams<NF> p, 
         Kf_out = (is_bot || is_top) ? Kc_new : jl_min(Kc_new, Kc_new_m);
         Kf_out_top = Kc_new;
     }
+#ifdef TRM_EXP_COMPUTE_ONLY
+    if (act && Unew == NF(-12345.678)) {   // never true: keeps the arithmetic alive without the stores
+#else
     if (act) {
+#endif
         v.U[c] = Unew;
         v.T[c] = Tn;
         v.liq[c] = ln;
@@ -550,8 +633,55 @@ __global__ void __launch_bounds__(256) k_step_wave(View<NF> v, DevParams<NF> p, 
             if (is_top) v.Kf_top[i] = Kf_out_top;
         }
         viol |= bad ? 1u : 0u;
-        if (viol) atomicOr(v.status, viol);
+        viol_all |= viol;
     }
+    };  // process
+
+#ifdef TRM_EXP_STAMPS   // diagnostic build: per-wave phase time stamps into the (unused) energy tendency buffer
+    {
+        unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        RawCell<NF> r0 = {};
+        if (wave0 < ngroups) r0 = load_cell(wave0);
+        NF sink = r0.U + r0.sat + r0.T + r0.liq + r0.psi;   // forces the wait for all five loads
+        asm volatile("" : "+v"(sink));
+        unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        if (wave0 < ngroups) process(wave0, r0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long t2 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && wave0 * 4 + 3 < (long)v.Nh * v.Nzp) {
+            unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
+            v.G_U[wave0 * 4 + 0] = (NF)(double)t0;
+            v.G_U[wave0 * 4 + 1] = (NF)(double)(t1 - t0);
+            v.G_U[wave0 * 4 + 2] = (NF)(double)(t2 - t1);
+            v.G_U[wave0 * 4 + 3] = (NF)(double)hw;
+        }
+        if (viol_all) atomicOr(v.status, viol_all);
+        return;
+    }
+#endif
+    if (!PERSIST) {
+        // GROUPS column groups per wave in straight-line code: all loads are issued up front, so the
+        // later groups' HBM latency hides behind the first group's arithmetic.
+        constexpr int GROUPS = TRM_STEP_GROUPS;
+        const long g0 = wave0 * GROUPS;
+        RawCell<NF> raw[GROUPS];
+#pragma unroll
+        for (int j = 0; j < GROUPS; ++j)
+            if (g0 + j < ngroups) raw[j] = load_cell(g0 + j);
+#pragma unroll
+        for (int j = 0; j < GROUPS; ++j)
+            if (g0 + j < ngroups) process(g0 + j, raw[j]);
+    } else {
+        RawCell<NF> cur = {};
+        if (wave0 < ngroups) cur = load_cell(wave0);
+        for (long group = wave0; group < ngroups; group += nwaves) {
+            RawCell<NF> nxt = {};
+            if (group + nwaves < ngroups) nxt = load_cell(group + nwaves);
+            process(group, cur);
+            cur = nxt;
+        }
+    }
+    if (viol_all) atomicOr(v.status, viol_all);
 }
 
 }  // namespace trm

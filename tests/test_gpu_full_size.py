@@ -1,0 +1,103 @@
+"""Full-size checks at BASELINE.json's configurations (N145 mask x 32 levels; 0.1-degree-sized shard in
+fp32): size-independent properties plus the oracle on a sample of columns -- columns are laterally
+independent, so every sampled column of the full-size GPU run must equal the oracle run on that
+column alone."""
+import numpy as np
+import pytest
+
+import workloads as W
+import terrarium_jl_amd as trm
+
+pytestmark = pytest.mark.gpu
+
+
+def sample_workload(w, sel):
+    ws = dict(w)
+    ws["Nh"] = sel.size
+    ws["fields"] = {k: (v[..., sel] if np.ndim(v) else v) for k, v in w["fields"].items()}
+    ws["bcs"] = {k: (kind, (val[sel] if np.ndim(val) else val)) for k, (kind, val) in w["bcs"].items()}
+    ws["inputs"] = {k: (v[sel] if np.ndim(v) else v) for k, v in w["inputs"].items()}
+    return ws
+
+
+@pytest.mark.parametrize("config,hydraulics,exact", [("richards", "default", True), ("heat", "default", True),
+                                                      ("land", "vg", False)])
+def test_n145_full_size_against_sampled_oracle(config, hydraulics, exact):
+    lat, lon = W.columns_from_mask("N145")
+    assert lat.size == 56951
+    w = W.make_workload(config, lat, lon, 32, hydraulics=hydraulics)
+    nsteps = 40
+    dev = W.setup_device(w)
+    dev.step(w["dt"], nsteps, finalize=True)
+    assert dev.status() == 0
+    rng = np.random.default_rng(11)
+    sel = np.unique(np.concatenate([[0, 1, 2, 31, 32, 63, 64, 65, lat.size - 2, lat.size - 1],
+                                    rng.integers(0, lat.size, 400)]))
+    orc = W.setup_oracle(sample_workload(w, sel))
+    # dx of the sampled oracle grid must be the full grid's (it enters the flux-BC scaling Az / V)
+    orc = _oracle_with_dx(sample_workload(w, sel), 1.0 / lat.size)
+    orc.run(w["dt"], nsteps)
+    for name in W.compared_fields(w):
+        a = dev.get(name)[..., sel]
+        b = orc.get(name)
+        assert np.all(np.isfinite(a)), name
+        if exact:
+            assert np.array_equal(a, b), name
+        else:
+            assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-10, name
+
+
+def _oracle_with_dx(ws, dx):
+    import oracle
+    p = oracle.default_params(**ws["params"])
+    o = oracle.Oracle(ws["Nh"], ws["thickness"], p, dtype=ws["dtype"], dx=dx)
+    for name, v in ws["fields"].items():
+        o.set(name, v)
+    for (var, side), (kind, value) in ws["bcs"].items():
+        o.set_bc(var, side, kind, value)
+    for name, v in ws["inputs"].items():
+        o.set(name, v)
+    o.initialize()
+    return o
+
+
+def test_n145_fused_equals_unfused_and_conserves_water():
+    lat, lon = W.columns_from_mask("N145")
+    w = W.make_workload("richards", lat, lon, 32)
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("step_kernel", "unfused")
+    water = lambda d: d.reduce("saturation_water_ice", "volume_integral_z")[0] * 0.49 + d.reduce("surface_excess_water", "sum")[0]
+    m0 = water(a)
+    a.step(w["dt"], 30, finalize=True)
+    b.step(w["dt"], 30, finalize=True)
+    for n in W.compared_fields(w):
+        assert np.array_equal(a.get(n), b.get(n)), n
+    # no-flux top and bottom: total water (pore water + surface excess) is conserved by the step
+    assert water(a) == pytest.approx(m0, rel=1e-12)
+    sat = a.saturation_water_ice
+    assert sat.min() >= 0.0 and sat.max() <= 1.0
+    # permutation equivariance: columns are independent, so reversing their order reverses the result
+    wr = W.make_workload("richards", lat[::-1].copy(), lon[::-1].copy(), 32)
+    wr["fields"] = {k: np.ascontiguousarray(v[..., ::-1]) for k, v in w["fields"].items()}
+    wr["bcs"] = {k: (kind, np.ascontiguousarray(val[::-1])) for k, (kind, val) in w["bcs"].items()}
+    r = W.setup_device(wr)
+    r.step(w["dt"], 30, finalize=True)
+    for n in ("temperature", "saturation_water_ice", "water_table"):
+        assert np.array_equal(r.get(n)[..., ::-1], a.get(n)), n
+
+
+def test_c5_shard_fp32_properties():
+    """0.1-degree-sized shard (fp32, 64 levels); 203 125 columns = a quarter of one GPU's C5 share."""
+    lat, lon = W.synthetic_columns(203125)
+    w = W.make_workload("land", lat, lon, 64, dtype=np.float32, hydraulics="vg")
+    dev = W.setup_device(w)
+    dev.step(w["dt"], 10, finalize=True)
+    assert dev.status() == 0
+    for n in ("temperature", "saturation_water_ice", "pressure_head", "skin_temperature", "ground_heat_flux"):
+        assert np.all(np.isfinite(dev.get(n))), n
+    sel = np.arange(0, 203125, 2031)
+    orc = _oracle_with_dx(sample_workload(w, sel), 1.0 / lat.size)
+    orc.run(w["dt"], 10)
+    for n in ("temperature", "saturation_water_ice", "internal_energy", "skin_temperature"):
+        a, b = dev.get(n)[..., sel].astype(np.float64), orc.get(n).astype(np.float64)
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-4, n
