@@ -73,6 +73,8 @@ def _lib(omp=False):
         build()
         name = "libterrarium_oracle_omp.so" if omp else "libterrarium_oracle.so"
         lib = C.CDLL(os.path.join(_HERE, "build", name))
+        lib.trm_oracle_set_threads.restype = C.c_int
+        lib.trm_oracle_set_threads.argtypes = [C.c_int]
         lib.trm_oracle_create.restype = C.c_void_p
         lib.trm_oracle_create.argtypes = [C.c_int, C.c_long, C.c_int, C.c_void_p, C.c_double, C.POINTER(ParamsD)]
         lib.trm_oracle_destroy.argtypes = [C.c_void_p]
@@ -115,6 +117,11 @@ def _lib(omp=False):
         lib.trm_oracle_skin_temperature_iterations.argtypes = [P] + [D] * 8 + [C.c_int, C.POINTER(D)]
         _libs[omp] = lib
     return _libs[omp]
+
+
+def set_threads(n, omp=True):
+    """OpenMP thread count of the timing leg; returns the count in effect."""
+    return _lib(omp).trm_oracle_set_threads(int(n))
 
 
 def scalar(name, *args):

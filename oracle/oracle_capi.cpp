@@ -3,6 +3,9 @@
 // ctypes harness in oracle/oracle.py.  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may load the resulting library.
 #include "terrarium_oracle.hpp"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 using namespace trm_oracle;
 
@@ -24,6 +27,17 @@ struct OracleHandle {
     } while (0)
 
 extern "C" {
+
+// number of OpenMP threads of the timing leg (no-op in the serial build); returns the count in effect
+int trm_oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
 
 OracleHandle* trm_oracle_create(int precision, long nh, int nz, const double* thickness, double dx, const ParamsD* params) {
     OracleHandle* h = new OracleHandle{precision, nullptr, nullptr};

@@ -1,0 +1,88 @@
+"""CPU-only checks: the C ABI library loads and exports every symbol include/terrarium_hip.h declares
+(no compute without a GPU), and the host-side mirror of the reference interface behaves."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import terrarium_jl_amd as trm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "terrarium_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(trm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 30
+    lib = ctypes.CDLL(trm._capi.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"libterrarium_hip.so does not export {n}"
+    assert sorted(trm._capi.EXPORTS) == names  # the Python binding covers the whole ABI, nothing more
+    assert lib.trm_abi_version() == 1
+
+
+def test_default_params_match_reference_defaults():
+    p = trm._capi.default_params()
+    # SURVEY Appendix A-0
+    assert (p.rho_w, p.Lsl, p.Tref, p.sigma) == (1000.0, 3.34e5, 273.15, 5.6704e-8)
+    assert (p.k_water, p.k_ice, p.k_air, p.k_mineral, p.k_organic) == (0.57, 2.2, 0.025, 3.8, 0.25)
+    assert (p.c_water, p.c_ice, p.c_air, p.c_mineral, p.c_organic) == (4.2e6, 1.9e6, 1.25e3, 2.0e6, 2.5e6)
+    assert (p.por_mineral, p.por_organic, p.K_sat, p.bc_psi_s, p.bc_lambda) == (0.49, 0.9, 1.0e-5, 0.01, 0.2)
+    assert (p.albedo, p.emissivity, p.kappa_s, p.C_h, p.tau_r) == (0.3, 0.97, 2.0, 1.2e-3, 3600.0)
+    assert (p.flow, p.swrc, p.unsat_k, p.seb, p.halo_policy) == (0, 0, 0, 0, 0)
+    import oracle
+    q = oracle.default_params()
+    for name, _ in trm._capi.TrmParams._fields_:
+        assert getattr(p, name) == getattr(q, name), name  # product and oracle agree on every default
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(trm.TerrariumHipError, match="no CPU fallback"):
+        trm.initialize(trm.SoilModel(trm.ColumnGrid(trm.ExponentialSpacing(N=10), 4)))
+
+
+def test_flatten_models():
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10), 3)
+    p = trm.flatten(trm.SoilModel(grid))
+    assert (p.flow, p.seb, p.swrc, p.unsat_k) == (0, 0, 0, 0)
+    hp = trm.ConstantSoilHydraulics(swrc=trm.VanGenuchten(alpha=2.0, n=2.0), unsat_hydraulic_cond=trm.UnsatKVanGenuchten())
+    soil = trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq(), hydraulic_properties=hp,
+                                                                 vwc_forcing=-1e-5))
+    p = trm.flatten(trm.LandModel(grid, soil=soil))
+    assert (p.flow, p.seb, p.swrc, p.unsat_k, p.vg_alpha, p.vg_n, p.vwc_forcing) == (1, 1, 1, 1, 2.0, 2.0, -1e-5)
+    with pytest.raises(ValueError):
+        bad = trm.ConstantSoilHydraulics(swrc=trm.BrooksCorey(), unsat_hydraulic_cond=trm.UnsatKVanGenuchten())
+        trm.flatten(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(hydraulic_properties=bad))))
+
+
+def test_column_ring_grid_scatter_gather():
+    # test/grids.jl:44-139: scatter/gather identity between the ring grid and the column vector
+    mask = trm.masks.load_land_mask("N72")
+    grid = trm.ColumnRingGrid(trm.ExponentialSpacing(N=30), mask)
+    assert grid.Nh == 14017 and grid.Nz == 30
+    cols = np.arange(grid.Nh, dtype=np.float64)
+    full = grid.scatter(cols)
+    assert full.shape == mask.shape and np.isnan(full[~mask]).all()
+    assert np.array_equal(grid.gather(full), cols)
+    lat, lon = trm.masks.masked_latlon(mask)
+    assert lat.shape == (14017,) and np.all(np.abs(lat) < np.pi / 2) and np.all((0 <= lon) & (lon < 2 * np.pi))
+    assert lat[0] > lat[-1]  # ring order runs north -> south
+
+
+def test_bc_aliases():
+    bcs = trm.merge_boundary_conditions(trm.PrescribedSurfaceTemperature("T_ub", 1.0), trm.GeothermalHeatFlux(0.05),
+                                        trm.FreeDrainage(), trm.ImpermeableBoundary())
+    assert bcs[("temperature", "top")] == ("value", 1.0)
+    assert bcs[("internal_energy", "bottom")] == ("flux", 0.05)
+    assert bcs[("pressure_head", "bottom")] == ("gradient", 0.0)
+    assert bcs[("saturation_water_ice", "bottom")][0] == "noflux"
