@@ -38,6 +38,7 @@ struct trm_ctx {
     std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
     double dzf_bot = 0, dzf_top = 0, dzc_bot = 0, dzc_top = 0, Az = 1;
     uint32_t* d_status = nullptr;
+    void* d_zero = nullptr;  // [Nh] zeros: stands in for the value array of every unset boundary condition
     double* d_reduce = nullptr;  // scratch for trm_reduce
     size_t reduce_cap = 0;
     double time = 0.0;
@@ -237,7 +238,7 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b) {
             v.bc.kind[a][b] = c->bc_kind[a][b];
-            v.bc.value[a][b] = c->bc_value[a][b];
+            v.bc.value[a][b] = c->bc_value[a][b] ? c->bc_value[a][b] : c->d_zero;
         }
     return v;
 }
@@ -392,8 +393,18 @@ template <class NF> struct Ops {
         } else {
             grid.x = (grid.x + TRM_STEP_GROUPS - 1) / TRM_STEP_GROUPS;  // each wave takes TRM_STEP_GROUPS column groups
         }
-        hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize,
-                           (c->opt_write_kf || finalize) ? 1 : 0);
+        // the branch-free kernel covers Value on temperature and Flux on the prognostics; anything else is generic
+        bool generic = false;
+        for (int side = 0; side < 2; ++side) {
+            generic = generic || c->bc_kind[TRM_BCV_TEMPERATURE][side] == TRM_BC_GRADIENT;
+            for (int var : {TRM_BCV_SATURATION_WATER_ICE, TRM_BCV_LIQUID_WATER_FRACTION, TRM_BCV_PRESSURE_HEAD})
+                generic = generic || c->bc_kind[var][side] == TRM_BC_VALUE || c->bc_kind[var][side] == TRM_BC_GRADIENT;
+        }
+        const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+        if (generic)
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
+        else
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
@@ -709,6 +720,8 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     hip(hipEventCreate(&c->ev0), "hipEventCreate");
     hip(hipEventCreate(&c->ev1), "hipEventCreate");
     hip(hipMalloc((void**)&c->d_status, sizeof(uint32_t)), "hipMalloc(status)");
+    hip(hipMalloc(&c->d_zero, (size_t)c->Nh * c->esize), "hipMalloc(zero)");
+    if (rc == TRM_OK) hip(hipMemset(c->d_zero, 0, (size_t)c->Nh * c->esize), "hipMemset(zero)");
     if (rc) return bail(rc);
     hip(hipMemset(c->d_status, 0, sizeof(uint32_t)), "hipMemset(status)");
     if ((rc = alloc_fields(c, c->state))) return bail(rc);
@@ -740,7 +753,7 @@ int trm_destroy(trm_ctx* c) {
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b)
             if (c->bc_value[a][b]) (void)hipFree(c->bc_value[a][b]);
-    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, (void*)c->d_status, (void*)c->d_reduce})
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_zero, (void*)c->d_status, (void*)c->d_reduce})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

@@ -57,6 +57,16 @@ template <> struct Limits<float> {
     static TRM_HD float inf() { return __builtin_huge_valf(); }
 };
 
+// Upwinded face conductivity of the Darcy flux (soil_hydrology_rre.jl:120-125):
+//     K* = (g < 0) * min(K[k-1], K[k]) + (g >= 0) * min(K[k], K[k+1])
+// The Bool factors are strong zeros, so for any non-NaN gradient exactly one term survives and the other
+// contributes a signed zero; q = -K* g, the flux difference and the `+ forcing` that follows absorb the
+// sign of a zero, and a NaN gradient gives q = NaN either way.  The select form is therefore
+// value-identical downstream (verified bit for bit against the oracle, which keeps the product form).
+template <class NF> TRM_DEV NF upwind_conductivity(NF g, NF Kdn, NF Kmid, NF Kup) {
+    return (g < NF(0)) ? jl_min(Kdn, Kmid) : jl_min(Kmid, Kup);
+}
+
 // src/utils/utils.jl:25
 template <class NF> TRM_HD NF safediv(NF x, NF y) { return (y == NF(0)) ? Limits<NF>::inf() : x / (y + Limits<NF>::eps()); }
 
@@ -122,9 +132,30 @@ TRM_DEV float sqrt_(float x) { return sqrtf(x); }
 TRM_DEV double fabs_(double x) { return fabs(x); }
 TRM_DEV float fabs_(float x) { return fabsf(x); }
 
+// pow_body(x, -5) with the loop unrolled: the same operations in the same order as pow_int(x, -5) for
+// finite x (x * 0 and 1 * x folded; they are exact), i.e. bit-identical -- the BrooksCorey default
+// lambda = 0.2 evaluates r^(-1/lambda) = r^(-5.0) for every cell and step.
+template <class NF> TRM_HD NF pow_int_m5(NF x) {
+    const NF rx = NF(1) / x;
+    const NF l0 = -fma_(x, rx, NF(-1)) * rx;     // low part of 1/x
+    // n = 5 (odd): y = rx, ynlo = 0 + l0
+    const NF ynlo = NF(0) + (l0 + NF(0));
+    NF err = rx * NF(2) * l0;
+    const NF x2 = rx * rx;
+    const NF l2 = fma_(rx, rx, -x2) + err;
+    // n = 2 (even)
+    err = x2 * NF(2) * l2;
+    const NF x4 = x2 * x2;
+    const NF l4 = fma_(x2, x2, -x4) + err;
+    // n = 1: combine
+    err = fma_(rx, l4, x4 * ynlo);
+    return (is_finite(x4) && is_finite(err)) ? fma_(x4, rx, err) : x4 * rx;
+}
+
 template <class NF> TRM_DEV NF jl_pow(NF x, const PowSpec<NF>& s) {
+    // (Base.:^ returns 1.0 for x === 1.0 up front; the integer path gives exactly 1 there anyway)
+    if (s.is_int) return (s.n == -5) ? pow_int_m5(x) : pow_int(x, s.n);
     if (x == NF(1)) return NF(1);
-    if (s.is_int) return pow_int(x, s.n);
     return pow_generic(x, s.y);
 }
 

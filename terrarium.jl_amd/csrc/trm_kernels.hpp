@@ -124,8 +124,8 @@ template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevP
         NF Km = face(k - 1), K0 = face(k), K1 = face(k + 1), K2 = face(k + 2);
         NF g_lo = (psi0 - psim) * v.rdzf[k];
         NF g_hi = (psip - psi0) * v.rdzf[k + 1];
-        NF Klo = boolmul(g_lo < NF(0), jl_min(Km, K0)) + boolmul(g_lo >= NF(0), jl_min(K0, K1));
-        NF Khi = boolmul(g_hi < NF(0), jl_min(K0, K1)) + boolmul(g_hi >= NF(0), jl_min(K1, K2));
+        NF Klo = upwind_conductivity(g_lo, Km, K0, K1);
+        NF Khi = upwind_conductivity(g_hi, K0, K1, K2);
         NF q_lo = -Klo * g_lo, q_hi = -Khi * g_hi;
         NF dtheta = -((q_hi - q_lo) * v.rdzc[k]) + NF(0) + p.vwc_forcing;
         v.G_sat[c] += div_const(dtheta, p.por, p.rpor);
@@ -294,6 +294,11 @@ TRM_DEV float shift_up(float x) { return __builtin_bit_cast(float, dpp_shr1(__bu
 TRM_DEV float shift_dn(float x) { return __builtin_bit_cast(float, dpp_shl1(__builtin_bit_cast(int, x))); }
 template <class NF, int LPC> TRM_DEV NF shfl_up1(NF x) { return shift_up(x); }
 template <class NF, int LPC> TRM_DEV NF shfl_dn1(NF x) { return shift_dn(x); }
+// ballot -> set of LEVELS at which any of the wave's columns has the bit set
+template <int LPC> TRM_DEV unsigned long long level_bits(unsigned long long ballot) {
+    if (LPC == 64) return ballot;
+    return (ballot | (ballot >> 32)) & 0xffffffffull;
+}
 template <int LPC> TRM_DEV unsigned long long group_mask(int lane) {
     if (LPC == 64) return ~0ull;
     return (lane & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
@@ -316,37 +321,46 @@ template <class NF> TRM_DEV LevelGeom<NF> level_geom(const View<NF>& v, int k) {
 }
 
 // adjust_saturation_profile! (soil_hydrology.jl:185-219) on a column held one level per lane.
-// Both passes are sequential in z; the lane-serial loops run only when a ballot finds a cell that
-// actually needs repair, otherwise the pass reduces to the `+ 0` the reference applies.
-// Returns the column's surface overflow (excess * dz_top), uniform over the column's lanes.
+// Both passes are sequential in z.  One ballot decides: if no cell below the top is oversaturated the
+// upward pass only applies its `+ 0`; the downward pass then sees the same profile, so the same ballot also
+// covers "no cell above the bottom is negative", and the whole repair reduces to `s + 0` plus the top
+// overflow and the bottom clamp, all lane-local.  Otherwise both passes run as lane-serial loops.
+// Returns excess * dz_top in the TOP lane (0 elsewhere): the column's overflow into surface_excess_water.
 template <class NF, int LPC>
 TRM_DEV NF repair_saturation(NF& snew, int k, int Nz, bool act, bool is_bot, bool is_top, const LevelGeom<NF>& L) {
-    {   // upward pass
-        const bool over = act && !is_top && !(jl_max(snew - NF(1), NF(0)) == NF(0));
-        if (__ballot(over) == 0ull) {
-            if (!is_bot) snew = snew + NF(0);  // sat[k+1] += 0 * dz[k] / dz[k+1]
-        } else {
+    const bool over = act && !is_top && !(jl_max(snew - NF(1), NF(0)) == NF(0));
+    const bool under = act && !is_bot && !(jl_max(-snew, NF(0)) == NF(0));
+    const unsigned long long any_over = __ballot(over);
+    const unsigned long long any_bad = __ballot(over || under);
+    // every cell but the bottom one receives `+ carry` / `+ deficit`; with nothing to move that is `+ 0`
+    // (idempotent, and absorbed by a later non-zero addend), so apply it once up front
+    snew = is_bot ? snew : snew + NF(0);
+    if (any_bad != 0ull) {
+        // Lane-serial passes, restricted to the levels that can change: the upward pass starts at the lowest
+        // oversaturated level and stops once the carry is zero with no oversaturated level left above;
+        // outside that range the reference's updates are the `+ 0` already applied.
+        if (any_over != 0ull) {
+            const unsigned long long lv = level_bits<LPC>(any_over);
             NF carry = NF(0);
-            for (int q = 0; q < Nz - 1; ++q) {
+            for (int q = __builtin_ctzll(lv); q < Nz - 1; ++q) {
                 NF cout = NF(0);
                 if (k == q) {
-                    if (q > 0) snew = snew + carry;
+                    snew = snew + carry;
                     NF e = jl_max(snew - NF(1), NF(0));
                     snew = snew - e;
                     cout = div_const(e * L.dzc, L.dzc_up, L.rdzc_up);
                 }
                 carry = shfl_from<NF, LPC>(cout, q);
+                if ((lv >> (q + 1)) == 0ull && __ballot(!(carry == NF(0))) == 0ull) break;
             }
             if (is_top) snew = snew + carry;
         }
-    }
-    {   // downward pass
-        const bool under = act && !is_bot && !(jl_max(-snew, NF(0)) == NF(0));
-        if (__ballot(under) == 0ull) {
-            if (!is_bot) snew = snew + NF(0);  // sat[k] += deficit (= 0)
-        } else {
+        const bool under2 = act && !is_bot && !(jl_max(-snew, NF(0)) == NF(0));
+        const unsigned long long any_under = __ballot(under2);
+        if (any_under != 0ull) {
+            const unsigned long long lv = level_bits<LPC>(any_under);
             NF pend = NF(0);
-            for (int q = Nz - 1; q >= 1; --q) {
+            for (int q = 63 - __builtin_clzll(lv); q >= 1; --q) {
                 NF pout = NF(0);
                 if (k == q) {
                     snew = snew - pend;
@@ -355,18 +369,15 @@ TRM_DEV NF repair_saturation(NF& snew, int k, int Nz, bool act, bool is_bot, boo
                     pout = div_const(d * L.dzc, L.dzc_dn, L.rdzc_dn);
                 }
                 pend = shfl_from<NF, LPC>(pout, q);
+                if ((lv & ((1ull << q) - 1ull)) == 0ull && __ballot(!(pend == NF(0))) == 0ull) break;
             }
             if (is_bot) snew = snew - pend;
         }
     }
-    // surface overflow joins surface_excess_water; bottom clamp
-    NF e_top = NF(0);
-    if (is_top) {
-        e_top = jl_max(snew - NF(1), NF(0));
-        snew = snew - e_top;
-    }
-    e_top = shfl_from<NF, LPC>(e_top, Nz - 1);
-    if (is_bot) snew = jl_max(snew, NF(0));
+    // surface overflow joins surface_excess_water (top lane); bottom clamp (bottom lane)
+    const NF e_top = is_top ? jl_max(snew - NF(1), NF(0)) : NF(0);
+    snew = snew - e_top;
+    snew = is_bot ? jl_max(snew, NF(0)) : snew;
     return e_top * L.dzc_top;
 }
 // compute_water_table! (soil_hydrology.jl:170-175, kernel_utils.jl:7-16): lower face of the first
@@ -396,7 +407,7 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
         NF over = repair_saturation<NF, LPC>(s, k, Nz, act, is_bot, is_top, L);
         if (act) {
             v.sat[c] = s;
-            if (is_bot) v.S[i] += over;
+            if (is_top) v.S[i] += over;
         }
     }
     NF z0 = water_table<NF, LPC>(s, act, lane, L);
@@ -427,7 +438,11 @@ template <class NF> struct RawCell { NF U, sat, T, liq, psi; };
 #define TRM_STEP_BLOCK 256
 #endif
 
-template <class NF, bool RICHARDS, int HYD, int LPC>
+// GENERIC_BC = false is the common case -- the only boundary conditions are Value conditions on
+// temperature and Flux conditions on the prognostic variables (everything the reference's models and
+// examples set up); it is handled without a single branch.  Any other kind (Gradient, Value on liquid
+// fraction / saturation / pressure head) takes the GENERIC_BC = true instantiation.
+template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
     constexpr int CPW = 64 / LPC;
     constexpr bool PERSIST = TRM_STEP_PERSISTENT != 0;
@@ -517,44 +532,79 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
     return;
 #endif
 
-    const Frac<NF> f = fractions(p, sat, liq, viol);
+    // (composition bounds of the incoming state were flagged by the launch that produced it)
+    uint32_t viol_old = 0;
+    const Frac<NF> f = fractions(p, sat, liq, viol_old);
     const NF kap = conductivity(p, f);
     const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD>(p, liq, f) : NF(0);
 
     // ---- neighbours by shuffle (executed by all lanes, never inside a divergent select) -----------
     const NF T_sh = shfl_up1<NF, LPC>(T), kap_sh = shfl_up1<NF, LPC>(kap);
-    // halo cells below the bottom / above the top cell, formed by the boundary lanes only
+    // halo cells below the bottom / above the top cell
     NF T_m = T_sh, kap_m = kap_sh, T_h = NF(0), kap_h = NF(0), psi_hb = NF(0), psi_ht = NF(0);
     NF flux_U = NF(0), flux_S = NF(0);  // compute_z_bcs! term of this lane's cell (0 in the interior)
-    if (is_bot) {
-        T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
-        kap_m = kap;
-        if (!same_bot) {
-            NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq, v.g);
-            NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat);
-            kap_m = conductivity(p, fractions(p, sh, lh, viol));
+    if (GENERIC_BC) {
+        if (is_bot) {
+            T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
+            kap_m = kap;
+            if (!same_bot) {
+                NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq, v.g);
+                NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat);
+                kap_m = conductivity(p, fractions(p, sh, lh, viol));
+            }
+            if (RICHARDS) psi_hb = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), ii, psi, v.g);
+            if (v.bc.kind[0][0] == 2) flux_U = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
+            if (RICHARDS && v.bc.kind[1][0] == 2) flux_S = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
         }
-        if (RICHARDS) psi_hb = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), ii, psi, v.g);
-        if (v.bc.kind[0][0] == 2) flux_U = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
-        if (RICHARDS && v.bc.kind[1][0] == 2) flux_S = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
-    }
-    if (is_top) {
-        T_h = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), ii, T, v.g);
-        kap_h = kap;
-        if (!same_top) {
-            NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, liq, v.g);
-            NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sat);
-            kap_h = conductivity(p, fractions(p, sh, lh, viol));
+        if (is_top) {
+            T_h = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), ii, T, v.g);
+            kap_h = kap;
+            if (!same_top) {
+                NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, liq, v.g);
+                NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sat);
+                kap_h = conductivity(p, fractions(p, sh, lh, viol));
+            }
+            if (RICHARDS) psi_ht = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), ii, psi, v.g);
+            // top flux BCs enter with a minus sign; LandModel wires ground_heat_flux / -infiltration
+            // (land_model.jl:56-61), produced by k_surface just before this launch
+            if (p.seb) {
+                flux_U = -flux_term_top(v.ghf[ii], v.g);
+                if (RICHARDS) flux_S = -flux_term_top(-v.infil[ii], v.g);
+            } else {
+                if (v.bc.kind[0][1] == 2) flux_U = -flux_term_top(bcval(v, 0, 1)[ii], v.g);
+                if (RICHARDS && v.bc.kind[1][1] == 2) flux_S = -flux_term_top(bcval(v, 1, 1)[ii], v.g);
+            }
         }
-        if (RICHARDS) psi_ht = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), ii, psi, v.g);
-        // top flux BCs enter with a minus sign; LandModel wires ground_heat_flux / -infiltration
-        // (land_model.jl:56-61), produced by k_surface just before this launch
-        if (p.seb) {
-            flux_U = -flux_term_top(v.ghf[ii], v.g);
-            if (RICHARDS) flux_S = -flux_term_top(-v.infil[ii], v.g);
-        } else {
-            if (v.bc.kind[0][1] == 2) flux_U = -flux_term_top(bcval(v, 0, 1)[ii], v.g);
-            if (RICHARDS && v.bc.kind[1][1] == 2) flux_S = -flux_term_top(bcval(v, 1, 1)[ii], v.g);
+    } else {
+        // Branch-free boundary handling.  Every BC value pointer is valid (unset conditions point at a zero
+        // array), all lanes of a column read the same address, and the selects are on wave-uniform kinds.
+        const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
+        const NF bTb = bcval(v, 2, 0)[ii], bTt = bcval(v, 2, 1)[ii];
+        const NF T_ext_b = T + div_const(T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
+        const NF T_ext_t = T + div_const(bTt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
+        T_m = is_bot ? (vTb ? T_ext_b : T) : T_sh;
+        T_h = vTt ? T_ext_t : T;
+        // liquid fraction / saturation / pressure head carry the default condition: halo = edge cell, so the halo
+        // cell's conductivity is the edge cell's, bit for bit -- except under NoFlow with the reference's
+        // never-filled saturation halo (SURVEY C-1), where the halo cell is dry
+        NF kap_halo = kap;
+        if (!RICHARDS && p.halo_policy != 1) kap_halo = conductivity(p, fractions(p, NF(0), liq, viol));
+        kap_m = is_bot ? kap_halo : kap_sh;
+        kap_h = kap_halo;
+        psi_hb = psi;
+        psi_ht = psi;
+        // flux conditions; LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by
+        // k_surface just before this launch.  Top terms enter with a minus sign.
+        const bool seb = p.seb != 0;
+        const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
+        const NF tUb = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
+        const NF tUt = flux_term_top(seb ? v.ghf[ii] : bcval(v, 0, 1)[ii], v.g);
+        flux_U = is_bot ? (fUb ? tUb : NF(0)) : (is_top ? (fUt ? -tUt : NF(0)) : NF(0));
+        if (RICHARDS) {
+            const bool fSb = v.bc.kind[1][0] == 2, fSt = seb || v.bc.kind[1][1] == 2;
+            const NF tSb = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
+            const NF tSt = flux_term_top(seb ? -v.infil[ii] : bcval(v, 1, 1)[ii], v.g);
+            flux_S = is_bot ? (fSb ? tSb : NF(0)) : (is_top ? (fSt ? -tSt : NF(0)) : NF(0));
         }
     }
     // ---- heat: every lane forms its lower face, the top lane also the boundary face -------------------
@@ -575,13 +625,13 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
         const NF Kf_p = is_top ? Kc : Kf_dn;      // face Nz repeats the top cell's value
         const NF psi_m = is_bot ? psi_hb : psi_sh;
         const NF g_lo = (psi - psi_m) * L.rdzf_lo;
-        const NF Ks_lo = boolmul(g_lo < NF(0), jl_min(Kf_m, Kf_lo)) + boolmul(g_lo >= NF(0), jl_min(Kf_lo, Kf_p));
+        const NF Ks_lo = upwind_conductivity(g_lo, Kf_m, Kf_lo, Kf_p);
         const NF qW_lo = -Ks_lo * g_lo;
         const NF qW_sh = shfl_dn1<NF, LPC>(qW_lo);
         NF qW_hi = qW_sh;
         if (is_top) {  // boundary face above the top cell
             const NF g_t = (psi_ht - psi) * L.rdzf_hi;
-            const NF Ks_t = boolmul(g_t < NF(0), jl_min(Kf_lo, Kc)) + boolmul(g_t >= NF(0), jl_min(Kc, NF(0)));
+            const NF Ks_t = upwind_conductivity(g_t, Kf_lo, Kc, NF(0));
             qW_hi = -Ks_t * g_t;
         }
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
@@ -599,15 +649,26 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
         bad = bad || (act && is_nan(snew));
         const NF over = repair_saturation<NF, LPC>(snew, k, Nz, act, is_bot, is_top, L);
         z0 = water_table<NF, LPC>(snew, act, lane, L);
-        if (act && is_bot) {
+        if (act && is_top) {
             // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler update, overflow
             NF S = v.S[i];
             S = S + (NF(0) + jl_min(NF(0), S)) * dt;
             v.S[i] = S + over;
             v.wt[i] = z0;
+            if (p.seb) v.Ts[i] = v.Ts[i] + NF(0) * dt;  // zero-tendency prognostic skin_temperature
         }
+    } else if (act && is_top && p.seb) {
+        v.Ts[i] = v.Ts[i] + NF(0) * dt;
     }
-    if (act && is_top && p.seb) v.Ts[i] = v.Ts[i] + NF(0) * dt;  // zero-tendency prognostic skin_temperature
+#ifdef TRM_EXP_EXTRA_VALU   // tuning experiment: N extra independent fp64 FMAs per lane (4 chains)
+    NF xa = U, xb = sat, xc = T, xd = liq;
+#pragma unroll
+    for (int j = 0; j < TRM_EXP_EXTRA_VALU / 4; ++j) {
+        xa = fma_(xa, NF(1.0000001), NF(1e-9)); xb = fma_(xb, NF(0.9999999), NF(1e-9));
+        xc = fma_(xc, NF(1.0000002), NF(1e-9)); xd = fma_(xd, NF(0.9999998), NF(1e-9));
+    }
+    if (xa + xb + xc + xd == NF(-12345.678)) bad = true;
+#endif
     // ---- closures: (U, sat) -> (T, liq, psi) ------------------------------------------------------------------
     NF ln, Tn;
     energy_closure(p, Unew, snew, ln, Tn, viol);

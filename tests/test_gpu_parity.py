@@ -236,6 +236,42 @@ def test_saturation_repair_cases_on_device():
     assert np.allclose(sat[:, 0], 1.0) and np.all(sat[:, 1] >= 0) and np.allclose(sat[:, 2], 0.0)
 
 
+@pytest.mark.parametrize("Nz", [2, 5, 32, 64, 100])
+def test_saturation_repair_random_profiles(Nz):
+    """adjust_saturation_profile! (soil_hydrology.jl:185-219) on random profiles through trm_closure: mostly legal
+    cells with sparse or dense over- (sat > 1) and undersaturated (sat < 0) runs, -0.0 cells, exact 0 and 1,
+    on a non-uniform grid.  The device runs range-limited lane-serial passes (sequential kernel for Nz > 64);
+    saturation and the surface overflow must match the oracle's full sequential passes bit for bit."""
+    import oracle
+    rng = np.random.Generator(np.random.PCG64(1234 + Nz))
+    Nh = 257
+    thickness = np.round(rng.uniform(0.05, 0.4, size=Nz), 3)
+    p = trm._capi.default_params()
+    p.flow = 1
+    grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(thickness)), Nh)
+    dev = trm.DeviceState(grid, p)
+    orc = oracle.Oracle(Nh, thickness, oracle.default_params(flow=1))
+    sat = rng.uniform(0.05, 0.999, size=(Nz, Nh))
+    density = rng.choice([0.0, 0.03, 0.2, 0.7], size=Nh)[None, :]        # per column: none / sparse / dense
+    r = rng.uniform(size=(Nz, Nh))
+    sat = np.where(r < 0.5 * density, rng.uniform(1.0, 1.6, size=(Nz, Nh)), sat)
+    sat = np.where((r >= 0.5 * density) & (r < density), rng.uniform(-0.5, 0.0, size=(Nz, Nh)), sat)
+    special = rng.uniform(size=(Nz, Nh))
+    sat = np.where(special < 0.02, -0.0, sat)
+    sat = np.where((special >= 0.02) & (special < 0.04), 1.0, sat)
+    sat = np.where((special >= 0.04) & (special < 0.05), 0.0, sat)
+    sat[:, 0] = np.linspace(1.2, 1.5, Nz)          # every level oversaturated: the carry runs the full column
+    sat[:, 1] = -np.linspace(0.1, 0.3, Nz)         # every level negative
+    dev.set("saturation_water_ice", sat)
+    orc.set("saturation_water_ice", sat)
+    dev.closure()
+    orc.closure()
+    for n in ("saturation_water_ice", "surface_excess_water"):
+        a, b = dev.get(n), orc.get(n)
+        assert np.array_equal(a, b), (n, np.argwhere(a != b)[:5])
+        assert np.array_equal(np.signbit(a), np.signbit(b)), n + " (sign of zero)"
+
+
 @pytest.mark.parametrize("kernel", ["fused", "unfused"])
 def test_saturation_repair_inside_step(kernel):
     """Drive the serial repair from legal states: a strong infiltration flux oversaturates the top cells; the
