@@ -44,7 +44,6 @@ struct trm_ctx {
     double time = 0.0;
     int64_t iteration = 0;
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1;
-    int max_step_blocks = 256 * 5;  // resident workgroups of the persistent fused step kernel
     std::string err;
 };
 
@@ -385,14 +384,8 @@ template <class NF> struct Ops {
     template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
         auto v = make_view<NF>(c, c->state);
         auto p = make_dev_params<NF>(c->params);
-        // persistent waves: at most 8 workgroups (32 waves) per CU's worth of the 256 CUs
         dim3 grid = wave_grid(c, LPC);
         grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
-        if (TRM_STEP_PERSISTENT) {
-            if (grid.x > (unsigned)c->max_step_blocks) grid.x = (unsigned)c->max_step_blocks;
-        } else {
-            grid.x = (grid.x + TRM_STEP_GROUPS - 1) / TRM_STEP_GROUPS;  // each wave takes TRM_STEP_GROUPS column groups
-        }
         // the branch-free kernel covers Value on temperature and Flux on the prognostics; anything else is generic
         bool generic = false;
         for (int side = 0; side < 2; ++side) {
@@ -691,8 +684,10 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     if (g->device < 0 || g->device >= ndev) return fail(nullptr, TRM_EINVAL, "trm_create: device ordinal out of range");
     {
         long nzp = g->num_layers <= 32 ? 32 : (g->num_layers <= 64 ? 64 : ((g->num_layers + 31) / 32) * 32);
-        if ((double)g->num_columns * (double)nzp >= 2147483648.0)
-            return fail(nullptr, TRM_EINVAL, "trm_create: num_columns * level pitch must stay below 2^31 per device");
+        const double esz = g->precision == TRM_F64 ? 8.0 : 4.0;
+        if ((double)g->num_columns * (double)nzp * esz >= 4294967296.0)
+            return fail(nullptr, TRM_EINVAL, "trm_create: one field (num_columns * level pitch * word size) must stay below 4 GiB per "
+                                             "device (32-bit byte offsets in the step kernel); shard the columns over more contexts");
     }
     trm_ctx* c = new trm_ctx();
     c->precision = g->precision;
@@ -702,7 +697,6 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     c->Nzp = c->Nz <= 32 ? 32 : (c->Nz <= 64 ? 64 : ((c->Nz + 31) / 32) * 32);
     c->device = g->device;
     c->params = *p;
-    if (const char* e = getenv("TRM_STEP_BLOCKS")) c->max_step_blocks = std::max(1, atoi(e));  // tuning knob
     c->Az = g->dx > 0 ? g->dx : 1.0 / (double)c->Nh;
     if (c->precision == TRM_F32) c->Az = (double)(float)c->Az;
     auto bail = [&](int rc) {

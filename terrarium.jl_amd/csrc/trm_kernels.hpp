@@ -305,6 +305,23 @@ template <int LPC> TRM_DEV unsigned long long group_mask(int lane) {
 }
 
 // per-lane grid constants of level k (fixed for the whole kernel: lane <-> level)
+// Global accesses with a 32-bit BYTE offset: `scalar base + zero-extended vector offset` is the one form the
+// backend maps onto global_load/store's saddr addressing, so a cell's ~30 accesses share a single offset
+// register instead of one 64-bit address computation each.  trm_create checks Nh * Nzp * sizeof(NF) < 2^32.
+template <class NF> TRM_DEV NF ldg(const NF* base, unsigned byte_off) {
+    return *reinterpret_cast<const NF*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <class NF> TRM_DEV void stg(NF* base, unsigned byte_off, NF x) {
+    *reinterpret_cast<NF*>(reinterpret_cast<char*>(base) + byte_off) = x;
+}
+// Instruction selection works one basic block at a time: an offset defined in another block has already been
+// widened to 64 bits there.  Re-materialising it (a no-op the optimiser cannot see through) keeps the
+// zero-extension, and with it the saddr form, inside the block that does the access.
+TRM_DEV unsigned block_local(unsigned byte_off) {
+    asm volatile("" : "+v"(byte_off));
+    return byte_off;
+}
+
 template <class NF> struct LevelGeom {
     NF zC, psiz, zFlo, dzc, rdzc, rdzf_lo, rdzf_hi, dzc_up, rdzc_up, dzc_dn, rdzc_dn, zF_top, dzc_top;
 };
@@ -313,9 +330,11 @@ template <class NF> TRM_DEV LevelGeom<NF> level_geom(const View<NF>& v, int k) {
     const int kk = k < Nz ? k : Nz - 1;
     const int ku = kk + 1 < Nz ? kk + 1 : kk, kd = kk > 0 ? kk - 1 : 0;
     LevelGeom<NF> L;
-    L.zC = v.zC[kk]; L.psiz = v.psiz[kk]; L.zFlo = v.zF[kk]; L.dzc = v.dzc[kk]; L.rdzc = v.rdzc[kk];
-    L.rdzf_lo = v.rdzf[kk]; L.rdzf_hi = v.rdzf[kk + 1];
-    L.dzc_up = v.dzc[ku]; L.rdzc_up = v.rdzc[ku]; L.dzc_dn = v.dzc[kd]; L.rdzc_dn = v.rdzc[kd];
+    const unsigned e = (unsigned)sizeof(NF);
+    const unsigned kb = (unsigned)kk * e, kub = (unsigned)ku * e, kdb = (unsigned)kd * e;
+    L.zC = ldg(v.zC, kb); L.psiz = ldg(v.psiz, kb); L.zFlo = ldg(v.zF, kb); L.dzc = ldg(v.dzc, kb); L.rdzc = ldg(v.rdzc, kb);
+    L.rdzf_lo = ldg(v.rdzf, kb); L.rdzf_hi = ldg(v.rdzf, kb + e);
+    L.dzc_up = ldg(v.dzc, kub); L.rdzc_up = ldg(v.rdzc, kub); L.dzc_dn = ldg(v.dzc, kdb); L.rdzc_dn = ldg(v.rdzc, kdb);
     L.zF_top = v.zF[Nz]; L.dzc_top = v.dzc[Nz - 1];
     return L;
 }
@@ -423,17 +442,6 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 // lane = level, one column per LPC lanes; every wave is independent (no LDS, no barrier):
 // 5 coalesced loads, ~300 fp64 instructions, 6 coalesced stores per cell.
 // ===========================================================================
-template <class NF> struct RawCell { NF U, sat, T, liq, psi; };
-
-#ifndef TRM_STEP_MIN_WAVES
-#define TRM_STEP_MIN_WAVES 1
-#endif
-#ifndef TRM_STEP_PERSISTENT
-#define TRM_STEP_PERSISTENT 0
-#endif
-#ifndef TRM_STEP_GROUPS
-#define TRM_STEP_GROUPS 1
-#endif
 #ifndef TRM_STEP_BLOCK
 #define TRM_STEP_BLOCK 256
 #endif
@@ -442,92 +450,40 @@ template <class NF> struct RawCell { NF U, sat, T, liq, psi; };
 // temperature and Flux conditions on the prognostic variables (everything the reference's models and
 // examples set up); it is handled without a single branch.  Any other kind (Gradient, Value on liquid
 // fraction / saturation / pressure head) takes the GENERIC_BC = true instantiation.
+//
+// Diagnostic builds (never shipped): -DTRM_EXP_MEMORY_ONLY (same traffic, no
+// arithmetic), -DTRM_EXP_COMPUTE_ONLY (no global traffic), -DTRM_EXP_EXTRA_VALU=N (N extra fp64 FMAs per lane).
 template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
-    constexpr int CPW = 64 / LPC;
-    constexpr bool PERSIST = TRM_STEP_PERSISTENT != 0;
-#ifdef TRM_EXP_EMPTY_WAVES   // tuning experiment: same register footprint, waves exit at once => pure launch throughput
-    if (finalize != 12345) return;
-#endif
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
+    constexpr int CPW = 64 / LPC;   // columns per wave
     const int lane = threadIdx.x & 63;
-    const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    const long ngroups = (v.Nh + CPW - 1) / CPW;   // column groups (CPW columns each), one per wave visit
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int k = lane % LPC, sub = lane / LPC;
-    const int Nz = v.Nz;
+    const int Nz = v.Nz, Nh = (int)v.Nh;
     const bool is_bot = k == 0, is_top = k == Nz - 1;
-#if TRM_STEP_PERSISTENT
-    // Persistent build: the per-level grid constants live in LDS and are re-read per column group, so that
-    // they do not stay in 26 VGPRs across the whole loop.
-    __shared__ LevelGeom<NF> geom_lds[LPC];
-    if (threadIdx.x < LPC) geom_lds[threadIdx.x] = level_geom(v, (int)threadIdx.x);
-    __syncthreads();
-#else
     const LevelGeom<NF> L = level_geom(v, k);
-#endif
     const bool need_kc = RICHARDS || write_kf;
-    // With the default (no-flux) conditions on liquid fraction and saturation the halo cell has the edge
-    // cell's composition, hence bit for bit its conductivity: nothing to recompute.
-    const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 &&
-                          (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
-    const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 &&
-                          (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
-    uint32_t viol_all = 0;
 
-    // 32-bit element offsets (Nh * Nzp < 2^31 is checked at trm_create): the loads and stores then use
-    // the scalar-base + 32-bit vector-offset addressing form instead of 64-bit vector address arithmetic
-    auto cell_index = [&](long group) {
-        const int i = (int)(group * CPW) + sub;
-        const int ii = i < (int)v.Nh ? i : (int)v.Nh - 1;
-        return (unsigned)(ii * v.Nzp + (k < Nz ? k : Nz - 1));
-    };
-    auto load_cell = [&](long group) {
-        const unsigned c = cell_index(group);
-        RawCell<NF> r;
-#ifdef TRM_EXP_COMPUTE_ONLY   // tuning experiment: plausible register inputs, no global loads
-        r.U = NF(1.0e6) + NF(c) * NF(3.0); r.sat = NF(0.5) + NF(c & 31) * NF(0.01); r.T = NF(2) + NF(c & 7);
-        r.liq = NF(1); r.psi = NF(-1) - NF(c & 15) * NF(0.1);
-        return r;
-#endif
-#ifdef TRM_EXP_RECOMPUTE_TL   // tuning experiment: derive T / liq from (U, sat) instead of reading them
-        r.U = v.U[c]; r.sat = v.sat[c];
-        { uint32_t vv = 0; energy_closure(p, r.U, r.sat, r.liq, r.T, vv); }
-        r.psi = RICHARDS ? v.psi[c] : NF(0);
-        return r;
-#endif
-        r.U = v.U[c]; r.sat = v.sat[c]; r.T = v.T[c]; r.liq = v.liq[c];
-        r.psi = RICHARDS ? v.psi[c] : NF(0);
-        return r;
-    };
-
-#ifdef TRM_EXP_STAGGER
-    // tuning experiment: de-phase the first generation of waves by their SIMD slot so that not every
-    // wave of the chip loads (then computes) at the same time
-    if (blockIdx.x < 256u * 6u) {
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 0xf;  // HW_ID.wave_id
-        for (unsigned j = 0; j < slot; ++j) __builtin_amdgcn_s_sleep(TRM_EXP_STAGGER);
-    }
-#endif
-    // One column group (CPW columns) per call.
-    auto process = [&](long group, const RawCell<NF>& cur) {
-#if TRM_STEP_PERSISTENT
-    int kopaque = k;
-    asm volatile("" : "+v"(kopaque));   // keeps the LDS reads inside the loop (no hoisting into long-lived VGPRs)
-    const LevelGeom<NF> L = geom_lds[kopaque];
-#endif
-    const long i = group * CPW + sub;
-    const bool colok = i < v.Nh;            // uniform within the column's lanes
+    const int i = wave * CPW + sub;
+    const bool colok = i < Nh;              // uniform within the column's lanes
     const bool act = colok && k < Nz;
-    const long ii = colok ? i : v.Nh - 1;   // safe index for per-column reads
-    const unsigned c = cell_index(group);
+    const int ii = colok ? i : Nh - 1;      // safe index for the tail wave
+    const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF), ib = ib0;
+    const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(k < Nz ? k : Nz - 1)) * (unsigned)sizeof(NF), cb = cb0;
     uint32_t viol = 0;
 
-    const NF U = cur.U, sat = cur.sat, T = cur.T, liq = cur.liq, psi = cur.psi;
-#ifdef TRM_EXP_MEMORY_ONLY   // tuning experiment: same traffic, no arithmetic
+#ifdef TRM_EXP_COMPUTE_ONLY   // plausible register inputs, no global loads
+    const NF U = NF(1.0e6) + NF(cb) * NF(3.0), sat = NF(0.5) + NF(cb & 31) * NF(0.01), T = NF(2) + NF(cb & 7);
+    const NF liq = NF(1), psi = NF(-1) - NF(cb & 15) * NF(0.1);
+#else
+    const NF U = ldg(v.U, cb), sat = ldg(v.sat, cb), T = ldg(v.T, cb), liq = ldg(v.liq, cb);
+    const NF psi = RICHARDS ? ldg(v.psi, cb) : NF(0);
+#endif
+#ifdef TRM_EXP_MEMORY_ONLY
     if (act) {
-        v.U[c] = U + dt; v.T[c] = T + dt; v.liq[c] = liq + dt;
-        if (RICHARDS) { v.sat[c] = sat + dt; v.psi[c] = psi + dt; }
-        if (write_kf) v.Kf[c] = U + sat;
+        stg(v.U, cb, U + dt); stg(v.T, cb, T + dt); stg(v.liq, cb, liq + dt);
+        if (RICHARDS) { stg(v.sat, cb, sat + dt); stg(v.psi, cb, psi + dt); }
+        if (write_kf) stg(v.Kf, cb, U + sat);
     }
     return;
 #endif
@@ -538,12 +494,18 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
     const NF kap = conductivity(p, f);
     const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD>(p, liq, f) : NF(0);
 
-    // ---- neighbours by shuffle (executed by all lanes, never inside a divergent select) -----------
+    // ---- neighbours by DPP row shifts (executed by all lanes, never inside a divergent select) -----------
     const NF T_sh = shfl_up1<NF, LPC>(T), kap_sh = shfl_up1<NF, LPC>(kap);
     // halo cells below the bottom / above the top cell
     NF T_m = T_sh, kap_m = kap_sh, T_h = NF(0), kap_h = NF(0), psi_hb = NF(0), psi_ht = NF(0);
     NF flux_U = NF(0), flux_S = NF(0);  // compute_z_bcs! term of this lane's cell (0 in the interior)
     if (GENERIC_BC) {
+        // With the default (no-flux) conditions on liquid fraction and saturation the halo cell has the edge
+        // cell's composition, hence bit for bit its conductivity: nothing to recompute.
+        const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 &&
+                              (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
+        const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 &&
+                              (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
         if (is_bot) {
             T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
             kap_m = kap;
@@ -579,7 +541,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
         // Branch-free boundary handling.  Every BC value pointer is valid (unset conditions point at a zero
         // array), all lanes of a column read the same address, and the selects are on wave-uniform kinds.
         const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
-        const NF bTb = bcval(v, 2, 0)[ii], bTt = bcval(v, 2, 1)[ii];
+        const NF bTb = ldg(bcval(v, 2, 0), ib), bTt = ldg(bcval(v, 2, 1), ib);
         const NF T_ext_b = T + div_const(T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
         const NF T_ext_t = T + div_const(bTt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
         T_m = is_bot ? (vTb ? T_ext_b : T) : T_sh;
@@ -597,13 +559,14 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
         // k_surface just before this launch.  Top terms enter with a minus sign.
         const bool seb = p.seb != 0;
         const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
-        const NF tUb = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
-        const NF tUt = flux_term_top(seb ? v.ghf[ii] : bcval(v, 0, 1)[ii], v.g);
+        const NF tUb = flux_term_bottom(ldg(bcval(v, 0, 0), ib), v.g);
+        const NF tUt = flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib), v.g);
         flux_U = is_bot ? (fUb ? tUb : NF(0)) : (is_top ? (fUt ? -tUt : NF(0)) : NF(0));
         if (RICHARDS) {
             const bool fSb = v.bc.kind[1][0] == 2, fSt = seb || v.bc.kind[1][1] == 2;
-            const NF tSb = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
-            const NF tSt = flux_term_top(seb ? -v.infil[ii] : bcval(v, 1, 1)[ii], v.g);
+            const NF tSb = flux_term_bottom(ldg(bcval(v, 1, 0), ib), v.g);
+            const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib);
+            const NF tSt = flux_term_top(seb ? -fS : fS, v.g);
             flux_S = is_bot ? (fSb ? tSb : NF(0)) : (is_top ? (fSt ? -tSt : NF(0)) : NF(0));
         }
     }
@@ -651,16 +614,18 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
         z0 = water_table<NF, LPC>(snew, act, lane, L);
         if (act && is_top) {
             // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler update, overflow
-            NF S = v.S[i];
+            const unsigned ib = block_local(ib0);
+            NF S = ldg(v.S, ib);
             S = S + (NF(0) + jl_min(NF(0), S)) * dt;
-            v.S[i] = S + over;
-            v.wt[i] = z0;
-            if (p.seb) v.Ts[i] = v.Ts[i] + NF(0) * dt;  // zero-tendency prognostic skin_temperature
+            stg(v.S, ib, S + over);
+            stg(v.wt, ib, z0);
         }
-    } else if (act && is_top && p.seb) {
-        v.Ts[i] = v.Ts[i] + NF(0) * dt;
     }
-#ifdef TRM_EXP_EXTRA_VALU   // tuning experiment: N extra independent fp64 FMAs per lane (4 chains)
+    if (act && is_top && p.seb) {   // zero-tendency prognostic skin_temperature
+        const unsigned ib = block_local(ib0);
+        stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
+    }
+#ifdef TRM_EXP_EXTRA_VALU
     NF xa = U, xb = sat, xc = T, xd = liq;
 #pragma unroll
     for (int j = 0; j < TRM_EXP_EXTRA_VALU / 4; ++j) {
@@ -685,64 +650,18 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK, TRM_STEP_MIN_WAVES) k_step_wav
 #else
     if (act) {
 #endif
-        v.U[c] = Unew;
-        v.T[c] = Tn;
-        v.liq[c] = ln;
-        if (RICHARDS) { v.sat[c] = snew; v.psi[c] = psin; }
+        const unsigned cb = block_local(cb0), ib = block_local(ib0);
+        stg(v.U, cb, Unew);
+        stg(v.T, cb, Tn);
+        stg(v.liq, cb, ln);
+        if (RICHARDS) { stg(v.sat, cb, snew); stg(v.psi, cb, psin); }
         if (write_kf) {
-            v.Kf[c] = Kf_out;
-            if (is_top) v.Kf_top[i] = Kf_out_top;
+            stg(v.Kf, block_local(cb0), Kf_out);
+            if (is_top) stg(v.Kf_top, block_local(ib0), Kf_out_top);
         }
         viol |= bad ? 1u : 0u;
-        viol_all |= viol;
     }
-    };  // process
-
-#ifdef TRM_EXP_STAMPS   // diagnostic build: per-wave phase time stamps into the (unused) energy tendency buffer
-    {
-        unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        RawCell<NF> r0 = {};
-        if (wave0 < ngroups) r0 = load_cell(wave0);
-        NF sink = r0.U + r0.sat + r0.T + r0.liq + r0.psi;   // forces the wait for all five loads
-        asm volatile("" : "+v"(sink));
-        unsigned long long t1 = __builtin_amdgcn_s_memtime();
-        if (wave0 < ngroups) process(wave0, r0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        if (lane == 0 && wave0 * 4 + 3 < (long)v.Nh * v.Nzp) {
-            unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);
-            v.G_U[wave0 * 4 + 0] = (NF)(double)t0;
-            v.G_U[wave0 * 4 + 1] = (NF)(double)(t1 - t0);
-            v.G_U[wave0 * 4 + 2] = (NF)(double)(t2 - t1);
-            v.G_U[wave0 * 4 + 3] = (NF)(double)hw;
-        }
-        if (viol_all) atomicOr(v.status, viol_all);
-        return;
-    }
-#endif
-    if (!PERSIST) {
-        // GROUPS column groups per wave in straight-line code: all loads are issued up front, so the
-        // later groups' HBM latency hides behind the first group's arithmetic.
-        constexpr int GROUPS = TRM_STEP_GROUPS;
-        const long g0 = wave0 * GROUPS;
-        RawCell<NF> raw[GROUPS];
-#pragma unroll
-        for (int j = 0; j < GROUPS; ++j)
-            if (g0 + j < ngroups) raw[j] = load_cell(g0 + j);
-#pragma unroll
-        for (int j = 0; j < GROUPS; ++j)
-            if (g0 + j < ngroups) process(g0 + j, raw[j]);
-    } else {
-        RawCell<NF> cur = {};
-        if (wave0 < ngroups) cur = load_cell(wave0);
-        for (long group = wave0; group < ngroups; group += nwaves) {
-            RawCell<NF> nxt = {};
-            if (group + nwaves < ngroups) nxt = load_cell(group + nwaves);
-            process(group, cur);
-            cur = nxt;
-        }
-    }
-    if (viol_all) atomicOr(v.status, viol_all);
+    if (viol) atomicOr(v.status, viol);
 }
 
 }  // namespace trm
