@@ -34,7 +34,7 @@ struct trm_ctx {
     bool has_stage = false;
     void* bc_value[TRM_BCV_COUNT][2] = {};
     int bc_kind[TRM_BCV_COUNT][2] = {};
-    void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr;
+    void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr, *d_lvl = nullptr;
     std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
     double dzf_bot = 0, dzf_top = 0, dzc_bot = 0, dzc_top = 0, Az = 1;
     uint32_t* d_status = nullptr;
@@ -221,6 +221,7 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     v.rdzc = (const NF*)c->d_rdzc;
     v.rdzf = (const NF*)c->d_rdzf;
     v.psiz = (const NF*)c->d_psiz;
+    v.lvl = (const NF*)c->d_lvl;
     BcGeom<NF>& g = v.g;
     g.dzf_bot = (NF)c->dzf_bot;
     g.dzf_top = (NF)c->dzf_top;
@@ -233,6 +234,8 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     g.V_top = g.Az * (NF)c->dzc_top;
     g.rV_bot = NF(1) / g.V_bot;
     g.rV_top = NF(1) / g.V_top;
+    g.zF_top = (NF)c->h_zF[c->Nz];
+    g.dzc_top = (NF)c->dzc_top;
     v.status = c->d_status;
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b) {
@@ -394,10 +397,12 @@ template <class NF> struct Ops {
                 generic = generic || c->bc_kind[var][side] == TRM_BC_VALUE || c->bc_kind[var][side] == TRM_BC_GRADIENT;
         }
         const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+        // tuning knob: unused dynamic LDS per workgroup caps the resident workgroups per CU (occupancy sweeps)
+        static const unsigned lds = getenv("TRM_EXP_LDS_BYTES") ? (unsigned)atoi(getenv("TRM_EXP_LDS_BYTES")) : 0u;
         if (generic)
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, wkf);
         else
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, wkf);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
@@ -505,6 +510,14 @@ template <class NF> int upload_grid(trm_ctx* c, const double* thickness) {
     if ((rc = up(&c->d_rdzc, g.rdzc))) return rc;
     if ((rc = up(&c->d_rdzf, g.rdzf))) return rc;
     if ((rc = up(&c->d_psiz, g.psiz))) return rc;
+    {   // per-level records for the lane = level kernels
+        std::vector<NF> lvl((size_t)c->Nz * 8, NF(0));
+        for (int k = 0; k < c->Nz; ++k) {
+            NF* q = &lvl[(size_t)k * 8];
+            q[0] = g.zC[k]; q[1] = g.psiz[k]; q[2] = g.zF[k]; q[3] = g.dzc[k]; q[4] = g.rdzc[k]; q[5] = g.rdzf[k]; q[6] = g.rdzf[k + 1];
+        }
+        if ((rc = up(&c->d_lvl, lvl))) return rc;
+    }
     c->h_zF.assign(g.zF.begin(), g.zF.end());
     c->h_zC.assign(g.zC.begin(), g.zC.end());
     c->h_dzc.assign(g.dzc.begin(), g.dzc.end());
@@ -747,7 +760,7 @@ int trm_destroy(trm_ctx* c) {
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b)
             if (c->bc_value[a][b]) (void)hipFree(c->bc_value[a][b]);
-    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_zero, (void*)c->d_status, (void*)c->d_reduce})
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, (void*)c->d_status, (void*)c->d_reduce})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -916,6 +929,12 @@ int trm_status(trm_ctx* c, uint32_t* flags) {
     if (!flags) return TRM_EINVAL;
     TRM_HIP(c, hipMemcpyAsync(flags, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
+#ifdef TRM_EXP_CONCURRENCY
+    unsigned long long h[4];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(trm::trm_exp_conc), sizeof(h));
+    fprintf(stderr, "[exp] waves in flight: now %llu  peak %llu  mean-at-start %.1f  (%llu wave starts)\n", h[0], h[1],
+            h[3] ? (double)h[2] / (double)h[3] : 0.0, h[3]);
+#endif
     return TRM_OK;
 }
 

@@ -29,8 +29,20 @@ TRM_HD bool is_finite(float x) { return __builtin_isfinite(x); }
 // The hardware v_min/v_max_f64 have the same zero ordering; they differ only when an operand is
 // already NaN (IEEE minNum returns the other operand).  A NaN state is reported through the status
 // word either way, so the one-instruction form is used on the device.
-TRM_DEV double jl_min(double x, double y) { return __builtin_fmin(x, y); }
-TRM_DEV double jl_max(double x, double y) { return __builtin_fmax(x, y); }
+// (Written as the instruction itself when both operands are variables: the builtin would first re-quiet each
+// operand the compiler cannot prove canonical -- values that arrive by load or DPP move -- with a v_max x, x.)
+TRM_DEV double jl_min(double x, double y) {
+    if (__builtin_constant_p(x) || __builtin_constant_p(y)) return __builtin_fmin(x, y);
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+TRM_DEV double jl_max(double x, double y) {
+    if (__builtin_constant_p(x) || __builtin_constant_p(y)) return __builtin_fmax(x, y);
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 TRM_DEV float jl_min(float x, float y) { return __builtin_fminf(x, y); }
 TRM_DEV float jl_max(float x, float y) { return __builtin_fmaxf(x, y); }
 
@@ -393,6 +405,7 @@ template <class NF> struct BcGeom {
     NF hdzf_bot, hdzf_top;           // dzf / 2
     NF rhdzf_bot, rhdzf_top;         // 1 / (dzf / 2)
     NF Az, V_bot, V_top, rV_bot, rV_top;  // Az = dx (Flat y), V = Az * dz of the boundary cell
+    NF zF_top, dzc_top;              // surface elevation zF[Nz], thickness of the top cell
 };
 // halo value above the top cell / below the bottom cell of a centre field
 template <class NF> TRM_DEV NF halo_top(int kind, const NF* val, long i, NF c_edge, const BcGeom<NF>& g) {

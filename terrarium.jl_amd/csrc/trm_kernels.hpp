@@ -40,6 +40,8 @@ template <class NF> struct View {
     // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f),
     // psiz[Nz] = zC - z_surface (elevation head)
     const NF *zC, *zF, *dzc, *rdzc, *rdzf, *psiz;
+    // the same, packed per level for the lane = level kernels: 8 words {zC, psiz, zF, dzc, rdzc, rdzf[k], rdzf[k+1], 0}
+    const NF* lvl;
     BcGeom<NF> g;
     uint32_t* status;
     BcSet bc;
@@ -274,8 +276,8 @@ template <class NF, int LPC> TRM_DEV NF shfl_from(NF x, int src_k) { return __sh
 // the whole wavefront, so with two columns per wave the lanes at a column edge receive the
 // neighbouring column's value -- exactly the lanes (bottom / top level) whose input is replaced by
 // the halo / boundary-face value anyway.
-TRM_DEV int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
-TRM_DEV int dpp_shl1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, false); }
+TRM_DEV int dpp_shr1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, true); }
+TRM_DEV int dpp_shl1(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x130, 0xf, 0xf, true); }
 TRM_DEV double shift_up(double x) {  // lane l receives lane l-1 (level k-1)
     union { double d; int w[2]; } u;
     u.d = x;
@@ -323,20 +325,28 @@ TRM_DEV unsigned block_local(unsigned byte_off) {
 }
 
 template <class NF> struct LevelGeom {
-    NF zC, psiz, zFlo, dzc, rdzc, rdzf_lo, rdzf_hi, dzc_up, rdzc_up, dzc_dn, rdzc_dn, zF_top, dzc_top;
+    NF zC, psiz, zFlo, dzc, rdzc, rdzf_lo, rdzf_hi, zF_top, dzc_top;
 };
+template <class NF> struct alignas(16) LevelPack { NF w[8]; };
 template <class NF> TRM_DEV LevelGeom<NF> level_geom(const View<NF>& v, int k) {
     const int Nz = v.Nz;
     const int kk = k < Nz ? k : Nz - 1;
-    const int ku = kk + 1 < Nz ? kk + 1 : kk, kd = kk > 0 ? kk - 1 : 0;
+    // one 16-byte-aligned record per level: 4 (fp64) / 2 (fp32) wide loads instead of 7 narrow ones
+    const LevelPack<NF> q = *reinterpret_cast<const LevelPack<NF>*>(reinterpret_cast<const char*>(v.lvl) + (unsigned)kk * (unsigned)sizeof(LevelPack<NF>));
     LevelGeom<NF> L;
-    const unsigned e = (unsigned)sizeof(NF);
-    const unsigned kb = (unsigned)kk * e, kub = (unsigned)ku * e, kdb = (unsigned)kd * e;
-    L.zC = ldg(v.zC, kb); L.psiz = ldg(v.psiz, kb); L.zFlo = ldg(v.zF, kb); L.dzc = ldg(v.dzc, kb); L.rdzc = ldg(v.rdzc, kb);
-    L.rdzf_lo = ldg(v.rdzf, kb); L.rdzf_hi = ldg(v.rdzf, kb + e);
-    L.dzc_up = ldg(v.dzc, kub); L.rdzc_up = ldg(v.rdzc, kub); L.dzc_dn = ldg(v.dzc, kdb); L.rdzc_dn = ldg(v.rdzc, kdb);
-    L.zF_top = v.zF[Nz]; L.dzc_top = v.dzc[Nz - 1];
+    L.zC = q.w[0]; L.psiz = q.w[1]; L.zFlo = q.w[2]; L.dzc = q.w[3]; L.rdzc = q.w[4]; L.rdzf_lo = q.w[5]; L.rdzf_hi = q.w[6];
+    L.zF_top = v.g.zF_top; L.dzc_top = v.g.dzc_top;
     return L;
+}
+// thickness of the neighbouring cells (serial repair passes only)
+template <class NF> struct NeighbourDz { NF dzc_up, rdzc_up, dzc_dn, rdzc_dn; };
+template <class NF> TRM_DEV NeighbourDz<NF> neighbour_dz(const View<NF>& v, int k) {
+    const int Nz = v.Nz;
+    const int kk = k < Nz ? k : Nz - 1;
+    const int ku = kk + 1 < Nz ? kk + 1 : kk, kd = kk > 0 ? kk - 1 : 0;
+    NeighbourDz<NF> n;
+    n.dzc_up = v.dzc[ku]; n.rdzc_up = v.rdzc[ku]; n.dzc_dn = v.dzc[kd]; n.rdzc_dn = v.rdzc[kd];
+    return n;
 }
 
 // adjust_saturation_profile! (soil_hydrology.jl:185-219) on a column held one level per lane.
@@ -346,7 +356,7 @@ template <class NF> TRM_DEV LevelGeom<NF> level_geom(const View<NF>& v, int k) {
 // overflow and the bottom clamp, all lane-local.  Otherwise both passes run as lane-serial loops.
 // Returns excess * dz_top in the TOP lane (0 elsewhere): the column's overflow into surface_excess_water.
 template <class NF, int LPC>
-TRM_DEV NF repair_saturation(NF& snew, int k, int Nz, bool act, bool is_bot, bool is_top, const LevelGeom<NF>& L) {
+TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, bool act, bool is_bot, bool is_top, const LevelGeom<NF>& L) {
     const bool over = act && !is_top && !(jl_max(snew - NF(1), NF(0)) == NF(0));
     const bool under = act && !is_bot && !(jl_max(-snew, NF(0)) == NF(0));
     const unsigned long long any_over = __ballot(over);
@@ -355,6 +365,7 @@ TRM_DEV NF repair_saturation(NF& snew, int k, int Nz, bool act, bool is_bot, boo
     // (idempotent, and absorbed by a later non-zero addend), so apply it once up front
     snew = is_bot ? snew : snew + NF(0);
     if (any_bad != 0ull) {
+        const NeighbourDz<NF> nb = neighbour_dz(v, k);
         // Lane-serial passes, restricted to the levels that can change: the upward pass starts at the lowest
         // oversaturated level and stops once the carry is zero with no oversaturated level left above;
         // outside that range the reference's updates are the `+ 0` already applied.
@@ -367,7 +378,7 @@ TRM_DEV NF repair_saturation(NF& snew, int k, int Nz, bool act, bool is_bot, boo
                     snew = snew + carry;
                     NF e = jl_max(snew - NF(1), NF(0));
                     snew = snew - e;
-                    cout = div_const(e * L.dzc, L.dzc_up, L.rdzc_up);
+                    cout = div_const(e * L.dzc, nb.dzc_up, nb.rdzc_up);
                 }
                 carry = shfl_from<NF, LPC>(cout, q);
                 if ((lv >> (q + 1)) == 0ull && __ballot(!(carry == NF(0))) == 0ull) break;
@@ -385,7 +396,7 @@ TRM_DEV NF repair_saturation(NF& snew, int k, int Nz, bool act, bool is_bot, boo
                     snew = snew - pend;
                     NF d = jl_max(-snew, NF(0));
                     snew = snew + d;
-                    pout = div_const(d * L.dzc, L.dzc_dn, L.rdzc_dn);
+                    pout = div_const(d * L.dzc, nb.dzc_dn, nb.rdzc_dn);
                 }
                 pend = shfl_from<NF, LPC>(pout, q);
                 if ((lv & ((1ull << q) - 1ull)) == 0ull && __ballot(!(pend == NF(0))) == 0ull) break;
@@ -423,7 +434,7 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
     const long c = (i < v.Nh ? i : v.Nh - 1) * v.Nzp + (k < Nz ? k : Nz - 1);
     NF s = v.sat[c];
     if (WITH_ADJUST) {
-        NF over = repair_saturation<NF, LPC>(s, k, Nz, act, is_bot, is_top, L);
+        NF over = repair_saturation<NF, LPC>(v, s, k, Nz, act, is_bot, is_top, L);
         if (act) {
             v.sat[c] = s;
             if (is_top) v.S[i] += over;
@@ -453,10 +464,24 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 //
 // Diagnostic builds (never shipped): -DTRM_EXP_MEMORY_ONLY (same traffic, no
 // arithmetic), -DTRM_EXP_COMPUTE_ONLY (no global traffic), -DTRM_EXP_EXTRA_VALU=N (N extra fp64 FMAs per lane).
+#ifdef TRM_EXP_CONCURRENCY   // diagnostic: waves in flight (current, peak, sum over wave starts, starts)
+__device__ unsigned long long trm_exp_conc[4];
+#endif
 template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
     constexpr int CPW = 64 / LPC;   // columns per wave
     const int lane = threadIdx.x & 63;
+#ifdef TRM_EXP_STAMPS   // diagnostic: per-wave start / end time stamps + HW_ID into the (unused) energy tendency buffer
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TRM_EXP_CONCURRENCY
+    if (lane == 0) {
+        unsigned long long cur = atomicAdd(&trm_exp_conc[0], 1ull) + 1ull;
+        atomicMax(&trm_exp_conc[1], cur);
+        atomicAdd(&trm_exp_conc[2], cur);
+        atomicAdd(&trm_exp_conc[3], 1ull);
+    }
+#endif
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int k = lane % LPC, sub = lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
@@ -610,7 +635,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
     if (RICHARDS) {
         snew = sat + gS * dt;
         bad = bad || (act && is_nan(snew));
-        const NF over = repair_saturation<NF, LPC>(snew, k, Nz, act, is_bot, is_top, L);
+        const NF over = repair_saturation<NF, LPC>(v, snew, k, Nz, act, is_bot, is_top, L);
         z0 = water_table<NF, LPC>(snew, act, lane, L);
         if (act && is_top) {
             // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler update, overflow
@@ -662,6 +687,23 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
         viol |= bad ? 1u : 0u;
     }
     if (viol) atomicOr(v.status, viol);
+#ifdef TRM_EXP_STAMPS
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_ID, all 32 bits
+        if (lane == 0 && wave * 4 + 3 < Nh * v.Nzp) {
+            v.G_U[wave * 4 + 0] = (NF)(double)t_start;
+            v.G_U[wave * 4 + 1] = (NF)(double)(t_end - t_start);
+            v.G_U[wave * 4 + 2] = (NF)(double)hw;
+            v.G_U[wave * 4 + 3] = (NF)(double)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);   // XCC_ID
+        }
+    }
+#endif
+#ifdef TRM_EXP_CONCURRENCY
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0) atomicAdd(&trm_exp_conc[0], ~0ull);
+#endif
 }
 
 }  // namespace trm
