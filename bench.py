@@ -35,8 +35,10 @@ WORKLOADS = {
     "c2": ("C2: N72 ERA5-land mask (14017 columns) x 30 levels, soil heat conduction only, fp64", "heat", "default", "N72", 30, "f64"),
     "c3": ("C3: N145 ERA5-land mask (56951 columns) x 32 levels, coupled heat + Richards (BrooksCorey SWRC, linear K), fp64", "richards", "default", "N145", 32, "f64"),
     "c3vg": ("C3-VG: N145 mask x 32 levels, heat + Richards (VanGenuchten SWRC + Mualem K with ice impedance), fp64", "richards", "vg", "N145", 32, "f64"),
-    "c4": ("C4: N145 mask x 32 levels, full bare-ground LandModel (heat + Richards + surface energy balance, PrescribedAtmosphere), fp64", "land", "vg", "N145", 32, "f64"),
-    "c5": ("C5: synthetic 0.1-degree grid, 812500 columns per GPU x 64 levels, heat + Richards + SEB, fp32", "land", "vg", 812500, 64, "f32"),
+    "c4": ("C4: N145 mask x 32 levels, full bare-ground LandModel (heat + Richards + surface energy balance, PrescribedAtmosphere), default hydraulics (BrooksCorey SWRC, linear K), fp64", "land", "default", "N145", 32, "f64"),
+    "c4vg": ("C4-VG: as C4 with the land-model test's hydraulics (VanGenuchten(alpha=2, n=2) SWRC + Mualem K with ice impedance), fp64", "land", "vg", "N145", 32, "f64"),
+    "c5": ("C5: synthetic 0.1-degree grid, 812500 columns per GPU x 64 levels, heat + Richards + SEB, default hydraulics, fp32", "land", "default", 812500, 64, "f32"),
+    "c5vg": ("C5-VG: as C5 with VanGenuchten SWRC + Mualem K, fp32", "land", "vg", 812500, 64, "f32"),
 }
 
 

@@ -11,7 +11,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 100 --warmup 10 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
-for wl in c2 c3vg c4 c5; do python bench.py --workload $wl --no-cpu-baseline --steps 50 --warmup 5 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; done
+for wl in c2 c3vg c4 c4vg c5 c5vg; do python bench.py --workload $wl --no-cpu-baseline --steps 50 --warmup 5 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; done
 python bench.py --kernel unfused --no-cpu-baseline > $OUT/bench_c3_unfused.json 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py --no-cpu-baseline --steps 100 --warmup 10 > $OUT/bench_trace.json 2> $OUT/trace.err
 B="python bench.py --no-cpu-baseline --steps 20 --warmup 2"

@@ -144,6 +144,11 @@ template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
     p.bc_psi_s = (NF)q.bc_psi_s;
     p.vg_alpha = (NF)q.vg_alpha;
     p.impedance = (NF)q.impedance;
+    {   // fully frozen cells: y = -impedance * (1 - 0); Base.:^ takes pow_body(10.0, Int(y)) when y is integer-valued
+        const NF y = -p.impedance * (NF(1) - NF(0));
+        p.impedance_int = ((NF)(int)y == y && y > NF(-4096) && y < NF(4096)) ? 1 : 0;
+        p.I_ice_frozen = p.impedance_int ? pow_int(NF(10), (int)y) : NF(0);
+    }
     p.vwc_forcing = (NF)q.vwc_forcing;
     p.neg_inv_alpha = NF(-1) / p.vg_alpha;
     NF lam = (NF)q.bc_lambda, n = (NF)q.vg_n;

@@ -605,7 +605,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
     NF gS = NF(0), Kf_lo = NF(0);
     if (need_kc) {
         const NF Kc_m = shfl_up1<NF, LPC>(Kc);
-        Kf_lo = (is_bot || is_top) ? Kc : jl_min(Kc, Kc_m);
+        const NF Kmin = jl_min(Kc, Kc_m);   // (formed outside the select: keeps it a select, not a branch)
+        Kf_lo = (is_bot || is_top) ? Kc : Kmin;
     }
     if (RICHARDS) {
         const NF Kf_up = shfl_up1<NF, LPC>(Kf_lo), Kf_dn = shfl_dn1<NF, LPC>(Kf_lo), psi_sh = shfl_up1<NF, LPC>(psi);
@@ -617,10 +618,11 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
         const NF qW_lo = -Ks_lo * g_lo;
         const NF qW_sh = shfl_dn1<NF, LPC>(qW_lo);
         NF qW_hi = qW_sh;
-        if (is_top) {  // boundary face above the top cell
+        {   // boundary face above the top cell (computed by every lane, kept by the top lane)
             const NF g_t = (psi_ht - psi) * L.rdzf_hi;
             const NF Ks_t = upwind_conductivity(g_t, Kf_lo, Kc, NF(0));
-            qW_hi = -Ks_t * g_t;
+            const NF qW_t = -Ks_t * g_t;
+            qW_hi = is_top ? qW_t : qW_sh;
         }
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
         gS = NF(0) + div_const(dtheta, p.por, p.rpor);
@@ -667,7 +669,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
     if (finalize && write_kf) {
         const NF Kc_new = conductivity_hydraulic<NF, HYD>(p, ln, fractions(p, snew, ln, viol));
         const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
-        Kf_out = (is_bot || is_top) ? Kc_new : jl_min(Kc_new, Kc_new_m);
+        const NF Kmin_new = jl_min(Kc_new, Kc_new_m);
+        Kf_out = (is_bot || is_top) ? Kc_new : Kmin_new;
         Kf_out_top = Kc_new;
     }
 #ifdef TRM_EXP_COMPUTE_ONLY
