@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 1
+#define TRM_ABI_VERSION 2
 
 typedef struct trm_ctx trm_ctx;
 
@@ -185,6 +185,30 @@ int trm_field_device_ptr(trm_ctx* ctx, int field, void** dev, int64_t* pitch_ele
 int trm_set_bc(trm_ctx* ctx, int bc_var, int side, int kind, const void* values, double scalar);
 /* update_inputs! (src/state_variables.jl:154-162): same as trm_upload on an input field. */
 int trm_set_forcing(trm_ctx* ctx, int input_field, const void* per_column);
+
+/* ---- time series input sources --------------------------------------------------------------------------
+ * FieldTimeSeriesInputSource (src/input_output/input_sources.jl:142-171): update_inputs! sets the input
+ * field to `fts[Time(clock.time)]`, Oceananigans' time interpolation of a FieldTimeSeries.  Here the whole
+ * series lives in HBM ([nt][Nh], uploaded once; 288 GB hold years of hourly forcing for a shard), and every
+ * step of a trm_step / trm_step_heun loop evaluates it at the context clock before anything else runs, so one
+ * call can span any number of forcing intervals.  `times` must be strictly increasing; nt >= 1.
+ * The same mechanism drives time-dependent boundary values (the reference's functional / discrete-form
+ * boundary conditions, evaluated on its own clock).
+ *   TRM_TIME_LINEAR    linear interpolation, linear extrapolation outside [t_1, t_nt]   (Oceananigans `Linear`)
+ *   TRM_TIME_CLAMP     linear interpolation, end values outside                         (`Clamp`)
+ *   TRM_TIME_CYCLICAL  periodic with period (t_nt - t_1) + (t_nt - t_{nt-1})            (`Cyclical`)
+ * Between nodes n1 < n2: value = v[n2] * f + v[n1] * (1 - f), f = (1 / (t[n2] - t[n1])) * (t - t[n1]), evaluated in
+ * double and rounded once to the context precision; on an interior node the node's values are copied. */
+enum { TRM_TIME_LINEAR = 0, TRM_TIME_CLAMP = 1, TRM_TIME_CYCLICAL = 2 };
+/* `values`: [nt][Nh] in the context precision.  Replaces any earlier series or constant of the same input. */
+int trm_set_forcing_series(trm_ctx* ctx, int input_field, int nt, const double* times, const void* values, int time_indexing);
+/* Boundary value series for (bc_var, side) with the given kind (VALUE / FLUX / GRADIENT). */
+int trm_set_bc_series(trm_ctx* ctx, int bc_var, int side, int kind, int nt, const double* times, const void* values, int time_indexing);
+/* Drops every series (inputs and boundary values keep what was last evaluated). */
+int trm_clear_series(trm_ctx* ctx);
+/* update_inputs!(state, clock): evaluates every series at the context clock (done implicitly by trm_step,
+ * trm_step_heun and trm_update_state). */
+int trm_update_inputs(trm_ctx* ctx);
 
 /* initialize!(state, model) process initialisers (soil_coupled.jl:45-54): hydraulics, water table,
  * sat -> psi, T -> U.  Call after uploading the initial temperature / saturation. */

@@ -23,6 +23,7 @@ FIELDS = dict(
 )
 BC_VARS = dict(internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4)
 BC_KINDS = dict(noflux=0, value=1, flux=2, gradient=3)
+TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2)
 
 
 class ParamsD(C.Structure):
@@ -85,6 +86,10 @@ def _lib(omp=False):
         lib.trm_oracle_get_halo.restype = C.c_double
         lib.trm_oracle_get_halo.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long]
         lib.trm_oracle_set_bc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double]
+        lib.trm_oracle_set_series.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.c_int]
+        lib.trm_oracle_clear_series.argtypes = [C.c_void_p]
+        lib.trm_oracle_update_inputs.argtypes = [C.c_void_p]
+        lib.trm_oracle_time_indices.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]
         lib.trm_oracle_set_land_model.argtypes = [C.c_void_p, C.c_int]
         lib.trm_oracle_grid.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         for f in ("fill_halo_regions", "initialize", "reset_tendencies", "compute_auxiliary", "compute_tendencies",
@@ -122,6 +127,14 @@ def _lib(omp=False):
 def set_threads(n, omp=True):
     """OpenMP thread count of the timing leg; returns the count in effect."""
     return _lib(omp).trm_oracle_set_threads(int(n))
+
+
+def time_indices(times, t, time_indexing="linear"):
+    """(f, n1, n2) of Oceananigans' FieldTimeSeries time interpolation as restated in the oracle (0-based nodes)."""
+    tt = np.ascontiguousarray(times, dtype=np.float64)
+    f, n1, n2 = C.c_double(), C.c_long(), C.c_long()
+    _lib().trm_oracle_time_indices(tt.ctypes.data, tt.size, TIME_INDEXING[time_indexing], float(t), C.byref(f), C.byref(n1), C.byref(n2))
+    return f.value, n1.value, n2.value
 
 
 def scalar(name, *args):
@@ -199,6 +212,29 @@ class Oracle:
         rc = self.lib.trm_oracle_set_bc(self.h, BC_VARS[var], top, BC_KINDS[kind], ptr, scalar_v)
         assert rc == 0
 
+    # -- time series input sources (input_sources.jl:142-171) -----------------
+    def _series(self, times, values):
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        v = np.ascontiguousarray(values, dtype=self.dtype)
+        if v.ndim == 1:
+            v = np.ascontiguousarray(np.broadcast_to(v[:, None], (v.size, self.Nh)))
+        assert v.shape == (t.size, self.Nh)
+        return t, v
+
+    def set_forcing_series(self, name, times, values, time_indexing="linear"):
+        t, v = self._series(times, values)
+        rc = self.lib.trm_oracle_set_series(self.h, 0, FIELDS[name], 0, 0, 0, t.size, t.ctypes.data, v.ctypes.data, TIME_INDEXING[time_indexing])
+        assert rc == 0
+
+    def set_bc_series(self, var, side, kind, times, values, time_indexing="linear"):
+        t, v = self._series(times, values)
+        top = {"top": 1, "bottom": 0}[side]
+        rc = self.lib.trm_oracle_set_series(self.h, 1, 0, BC_VARS[var], top, BC_KINDS[kind], t.size, t.ctypes.data, v.ctypes.data, TIME_INDEXING[time_indexing])
+        assert rc == 0
+
+    def clear_series(self): self.lib.trm_oracle_clear_series(self.h)
+    def update_inputs(self): self.lib.trm_oracle_update_inputs(self.h)
+
     def set_land_model(self, on=True):
         self.lib.trm_oracle_set_land_model(self.h, int(on))
 
@@ -229,6 +265,9 @@ class Oracle:
         t, it = C.c_double(), C.c_longlong()
         self.lib.trm_oracle_clock(self.h, C.byref(t), C.byref(it))
         return t.value, it.value
+
+    def set_clock(self, time, iteration=0):
+        self.lib.trm_oracle_set_clock(self.h, float(time), int(iteration))
 
     def status(self):
         return self.lib.trm_oracle_status(self.h)

@@ -73,6 +73,16 @@ int trm_oracle_set_bc(OracleHandle* h, int var, int top, int kind, const void* v
     if (h->precision == 0) return h->d->set_bc(var, top, kind, (const double*)values, scalar);
     return h->f->set_bc(var, top, kind, (const float*)values, (float)scalar);
 }
+int trm_oracle_set_series(OracleHandle* h, int is_bc, int field, int var, int top, int kind, long nt, const double* times, const void* values, int indexing) {
+    if (h->precision == 0) return h->d->set_series(is_bc != 0, field, var, top, kind, nt, times, (const double*)values, indexing);
+    return h->f->set_series(is_bc != 0, field, var, top, kind, nt, times, (const float*)values, indexing);
+}
+void trm_oracle_clear_series(OracleHandle* h) { DISPATCH(h, o->series.clear()); }
+void trm_oracle_update_inputs(OracleHandle* h) { DISPATCH(h, o->update_inputs()); }
+void trm_oracle_time_indices(const double* times, long nt, int indexing, double t, double* f, long* n1, long* n2) {
+    std::vector<double> tv(times, times + nt);
+    trm_oracle::Oracle<double>::interpolating_time_indices(tv, indexing, t, *f, *n1, *n2);
+}
 void trm_oracle_set_land_model(OracleHandle* h, int on) { DISPATCH(h, o->land_model = on != 0); }
 void trm_oracle_grid(OracleHandle* h, double* zF /*Nz+1*/, double* zC /*Nz*/, double* dzc /*Nz*/, double* dzf /*Nz+1*/) {
     DISPATCH(h, {

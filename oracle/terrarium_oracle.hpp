@@ -499,6 +499,90 @@ template <class NF> class Oracle {
         return 0;
     }
 
+    // ---- FieldTimeSeriesInputSource / update_inputs! (input_sources.jl:142-171) -------------
+    // `set!(field, fts[Time(clock.time)])`.  The time interpolation is Oceananigans' FieldTimeSeries indexing
+    // (OutputReaders, not part of the reference tree: restated from its published behaviour, PARITY UNPINNED):
+    //   find_time_index: binary search for the bracketing nodes n1 < n2 (an interior node hit gives n1 == n2;
+    //   outside the range the first / last interval is used => Linear extrapolates), fraction
+    //   f = (n2 - n1) / (t[n2] - t[n1]) * (t - t[n1]);  Clamp: end values outside the range;  Cyclical: time taken
+    //   modulo the period (last node -> first node closes the cycle with the last interval's length);
+    //   getindex(fts, Time(t)) = v[n2] * f + v[n1] * (1 - f)  (Float64 scalar times NF field, stored as NF).
+    struct Series {
+        bool is_bc = false;
+        int field = 0, var = 0, top = 0, indexing = 0;
+        std::vector<double> times;
+        std::vector<NF> values;  // [nt][Nh]
+    };
+    std::vector<Series> series;
+    enum { TIME_LINEAR = 0, TIME_CLAMP = 1, TIME_CYCLICAL = 2 };
+
+    static void find_time_index(const std::vector<double>& times, double t, double& f, long& n1, long& n2) {
+        long Nt = (long)times.size();
+        long low = 0, high = Nt - 1;   // index_binary_search, 0-based
+        while (low + 1 < high) {
+            long mid = (low + high) / 2;
+            if (times[mid] == t) { n1 = n2 = mid; f = 0.0; return; }
+            if (times[mid] < t) low = mid; else high = mid;
+        }
+        n1 = low; n2 = high;
+        double dt = times[n2] - times[n1];
+        f = (double)(n2 - n1) / dt * (t - times[n1]);
+    }
+    static void interpolating_time_indices(const std::vector<double>& times, int indexing, double t, double& f, long& n1, long& n2) {
+        long Nt = (long)times.size();
+        if (Nt == 1) { f = 0.0; n1 = n2 = 0; return; }
+        if (indexing == TIME_CYCLICAL) {
+            double t1 = times[0], tN = times[Nt - 1];
+            double T = (tN - t1) + (tN - times[Nt - 2]);
+            double tau = t - t1;
+            double mod_tau = std::fmod(tau, T);
+            if (mod_tau < 0) mod_tau += T;
+            double mod_t = mod_tau + t1;
+            if (mod_t > tN) {  // cycling: between tN and t1 + T
+                double dT = T - (tN - t1);
+                f = 1.0 / dT * (mod_t - tN);
+                n1 = Nt - 1; n2 = 0;
+                return;
+            }
+            find_time_index(times, mod_t, f, n1, n2);
+            return;
+        }
+        find_time_index(times, t, f, n1, n2);
+        if (indexing == TIME_CLAMP) {
+            if (t >= times[Nt - 1]) { f = 0.0; n1 = n2 = Nt - 1; }
+            else if (t <= times[0]) { f = 0.0; n1 = n2 = 0; }
+        }
+    }
+    int set_series(bool is_bc, int field, int var, int top, int kind, long nt, const double* times, const NF* values, int indexing) {
+        if (nt < 1) return 1;
+        Series sr;
+        sr.is_bc = is_bc; sr.field = field; sr.var = var; sr.top = top ? 1 : 0; sr.indexing = indexing;
+        sr.times.assign(times, times + nt);
+        sr.values.assign(values, values + (size_t)nt * Nh);
+        for (size_t n = 0; n < series.size(); ++n) {
+            const Series& o = series[n];
+            if (o.is_bc == is_bc && (is_bc ? (o.var == var && o.top == sr.top) : o.field == field)) { series.erase(series.begin() + (long)n); break; }
+        }
+        if (is_bc) {
+            Bc<NF>& b = bc[var][sr.top];
+            b.kind = kind;
+            b.value.assign(Nh, NF(0));
+        }
+        series.push_back(std::move(sr));
+        return 0;
+    }
+    void update_inputs() {
+        for (const Series& sr : series) {
+            double f; long n1, n2;
+            interpolating_time_indices(sr.times, sr.indexing, time, f, n1, n2);
+            std::vector<NF>* dst = sr.is_bc ? &bc[sr.var][sr.top].value : field2(sr.field);
+            const NF* v1 = &sr.values[(size_t)n1 * Nh];
+            const NF* v2 = &sr.values[(size_t)n2 * Nh];
+            for (long i = 0; i < Nh; ++i)
+                (*dst)[i] = (n1 == n2) ? v1[i] : (NF)((double)v2[i] * f + (double)v1[i] * (1.0 - f));
+        }
+    }
+
     // ---- fill_halo_regions!(state) (state_variables.jl:85-100) --------------
     // Oceananigans z-halo rules: Value -> linear
     // extrapolation through the boundary value with the boundary-face spacing;
@@ -688,7 +772,7 @@ template <class NF> class Oracle {
     }
     void update_state(bool tendencies = true) {
         reset_tendencies();
-        // update_inputs!: forcing arrays are set by the harness before the call
+        update_inputs();  // constant inputs are set by the harness before the call; series are evaluated at `time`
         fill_halo_regions();
         compute_auxiliary();
         if (tendencies) compute_tendencies();

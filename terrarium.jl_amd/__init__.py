@@ -22,7 +22,7 @@ from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapac
                      SoilInitializer, SoilModel, LandModel, flatten)
 from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, PrescribedBottomTemperature,
                          GroundHeatFlux, GeothermalHeatFlux, InfiltrationFlux, ImpermeableBoundary, FreeDrainage,
-                         merge_boundary_conditions, DeviceState, ModelIntegrator, initialize, initialize_integrator,
+                         merge_boundary_conditions, DeviceState, ModelIntegrator, FieldTimeSeries, InputSource, InputSources, initialize, initialize_integrator,
                          timestep, run, current_time, compute_auxiliary, compute_tendencies, closure, invclosure,
                          update_state)
 from ._capi import TerrariumHipError

@@ -36,7 +36,9 @@ EXPORTS = (
     "trm_upload trm_download trm_field_device_ptr trm_set_bc trm_set_forcing trm_initialize trm_update_state "
     "trm_compute_auxiliary trm_compute_tendencies trm_reset_tendencies trm_explicit_step trm_closure trm_invclosure "
     "trm_step trm_step_heun trm_step_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_option "
-    "trm_get_option trm_set_stream trm_synchronize").split()
+    "trm_get_option trm_set_stream trm_synchronize "
+    "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs").split()
+TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2)
 
 
 class TrmGrid(C.Structure):
@@ -86,6 +88,10 @@ def lib():
     L.trm_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64)]
     L.trm_set_bc.argtypes = [vp, i32, i32, i32, vp, dbl]
     L.trm_set_forcing.argtypes = [vp, i32, vp]
+    L.trm_set_forcing_series.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.trm_set_bc_series.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32]
+    L.trm_clear_series.argtypes = [vp]
+    L.trm_update_inputs.argtypes = [vp]
     for name in ("trm_initialize", "trm_compute_auxiliary", "trm_compute_tendencies", "trm_reset_tendencies",
                  "trm_closure", "trm_invclosure", "trm_synchronize"):
         getattr(L, name).argtypes = [vp]

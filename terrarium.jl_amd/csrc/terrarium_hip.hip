@@ -38,6 +38,15 @@ struct trm_ctx {
     std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
     double dzf_bot = 0, dzf_top = 0, dzc_bot = 0, dzc_top = 0, Az = 1;
     uint32_t* d_status = nullptr;
+    // time series input sources: whole series resident on the device, evaluated at the clock every step
+    struct Series {
+        bool is_bc = false;
+        int field = 0, var = 0, side = 0, indexing = 0;
+        std::vector<double> times;
+        void* d_values = nullptr;   // [nt][Nh]
+    };
+    std::vector<Series> series;
+    void* bc_value_stage[TRM_BCV_COUNT][2] = {};  // Heun: the stage evaluates its boundary series at t + dt
     void* d_zero = nullptr;  // [Nh] zeros: stands in for the value array of every unset boundary condition
     double* d_reduce = nullptr;  // scratch for trm_reduce
     size_t reduce_cap = 0;
@@ -245,7 +254,8 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b) {
             v.bc.kind[a][b] = c->bc_kind[a][b];
-            v.bc.value[a][b] = c->bc_value[a][b] ? c->bc_value[a][b] : c->d_zero;
+            void* val = (&s == &c->stage && c->bc_value_stage[a][b]) ? c->bc_value_stage[a][b] : c->bc_value[a][b];
+            v.bc.value[a][b] = val ? val : c->d_zero;
         }
     return v;
 }
@@ -258,8 +268,84 @@ dim3 wave_grid(const trm_ctx* c, int lpc) {
     return dim3((unsigned)((waves + 3) / 4), 1, 1);
 }
 
+// Time interpolation indices of a series at time t -- Oceananigans' FieldTimeSeries indexing (Linear / Clamp /
+// Cyclical), restated; that package is not part of the reference tree (parity unpinned).
+// Returns 0-based nodes n1, n2 and the fraction f: value = v[n2] * f + v[n1] * (1 - f); n1 == n2 means "copy".
+void series_time_indices(const std::vector<double>& times, int indexing, double t, int& n1, int& n2, double& f) {
+    const int nt = (int)times.size();
+    n1 = n2 = 0;
+    f = 0.0;
+    if (nt == 1) return;
+    auto find = [&](double tq) {
+        // binary search for the bracketing interval; an interior node hit returns (n, n); outside the range the
+        // first / last interval is returned (linear extrapolation)
+        int low = 0, high = nt - 1;
+        while (low + 1 < high) {
+            int mid = (low + high) / 2;
+            if (times[mid] == tq) { n1 = n2 = mid; f = 0.0; return; }
+            if (times[mid] < tq) low = mid; else high = mid;
+        }
+        n1 = low;
+        n2 = high;
+        f = (1.0 / (times[n2] - times[n1])) * (tq - times[n1]);
+    };
+    if (indexing == TRM_TIME_CYCLICAL) {
+        const double t1 = times[0], tN = times[nt - 1];
+        const double period = (tN - t1) + (tN - times[nt - 2]);
+        double tau = std::fmod(t - t1, period);
+        if (tau < 0) tau += period;
+        const double tm = tau + t1;
+        if (tm > tN) {   // between the last node and the first node of the next cycle
+            n1 = nt - 1;
+            n2 = 0;
+            f = (1.0 / (period - (tN - t1))) * (tm - tN);
+            return;
+        }
+        find(tm);
+        return;
+    }
+    find(t);
+    if (indexing == TRM_TIME_CLAMP) {
+        if (t >= times[nt - 1]) { n1 = n2 = nt - 1; f = 0.0; }
+        else if (t <= times[0]) { n1 = n2 = 0; f = 0.0; }
+    }
+}
+
 template <class NF> struct Ops {
     static bool richards(const trm_ctx* c) { return c->params.flow == TRM_FLOW_RICHARDS; }
+
+    // update_inputs!(state, clock) for the time series sources: evaluates every series at `time` into the input
+    // field / boundary value array of field set `s` (the Heun stage has its own copies)
+    static int update_inputs(trm_ctx* c, const FieldSet& s, double time) {
+        if (c->series.empty()) return TRM_OK;
+        const bool stage = &s == &c->stage;
+        SeriesJobs<NF> jobs;
+        int nj = 0;
+        auto flush = [&]() -> int {
+            if (nj == 0) return TRM_OK;
+            hipLaunchKernelGGL(k_interp_series<NF>, dim3((unsigned)((c->Nh + 255) / 256), (unsigned)nj), dim3(256), 0, c->stream, jobs, c->Nh);
+            TRM_HIP(c, hipGetLastError());
+            nj = 0;
+            return TRM_OK;
+        };
+        for (auto& sr : c->series) {
+            int n1, n2;
+            double f;
+            series_time_indices(sr.times, sr.indexing, time, n1, n2, f);
+            NF* dst;
+            if (sr.is_bc) {
+                void*& slot = stage ? c->bc_value_stage[sr.var][sr.side] : c->bc_value[sr.var][sr.side];
+                if (!slot) TRM_HIP(c, hipMalloc(&slot, (size_t)c->Nh * sizeof(NF)));
+                dst = (NF*)slot;
+            } else {
+                dst = (NF*)s.f[sr.field];
+            }
+            const NF* base = (const NF*)sr.d_values;
+            jobs.job[nj++] = SeriesJob<NF>{dst, base + (size_t)n1 * c->Nh, base + (size_t)n2 * c->Nh, f};
+            if (nj == 16) { int rc = flush(); if (rc) return rc; }
+        }
+        return flush();
+    }
 
     // hydraulics specialisation of this context (trm_device.hpp: HYD_*)
     static int hyd(const trm_ctx* c) {
@@ -434,7 +520,8 @@ template <class NF> struct Ops {
             // the fused kernel maps one soil level to one lane: columns deeper than 64 levels take the
             // reference-order kernels
             const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
-            int rc = TRM_OK;
+            int rc = update_inputs(c, c->state, c->time);
+            if (rc) return rc;
             if (!fused) {
                 rc = unfused_step(c, dt, fin);
             } else {
@@ -466,10 +553,12 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
-        int rc = update_state(c, c->state, true);
+        int rc = update_inputs(c, c->state, c->time);
+        if (!rc) rc = update_state(c, c->state, true);
         if (!rc) rc = copy_state_to_stage(c);
         if (!rc) rc = explicit_step(c, c->stage, dt);
         if (!rc) rc = closure(c, c->stage);
+        if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // the stage's clock has ticked (heun.jl:52)
         if (!rc) rc = update_state(c, c->stage, true);
         if (!rc) rc = average(c, TRM_FIELD_TEND_INTERNAL_ENERGY);
         if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SATURATION_WATER_ICE);
@@ -764,7 +853,12 @@ int trm_destroy(trm_ctx* c) {
     if (c->stage.kf_top) (void)hipFree(c->stage.kf_top);
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b)
+        {
             if (c->bc_value[a][b]) (void)hipFree(c->bc_value[a][b]);
+            if (c->bc_value_stage[a][b]) (void)hipFree(c->bc_value_stage[a][b]);
+        }
+    for (auto& sr : c->series)
+        if (sr.d_values) (void)hipFree(sr.d_values);
     for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, (void*)c->d_status, (void*)c->d_reduce})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -837,6 +931,70 @@ int trm_set_forcing(trm_ctx* c, int input_field, const void* per_column) {
     return trm_upload(c, input_field, per_column);
 }
 
+namespace {
+int add_series(trm_ctx* c, trm_ctx::Series&& sr, int nt, const double* times, const void* values, const char* who) {
+    if (nt < 1 || !times || !values) return fail(c, TRM_EINVAL, std::string(who) + ": nt >= 1, times and values are required");
+    for (int n = 1; n < nt; ++n)
+        if (!(times[n] > times[n - 1])) return fail(c, TRM_EINVAL, std::string(who) + ": times must be strictly increasing");
+    if (sr.indexing < TRM_TIME_LINEAR || sr.indexing > TRM_TIME_CYCLICAL) return fail(c, TRM_EINVAL, std::string(who) + ": bad time_indexing");
+    TRM_HIP(c, hipSetDevice(c->device));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    // replace an earlier series with the same target
+    for (size_t n = 0; n < c->series.size(); ++n) {
+        auto& o = c->series[n];
+        if (o.is_bc == sr.is_bc && (sr.is_bc ? (o.var == sr.var && o.side == sr.side) : o.field == sr.field)) {
+            if (o.d_values) (void)hipFree(o.d_values);
+            c->series.erase(c->series.begin() + (long)n);
+            break;
+        }
+    }
+    sr.times.assign(times, times + nt);
+    size_t bytes = (size_t)nt * (size_t)c->Nh * c->esize;
+    TRM_HIP(c, hipMalloc(&sr.d_values, bytes));
+    TRM_HIP(c, hipMemcpy(sr.d_values, values, bytes, hipMemcpyHostToDevice));
+    c->series.push_back(std::move(sr));
+    return TRM_OK;
+}
+}  // namespace
+
+int trm_set_forcing_series(trm_ctx* c, int input_field, int nt, const double* times, const void* values, int time_indexing) {
+    if (!c || input_field < TRM_FIELD_AIR_TEMPERATURE || input_field > TRM_FIELD_SURFACE_LONGWAVE_DOWN)
+        return fail(c, TRM_EINVAL, "trm_set_forcing_series: not an input field");
+    trm_ctx::Series sr;
+    sr.is_bc = false;
+    sr.field = input_field;
+    sr.indexing = time_indexing;
+    return add_series(c, std::move(sr), nt, times, values, "trm_set_forcing_series");
+}
+
+int trm_set_bc_series(trm_ctx* c, int var, int side, int kind, int nt, const double* times, const void* values, int time_indexing) {
+    if (!c || var < 0 || var >= TRM_BCV_COUNT || (side != TRM_TOP && side != TRM_BOTTOM) || kind <= TRM_BC_NOFLUX || kind > TRM_BC_GRADIENT)
+        return fail(c, TRM_EINVAL, "trm_set_bc_series: bad argument");
+    trm_ctx::Series sr;
+    sr.is_bc = true;
+    sr.var = var;
+    sr.side = side;
+    sr.indexing = time_indexing;
+    int rc = add_series(c, std::move(sr), nt, times, values, "trm_set_bc_series");
+    if (rc) return rc;
+    c->bc_kind[var][side] = kind;
+    if (!c->bc_value[var][side]) {
+        TRM_HIP(c, hipMalloc(&c->bc_value[var][side], (size_t)c->Nh * c->esize));
+        TRM_HIP(c, hipMemset(c->bc_value[var][side], 0, (size_t)c->Nh * c->esize));
+    }
+    return TRM_OK;
+}
+
+int trm_clear_series(trm_ctx* c) {
+    if (!c) return TRM_EINVAL;
+    TRM_HIP(c, hipSetDevice(c->device));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto& sr : c->series)
+        if (sr.d_values) (void)hipFree(sr.d_values);
+    c->series.clear();
+    return TRM_OK;
+}
+
 #define TRM_ENTER(c)                                         \
     if (!(c)) return TRM_EINVAL;                             \
     TRM_HIP(c, hipSetDevice((c)->device));
@@ -845,8 +1003,14 @@ int trm_initialize(trm_ctx* c) {
     TRM_ENTER(c);
     return finish(c, DISPATCH(c, initialize(c)));
 }
+int trm_update_inputs(trm_ctx* c) {
+    TRM_ENTER(c);
+    return finish(c, DISPATCH(c, update_inputs(c, c->state, c->time)));
+}
 int trm_update_state(trm_ctx* c, int compute_tendencies) {
     TRM_ENTER(c);
+    int rc = DISPATCH(c, update_inputs(c, c->state, c->time));
+    if (rc) return rc;
     return finish(c, DISPATCH(c, update_state(c, c->state, compute_tendencies != 0)));
 }
 int trm_compute_auxiliary(trm_ctx* c) {

@@ -224,6 +224,23 @@ template <class NF> __global__ void k_invclosure_energy(View<NF> v, DevParams<NF
     if (viol) atomicOr(v.status, viol);
 }
 // Heun: state.tendencies .= (state.tendencies + stage.tendencies) / 2 (heun.jl:27-35)
+// update_inputs! for time series sources (input_sources.jl:162-168): dst = v2 * f + v1 * (1 - f) in double,
+// rounded once to NF; f == 0 with v1 == v2 (same node) is the plain copy.  Up to 16 series per launch
+// (blockIdx.y = series).
+template <class NF> struct SeriesJob { NF* dst; const NF* v1; const NF* v2; double f; };
+template <class NF> struct SeriesJobs { SeriesJob<NF> job[16]; };
+template <class NF> __global__ void k_interp_series(SeriesJobs<NF> jobs, long Nh) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nh) return;
+    const SeriesJob<NF>& j = jobs.job[blockIdx.y];
+    if (j.v1 == j.v2) {
+        j.dst[i] = j.v1[i];
+    } else {
+        const double a = (double)j.v1[i], b = (double)j.v2[i];
+        j.dst[i] = (NF)(b * j.f + a * (1.0 - j.f));
+    }
+}
+
 template <class NF> __global__ void k_average(NF* a, const NF* b, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = (a[i] + b[i]) / NF(2);

@@ -77,6 +77,38 @@ def merge_boundary_conditions(*bcs):
 
 
 # ---- device context -------------------------------------------------------------
+class FieldTimeSeries:
+    """Stand-in for an Oceananigans `FieldTimeSeries` of a 2-D field: `values[nt][Nh]` (or `[nt]`, broadcast over the
+    columns) at strictly increasing `times[nt]` (seconds), with `time_indexing` in {"linear", "clamp", "cyclical"}.
+    Given as an input (`InputSource(fts; name)`, input_sources.jl:142-171) or as a boundary value it is uploaded
+    once and evaluated on the device at the integrator's clock by every step, so `run!` stays ONE library call."""
+
+    def __init__(self, times, values, time_indexing="linear"):
+        self.times = np.asarray(times, dtype=np.float64)
+        self.values = np.asarray(values)
+        if time_indexing not in _capi.TIME_INDEXING:
+            raise ValueError(f"time_indexing must be one of {sorted(_capi.TIME_INDEXING)}")
+        if self.values.shape[0] != self.times.size:
+            raise ValueError("values must have one row per time")
+        self.time_indexing = time_indexing
+
+    @classmethod
+    def from_function(cls, f, times, time_indexing="linear"):
+        """Samples f(t) -> number | per-column array at `times`."""
+        times = np.asarray(times, dtype=np.float64)
+        return cls(times, np.stack([np.asarray(f(float(t)), dtype=np.float64) for t in times]), time_indexing)
+
+
+def InputSource(source, name):
+    """InputSource(field | fts; name) (input_sources.jl:104-160): a (name, source) pair for `initialize(...; inputs)`."""
+    return (name, source)
+
+
+def InputSources(*sources):
+    """InputSources(sources...) (input_sources.jl:32-50) -> dict for `initialize(...; inputs)`."""
+    return dict(sources)
+
+
 class DeviceState:
     """Owns one `trm_ctx` (one device's shard of columns) and exposes the state
     variables by the reference's names; reading an attribute downloads the field
@@ -162,6 +194,31 @@ class DeviceState:
         a = np.empty(self.grid.Nh, dtype=self.dtype)
         a[...] = value
         self._check(self._lib.trm_set_forcing(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_set_forcing")
+
+    # -- time series input sources (input_sources.jl:142-171) ------------------------
+    def _series_args(self, times, values, time_indexing):
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        vals = np.ascontiguousarray(values, dtype=self.dtype)
+        if vals.ndim == 1:      # one value per time, broadcast over the columns
+            vals = np.ascontiguousarray(np.broadcast_to(vals[:, None], (vals.size, self.grid.Nh)))
+        assert vals.shape == (times.size, self.grid.Nh), (vals.shape, times.size, self.grid.Nh)
+        return times, vals, _capi.TIME_INDEXING[time_indexing]
+
+    def set_forcing_series(self, name, times, values, time_indexing="linear"):
+        """FieldTimeSeriesInputSource: `values[nt][Nh]` at `times[nt]`, resident on the device and evaluated at
+        the clock by every step (trm_set_forcing_series)."""
+        t, v, ti = self._series_args(times, values, time_indexing)
+        self._check(self._lib.trm_set_forcing_series(self._ctx, _capi.FIELD[name], t.size, t.ctypes.data, v.ctypes.data, ti),
+                    "trm_set_forcing_series")
+
+    def set_bc_series(self, var, side, kind, times, values, time_indexing="linear"):
+        """Time-dependent boundary values (the reference's functional boundary conditions sampled at `times`)."""
+        t, v, ti = self._series_args(times, values, time_indexing)
+        self._check(self._lib.trm_set_bc_series(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], _capi.BC_KIND[kind],
+                                                t.size, t.ctypes.data, v.ctypes.data, ti), "trm_set_bc_series")
+
+    def clear_series(self): self._check(self._lib.trm_clear_series(self._ctx), "trm_clear_series")
+    def update_inputs(self): self._check(self._lib.trm_update_inputs(self._ctx), "trm_update_inputs")
 
     # -- grid ---------------------------------------------------------------------
     def _grid_arrays(self):
@@ -293,9 +350,10 @@ def initialize(model, timestepper=None, boundary_conditions=None, initializers=N
     """initialize(model, timestepper; boundary_conditions, initializers) (model_integrator.jl:145-161).
 
     `boundary_conditions`: dict {(variable, side): (kind, value)} as built by the aliases above; a value may
-    be a number, a per-column array, or a function of time returning one of those.
+    be a number, a per-column array, a `FieldTimeSeries` (evaluated on the device every step) or a function of
+    time returning a number / array (evaluated on the host before every step: one library call per step).
     `initializers`: dict {field name: number | array | function(x, z)} (`set!` arguments).
-    `inputs`: dict {input field: number | array | function(t)} (InputSource stand-in)."""
+    `inputs`: dict {input field: number | array | FieldTimeSeries | function(t)} (`InputSources(InputSource(...))`)."""
     timestepper = timestepper or ForwardEuler()
     bcs = dict(boundary_conditions or {})
     inits = dict(initializers or {})
@@ -311,10 +369,18 @@ def initialize_integrator(integ: ModelIntegrator):
     model initializer, process initializers."""
     st = integ.state
     st.set_clock(0.0, 0)
+    st.clear_series()
     for (var, side), (kind, value) in integ.boundary_conditions.items():
-        st.set_bc(var, side, kind, value(0.0) if callable(value) else value)
+        if isinstance(value, FieldTimeSeries):
+            st.set_bc_series(var, side, kind, value.times, value.values, value.time_indexing)
+        else:
+            st.set_bc(var, side, kind, value(0.0) if callable(value) else value)
     for name, value in integ.inputs.items():
-        st.set_forcing(name, value(0.0) if callable(value) else value)
+        if isinstance(value, FieldTimeSeries):
+            st.set_forcing_series(name, value.times, value.values, value.time_indexing)
+        else:
+            st.set_forcing(name, value(0.0) if callable(value) else value)
+    st.update_inputs()   # initialize!(fields, source, clock) = update_inputs! at the start time
     for name, value in integ.initializers.items():
         st.set(name, value)
     _apply_model_initializer(st, integ.model)

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libterrarium_hip.so does not export {n}"
     assert sorted(trm._capi.EXPORTS) == names  # the Python binding covers the whole ABI, nothing more
-    assert lib.trm_abi_version() == 1
+    assert lib.trm_abi_version() == 2
 
 
 def test_default_params_match_reference_defaults():

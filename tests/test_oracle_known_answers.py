@@ -389,3 +389,42 @@ def test_julia_integer_power_path():
         assert v == pytest.approx(x ** -5.0, rel=4e-16)
     assert scalar("pow", 10.0, -0.0) == 1.0
     assert scalar("safediv", 1.0, 0.0) == math.inf  # src/utils/utils.jl:25 (test/utils.jl:39 is stale)
+
+
+# ---- FieldTimeSeriesInputSource (input_sources.jl:142-171); Oceananigans time indexing restated, unpinned ----------
+def test_time_series_indices():
+    import oracle
+    t = [0.0, 10.0, 20.0, 40.0]
+    ti = lambda q, m: oracle.time_indices(t, q, m)
+    assert ti(5.0, "linear") == (0.5, 0, 1) and ti(30.0, "linear") == (0.5, 2, 3)
+    assert ti(10.0, "linear") == (0.0, 1, 1)                    # interior node: plain copy
+    assert ti(0.0, "linear") == (0.0, 0, 1) and ti(40.0, "linear") == (1.0, 2, 3)   # end nodes: f = 0 / 1
+    assert ti(-5.0, "linear") == (-0.5, 0, 1) and ti(50.0, "linear") == (1.5, 2, 3)  # linear extrapolation
+    assert ti(-5.0, "clamp") == (0.0, 0, 0) and ti(50.0, "clamp") == (0.0, 3, 3) and ti(15.0, "clamp") == (0.5, 1, 2)
+    # cyclical: period = (40 - 0) + (40 - 20) = 60; the last node connects to the first
+    assert ti(50.0, "cyclical") == (0.5, 3, 0) and ti(65.0, "cyclical") == (0.5, 0, 1) and ti(-5.0, "cyclical") == (0.75, 3, 0)
+    assert oracle.time_indices([7.0], 100.0, "linear") == (0.0, 0, 0)
+
+
+def test_update_inputs_from_series():
+    import oracle
+    thickness = np.full(6, 0.1)
+    o = oracle.Oracle(3, thickness, oracle.default_params(flow=1, seb=1))
+    times = np.array([0.0, 100.0, 300.0])
+    vals = np.array([[1.0, 2.0, 3.0], [3.0, 2.0, 1.0], [7.0, 7.0, 7.0]])
+    o.set_forcing_series("air_temperature", times, vals)
+    o.set_bc_series("temperature", "top", "value", times, [10.0, 20.0, 40.0], "clamp")
+    o.set_clock(50.0, 0)
+    o.update_inputs()
+    assert np.array_equal(o.get("air_temperature"), [2.0, 2.0, 2.0])
+    o.set_clock(200.0, 0)
+    o.update_inputs()
+    assert np.array_equal(o.get("air_temperature"), vals[2] * 0.5 + vals[1] * 0.5)
+    # the boundary series feeds the halo: value BC => halo = 2 v - T_top
+    o.set("temperature", np.zeros((6, 3)))
+    o.fill_halo_regions()
+    assert o.halo("temperature", 1) == pytest.approx(2 * 30.0)
+    o.set_clock(1000.0, 0)
+    o.update_inputs()
+    o.fill_halo_regions()
+    assert o.halo("temperature", 1) == pytest.approx(2 * 40.0)   # clamped
