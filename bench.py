@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
+    ap.add_argument("--integrator", default="euler", choices=["euler", "heun"], help="ForwardEuler (headline) or Heun (two fused launches per step)")
     ap.add_argument("--skip-kf", action="store_true", help="store hydraulic_conductivity only when finalizing")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -108,11 +109,17 @@ def main():
         torch.cuda.synchronize()
 
     # warmup (untimed)
+    heun = args.integrator == "heun"
     if args.warmup > 0:
-        dev.step(dt, args.warmup, finalize=False)
+        (dev.step_heun if heun else dev.step)(dt, args.warmup, finalize=False)
     barrier()
     t0 = time.perf_counter()
-    ms = dev.step_timed(dt, args.steps, finalize=False)  # exactly K steps = K launches, HIP events on the library's stream
+    if heun:    # no event-timed entry point for Heun: the wall clock of the synchronous call stands in
+        dev.step_heun(dt, args.steps, finalize=False)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+    else:
+        ms = dev.step_timed(dt, args.steps, finalize=False)  # exactly K steps = K launches, HIP events on the library's stream
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -149,7 +156,7 @@ def main():
         "vs_baseline": None,
         "dtype": dt_name,
         "data": "synthetic forcing and initial state on the reference's ERA5-land mask columns (SURVEY 8(d)); seeded",
-        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": dt, "kernel": args.kernel,
+        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": dt, "kernel": args.kernel, "integrator": args.integrator,
                    "parallelism": f"columns block-sharded over {n_gpus} GPU(s), no data-path collective",
                    "status_flags": int(nan_flag)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

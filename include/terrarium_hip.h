@@ -231,7 +231,8 @@ int trm_invclosure(trm_ctx* ctx);
  * if `finalize` (forward_euler.jl:19-31, model_integrator.jl:72-88,124-131).  nsteps = 1, finalize = 1
  * is the reference's timestep!(integrator, dt); finalize = 1 with nsteps = n is run!(steps = n). */
 int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
-/* Same for Heun (heun.jl:37-71). */
+/* Same for Heun (heun.jl:37-71): with TRM_KERNEL_FUSED two launches per step (predictor into the stage buffers,
+ * corrector from the stage's tendencies), otherwise the reference-order kernels on a second copy of the state. */
 int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
 int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);

@@ -475,38 +475,64 @@ template <class NF> struct Ops {
     }
 
     // ---- fused step, column per (half-)wavefront ------------------------------------------------------
-    template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
-        auto v = make_view<NF>(c, c->state);
-        auto p = make_dev_params<NF>(c->params);
-        dim3 grid = wave_grid(c, LPC);
-        grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
-        // the branch-free kernel covers Value on temperature and Flux on the prognostics; anything else is generic
+    // the branch-free fused kernel covers Value on temperature and Flux on the prognostics; anything else is generic
+    static bool generic_bcs(const trm_ctx* c) {
         bool generic = false;
         for (int side = 0; side < 2; ++side) {
             generic = generic || c->bc_kind[TRM_BCV_TEMPERATURE][side] == TRM_BC_GRADIENT;
             for (int var : {TRM_BCV_SATURATION_WATER_ICE, TRM_BCV_LIQUID_WATER_FRACTION, TRM_BCV_PRESSURE_HEAD})
                 generic = generic || c->bc_kind[var][side] == TRM_BC_VALUE || c->bc_kind[var][side] == TRM_BC_GRADIENT;
         }
-        const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+        return generic;
+    }
+    static StageView<NF> make_stage_view(const trm_ctx* c) {
+        StageView<NF> w{};
+        if (!c->has_stage) return w;
+        auto F = [&](int id) { return (NF*)c->stage.f[id]; };
+        w.U = F(TRM_FIELD_INTERNAL_ENERGY);
+        w.sat = F(TRM_FIELD_SATURATION_WATER_ICE);
+        w.T = F(TRM_FIELD_TEMPERATURE);
+        w.liq = F(TRM_FIELD_LIQUID_WATER_FRACTION);
+        w.psi = F(TRM_FIELD_PRESSURE_HEAD);
+        w.S = F(TRM_FIELD_SURFACE_EXCESS_WATER);
+        w.wt = F(TRM_FIELD_WATER_TABLE);
+        w.Ts = F(TRM_FIELD_SKIN_TEMPERATURE);
+        auto bc = [&](int side) {
+            void* q = c->bc_value_stage[TRM_BCV_TEMPERATURE][side] ? c->bc_value_stage[TRM_BCV_TEMPERATURE][side] : c->bc_value[TRM_BCV_TEMPERATURE][side];
+            return (const NF*)(q ? q : c->d_zero);
+        };
+        w.bcT_bot = bc(0);
+        w.bcT_top = bc(1);
+        return w;
+    }
+    // ---- fused step, column per (half-)wavefront ------------------------------------------------------
+    template <bool RICH, int H, int LPC, int MODE> static int launch_wave(trm_ctx* c, double dt, int finalize) {
+        auto v = make_view<NF>(c, c->state);
+        auto w = make_stage_view(c);
+        auto p = make_dev_params<NF>(c->params);
+        dim3 grid = wave_grid(c, LPC);
+        grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
+        const int wkf = MODE == STEP_HEUN_FINAL ? finalize : ((c->opt_write_kf || finalize) ? 1 : 0);
         // tuning knob: unused dynamic LDS per workgroup caps the resident workgroups per CU (occupancy sweeps)
         static const unsigned lds = getenv("TRM_EXP_LDS_BYTES") ? (unsigned)atoi(getenv("TRM_EXP_LDS_BYTES")) : 0u;
-        if (generic)
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, wkf);
+        if (MODE == STEP_EULER && generic_bcs(c))
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true, STEP_EULER>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, w, p, (NF)dt, finalize, wkf);
         else
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, p, (NF)dt, finalize, wkf);
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false, MODE>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, w, p, (NF)dt, finalize, wkf);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
-    template <bool RICH, int H> static int wave_lpc(trm_ctx* c, double dt, int finalize) {
-        if (c->Nz <= 32) return launch_wave<RICH, H, 32>(c, dt, finalize);
-        return launch_wave<RICH, H, 64>(c, dt, finalize);
+    template <bool RICH, int H, int MODE> static int wave_lpc(trm_ctx* c, double dt, int finalize) {
+        if (c->Nz <= 32) return launch_wave<RICH, H, 32, MODE>(c, dt, finalize);
+        return launch_wave<RICH, H, 64, MODE>(c, dt, finalize);
     }
-    static int wave_step(trm_ctx* c, double dt, int finalize) {
+    template <int MODE> static int wave_step_mode(trm_ctx* c, double dt, int finalize) {
         int rc = TRM_OK;
-        if (richards(c)) { TRM_BY_HYD(c, rc = (wave_lpc<true, H>(c, dt, finalize))); }
-        else { TRM_BY_HYD(c, rc = (wave_lpc<false, H>(c, dt, finalize))); }
+        if (richards(c)) { TRM_BY_HYD(c, rc = (wave_lpc<true, H, MODE>(c, dt, finalize))); }
+        else { TRM_BY_HYD(c, rc = (wave_lpc<false, H, MODE>(c, dt, finalize))); }
         return rc;
     }
+    static int wave_step(trm_ctx* c, double dt, int finalize) { return wave_step_mode<STEP_EULER>(c, dt, finalize); }
     static int unfused_step(trm_ctx* c, double dt, int finalize) {
         int rc = update_state(c, c->state, true);
         if (!rc) rc = explicit_step(c, c->state, dt);
@@ -552,7 +578,21 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
+    // Heun in two fused launches (TRM_KERNEL_FUSED, Nz <= 64, no generic boundary kinds): predictor into the stage
+    // buffers with G1 kept in the state's tendency fields, then the corrector from the stage's tendencies.  The
+    // stage's surface energy balance is not evaluated: its fluxes would only enter through compute_z_bcs!, which
+    // the reference runs for the state alone (heun.jl:54-69).
+    static int heun_step_fused(trm_ctx* c, double dt, int finalize) {
+        int rc = update_inputs(c, c->state, c->time);
+        if (!rc && c->params.seb) rc = surface(c, c->state, true);
+        if (!rc) rc = wave_step_mode<STEP_HEUN_STAGE>(c, dt, 0);
+        if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock
+        if (!rc) rc = wave_step_mode<STEP_HEUN_FINAL>(c, dt, finalize);
+        if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
+        return rc;
+    }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c)) return heun_step_fused(c, dt, finalize);
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_state(c, c->state, true);
         if (!rc) rc = copy_state_to_stage(c);

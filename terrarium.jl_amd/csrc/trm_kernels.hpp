@@ -484,8 +484,21 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 #ifdef TRM_EXP_CONCURRENCY   // diagnostic: waves in flight (current, peak, sum over wave starts, starts)
 __device__ unsigned long long trm_exp_conc[4];
 #endif
-template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
+//
+// MODE selects the integrator stage (heun.jl:37-71); `w` holds the Heun stage's buffers:
+//   STEP_EULER        v -> v                                   (forward_euler.jl:19-31)
+//   STEP_HEUN_STAGE   reads the state v, keeps its tendencies G1 in v's tendency fields, writes the Euler
+//                     predictor (+ closure) into the stage w                         (heun.jl:41-52)
+//   STEP_HEUN_FINAL   tendencies G2 of the stage w, G = (G1 + G2) / 2, boundary fluxes of the state (the stage's
+//                     boundary fluxes never enter: compute_z_bcs! runs inside explicit_step! only), v -> v   (heun.jl:54-69)
+enum { STEP_EULER = 0, STEP_HEUN_STAGE = 1, STEP_HEUN_FINAL = 2 };
+template <class NF> struct StageView {
+    NF *U, *sat, *T, *liq, *psi, *S, *wt, *Ts;
+    const NF *bcT_bot, *bcT_top;   // the stage's temperature boundary values (evaluated at t + dt for a series)
+};
+template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC, int MODE>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageView<NF> w, DevParams<NF> p, NF dt, int finalize, int write_kf) {
+    static_assert(!(GENERIC_BC && MODE != STEP_EULER), "the Heun stages use the branch-free boundary path");
     constexpr int CPW = 64 / LPC;   // columns per wave
     const int lane = threadIdx.x & 63;
 #ifdef TRM_EXP_STAMPS   // diagnostic: per-wave start / end time stamps + HW_ID into the (unused) energy tendency buffer
@@ -518,9 +531,15 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
     const NF U = NF(1.0e6) + NF(cb) * NF(3.0), sat = NF(0.5) + NF(cb & 31) * NF(0.01), T = NF(2) + NF(cb & 7);
     const NF liq = NF(1), psi = NF(-1) - NF(cb & 15) * NF(0.1);
 #else
-    const NF U = ldg(v.U, cb), sat = ldg(v.sat, cb), T = ldg(v.T, cb), liq = ldg(v.liq, cb);
-    const NF psi = RICHARDS ? ldg(v.psi, cb) : NF(0);
+    // (U, sat, T, liq, psi): the state the tendencies are evaluated at -- the stage's in STEP_HEUN_FINAL
+    const bool from_stage = MODE == STEP_HEUN_FINAL;
+    // (without Richards flow the saturation is not prognostic: the stage never gets a copy, the state's is read)
+    const NF U = ldg(from_stage ? w.U : v.U, cb), sat = ldg((from_stage && RICHARDS) ? w.sat : v.sat, cb);
+    const NF T = ldg(from_stage ? w.T : v.T, cb), liq = ldg(from_stage ? w.liq : v.liq, cb);
+    const NF psi = RICHARDS ? ldg(from_stage ? w.psi : v.psi, cb) : NF(0);
 #endif
+    // (U0, sat0): the state that is advanced
+    const NF U0 = from_stage ? ldg(v.U, cb) : U, sat0 = from_stage ? ldg(v.sat, cb) : sat;
 #ifdef TRM_EXP_MEMORY_ONLY
     if (act) {
         stg(v.U, cb, U + dt); stg(v.T, cb, T + dt); stg(v.liq, cb, liq + dt);
@@ -583,7 +602,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
         // Branch-free boundary handling.  Every BC value pointer is valid (unset conditions point at a zero
         // array), all lanes of a column read the same address, and the selects are on wave-uniform kinds.
         const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
-        const NF bTb = ldg(bcval(v, 2, 0), ib), bTt = ldg(bcval(v, 2, 1), ib);
+        const NF bTb = ldg(from_stage ? w.bcT_bot : bcval(v, 2, 0), ib), bTt = ldg(from_stage ? w.bcT_top : bcval(v, 2, 1), ib);
         const NF T_ext_b = T + div_const(T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
         const NF T_ext_t = T + div_const(bTt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
         T_m = is_bot ? (vTb ? T_ext_b : T) : T_sh;
@@ -644,15 +663,21 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
         gS = NF(0) + div_const(dtheta, p.por, p.rpor);
     }
+    // ---- Heun: keep G1 (stage launch) / average with G1 (final launch), average_tendencies! heun.jl:27-35 ----
+    const NF gU_stage = gU, gS_stage = gS;
+    if (MODE == STEP_HEUN_FINAL) {
+        gU = (ldg(v.G_U, cb) + gU) / NF(2);
+        if (RICHARDS) gS = (ldg(v.G_sat, cb) + gS) / NF(2);
+    }
     // ---- compute_z_bcs!: flux BCs into the boundary cells (x + 0 is exact for the interior lanes) -------
     gU += flux_U;
     if (RICHARDS) gS += flux_S;
     // ---- explicit Euler update ------------------------------------------------------------------------------------
-    const NF Unew = U + gU * dt;
+    const NF Unew = U0 + gU * dt;
     bool bad = act && is_nan(Unew);
-    NF snew = sat, z0 = NF(0);
+    NF snew = sat0, z0 = NF(0);
     if (RICHARDS) {
-        snew = sat + gS * dt;
+        snew = sat0 + gS * dt;
         bad = bad || (act && is_nan(snew));
         const NF over = repair_saturation<NF, LPC>(v, snew, k, Nz, act, is_bot, is_top, L);
         z0 = water_table<NF, LPC>(snew, act, lane, L);
@@ -660,14 +685,17 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
             // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler update, overflow
             const unsigned ib = block_local(ib0);
             NF S = ldg(v.S, ib);
-            S = S + (NF(0) + jl_min(NF(0), S)) * dt;
-            stg(v.S, ib, S + over);
-            stg(v.wt, ib, z0);
+            NF GS = NF(0) + jl_min(NF(0), MODE == STEP_HEUN_FINAL ? ldg(w.S, ib) : S);
+            if (MODE == STEP_HEUN_STAGE) stg(v.G_S, ib, GS);
+            if (MODE == STEP_HEUN_FINAL) GS = (ldg(v.G_S, ib) + GS) / NF(2);
+            S = S + GS * dt;
+            stg(MODE == STEP_HEUN_STAGE ? w.S : v.S, ib, S + over);
+            stg(MODE == STEP_HEUN_STAGE ? w.wt : v.wt, ib, z0);
         }
     }
     if (act && is_top && p.seb) {   // zero-tendency prognostic skin_temperature
         const unsigned ib = block_local(ib0);
-        stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
+        stg(MODE == STEP_HEUN_STAGE ? w.Ts : v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
     }
 #ifdef TRM_EXP_EXTRA_VALU
     NF xa = U, xb = sat, xc = T, xd = liq;
@@ -696,11 +724,17 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
     if (act) {
 #endif
         const unsigned cb = block_local(cb0), ib = block_local(ib0);
-        stg(v.U, cb, Unew);
-        stg(v.T, cb, Tn);
-        stg(v.liq, cb, ln);
-        if (RICHARDS) { stg(v.sat, cb, snew); stg(v.psi, cb, psin); }
-        if (write_kf) {
+        const bool to_stage = MODE == STEP_HEUN_STAGE;
+        stg(to_stage ? w.U : v.U, cb, Unew);
+        stg(to_stage ? w.T : v.T, cb, Tn);
+        stg(to_stage ? w.liq : v.liq, cb, ln);
+        if (RICHARDS) { stg(to_stage ? w.sat : v.sat, cb, snew); stg(to_stage ? w.psi : v.psi, cb, psin); }
+        if (MODE == STEP_HEUN_STAGE) {
+            stg(v.G_U, cb, gU_stage);
+            if (RICHARDS) stg(v.G_sat, cb, gS_stage);
+        }
+        // hydraulic_conductivity of the state: K(old state) from the Euler / stage launch, K(new state) when finalizing
+        if (write_kf && (MODE != STEP_HEUN_FINAL || finalize)) {
             stg(v.Kf, block_local(cb0), Kf_out);
             if (is_top) stg(v.Kf_top, block_local(ib0), Kf_out_top);
         }

@@ -164,6 +164,27 @@ def test_heun_parity(config, hydraulics):
     assert dev.clock() == orc.clock()
 
 
+@pytest.mark.parametrize("config,hydraulics,Nz", [("heat", "default", 20), ("richards", "default", 32), ("richards", "vg", 64),
+                                                   ("land", "default", 32), ("land", "vg", 20)])
+def test_heun_fused_equals_unfused_bitwise(config, hydraulics, Nz):
+    """Heun in two fused launches (predictor into the stage, corrector from the stage's tendencies) against the
+    reference-order kernels on a second copy of the state: same arithmetic, so bit for bit -- including the stored
+    hydraulic conductivity, surface excess water, water table and skin temperature."""
+    lat, lon = small_columns(131)
+    w = W.make_workload(config, lat, lon, Nz, hydraulics=hydraulics)
+    if config == "richards":
+        w["bcs"][("saturation_water_ice", "top")] = ("flux", np.where(np.arange(131) % 3 == 0, -2.0e-4, 0.0))
+        w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(131, 0.05))
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("step_kernel", "unfused")
+    for nsteps, fin in ((3, False), (4, True)):
+        a.step_heun(w["dt"], nsteps, fin)
+        b.step_heun(w["dt"], nsteps, fin)
+        for n in W.compared_fields(w):
+            assert np.array_equal(a.get(n), b.get(n), equal_nan=True), (n, nsteps)
+    assert a.clock() == b.clock() and a.status() == b.status()
+
+
 def test_halo_policy_mirror():
     lat, lon = small_columns(70)
     w = W.make_workload("heat", lat, lon, 20, halo_policy="mirror")
