@@ -125,11 +125,24 @@ class ColumnRingGrid(ColumnGrid):
         self.dx = (self.num_columns - 1) / self.num_columns if self.num_columns > 1 else 1.0
 
     def scatter(self, columns: np.ndarray, fill=np.nan) -> np.ndarray:
-        """Column vector -> full ring grid (column_ring_grid.jl:124-149)."""
-        out = np.full(self.mask.size, fill, dtype=np.asarray(columns).dtype)
-        out[self.mask_index] = columns
-        return out.reshape(self.mask.shape)
+        """`RingGrids.Field(field, grid; fill_value)` (column_ring_grid.jl:102-115): column data `[Nh]` or
+        `[rows][Nh]` (the layout of `DeviceState.get`) -> the full ring grid `[nlat][nlon]` / `[rows][nlat][nlon]`,
+        `fill` at the unmasked points."""
+        columns = np.asarray(columns)
+        if columns.shape[-1] != self.num_columns:
+            raise ValueError(f"last axis must hold the {self.num_columns} columns of the mask")
+        dtype = columns.dtype if np.issubdtype(columns.dtype, np.floating) or not np.isnan(fill) else np.float64
+        out = np.full(columns.shape[:-1] + (self.mask.size,), fill, dtype=dtype)
+        out[..., self.mask_index] = columns
+        return out.reshape(columns.shape[:-1] + self.mask.shape)
 
     def gather(self, full: np.ndarray) -> np.ndarray:
-        """Full ring grid -> column vector (column_ring_grid.jl:102-115)."""
-        return np.asarray(full).ravel()[self.mask_index]
+        """`Oceananigans.Field(ring_field, grid)` (column_ring_grid.jl:117-149): full ring grid `[nlat][nlon]` or
+        `[rows][nlat][nlon]` -> the masked points in ring order, `[Nh]` / `[rows][Nh]` (what `DeviceState.set`,
+        `set_forcing` and the series calls take)."""
+        full = np.asarray(full)
+        nd = self.mask.ndim
+        if full.shape[-nd:] != self.mask.shape:
+            raise ValueError(f"trailing axes must match the mask shape {self.mask.shape}")
+        flat = full.reshape(full.shape[:-nd] + (self.mask.size,))
+        return np.ascontiguousarray(flat[..., self.mask_index])

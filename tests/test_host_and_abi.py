@@ -86,3 +86,22 @@ def test_bc_aliases():
     assert bcs[("internal_energy", "bottom")] == ("flux", 0.05)
     assert bcs[("pressure_head", "bottom")] == ("gradient", 0.0)
     assert bcs[("saturation_water_ice", "bottom")][0] == "noflux"
+
+
+def test_ring_grid_scatter_gather_2d_and_3d():
+    """column_ring_grid.jl:102-149: RingGrids.Field(field, grid; fill_value) and Field(ring_field, grid)."""
+    mask = trm.masks.load_land_mask("N72")
+    grid = trm.ColumnRingGrid(trm.ExponentialSpacing(N=5), mask)
+    assert grid.num_columns == 14017
+    cols = np.arange(grid.num_columns, dtype=np.float64)
+    full = grid.scatter(cols)
+    assert full.shape == mask.shape and np.isnan(full[~mask]).all() and np.array_equal(full[mask], cols)
+    assert np.array_equal(grid.gather(full), cols)
+    f3 = np.arange(5 * grid.num_columns, dtype=np.float32).reshape(5, -1)
+    full3 = grid.scatter(f3, fill=-1.0)
+    assert full3.shape == (5,) + mask.shape and full3.dtype == np.float32 and (full3[:, ~mask] == -1.0).all()
+    assert np.array_equal(grid.gather(full3), f3)
+    with pytest.raises(ValueError):
+        grid.scatter(np.zeros(7))
+    with pytest.raises(ValueError):
+        grid.gather(np.zeros((3, 4)))
