@@ -599,14 +599,21 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
             }
         }
     } else {
-        // Branch-free boundary handling.  Every BC value pointer is valid (unset conditions point at a zero
-        // array), all lanes of a column read the same address, and the selects are on wave-uniform kinds.
+        // Boundary handling without divergence: every condition that is not set costs one wave-uniform branch
+        // (the kinds are launch constants), every condition that is set is computed by all lanes and kept by the
+        // edge lane (all lanes of a column read the same boundary value).
         const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
-        const NF bTb = ldg(from_stage ? w.bcT_bot : bcval(v, 2, 0), ib), bTt = ldg(from_stage ? w.bcT_top : bcval(v, 2, 1), ib);
-        const NF T_ext_b = T + div_const(T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
-        const NF T_ext_t = T + div_const(bTt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
-        T_m = is_bot ? (vTb ? T_ext_b : T) : T_sh;
-        T_h = vTt ? T_ext_t : T;
+        NF T_ext_b = T, T_ext_t = T;
+        if (vTb) {
+            const NF bTb = ldg(from_stage ? w.bcT_bot : bcval(v, 2, 0), ib);
+            T_ext_b = T + div_const(T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
+        }
+        if (vTt) {
+            const NF bTt = ldg(from_stage ? w.bcT_top : bcval(v, 2, 1), ib);
+            T_ext_t = T + div_const(bTt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
+        }
+        T_m = is_bot ? T_ext_b : T_sh;
+        T_h = T_ext_t;
         // liquid fraction / saturation / pressure head carry the default condition: halo = edge cell, so the halo
         // cell's conductivity is the edge cell's, bit for bit -- except under NoFlow with the reference's
         // never-filled saturation halo (SURVEY C-1), where the halo cell is dry
@@ -620,15 +627,19 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         // k_surface just before this launch.  Top terms enter with a minus sign.
         const bool seb = p.seb != 0;
         const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
-        const NF tUb = flux_term_bottom(ldg(bcval(v, 0, 0), ib), v.g);
-        const NF tUt = flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib), v.g);
-        flux_U = is_bot ? (fUb ? tUb : NF(0)) : (is_top ? (fUt ? -tUt : NF(0)) : NF(0));
+        NF eU_b = NF(0), eU_t = NF(0);   // edge terms: 0 unless a flux condition is set
+        if (fUb) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib), v.g);
+        if (fUt) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib), v.g);
+        flux_U = is_bot ? eU_b : (is_top ? eU_t : NF(0));
         if (RICHARDS) {
             const bool fSb = v.bc.kind[1][0] == 2, fSt = seb || v.bc.kind[1][1] == 2;
-            const NF tSb = flux_term_bottom(ldg(bcval(v, 1, 0), ib), v.g);
-            const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib);
-            const NF tSt = flux_term_top(seb ? -fS : fS, v.g);
-            flux_S = is_bot ? (fSb ? tSb : NF(0)) : (is_top ? (fSt ? -tSt : NF(0)) : NF(0));
+            NF eS_b = NF(0), eS_t = NF(0);
+            if (fSb) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib), v.g);
+            if (fSt) {
+                const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib);
+                eS_t = -flux_term_top(seb ? -fS : fS, v.g);
+            }
+            flux_S = is_bot ? eS_b : (is_top ? eS_t : NF(0));
         }
     }
     // ---- heat: every lane forms its lower face, the top lane also the boundary face -------------------
