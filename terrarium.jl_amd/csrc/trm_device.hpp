@@ -213,26 +213,30 @@ enum { HYD_BC_LINEAR = 0,   // BrooksCorey SWRC + UnsatKLinear: the reference de
        HYD_GENERIC = 2 };   // any combination, decided at run time
 
 template <class NF> struct DevParams {
+    // Member order = order of use in the fused step kernel: the kernel arguments are fetched by scalar loads of up
+    // to 64 contiguous bytes, so what the reference-default path needs comes first and packed.
     // composition (homogeneous_strat.jl:34-61, soil_volume.jl:52-67,103-107)
-    NF org, por, rpor, solid_frac, frac_organic, frac_mineral;
+    NF por, rpor;
     // thermal (soil_thermal_properties.jl:90-107,119-123)
     NF sk_water, sk_ice, sk_air;      // sqrt(k_i)
     NF kterm_mineral, kterm_organic;  // sqrt(k_m)*mineral, sqrt(k_o)*organic
+    NF K_sat;
+    int flow, swrc, unsat_k, seb, halo_policy, impedance_int;
     NF c_water, c_ice, c_air;
     NF cterm_mineral, cterm_organic;  // c_m*mineral, c_o*organic
     NF L;                             // rho_w * Lsl (soil_energy_closures.jl:107)
     // hydrology
-    NF K_sat, theta_res, theta_span, rtheta_span, bc_psi_s, vg_alpha, impedance, vwc_forcing;  // theta_span = por - theta_res
+    NF theta_res, theta_span, rtheta_span, bc_psi_s, vwc_forcing;  // theta_span = por - theta_res
+    PowSpec<NF> bc_neg_inv_lambda, bc_lambda;             // -1/lambda, lambda
+    NF vg_alpha, impedance;
     NF I_ice_frozen;                                      // 10^(-impedance) by the integer path (impedance_int != 0)
-    int impedance_int;
     NF neg_inv_alpha;                                     // -1/alpha
-    PowSpec<NF> bc_lambda, bc_neg_inv_lambda;             // lambda, -1/lambda
     PowSpec<NF> vg_n, vg_neg_m, vg_neg_inv_m, vg_inv_n;   // n, -m, -1/m, 1/n
     PowSpec<NF> vgk_e1, vgk_e2;                           // n/(n+1), (n-1)/n
+    NF org, solid_frac, frac_organic, frac_mineral;
     // surface energy balance
     NF albedo, emissivity, one_minus_emissivity, eps_sigma, kappa_s2, rkappa_s2, C_h, min_windspeed, tau_r, rtau_r, beta_evap;
     NF Tref, eps_mw, one_minus_eps_mw, ca_rhoa, Llg_rhoa;
-    int flow, swrc, unsat_k, seb, halo_policy;
 };
 
 template <class NF> struct Frac { NF water, ice, air; };

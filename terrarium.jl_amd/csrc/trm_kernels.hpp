@@ -29,22 +29,26 @@
 namespace trm {
 
 template <class NF> struct View {
+    // (member order = order of use in the fused step kernel, see DevParams)
     long Nh;
     int Nz, Nzp;
+    // per-level grid records for the lane = level kernels: 8 words {zC, psiz, zF, dzc, rdzc, rdzf[k], rdzf[k+1], 0}
+    const NF* lvl;
     // 3-D, [Nh][Nzp]
-    NF *U, *sat, *T, *liq, *psi, *Kf, *G_U, *G_sat;
+    NF *U, *sat, *T, *liq, *psi;
+    BcSet bc;
+    BcGeom<NF> g;
+    NF *S, *wt;
+    NF *Kf;
+    NF *Kf_top;  // hydraulic conductivity of the top face (face Nz), [Nh]
+    uint32_t* status;
+    NF *G_U, *G_sat, *G_S;
     // 2-D, [Nh]
-    NF *Kf_top;  // hydraulic conductivity of the top face (face Nz)
-    NF *S, *G_S, *wt, *Ts, *ghf, *swu, *lwu, *rnet, *Hs, *Hl, *evap, *infil, *runoff;
+    NF *Ts, *ghf, *infil, *swu, *lwu, *rnet, *Hs, *Hl, *evap, *runoff;
     const NF *Tair, *pres, *wind, *qair, *rain, *swd, *lwd;
     // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f),
     // psiz[Nz] = zC - z_surface (elevation head)
     const NF *zC, *zF, *dzc, *rdzc, *rdzf, *psiz;
-    // the same, packed per level for the lane = level kernels: 8 words {zC, psiz, zF, dzc, rdzc, rdzf[k], rdzf[k+1], 0}
-    const NF* lvl;
-    BcGeom<NF> g;
-    uint32_t* status;
-    BcSet bc;
 };
 
 template <class NF> TRM_DEV const NF* bcval(const View<NF>& v, int var, int side) { return (const NF*)v.bc.value[var][side]; }
