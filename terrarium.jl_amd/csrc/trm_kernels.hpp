@@ -378,8 +378,9 @@ template <class NF> TRM_DEV NeighbourDz<NF> neighbour_dz(const View<NF>& v, int 
 // Returns excess * dz_top in the TOP lane (0 elsewhere): the column's overflow into surface_excess_water.
 template <class NF, int LPC>
 TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, bool act, bool is_bot, bool is_top, const LevelGeom<NF>& L) {
-    const bool over = act && !is_top && !(jl_max(snew - NF(1), NF(0)) == NF(0));
-    const bool under = act && !is_bot && !(jl_max(-snew, NF(0)) == NF(0));
+    // (max(s - 1, 0) != 0  <=>  s > 1  and  max(-s, 0) != 0  <=>  s < 0, NaN included: both sides false)
+    const bool over = act && !is_top && snew > NF(1);
+    const bool under = act && !is_bot && snew < NF(0);
     const unsigned long long any_over = __ballot(over);
     const unsigned long long any_bad = __ballot(over || under);
     // every cell but the bottom one receives `+ carry` / `+ deficit`; with nothing to move that is `+ 0`
@@ -670,9 +671,17 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         const NF qW_sh = shfl_dn1<NF, LPC>(qW_lo);
         NF qW_hi = qW_sh;
         {   // boundary face above the top cell (computed by every lane, kept by the top lane)
-            const NF g_t = (psi_ht - psi) * L.rdzf_hi;
-            const NF Ks_t = upwind_conductivity(g_t, Kf_lo, Kc, NF(0));
-            const NF qW_t = -Ks_t * g_t;
+            NF qW_t;
+            if (GENERIC_BC) {
+                const NF g_t = (psi_ht - psi) * L.rdzf_hi;
+                const NF Ks_t = upwind_conductivity(g_t, Kf_lo, Kc, NF(0));
+                qW_t = -Ks_t * g_t;
+            } else {
+                // default condition: the halo cell repeats psi, so the head difference is +0 (NaN for a non-finite
+                // psi), never negative: K* = min(K, K_halo_face = 0), and (x * rdzf) keeps a zero / NaN as it is
+                const NF zero_or_nan = psi - psi;
+                qW_t = -jl_min(Kc, NF(0)) * zero_or_nan;
+            }
             qW_hi = is_top ? qW_t : qW_sh;
         }
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
