@@ -74,10 +74,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    # Rehearsal knobs (not used by the driver): TRM_BENCH_BACKEND=gloo + TRM_BENCH_SHARE_DEVICE=1 run the N > 1 code
+    # path with several ranks on ONE GPU (RCCL refuses two ranks per device).
+    backend = os.environ.get("TRM_BENCH_BACKEND", "nccl")
+    if os.environ.get("TRM_BENCH_SHARE_DEVICE"):
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
 
     import workloads as W
@@ -126,7 +134,7 @@ def main():
     status = dev.status()
 
     # max over ranks, total columns over ranks
-    stats = torch.tensor([elapsed, ms, float(Nh)], dtype=torch.float64, device="cuda")
+    stats = torch.tensor([elapsed, ms, float(Nh)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         mx = stats.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
