@@ -99,7 +99,11 @@ enum {
     TRM_FIELD_RAINFALL = 25,
     TRM_FIELD_SURFACE_SHORTWAVE_DOWN = 26,
     TRM_FIELD_SURFACE_LONGWAVE_DOWN = 27,
-    TRM_FIELD_COUNT = 28
+    /* 3-D, Nz rows: the user `vwc_forcing` (soil_hydrology.jl:37-38, forcings.jl:13-15) evaluated per cell by the
+     * caller [1/s].  Uploading it switches the Richards tendency from the scalar trm_params.vwc_forcing to this
+     * field; TRM_OPT_VWC_FORCING_FIELD = 0 switches back. */
+    TRM_FIELD_VWC_FORCING = 28,
+    TRM_FIELD_COUNT = 29
 };
 
 /* ---- diagnostics ---------------------------------------------------------- */
@@ -112,8 +116,9 @@ enum { TRM_STATUS_NAN = 1u, TRM_STATUS_COMPOSITION_OUT_OF_RANGE = 2u };
 enum {
     TRM_OPT_ASYNC = 0,          /* 1: trm_step & co. return after enqueueing on the context stream          */
     TRM_OPT_STEP_KERNEL = 1,    /* TRM_KERNEL_*: which implementation trm_step uses                          */
-    TRM_OPT_WRITE_KF_EVERY_STEP = 2 /* 1 (default): hydraulic_conductivity is stored by every step launch;   */
+    TRM_OPT_WRITE_KF_EVERY_STEP = 2,/* 1 (default): hydraulic_conductivity is stored by every step launch;   */
                                     /* 0: only by launches that finalize (it is never an input of a step)   */
+    TRM_OPT_VWC_FORCING_FIELD = 3   /* 1 after TRM_FIELD_VWC_FORCING was uploaded: per-cell vwc_forcing; 0: scalar */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

@@ -19,7 +19,7 @@ FIELDS = dict(
     tend_surface_excess_water=9, water_table=10, skin_temperature=11, ground_heat_flux=12, surface_shortwave_up=13,
     surface_longwave_up=14, surface_net_radiation=15, sensible_heat_flux=16, latent_heat_flux=17,
     evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
-    specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27,
+    specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27, vwc_forcing=28,
 )
 BC_VARS = dict(internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4)
 BC_KINDS = dict(noflux=0, value=1, flux=2, gradient=3)

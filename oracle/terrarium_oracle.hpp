@@ -368,7 +368,8 @@ enum FieldId {
     // inputs (PrescribedAtmosphere)
     F_AIR_TEMPERATURE = 21, F_AIR_PRESSURE = 22, F_WINDSPEED = 23, F_SPECIFIC_HUMIDITY = 24, F_RAINFALL = 25,
     F_SW_DOWN = 26, F_LW_DOWN = 27,
-    F_COUNT = 28
+    F_VWC_FORCING = 28,  // user vwc_forcing evaluated per cell (soil_hydrology.jl:37-38, forcings.jl:13-15)
+    F_COUNT = 29
 };
 
 template <class NF> struct Bc {
@@ -388,6 +389,8 @@ template <class NF> class Oracle {
 
     // 3-D centre fields with z halos: (Nz+2) x Nh
     std::vector<NF> U, sat, T, liq, psi, G_U, G_sat;
+    std::vector<NF> Fvwc;        // per-cell vwc_forcing (halo layout); used instead of p.vwc_forcing once set
+    bool use_Fvwc = false;
     // face field with halos: (Nz+3) x Nh (faces 0..Nz+2)
     std::vector<NF> Kf;
     // 2-D
@@ -399,7 +402,7 @@ template <class NF> class Oracle {
     Oracle(long nh, int nz, const double* thickness, double dx, const ParamsD& pd) : p(pd), Nh(nh), Nz(nz) {
         g.build(nh, nz, thickness, dx);
         size_t n3 = (size_t)(nz + 2) * nh, nf = (size_t)(nz + 3) * nh, n2 = (size_t)nh;
-        for (auto* v : {&U, &sat, &T, &liq, &psi, &G_U, &G_sat}) v->assign(n3, NF(0));
+        for (auto* v : {&U, &sat, &T, &liq, &psi, &G_U, &G_sat, &Fvwc}) v->assign(n3, NF(0));
         Kf.assign(nf, NF(0));
         for (auto* v : {&S, &G_S, &wt, &Ts, &ghf, &swu, &lwu, &rnet, &Hs, &Hl, &evap, &infil, &runoff}) v->assign(n2, NF(0));
         // input defaults (prescribed_atmosphere.jl:90-92,148,221-223)
@@ -427,6 +430,7 @@ template <class NF> class Oracle {
             case F_PRESSURE_HEAD: return &psi;
             case F_TEND_INTERNAL_ENERGY: return &G_U;
             case F_TEND_SATURATION: return &G_sat;
+            case F_VWC_FORCING: return &Fvwc;
             default: return nullptr;
         }
     }
@@ -457,7 +461,7 @@ template <class NF> class Oracle {
     }
     long field_rows(int id) const {
         if (id == F_HYDRAULIC_CONDUCTIVITY) return Nz + 1;
-        if (id <= F_TEND_SATURATION) return Nz;
+        if (id <= F_TEND_SATURATION || id == F_VWC_FORCING) return Nz;
         return 1;
     }
     int set_field(int id, const NF* src) {  // set!(field, array): interior only
@@ -467,6 +471,7 @@ template <class NF> class Oracle {
         }
         if (auto* v = field3(id)) {
             for (int k = 1; k <= Nz; ++k) std::memcpy(&(*v)[C(k, 0)], src + (size_t)(k - 1) * Nh, sizeof(NF) * Nh);
+            if (id == F_VWC_FORCING) use_Fvwc = true;
             return 0;
         }
         if (auto* v = field2(id)) { std::memcpy(v->data(), src, sizeof(NF) * Nh); return 0; }
@@ -740,7 +745,8 @@ template <class NF> class Oracle {
                 };
                 for (int k = 1; k <= Nz; ++k) {
                     NF div = (darcy(k + 1) - darcy(k)) * g.rdzc[k];
-                    NF dtheta = -div + NF(0) /*ET forcing: evtr is never passed (soil_coupled.jl:86)*/ + p.vwc_forcing;
+                    NF F_user = use_Fvwc ? Fvwc[C(k, i)] : p.vwc_forcing;   // forcing(i, j, k, grid, clock, fields, vwc_forcing, ...)
+                    NF dtheta = -div + NF(0) /*ET forcing: evtr is never passed (soil_coupled.jl:86)*/ + F_user;
                     G_sat[C(k, i)] += dtheta / por;
                 }
                 // surface excess water: evaluated once per column (SURVEY C-3)

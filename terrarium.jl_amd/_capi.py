@@ -22,12 +22,12 @@ FIELD = dict(
     tend_surface_excess_water=9, water_table=10, skin_temperature=11, ground_heat_flux=12, surface_shortwave_up=13,
     surface_longwave_up=14, surface_net_radiation=15, sensible_heat_flux=16, latent_heat_flux=17,
     evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
-    specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27,
+    specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27, vwc_forcing=28,
 )
 INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidity", "rainfall",
                 "surface_shortwave_down", "surface_longwave_down")
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
-OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2)
+OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3)
 KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
 

@@ -52,7 +52,7 @@ struct trm_ctx {
     size_t reduce_cap = 0;
     double time = 0.0;
     int64_t iteration = 0;
-    int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1;
+    int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
     std::string err;
 };
 
@@ -75,11 +75,11 @@ int fail(trm_ctx* ctx, int code, const std::string& msg) {
 
 long field_rows(const trm_ctx* c, int field) {
     if (field == TRM_FIELD_HYDRAULIC_CONDUCTIVITY) return c->Nz + 1;
-    if (field <= TRM_FIELD_TEND_SATURATION_WATER_ICE) return c->Nz;
+    if (field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING) return c->Nz;
     return 1;
 }
 bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
-bool is_3d(int field) { return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE; }
+bool is_3d(int field) { return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING; }
 // elements of the device buffer of a field: [Nh][Nzp] for 3-D fields, [Nh] for 2-D fields
 size_t field_elems(const trm_ctx* c, int field) { return is_3d(field) ? (size_t)c->Nh * c->Nzp : (size_t)c->Nh; }
 
@@ -236,6 +236,7 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     v.rdzf = (const NF*)c->d_rdzf;
     v.psiz = (const NF*)c->d_psiz;
     v.lvl = (const NF*)c->d_lvl;
+    v.Fvwc = c->opt_vwc_field ? (const NF*)c->state.f[TRM_FIELD_VWC_FORCING] : nullptr;   // static: shared by the Heun stage
     BcGeom<NF>& g = v.g;
     g.dzf_bot = (NF)c->dzf_bot;
     g.dzf_top = (NF)c->dzf_top;
@@ -926,7 +927,9 @@ int trm_get_grid(const trm_ctx* c, double* z_faces, double* z_centers, double* d
 int trm_upload(trm_ctx* c, int field, const void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_upload: bad argument");
     TRM_HIP(c, hipSetDevice(c->device));
-    return c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
+    int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
+    if (!rc && field == TRM_FIELD_VWC_FORCING) c->opt_vwc_field = 1;
+    return rc;
 }
 
 int trm_download(trm_ctx* c, int field, void* host) {
@@ -1156,6 +1159,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             c->opt_kernel = value;
             return TRM_OK;
         case TRM_OPT_WRITE_KF_EVERY_STEP: c->opt_write_kf = value != 0; return TRM_OK;
+        case TRM_OPT_VWC_FORCING_FIELD: c->opt_vwc_field = value != 0; return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -1166,6 +1170,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_ASYNC: *value = c->opt_async; return TRM_OK;
         case TRM_OPT_STEP_KERNEL: *value = c->opt_kernel; return TRM_OK;
         case TRM_OPT_WRITE_KF_EVERY_STEP: *value = c->opt_write_kf; return TRM_OK;
+        case TRM_OPT_VWC_FORCING_FIELD: *value = c->opt_vwc_field; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

@@ -43,6 +43,7 @@ template <class NF> struct View {
     NF *Kf_top;  // hydraulic conductivity of the top face (face Nz), [Nh]
     uint32_t* status;
     NF *G_U, *G_sat, *G_S;
+    const NF* Fvwc;   // per-cell vwc_forcing [Nh][Nzp], or null: the scalar DevParams::vwc_forcing applies
     // 2-D, [Nh]
     NF *Ts, *ghf, *infil, *swu, *lwu, *rnet, *Hs, *Hl, *evap, *runoff;
     const NF *Tair, *pres, *wind, *qair, *rain, *swd, *lwd;
@@ -133,7 +134,7 @@ template <class NF, bool RICHARDS> __global__ void k_tendencies(View<NF> v, DevP
         NF Klo = upwind_conductivity(g_lo, Km, K0, K1);
         NF Khi = upwind_conductivity(g_hi, K0, K1, K2);
         NF q_lo = -Klo * g_lo, q_hi = -Khi * g_hi;
-        NF dtheta = -((q_hi - q_lo) * v.rdzc[k]) + NF(0) + p.vwc_forcing;
+        NF dtheta = -((q_hi - q_lo) * v.rdzc[k]) + NF(0) + (v.Fvwc ? v.Fvwc[c] : p.vwc_forcing);
         v.G_sat[c] += div_const(dtheta, p.por, p.rpor);
         if (k == 0) v.G_S[i] += jl_min(NF(0), v.S[i]);
     }
@@ -684,7 +685,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
             }
             qW_hi = is_top ? qW_t : qW_sh;
         }
-        const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
+        // (+ 0: the evapotranspiration forcing, never passed for bare ground, soil_coupled.jl:86) + user forcing
+        const NF F_user = v.Fvwc ? ldg(v.Fvwc, cb) : p.vwc_forcing;
+        const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + F_user;
         gS = NF(0) + div_const(dtheta, p.por, p.rpor);
     }
     // ---- Heun: keep G1 (stage launch) / average with G1 (final launch), average_tendencies! heun.jl:27-35 ----

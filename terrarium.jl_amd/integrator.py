@@ -381,6 +381,10 @@ def initialize_integrator(integ: ModelIntegrator):
         else:
             st.set_forcing(name, value(0.0) if callable(value) else value)
     st.update_inputs()   # initialize!(fields, source, clock) = update_inputs! at the start time
+    soil = getattr(integ.model, "soil", None)
+    forcing = getattr(getattr(soil, "hydrology", None), "vwc_forcing", None)
+    if forcing is not None and not isinstance(forcing, (int, float)):
+        st.set("vwc_forcing", forcing)   # per-cell user forcing (soil_hydrology.jl:37-38)
     for name, value in integ.initializers.items():
         st.set(name, value)
     _apply_model_initializer(st, integ.model)

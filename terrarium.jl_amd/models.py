@@ -133,11 +133,12 @@ class RichardsEq:
 
 @dataclass
 class SoilHydrology:
-    """soil_hydrology.jl:21-53.  `vwc_forcing` is a spatially constant source/sink
-    [1/s]; general Oceananigans `Forcing` callbacks do not cross the C ABI."""
+    """soil_hydrology.jl:21-53.  `vwc_forcing` [1/s]: a number (spatially constant source/sink), a per-cell array
+    `[Nz][Nh]` / vertical profile `[Nz]`, or a function (x, z) evaluated once per cell (an Oceananigans `Forcing`
+    that depends on position only); forcings that depend on the evolving fields do not cross the C ABI."""
     vertical_flow: Union[NoFlow, RichardsEq] = field(default_factory=NoFlow)
     hydraulic_properties: ConstantSoilHydraulics = field(default_factory=ConstantSoilHydraulics)
-    vwc_forcing: Optional[float] = None
+    vwc_forcing: Optional[object] = None
 
 
 @dataclass
@@ -304,7 +305,7 @@ def flatten(model) -> "_capi.TrmParams":
     else:
         p.unsat_k = _capi.UNSATK["linear"]
     p.flow = _capi.FLOW["richards"] if isinstance(hyd.vertical_flow, RichardsEq) else _capi.FLOW["noflow"]
-    p.vwc_forcing = 0.0 if hyd.vwc_forcing is None else float(hyd.vwc_forcing)
+    p.vwc_forcing = float(hyd.vwc_forcing) if isinstance(hyd.vwc_forcing, (int, float)) else 0.0  # arrays: uploaded by initialize
     # surface defaults (used only when seb = 1)
     p.albedo, p.emissivity, p.kappa_s, p.C_h = 0.3, 0.97, 2.0, 1.2e-3
     p.min_windspeed, p.tau_r, p.beta_evap = 0.01, 3600.0, 1.0

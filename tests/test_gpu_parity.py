@@ -374,3 +374,35 @@ def test_deep_columns_take_the_unfused_kernels():
     orc.run(w["dt"], 20)
     dev.step(w["dt"], 20, True)
     assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, "Nz=100 ")
+
+
+@pytest.mark.parametrize("kernel", ["fused", "unfused"])
+@pytest.mark.parametrize("heun", [False, True])
+def test_per_cell_vwc_forcing(kernel, heun):
+    """The user `vwc_forcing` (soil_hydrology.jl:37-38; K15, soil_hydrology_tests.jl:195-232) as a per-cell field:
+    a root-zone sink profile that differs per column.  BrooksCorey + linear K => bit-exact."""
+    lat, lon = small_columns(70)
+    w = W.make_workload("richards", lat, lon, 32)
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    dev.set_option("step_kernel", kernel)
+    zc = dev.z_centers()
+    F = -2.0e-7 * np.exp(zc / 0.5)[:, None] * (1.0 + 0.5 * np.cos(np.arange(70)))[None, :]
+    dev.set("vwc_forcing", F)
+    orc.set("vwc_forcing", F)
+    if heun:
+        for k in range(6):
+            orc.timestep_heun(w["dt"], True)
+        dev.step_heun(w["dt"], 6, True)
+    else:
+        orc.run(w["dt"], 20)
+        dev.step(w["dt"], 20, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, "vwc forcing field ")
+    # the field is really used, and the option switches back to the scalar
+    ref = W.setup_device(w)
+    (ref.step_heun(w["dt"], 6, True) if heun else ref.step(w["dt"], 20, True))
+    assert not np.array_equal(ref.get("saturation_water_ice"), dev.get("saturation_water_ice"))
+    dev2 = W.setup_device(w)
+    dev2.set("vwc_forcing", F)
+    dev2.set_option("vwc_forcing_field", 0)
+    (dev2.step_heun(w["dt"], 6, True) if heun else dev2.step(w["dt"], 20, True))
+    assert np.array_equal(ref.get("saturation_water_ice"), dev2.get("saturation_water_ice"))
