@@ -47,6 +47,8 @@ struct trm_ctx {
     };
     std::vector<Series> series;
     void* bc_value_stage[TRM_BCV_COUNT][2] = {};  // Heun: the stage evaluates its boundary series at t + dt
+    void* d_top3 = nullptr;  // LandModel: [3][Nh] (T, sat, liq) of the top cell as left by the last fused step
+    bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)
     void* d_zero = nullptr;  // [Nh] zeros: stands in for the value array of every unset boundary condition
     double* d_reduce = nullptr;  // scratch for trm_reduce
     size_t reduce_cap = 0;
@@ -207,6 +209,9 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     v.psi = F(TRM_FIELD_PRESSURE_HEAD);
     v.Kf = F(TRM_FIELD_HYDRAULIC_CONDUCTIVITY);
     v.Kf_top = (NF*)s.kf_top;
+    v.top_T = (NF*)c->d_top3;
+    v.top_sat = v.top_T ? v.top_T + c->Nh : nullptr;
+    v.top_liq = v.top_T ? v.top_T + 2 * c->Nh : nullptr;
     v.G_U = F(TRM_FIELD_TEND_INTERNAL_ENERGY);
     v.G_sat = F(TRM_FIELD_TEND_SATURATION_WATER_ICE);
     v.S = F(TRM_FIELD_SURFACE_EXCESS_WATER);
@@ -371,12 +376,15 @@ template <class NF> struct Ops {
     static int surface(trm_ctx* c, const FieldSet& s, bool from_state = false) {
         auto v = make_view<NF>(c, s);
         auto p = make_dev_params<NF>(c->params);
-        if (from_state) {
-            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
-            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
+        if (from_state && c->top_valid && &s == &c->state) {
+            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
+            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
+        } else if (from_state) {
+            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true, false>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
+            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true, false>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
         } else {
-            if (richards(c)) hipLaunchKernelGGL((k_surface<NF, true, HYD_GENERIC, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
-            else hipLaunchKernelGGL((k_surface<NF, false, HYD_GENERIC, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
+            if (richards(c)) hipLaunchKernelGGL((k_surface<NF, true, HYD_GENERIC, false, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
+            else hipLaunchKernelGGL((k_surface<NF, false, HYD_GENERIC, false, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
         }
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
@@ -550,12 +558,14 @@ template <class NF> struct Ops {
             int rc = update_inputs(c, c->state, c->time);
             if (rc) return rc;
             if (!fused) {
+                c->top_valid = false;
                 rc = unfused_step(c, dt, fin);
             } else {
                 // LandModel: the 0-D surface processes run as their own small launch in front of the fused
                 // column kernel (and once more after it when finalizing)
                 if (c->params.seb) rc = surface(c, c->state, true);
                 if (!rc) rc = wave_step(c, dt, fin);
+                c->top_valid = c->params.seb != 0 && !rc;
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             }
             if (rc) return rc;
@@ -589,11 +599,13 @@ template <class NF> struct Ops {
         if (!rc) rc = wave_step_mode<STEP_HEUN_STAGE>(c, dt, 0);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock
         if (!rc) rc = wave_step_mode<STEP_HEUN_FINAL>(c, dt, finalize);
+        c->top_valid = c->params.seb != 0 && !rc;
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
     }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c)) return heun_step_fused(c, dt, finalize);
+        c->top_valid = false;
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_state(c, c->state, true);
         if (!rc) rc = copy_state_to_stage(c);
@@ -863,6 +875,7 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     hip(hipEventCreate(&c->ev1), "hipEventCreate");
     hip(hipMalloc((void**)&c->d_status, sizeof(uint32_t)), "hipMalloc(status)");
     hip(hipMalloc(&c->d_zero, (size_t)c->Nh * c->esize), "hipMalloc(zero)");
+    if (c->params.seb) hip(hipMalloc(&c->d_top3, 3 * (size_t)c->Nh * c->esize), "hipMalloc(top cells)");
     if (rc == TRM_OK) hip(hipMemset(c->d_zero, 0, (size_t)c->Nh * c->esize), "hipMemset(zero)");
     if (rc) return bail(rc);
     hip(hipMemset(c->d_status, 0, sizeof(uint32_t)), "hipMemset(status)");
@@ -900,7 +913,7 @@ int trm_destroy(trm_ctx* c) {
         }
     for (auto& sr : c->series)
         if (sr.d_values) (void)hipFree(sr.d_values);
-    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, (void*)c->d_status, (void*)c->d_reduce})
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, c->d_top3, (void*)c->d_status, (void*)c->d_reduce})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -929,6 +942,7 @@ int trm_upload(trm_ctx* c, int field, const void* host) {
     TRM_HIP(c, hipSetDevice(c->device));
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
     if (!rc && field == TRM_FIELD_VWC_FORCING) c->opt_vwc_field = 1;
+    c->top_valid = false;
     return rc;
 }
 
@@ -1044,6 +1058,7 @@ int trm_clear_series(trm_ctx* c) {
 
 int trm_initialize(trm_ctx* c) {
     TRM_ENTER(c);
+    c->top_valid = false;
     return finish(c, DISPATCH(c, initialize(c)));
 }
 int trm_update_inputs(trm_ctx* c) {
@@ -1070,14 +1085,17 @@ int trm_reset_tendencies(trm_ctx* c) {
 }
 int trm_explicit_step(trm_ctx* c, double dt) {
     TRM_ENTER(c);
+    c->top_valid = false;
     return finish(c, DISPATCH(c, explicit_step(c, c->state, dt)));
 }
 int trm_closure(trm_ctx* c) {
     TRM_ENTER(c);
+    c->top_valid = false;
     return finish(c, DISPATCH(c, closure(c, c->state)));
 }
 int trm_invclosure(trm_ctx* c) {
     TRM_ENTER(c);
+    c->top_valid = false;
     return finish(c, DISPATCH(c, invclosure(c, c->state)));
 }
 

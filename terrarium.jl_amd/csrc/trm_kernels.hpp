@@ -46,6 +46,9 @@ template <class NF> struct View {
     const NF* Fvwc;   // per-cell vwc_forcing [Nh][Nzp], or null: the scalar DevParams::vwc_forcing applies
     // 2-D, [Nh]
     NF *Ts, *ghf, *infil, *swu, *lwu, *rnet, *Hs, *Hl, *evap, *runoff;
+    // LandModel: (T, sat, liq) of the top cell, [Nh] each, written by the fused step for the next k_surface launch
+    // (a coalesced read instead of one cache line per column); null without the surface energy balance
+    NF *top_T, *top_sat, *top_liq;
     const NF *Tair, *pres, *wind, *qair, *rain, *swd, *lwd;
     // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f),
     // psiz[Nz] = zC - z_surface (elevation head)
@@ -102,16 +105,23 @@ template <class NF, int HYD> __global__ void k_hydraulics(View<NF> v, DevParams<
 // (what compute_hydraulics! would store there, soil_hydrology.jl:156-158) instead of reading the
 // hydraulic_conductivity field -- used in front of the fused step kernel, which does not
 // materialise K before the surface processes run.
-template <class NF, bool RICHARDS, int HYD, bool FROM_STATE> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
+// TOP_ARRAYS (with FROM_STATE): the top cell's (T, sat, liq) come from the compact per-column arrays the fused step wrote.
+template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.Nh) return;
     const long top = i * v.Nzp + (v.Nz - 1);
     SebIn<NF> in = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i]};
     SebOut<NF> o;
     uint32_t viol = 0;
-    NF Kf_top = FROM_STATE ? conductivity_hydraulic<NF, HYD>(p, v.liq[top], fractions(p, v.sat[top], v.liq[top], viol))
-                           : v.Kf[top];
-    surface_processes(p, in, v.Ts[i], v.T[top], v.sat[top], Kf_top, v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
+    const NF T_top = TOP_ARRAYS ? v.top_T[i] : v.T[top], sat_top = TOP_ARRAYS ? v.top_sat[i] : v.sat[top];
+    NF Kf_top;
+    if (FROM_STATE) {
+        const NF liq_top = TOP_ARRAYS ? v.top_liq[i] : v.liq[top];
+        Kf_top = conductivity_hydraulic<NF, HYD>(p, liq_top, fractions(p, sat_top, liq_top, viol));
+    } else {
+        Kf_top = v.Kf[top];
+    }
+    surface_processes(p, in, v.Ts[i], T_top, sat_top, Kf_top, v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
     v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
     v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
 }
@@ -759,6 +769,11 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         if (MODE == STEP_HEUN_STAGE) {
             stg(v.G_U, cb, gU_stage);
             if (RICHARDS) stg(v.G_sat, cb, gS_stage);
+        }
+        if (MODE != STEP_HEUN_STAGE && is_top && p.seb) {   // the next surface energy balance reads these
+            stg(v.top_T, ib, Tn);
+            stg(v.top_sat, ib, snew);
+            stg(v.top_liq, ib, ln);
         }
         // hydraulic_conductivity of the state: K(old state) from the Euler / stage launch, K(new state) when finalizing
         if (write_kf && (MODE != STEP_HEUN_FINAL || finalize)) {
