@@ -406,3 +406,35 @@ def test_per_cell_vwc_forcing(kernel, heun):
     dev2.set_option("vwc_forcing_field", 0)
     (dev2.step_heun(w["dt"], 6, True) if heun else dev2.step(w["dt"], 20, True))
     assert np.array_equal(ref.get("saturation_water_ice"), dev2.get("saturation_water_ice"))
+
+
+def test_land_surface_inputs_follow_external_state_changes():
+    """The fused LandModel step hands (T, sat, liq) of the top cell to the next surface-energy-balance launch through
+    compact arrays; anything else that writes the state (upload, invclosure, closure, the process interface) must
+    make the next launch read the fields again.  Sequence mirrored on the oracle."""
+    lat, lon = small_columns(77)
+    w = W.make_workload("land", lat, lon, 32)
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    names = W.compared_fields(w)
+
+    def both(f):
+        f(orc)
+        f(dev)
+
+    orc.steps(w["dt"], 4)
+    dev.step(w["dt"], 4, False)
+    T2 = dev.get("temperature") + np.linspace(-3.0, 3.0, 77)[None, :]
+    both(lambda o: (o.set("temperature", T2), o.invclosure()))                 # new temperature -> new internal energy
+    orc.steps(w["dt"], 3)
+    dev.step(w["dt"], 3, False)
+    sat2 = np.clip(dev.get("saturation_water_ice") * 0.9, 0.05, 1.0)
+    both(lambda o: (o.set("saturation_water_ice", sat2), o.closure()))
+    orc.run(w["dt"], 3)
+    dev.step(w["dt"], 3, True)
+    assert_fields_match(dev, orc, names, False, TOL64, "external writes ")
+    # process interface in between (unfused kernels), then fused steps again
+    both(lambda o: (o.update_state(True), o.explicit_step(w["dt"]), o.closure()))
+    dev.set_clock(*orc.clock())
+    orc.run(w["dt"], 2)
+    dev.step(w["dt"], 2, True)
+    assert_fields_match(dev, orc, names, False, TOL64, "after process interface ")
