@@ -49,6 +49,7 @@ struct trm_ctx {
     void* bc_value_stage[TRM_BCV_COUNT][2] = {};  // Heun: the stage evaluates its boundary series at t + dt
     void* d_top3 = nullptr;  // LandModel: [3][Nh] (T, sat, liq) of the top cell as left by the last fused step
     bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)
+    bool top_escaped = false;  // a device pointer to T / sat / liq was handed out: never trust the copies again
     void* d_zero = nullptr;  // [Nh] zeros: stands in for the value array of every unset boundary condition
     double* d_reduce = nullptr;  // scratch for trm_reduce
     size_t reduce_cap = 0;
@@ -565,7 +566,7 @@ template <class NF> struct Ops {
                 // column kernel (and once more after it when finalizing)
                 if (c->params.seb) rc = surface(c, c->state, true);
                 if (!rc) rc = wave_step(c, dt, fin);
-                c->top_valid = c->params.seb != 0 && !rc;
+                c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             }
             if (rc) return rc;
@@ -599,7 +600,7 @@ template <class NF> struct Ops {
         if (!rc) rc = wave_step_mode<STEP_HEUN_STAGE>(c, dt, 0);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock
         if (!rc) rc = wave_step_mode<STEP_HEUN_FINAL>(c, dt, finalize);
-        c->top_valid = c->params.seb != 0 && !rc;
+        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
     }
@@ -956,6 +957,10 @@ int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems
     if (!c || !dev || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_field_device_ptr: bad argument");
     *dev = c->state.f[field];
     if (pitch_elems) *pitch_elems = is_3d(field) ? c->Nzp : 1;
+    // the caller may write the state behind the library's back from now on: stop trusting the top-cell copies
+    if (field == TRM_FIELD_TEMPERATURE || field == TRM_FIELD_SATURATION_WATER_ICE || field == TRM_FIELD_LIQUID_WATER_FRACTION)
+        c->top_escaped = true;
+    c->top_valid = false;
     return TRM_OK;
 }
 
