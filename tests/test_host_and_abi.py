@@ -105,3 +105,9 @@ def test_ring_grid_scatter_gather_2d_and_3d():
         grid.scatter(np.zeros(7))
     with pytest.raises(ValueError):
         grid.gather(np.zeros((3, 4)))
+
+
+def test_graft_entry_build_runs():
+    """The driver's build() entry point: compiles (no-op when up to date), imports, checks the exported ABI."""
+    import __graft_entry__ as g
+    g.build()
