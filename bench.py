@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
     ap.add_argument("--integrator", default="euler", choices=["euler", "heun"], help="ForwardEuler (headline) or Heun (two fused launches per step)")
+    ap.add_argument("--series", action="store_true", help="drive the time-dependent boundary value / atmospheric inputs from device-resident time series (forcing feed) instead of constants")
     ap.add_argument("--skip-kf", action="store_true", help="store hydraulic_conductivity only when finalizing")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,6 +107,16 @@ def main():
 
     dev = W.setup_device(w, device=local_rank)
     dev.set_option("step_kernel", args.kernel)
+    if args.series:
+        # the SURVEY 8(d) diurnal cycle sampled every 10 minutes over the run, linear in between
+        DAY = 86400.0
+        nodes = np.arange(0.0, (args.steps + args.warmup + 2) * w["dt"] + 600.0, 600.0)
+        ph = 2 * np.pi * nodes[:, None] / DAY - w["lon"][None, :]
+        if config == "land":
+            dev.set_forcing_series("air_temperature", nodes, w["T0"][None, :] + 5.0 * np.sin(ph))
+            dev.set_forcing_series("surface_shortwave_down", nodes, np.maximum(0.0, 600.0 * np.sin(ph)))
+        else:
+            dev.set_bc_series("temperature", "top", "value", nodes, w["T0"][None, :] + 10.0 * np.sin(ph))
     if args.skip_kf:
         dev.set_option("write_kf_every_step", 0)
     dt = w["dt"]
@@ -164,7 +175,7 @@ def main():
         "vs_baseline": None,
         "dtype": dt_name,
         "data": "synthetic forcing and initial state on the reference's ERA5-land mask columns (SURVEY 8(d)); seeded",
-        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": dt, "kernel": args.kernel, "integrator": args.integrator,
+        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": dt, "kernel": args.kernel, "integrator": args.integrator, "series": bool(args.series),
                    "parallelism": f"columns block-sharded over {n_gpus} GPU(s), no data-path collective",
                    "status_flags": int(nan_flag)},
         "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
