@@ -169,3 +169,32 @@ def test_run_soil_model(stepper):
         trm.run(integ, steps=2, period=3600.0)
     with pytest.raises(ValueError):
         trm.run(integ)
+
+
+def test_example_soil_heat_global_matches_oracle():
+    """examples/soil_heat_global.py (the mirror of the reference's examples/simulations/soil_heat_global.jl) for two
+    hours on the N72 mask, against the oracle stepping with the same boundary function evaluated per step."""
+    import importlib.util
+    import os
+    import oracle
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "soil_heat_global.py")
+    spec = importlib.util.spec_from_file_location("soil_heat_global", path)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    dt = 600.0
+    grid, integ, nsteps, periodic_bc = ex.build("N72", np.float64, hours=2.0, dt=dt)
+    assert grid.num_columns == 14017 and nsteps == 12
+    T_init, sat_init = integ.state.get("temperature"), integ.state.get("saturation_water_ice")
+    trm.run(integ, steps=nsteps, dt=dt)
+    orc = oracle.Oracle(grid.num_columns, grid.thickness, oracle.default_params())
+    orc.set("temperature", T_init)
+    orc.set("saturation_water_ice", sat_init)      # no initializer in the example: the Field's zeros
+    orc.set_bc("temperature", "top", "value", periodic_bc(0.0))
+    orc.initialize()
+    for n in range(nsteps):
+        orc.set_bc("temperature", "top", "value", periodic_bc(n * dt))
+        orc.timestep(dt, finalize=(n == nsteps - 1))
+    for name in ("temperature", "internal_energy", "liquid_water_fraction"):
+        assert np.array_equal(integ.state.get(name), orc.get(name)), name
+    full = grid.scatter(integ.state.get("temperature")[-1])
+    assert full.shape == (144, 288) and np.isnan(full[~grid.mask]).all()
