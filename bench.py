@@ -33,6 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s
 WORKLOADS = {
     # name: (description, config, hydraulics, mask/columns, Nz, dtype)
     "c2": ("C2: N72 ERA5-land mask (14017 columns) x 30 levels, soil heat conduction only, fp64", "heat", "default", "N72", 30, "f64"),
+    "c2n145": ("C2 physics on the N145 mask (56951 columns) x 30 levels: soil heat conduction only, fp64", "heat", "default", "N145", 30, "f64"),
     "c3": ("C3: N145 ERA5-land mask (56951 columns) x 32 levels, coupled heat + Richards (BrooksCorey SWRC, linear K), fp64", "richards", "default", "N145", 32, "f64"),
     "c3vg": ("C3-VG: N145 mask x 32 levels, heat + Richards (VanGenuchten SWRC + Mualem K with ice impedance), fp64", "richards", "vg", "N145", 32, "f64"),
     "c4": ("C4: N145 mask x 32 levels, full bare-ground LandModel (heat + Richards + surface energy balance, PrescribedAtmosphere), default hydraulics (BrooksCorey SWRC, linear K), fp64", "land", "default", "N145", 32, "f64"),

@@ -438,3 +438,15 @@ def test_land_surface_inputs_follow_external_state_changes():
     orc.run(w["dt"], 2)
     dev.step(w["dt"], 2, True)
     assert_fields_match(dev, orc, names, False, TOL64, "after process interface ")
+
+
+def test_create_rejects_fields_beyond_the_32bit_offset_range():
+    """The step kernel addresses a field with 32-bit byte offsets: one field must stay below 4 GiB per context
+    (8.4 M columns x 64 levels in fp64); trm_create says so instead of wrapping around."""
+    p = trm._capi.default_params()
+    with pytest.raises(trm.TerrariumHipError, match="4 GiB"):
+        trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=32), 2 ** 24), p)          # 2^24 * 32 * 8 B = 4 GiB
+    with pytest.raises(trm.TerrariumHipError, match="4 GiB"):
+        trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=64), 2 ** 24, dtype=np.float32), p)
+    with pytest.raises(trm.TerrariumHipError):
+        trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=1), 4), p)                 # Nz >= 2
