@@ -242,6 +242,11 @@ int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
 int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);
 
+/* Device-side checkpoint of the whole state (every field, the clock, the status word): trm_save_state copies it into
+ * a second set of buffers owned by the context, trm_restore_state copies it back.  One slot; no host traffic. */
+int trm_save_state(trm_ctx* ctx);
+int trm_restore_state(trm_ctx* ctx);
+
 int trm_clock(const trm_ctx* ctx, double* time, int64_t* iteration);
 int trm_set_clock(trm_ctx* ctx, double time, int64_t iteration);
 

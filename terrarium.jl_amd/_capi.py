@@ -37,7 +37,7 @@ EXPORTS = (
     "trm_compute_auxiliary trm_compute_tendencies trm_reset_tendencies trm_explicit_step trm_closure trm_invclosure "
     "trm_step trm_step_heun trm_step_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_option "
     "trm_get_option trm_set_stream trm_synchronize "
-    "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs").split()
+    "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs trm_save_state trm_restore_state").split()
 TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2)
 
 
@@ -92,6 +92,8 @@ def lib():
     L.trm_set_bc_series.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32]
     L.trm_clear_series.argtypes = [vp]
     L.trm_update_inputs.argtypes = [vp]
+    L.trm_save_state.argtypes = [vp]
+    L.trm_restore_state.argtypes = [vp]
     for name in ("trm_initialize", "trm_compute_auxiliary", "trm_compute_tendencies", "trm_reset_tendencies",
                  "trm_closure", "trm_invclosure", "trm_synchronize"):
         getattr(L, name).argtypes = [vp]

@@ -30,8 +30,11 @@ struct trm_ctx {
     trm_params params;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    FieldSet state{}, stage{};
-    bool has_stage = false;
+    FieldSet state{}, stage{}, saved{};
+    bool has_stage = false, has_saved = false;
+    double saved_time = 0.0;
+    int64_t saved_iteration = 0;
+    uint32_t saved_status = 0;
     void* bc_value[TRM_BCV_COUNT][2] = {};
     int bc_kind[TRM_BCV_COUNT][2] = {};
     void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr, *d_lvl = nullptr;
@@ -903,9 +906,11 @@ int trm_destroy(trm_ctx* c) {
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
         if (c->state.f[f]) (void)hipFree(c->state.f[f]);
         if (c->stage.f[f]) (void)hipFree(c->stage.f[f]);
+        if (c->saved.f[f]) (void)hipFree(c->saved.f[f]);
     }
     if (c->state.kf_top) (void)hipFree(c->state.kf_top);
     if (c->stage.kf_top) (void)hipFree(c->stage.kf_top);
+    if (c->saved.kf_top) (void)hipFree(c->saved.kf_top);
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b)
         {
@@ -1137,6 +1142,35 @@ int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
         c->time += dt;
         c->iteration += 1;
     }
+    return finish(c, TRM_OK);
+}
+
+int trm_save_state(trm_ctx* c) {
+    TRM_ENTER(c);
+    if (!c->has_saved) {
+        int rc = alloc_fields(c, c->saved);
+        if (rc) return rc;
+        c->has_saved = true;
+    }
+    for (int f = 0; f < TRM_FIELD_COUNT; ++f)
+        TRM_HIP(c, hipMemcpyAsync(c->saved.f[f], c->state.f[f], field_elems(c, f) * c->esize, hipMemcpyDeviceToDevice, c->stream));
+    TRM_HIP(c, hipMemcpyAsync(c->saved.kf_top, c->state.kf_top, (size_t)c->Nh * c->esize, hipMemcpyDeviceToDevice, c->stream));
+    TRM_HIP(c, hipMemcpyAsync(&c->saved_status, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    c->saved_time = c->time;
+    c->saved_iteration = c->iteration;
+    return TRM_OK;
+}
+int trm_restore_state(trm_ctx* c) {
+    TRM_ENTER(c);
+    if (!c->has_saved) return fail(c, TRM_EINVAL, "trm_restore_state: nothing was saved");
+    for (int f = 0; f < TRM_FIELD_COUNT; ++f)
+        TRM_HIP(c, hipMemcpyAsync(c->state.f[f], c->saved.f[f], field_elems(c, f) * c->esize, hipMemcpyDeviceToDevice, c->stream));
+    TRM_HIP(c, hipMemcpyAsync(c->state.kf_top, c->saved.kf_top, (size_t)c->Nh * c->esize, hipMemcpyDeviceToDevice, c->stream));
+    TRM_HIP(c, hipMemcpyAsync(c->d_status, &c->saved_status, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    c->time = c->saved_time;
+    c->iteration = c->saved_iteration;
+    c->top_valid = false;
     return finish(c, TRM_OK);
 }
 

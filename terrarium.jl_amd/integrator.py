@@ -217,6 +217,8 @@ class DeviceState:
         self._check(self._lib.trm_set_bc_series(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], _capi.BC_KIND[kind],
                                                 t.size, t.ctypes.data, v.ctypes.data, ti), "trm_set_bc_series")
 
+    def save_state(self): self._check(self._lib.trm_save_state(self._ctx), "trm_save_state")
+    def restore_state(self): self._check(self._lib.trm_restore_state(self._ctx), "trm_restore_state")
     def clear_series(self): self._check(self._lib.trm_clear_series(self._ctx), "trm_clear_series")
     def update_inputs(self): self._check(self._lib.trm_update_inputs(self._ctx), "trm_update_inputs")
 

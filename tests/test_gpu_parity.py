@@ -450,3 +450,23 @@ def test_create_rejects_fields_beyond_the_32bit_offset_range():
         trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=64), 2 ** 24, dtype=np.float32), p)
     with pytest.raises(trm.TerrariumHipError):
         trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=1), 4), p)                 # Nz >= 2
+
+
+def test_save_and_restore_state_on_device():
+    """trm_save_state / trm_restore_state: a device-side checkpoint of every field, the clock and the status word."""
+    lat, lon = small_columns(50)
+    w = W.make_workload("land", lat, lon, 20)
+    dev = W.setup_device(w)
+    with pytest.raises(trm.TerrariumHipError):
+        dev.restore_state()
+    dev.step(w["dt"], 3, False)
+    dev.save_state()
+    dev.step(w["dt"], 7, True)
+    a = {n: dev.get(n) for n in W.compared_fields(w)}
+    clock_a = dev.clock()
+    dev.restore_state()
+    assert dev.clock() == (3 * w["dt"], 3)
+    dev.step(w["dt"], 7, True)
+    assert dev.clock() == clock_a
+    for n, v in a.items():
+        assert np.array_equal(dev.get(n), v, equal_nan=True), n
