@@ -543,12 +543,12 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(k < Nz ? k : Nz - 1)) * (unsigned)sizeof(NF), cb = cb0;
     uint32_t viol = 0;
 
+    // (U, sat, T, liq, psi): the state the tendencies are evaluated at -- the stage's in STEP_HEUN_FINAL
+    const bool from_stage = MODE == STEP_HEUN_FINAL;
 #ifdef TRM_EXP_COMPUTE_ONLY   // plausible register inputs, no global loads
     const NF U = NF(1.0e6) + NF(cb) * NF(3.0), sat = NF(0.5) + NF(cb & 31) * NF(0.01), T = NF(2) + NF(cb & 7);
     const NF liq = NF(1), psi = NF(-1) - NF(cb & 15) * NF(0.1);
 #else
-    // (U, sat, T, liq, psi): the state the tendencies are evaluated at -- the stage's in STEP_HEUN_FINAL
-    const bool from_stage = MODE == STEP_HEUN_FINAL;
     // (without Richards flow the saturation is not prognostic: the stage never gets a copy, the state's is read)
     const NF U = ldg(from_stage ? w.U : v.U, cb), sat = ldg((from_stage && RICHARDS) ? w.sat : v.sat, cb);
     const NF T = ldg(from_stage ? w.T : v.T, cb), liq = ldg(from_stage ? w.liq : v.liq, cb);
