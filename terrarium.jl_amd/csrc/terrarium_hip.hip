@@ -490,7 +490,7 @@ template <class NF> struct Ops {
     // ---- fused step, column per (half-)wavefront ------------------------------------------------------
     // the branch-free fused kernel covers Value on temperature and Flux on the prognostics; anything else is generic
     static bool generic_bcs(const trm_ctx* c) {
-        bool generic = false;
+        bool generic = c->opt_vwc_field != 0;   // a per-cell vwc_forcing field is read by the generic instance only
         for (int side = 0; side < 2; ++side) {
             generic = generic || c->bc_kind[TRM_BCV_TEMPERATURE][side] == TRM_BC_GRADIENT;
             for (int var : {TRM_BCV_SATURATION_WATER_ICE, TRM_BCV_LIQUID_WATER_FRACTION, TRM_BCV_PRESSURE_HEAD})

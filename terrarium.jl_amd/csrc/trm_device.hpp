@@ -126,20 +126,17 @@ enum { POW_GENERIC = 0, POW_INT = 1, POW_HALVES = 2, POW_THIRDS = 3 };
 template <class NF> struct PowSpec {
     NF y;
     int n;
-    int is_int;   // POW_INT only (kept as its own flag: the integer path is the bit-exact one)
     int kind;
 };
 template <class NF> inline PowSpec<NF> make_pow_spec(NF y) {
     PowSpec<NF> s;
     s.y = y;
     s.n = 0;
-    s.is_int = 0;
     s.kind = POW_GENERIC;
     double yd = (double)y;
     if (yd > -4096.5 && yd < 24576.5) {
         long long yi = (long long)yd;
         if ((double)yi == yd && yi >= -4096 && yi <= 24576) {
-            s.is_int = 1;
             s.kind = POW_INT;
             s.n = (int)yi;
             return s;
@@ -189,7 +186,7 @@ TRM_DEV double cbrt_(double x) { return cbrt(x); }
 TRM_DEV float cbrt_(float x) { return cbrtf(x); }
 template <class NF> TRM_DEV NF jl_pow(NF x, const PowSpec<NF>& s) {
     // (Base.:^ returns 1.0 for x === 1.0 up front; the integer path gives exactly 1 there anyway)
-    if (s.is_int) return (s.n == -5) ? pow_int_m5(x) : pow_int(x, s.n);
+    if (s.kind == POW_INT) return (s.n == -5) ? pow_int_m5(x) : pow_int(x, s.n);   // the bit-exact path
     if (x == NF(1)) return NF(1);
     if (s.kind == POW_HALVES) {
         const NF r = sqrt_(x);                       // NaN for x < 0, as the domain error of Base's pow

@@ -696,7 +696,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
             qW_hi = is_top ? qW_t : qW_sh;
         }
         // (+ 0: the evapotranspiration forcing, never passed for bare ground, soil_coupled.jl:86) + user forcing
-        const NF F_user = v.Fvwc ? ldg(v.Fvwc, cb) : p.vwc_forcing;
+        // (the per-cell field is served by the generic instance only: its pointer test costs the van Genuchten
+        // instances 5 % through register pressure, and a spatially varying user forcing is the rare case)
+        const NF F_user = (GENERIC_BC && v.Fvwc) ? ldg(v.Fvwc, cb) : p.vwc_forcing;
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + F_user;
         gS = NF(0) + div_const(dtheta, p.por, p.rpor);
     }
