@@ -101,6 +101,9 @@ def main():
         lat, lon = W.columns_from_mask(columns)
     else:
         lat, lon = W.synthetic_columns(columns)
+    if os.environ.get("TRM_BENCH_SHARD_OF"):    # rehearsal: the shard one rank of an N-way strong-scaling run would hold
+        lo, hi = parallel.shard_range(lat.size, int(os.environ["TRM_BENCH_SHARD_OF"]), 0)
+        lat, lon = lat[lo:hi], lon[lo:hi]
     if args.scaling == "strong" and world > 1:
         lo, hi = parallel.shard_range(lat.size, world, rank)
         lat, lon = lat[lo:hi], lon[lo:hi]
