@@ -118,7 +118,9 @@ enum {
     TRM_OPT_STEP_KERNEL = 1,    /* TRM_KERNEL_*: which implementation trm_step uses                          */
     TRM_OPT_WRITE_KF_EVERY_STEP = 2,/* 1 (default): hydraulic_conductivity is stored by every step launch;   */
                                     /* 0: only by launches that finalize (it is never an input of a step)   */
-    TRM_OPT_VWC_FORCING_FIELD = 3   /* 1 after TRM_FIELD_VWC_FORCING was uploaded: per-cell vwc_forcing; 0: scalar */
+    TRM_OPT_VWC_FORCING_FIELD = 3,  /* 1 after TRM_FIELD_VWC_FORCING was uploaded: per-cell vwc_forcing; 0: scalar */
+    TRM_OPT_PACKED_F32 = 4          /* 1 (default): fp32 contexts with the reference-default hydraulics step two       */
+                                    /* columns per lane with packed fp32 instructions (bit-identical results); 0: off */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

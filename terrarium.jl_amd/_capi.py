@@ -27,7 +27,7 @@ FIELD = dict(
 INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidity", "rainfall",
                 "surface_shortwave_down", "surface_longwave_down")
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
-OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3)
+OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4)
 KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
 

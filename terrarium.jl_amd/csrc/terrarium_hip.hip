@@ -2,8 +2,10 @@
 // (include/terrarium_hip.h).  gfx950 only; no CPU fallback.
 #include "../../include/terrarium_hip.h"
 #include "trm_kernels.hpp"
+#include "trm_packed_f32.hpp"
 
 #include <cmath>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +60,7 @@ struct trm_ctx {
     size_t reduce_cap = 0;
     double time = 0.0;
     int64_t iteration = 0;
+    int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
     std::string err;
 };
@@ -528,6 +531,18 @@ template <class NF> struct Ops {
         const int wkf = MODE == STEP_HEUN_FINAL ? finalize : ((c->opt_write_kf || finalize) ? 1 : 0);
         // tuning knob: unused dynamic LDS per workgroup caps the resident workgroups per CU (occupancy sweeps)
         static const unsigned lds = getenv("TRM_EXP_LDS_BYTES") ? (unsigned)atoi(getenv("TRM_EXP_LDS_BYTES")) : 0u;
+        if constexpr (std::is_same<NF, float>::value && H == HYD_BC_LINEAR && MODE == STEP_EULER) {
+            // fp32, reference-default hydraulics: two columns per lane with packed math (trm_packed_f32.hpp)
+            const auto& spec = p.bc_neg_inv_lambda;
+            if (c->opt_packed && !generic_bcs(c) && spec.kind == POW_INT && spec.n == -5) {
+                const long pairs = (c->Nh + 1) / 2;
+                const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
+                dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
+                hipLaunchKernelGGL((k_step_pk<RICH, LPC>), pg, dim3(TRM_STEP_BLOCK), lds, c->stream, v, p, (float)dt, finalize, wkf);
+                TRM_HIP(c, hipGetLastError());
+                return TRM_OK;
+            }
+        }
         if (MODE == STEP_EULER && generic_bcs(c))
             hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true, STEP_EULER>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, w, p, (NF)dt, finalize, wkf);
         else
@@ -1217,6 +1232,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             return TRM_OK;
         case TRM_OPT_WRITE_KF_EVERY_STEP: c->opt_write_kf = value != 0; return TRM_OK;
         case TRM_OPT_VWC_FORCING_FIELD: c->opt_vwc_field = value != 0; return TRM_OK;
+        case TRM_OPT_PACKED_F32: c->opt_packed = value != 0; return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -1228,6 +1244,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_STEP_KERNEL: *value = c->opt_kernel; return TRM_OK;
         case TRM_OPT_WRITE_KF_EVERY_STEP: *value = c->opt_write_kf; return TRM_OK;
         case TRM_OPT_VWC_FORCING_FIELD: *value = c->opt_vwc_field; return TRM_OK;
+        case TRM_OPT_PACKED_F32: *value = c->opt_packed; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

@@ -43,8 +43,18 @@ TRM_DEV double jl_max(double x, double y) {
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
     return r;
 }
-TRM_DEV float jl_min(float x, float y) { return __builtin_fminf(x, y); }
-TRM_DEV float jl_max(float x, float y) { return __builtin_fmaxf(x, y); }
+TRM_DEV float jl_min(float x, float y) {
+    if (__builtin_constant_p(x) || __builtin_constant_p(y)) return __builtin_fminf(x, y);
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+TRM_DEV float jl_max(float x, float y) {
+    if (__builtin_constant_p(x) || __builtin_constant_p(y)) return __builtin_fmaxf(x, y);
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
 // a / b for a divisor b that is constant over the launch, given rb = RN(1/b) formed on the host by
 // an IEEE division.  Markstein's theorem: with q = RN(a*rb) and the exact residual r = a - b*q (one

@@ -1,0 +1,283 @@
+// Fused Euler step in fp32 with TWO columns per lane (packed math).
+//
+// fp32 instructions issue at the fp64 rate unless they are the packed v_pk_{add,mul,fma}_f32 forms, which do two
+// operations per lane.  The step kernel is bound by instruction issue, so the 0.1-degree fp32 configuration
+// (BASELINE C5) gains nothing from its halved bytes with the scalar kernel.  Here every lane carries the SAME soil
+// level of two neighbouring columns in a 2-vector: sums, products and fmas become packed instructions, the per-wave
+// overhead (kernel arguments, per-level records, wave-uniform boundary logic) is shared by twice the cells; compares,
+// selects, divides, min/max, DPP moves and ballots stay per component.
+//
+// Scope: trm_step with TRM_F32, reference-default hydraulics (BrooksCorey with r^(-5), linear K), the branch-free
+// boundary kinds, Nz <= 64.  Everything else takes the scalar kernels.  Every operation is the scalar kernel's, in
+// the same order (k_step_wave, trm_kernels.hpp), so the two agree bit for bit
+// (tests/test_gpu_parity.py::test_packed_fp32_equals_scalar_bitwise).
+#pragma once
+#include "trm_kernels.hpp"
+
+namespace trm {
+namespace pk {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct M2 { bool x, y; };   // per-component predicate
+
+TRM_DEV v2f splat(float a) { return v2f{a, a}; }
+TRM_DEV v2f sel(M2 m, v2f a, v2f b) { return v2f{m.x ? a.x : b.x, m.y ? a.y : b.y}; }
+TRM_DEV v2f sel(bool m, v2f a, v2f b) { return v2f{m ? a.x : b.x, m ? a.y : b.y}; }   // lane predicate (level)
+TRM_DEV M2 lt(v2f a, v2f b) { return M2{a.x < b.x, a.y < b.y}; }
+TRM_DEV M2 ge(v2f a, v2f b) { return M2{a.x >= b.x, a.y >= b.y}; }
+TRM_DEV M2 eq(v2f a, v2f b) { return M2{a.x == b.x, a.y == b.y}; }
+TRM_DEV M2 operator||(M2 a, M2 b) { return M2{a.x || b.x, a.y || b.y}; }
+TRM_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+TRM_DEV v2f min2(v2f a, v2f b) { return v2f{jl_min(a.x, b.x), jl_min(a.y, b.y)}; }
+TRM_DEV v2f max2(v2f a, v2f b) { return v2f{jl_max(a.x, b.x), jl_max(a.y, b.y)}; }
+TRM_DEV v2f div2(v2f a, v2f b) { return v2f{a.x / b.x, a.y / b.y}; }
+TRM_DEV v2f up2(v2f a) { return v2f{shift_up(a.x), shift_up(a.y)}; }
+TRM_DEV v2f dn2(v2f a) { return v2f{shift_dn(a.x), shift_dn(a.y)}; }
+TRM_DEV v2f ld2(const float* base, unsigned off0, unsigned off1) { return v2f{ldg(base, off0), ldg(base, off1)}; }
+
+// div_const (trm_device.hpp) on both components
+TRM_DEV v2f div_const2(v2f a, float b, float rb) {
+    const v2f q = a * rb;
+    const v2f r = fma2(-q, splat(b), a);
+    const v2f q2 = fma2(r, splat(rb), q);
+    return sel(eq(q, splat(0.0f)), q, q2);
+}
+
+struct Frac2 { v2f water, ice, air; };
+TRM_DEV Frac2 fractions2(const DevParams<float>& p, v2f sat, v2f liq, uint32_t& viol) {
+    const bool okx = (0.0f <= sat.x && sat.x <= 1.0f) && (0.0f <= liq.x && liq.x <= 1.0f);
+    const bool oky = (0.0f <= sat.y && sat.y <= 1.0f) && (0.0f <= liq.y && liq.y <= 1.0f);
+    viol |= (okx && oky) ? 0u : 2u;
+    Frac2 f;
+    const v2f wi = sat * p.por;
+    f.water = wi * liq;
+    f.ice = wi * (splat(1.0f) - liq);
+    f.air = (splat(1.0f) - sat) * p.por;
+    return f;
+}
+TRM_DEV v2f conductivity2(const DevParams<float>& p, const Frac2& f) {
+    v2f s = f.water * p.sk_water;
+    s = s + f.ice * p.sk_ice;
+    s = s + f.air * p.sk_air;
+    s = s + p.kterm_mineral;
+    s = s + p.kterm_organic;
+    return s * s;
+}
+TRM_DEV v2f heat_capacity2(const DevParams<float>& p, const Frac2& f) {
+    v2f s = f.water * p.c_water;
+    s = s + f.ice * p.c_ice;
+    s = s + f.air * p.c_air;
+    s = s + p.cterm_mineral;
+    s = s + p.cterm_organic;
+    return s;
+}
+TRM_DEV v2f conductivity_linear2(const DevParams<float>& p, const Frac2& f) {
+    const v2f theta_sat = f.water + f.ice + f.air;
+    return div2(f.water * p.K_sat, theta_sat);
+}
+// energy_closure (trm_device.hpp) on both components
+TRM_DEV void energy_closure2(const DevParams<float>& p, v2f U, v2f sat, v2f& liq, v2f& T, uint32_t& viol) {
+    const v2f Lth = sat * p.L * p.por;   // (p.L * sat) * por: multiplication by the scalar commutes bit for bit
+    const v2f nLth = -Lth;
+    // liq = (U >= 0) ? 1 : boolmul(U >= -Lth, 1 - safediv(U, -Lth))
+    const float eps = Limits<float>::eps();
+    const v2f den = nLth + eps;
+    const v2f sd = v2f{(nLth.x == 0.0f) ? Limits<float>::inf() : U.x / den.x, (nLth.y == 0.0f) ? Limits<float>::inf() : U.y / den.y};
+    const v2f x = splat(1.0f) - sd;
+    const v2f bm = v2f{(U.x >= nLth.x) ? x.x : copysign_(0.0f, x.x), (U.y >= nLth.y) ? x.y : copysign_(0.0f, x.y)};
+    liq = sel(ge(U, splat(0.0f)), splat(1.0f), bm);
+    const v2f C = heat_capacity2(p, fractions2(p, sat, liq, viol));
+    const M2 frozen = lt(U, nLth);
+    const v2f num = sel(frozen, U + Lth, U);
+    const v2f quo = div2(num, C);
+    T = sel(frozen || ge(U, splat(0.0f)), quo, splat(0.0f));
+}
+// pow_int_m5 (trm_device.hpp) on both components
+TRM_DEV v2f pow_int_m5_2(v2f x) {
+    const v2f rx = div2(splat(1.0f), x);
+    const v2f l0 = -fma2(x, rx, splat(-1.0f)) * rx;
+    const v2f ynlo = splat(0.0f) + (l0 + splat(0.0f));
+    v2f err = rx * 2.0f * l0;
+    const v2f x2 = rx * rx;
+    const v2f l2 = fma2(rx, rx, -x2) + err;
+    err = x2 * 2.0f * l2;
+    const v2f x4 = x2 * x2;
+    const v2f l4 = fma2(x2, x2, -x4) + err;
+    err = fma2(rx, l4, x4 * ynlo);
+    const v2f a = fma2(x4, rx, err), b = x4 * rx;
+    return v2f{(is_finite(x4.x) && is_finite(err.x)) ? a.x : b.x, (is_finite(x4.y) && is_finite(err.y)) ? a.y : b.y};
+}
+// pressure_head<float, HYD_BC_LINEAR> on both components (z0: per-component water table)
+TRM_DEV v2f pressure_head2(const DevParams<float>& p, v2f sat, float z, float psiz, v2f z0) {
+    const v2f theta = sat * p.por;
+    const v2f r = div_const2(theta - p.theta_res, p.theta_span, p.rtheta_span);
+    const v2f v = pow_int_m5_2(r) * (-p.bc_psi_s);
+    const v2f psim = sel(lt(theta, splat(p.por)), v, splat(-p.bc_psi_s));
+    const v2f psih = max2(splat(0.0f), z0 - z);
+    return psih + psim + psiz;
+}
+// upwind_conductivity on both components
+TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(lt(g, splat(0.0f)), Kdn, Kup)); }
+
+}  // namespace pk
+
+// grid: one wave per 2 * (64 / LPC) columns
+template <bool RICHARDS, int LPC>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevParams<float> p, float dt, int finalize, int write_kf) {
+    using namespace pk;
+    typedef float NF;
+    constexpr int HYD = HYD_BC_LINEAR;
+    constexpr int CPW = 64 / LPC;   // column PAIRS per wave
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int k = lane % LPC, sub = lane / LPC;
+    const int Nz = v.Nz, Nh = (int)v.Nh;
+    const bool is_bot = k == 0, is_top = k == Nz - 1;
+    const LevelGeom<NF> L = level_geom(v, k);
+    const bool need_kc = RICHARDS || write_kf;
+
+    const int i0 = (wave * CPW + sub) * 2, i1 = i0 + 1;
+    const bool act0 = i0 < Nh && k < Nz, act1 = i1 < Nh && k < Nz;
+    const int j0 = i0 < Nh ? i0 : Nh - 1, j1 = i1 < Nh ? i1 : Nh - 1;
+    const unsigned kk = (unsigned)(k < Nz ? k : Nz - 1);
+    const unsigned ib0 = (unsigned)j0 * 4u, ib1 = (unsigned)j1 * 4u;
+    const unsigned cb0 = ((unsigned)j0 * (unsigned)v.Nzp + kk) * 4u, cb1 = ((unsigned)j1 * (unsigned)v.Nzp + kk) * 4u;
+    uint32_t viol = 0;
+
+    const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1), T = ld2(v.T, cb0, cb1), liq = ld2(v.liq, cb0, cb1);
+    const v2f psi = RICHARDS ? ld2(v.psi, cb0, cb1) : splat(0.0f);
+
+    uint32_t viol_old = 0;   // (bounds of the incoming state were flagged by the launch that produced it)
+    const Frac2 f = fractions2(p, sat, liq, viol_old);
+    const v2f kap = conductivity2(p, f);
+    const v2f Kc = need_kc ? conductivity_linear2(p, f) : splat(0.0f);
+
+    const v2f T_sh = up2(T), kap_sh = up2(kap);
+    v2f flux_U = splat(0.0f), flux_S = splat(0.0f);
+    // ---- boundary conditions: one wave-uniform branch per condition that is not set (k_step_wave, GENERIC_BC = false)
+    const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
+    v2f T_ext_b = T, T_ext_t = T;
+    if (vTb) {
+        const v2f b = ld2(bcval(v, 2, 0), ib0, ib1);
+        T_ext_b = T + div_const2(T - b, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
+    }
+    if (vTt) {
+        const v2f b = ld2(bcval(v, 2, 1), ib0, ib1);
+        T_ext_t = T + div_const2(b - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
+    }
+    const v2f T_m = sel(is_bot, T_ext_b, T_sh);
+    const v2f T_h = T_ext_t;
+    v2f kap_halo = kap;
+    if (!RICHARDS && p.halo_policy != 1) kap_halo = conductivity2(p, fractions2(p, splat(0.0f), liq, viol));
+    const v2f kap_m = sel(is_bot, kap_halo, kap_sh);
+    const v2f kap_h = kap_halo;
+    const bool seb = p.seb != 0;
+    {
+        const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
+        v2f eU_b = splat(0.0f), eU_t = splat(0.0f);
+        if (fUb) eU_b = div_const2(ld2(bcval(v, 0, 0), ib0, ib1) * v.g.Az, v.g.V_bot, v.g.rV_bot);
+        if (fUt) eU_t = -div_const2(ld2(seb ? v.ghf : bcval(v, 0, 1), ib0, ib1) * v.g.Az, v.g.V_top, v.g.rV_top);
+        flux_U = sel(is_bot, eU_b, sel(is_top, eU_t, splat(0.0f)));
+        if (RICHARDS) {
+            const bool fSb = v.bc.kind[1][0] == 2, fSt = seb || v.bc.kind[1][1] == 2;
+            v2f eS_b = splat(0.0f), eS_t = splat(0.0f);
+            if (fSb) eS_b = div_const2(ld2(bcval(v, 1, 0), ib0, ib1) * v.g.Az, v.g.V_bot, v.g.rV_bot);
+            if (fSt) {
+                const v2f fS = ld2(seb ? v.infil : bcval(v, 1, 1), ib0, ib1);
+                eS_t = -div_const2((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top);
+            }
+            flux_S = sel(is_bot, eS_b, sel(is_top, eS_t, splat(0.0f)));
+        }
+    }
+    // ---- heat
+    const v2f qT_lo = -((kap + kap_m) * 0.5f) * ((T - T_m) * L.rdzf_lo);
+    const v2f qT_sh = dn2(qT_lo);
+    const v2f qT_top = -((kap_h + kap) * 0.5f) * ((T_h - T) * L.rdzf_hi);
+    const v2f qT_hi = sel(is_top, qT_top, qT_sh);
+    v2f gU = splat(0.0f) + (-((qT_hi - qT_lo) * L.rdzc));
+    // ---- Richards
+    v2f gS = splat(0.0f), Kf_lo = splat(0.0f);
+    if (need_kc) {
+        const v2f Kmin = min2(Kc, up2(Kc));
+        Kf_lo = sel(is_bot || is_top, Kc, Kmin);
+    }
+    if (RICHARDS) {
+        const v2f Kf_up = up2(Kf_lo), Kf_dn = dn2(Kf_lo), psi_sh = up2(psi);
+        const v2f Kf_m = sel(is_bot, splat(0.0f), Kf_up);
+        const v2f Kf_p = sel(is_top, Kc, Kf_dn);
+        const v2f psi_m = sel(is_bot, psi, psi_sh);
+        const v2f g_lo = (psi - psi_m) * L.rdzf_lo;
+        const v2f Ks_lo = upwind2(g_lo, Kf_m, Kf_lo, Kf_p);
+        const v2f qW_lo = -Ks_lo * g_lo;
+        const v2f qW_sh = dn2(qW_lo);
+        const v2f zero_or_nan = psi - psi;
+        const v2f qW_t = -min2(Kc, splat(0.0f)) * zero_or_nan;
+        const v2f qW_hi = sel(is_top, qW_t, qW_sh);
+        const v2f dtheta = -((qW_hi - qW_lo) * L.rdzc) + splat(0.0f) + p.vwc_forcing;
+        gS = splat(0.0f) + div_const2(dtheta, p.por, p.rpor);
+    }
+    gU += flux_U;
+    if (RICHARDS) gS += flux_S;
+    // ---- explicit Euler update
+    const v2f Unew = U + gU * dt;
+    bool bad = (act0 && is_nan(Unew.x)) || (act1 && is_nan(Unew.y));
+    v2f snew = sat, z0 = splat(0.0f);
+    if (RICHARDS) {
+        snew = sat + gS * dt;
+        bad = bad || (act0 && is_nan(snew.x)) || (act1 && is_nan(snew.y));
+        float sx = snew.x, sy = snew.y;
+        const float over0 = repair_saturation<NF, LPC>(v, sx, k, Nz, act0, is_bot, is_top, L);
+        const float over1 = repair_saturation<NF, LPC>(v, sy, k, Nz, act1, is_bot, is_top, L);
+        snew = v2f{sx, sy};
+        z0 = v2f{water_table<NF, LPC>(sx, act0, lane, L), water_table<NF, LPC>(sy, act1, lane, L)};
+        if (is_top && k < Nz) {
+            if (act0) {
+                float S = ldg(v.S, ib0);
+                S = S + (0.0f + jl_min(0.0f, S)) * dt;
+                stg(v.S, ib0, S + over0);
+                stg(v.wt, ib0, z0.x);
+            }
+            if (act1) {
+                float S = ldg(v.S, ib1);
+                S = S + (0.0f + jl_min(0.0f, S)) * dt;
+                stg(v.S, ib1, S + over1);
+                stg(v.wt, ib1, z0.y);
+            }
+        }
+    }
+    if (is_top && seb) {   // zero-tendency prognostic skin_temperature
+        if (act0) stg(v.Ts, ib0, ldg(v.Ts, ib0) + 0.0f * dt);
+        if (act1) stg(v.Ts, ib1, ldg(v.Ts, ib1) + 0.0f * dt);
+    }
+    // ---- closures
+    v2f ln, Tn;
+    energy_closure2(p, Unew, snew, ln, Tn, viol);
+    const v2f psin = RICHARDS ? pressure_head2(p, snew, L.zC, L.psiz, z0) : splat(0.0f);
+    v2f Kf_out = Kf_lo, Kf_out_top = Kc;
+    if (finalize && write_kf) {
+        const v2f Kc_new = conductivity_linear2(p, fractions2(p, snew, ln, viol));
+        const v2f Kmin_new = min2(Kc_new, up2(Kc_new));
+        Kf_out = sel(is_bot || is_top, Kc_new, Kmin_new);
+        Kf_out_top = Kc_new;
+    }
+    auto store = [&](bool act, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft) {
+        if (!act) return;
+        const unsigned cb = block_local(cb_), ib = block_local(ib_);   // keeps the saddr form inside this block
+        stg(v.U, cb, u);
+        stg(v.T, cb, t);
+        stg(v.liq, cb, l);
+        if (RICHARDS) { stg(v.sat, cb, s); stg(v.psi, cb, ps); }
+        if (is_top && seb) { stg(v.top_T, ib, t); stg(v.top_sat, ib, s); stg(v.top_liq, ib, l); }
+        if (write_kf) {
+            stg(v.Kf, cb, kf);
+            if (is_top) stg(v.Kf_top, ib, kft);
+        }
+    };
+    store(act0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x);
+    store(act1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y);
+    // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
+    if (act0 || act1) viol |= bad ? 1u : 0u;
+    if (viol && (act0 || act1)) atomicOr(v.status, viol);
+}
+
+}  // namespace trm

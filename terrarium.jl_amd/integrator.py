@@ -284,6 +284,11 @@ class DeviceState:
             value = _capi.KERNEL[value]
         self._check(self._lib.trm_set_option(self._ctx, _capi.OPTION[option], int(value)), "trm_set_option")
 
+    def get_option(self, option) -> int:
+        v = C.c_int()
+        self._check(self._lib.trm_get_option(self._ctx, _capi.OPTION[option], C.byref(v)), "trm_get_option")
+        return int(v.value)
+
     def set_stream(self, hip_stream_handle):
         self._check(self._lib.trm_set_stream(self._ctx, C.c_void_p(hip_stream_handle)), "trm_set_stream")
 

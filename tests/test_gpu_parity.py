@@ -470,3 +470,28 @@ def test_save_and_restore_state_on_device():
     assert dev.clock() == clock_a
     for n, v in a.items():
         assert np.array_equal(dev.get(n), v, equal_nan=True), n
+
+
+@pytest.mark.parametrize("config,Nz,Nh", [("heat", 20, 101), ("richards", 32, 130), ("richards", 64, 77), ("land", 64, 64), ("land", 20, 33),
+                                          ("richards", 5, 1), ("land", 32, 2)])
+def test_packed_fp32_equals_scalar_bitwise(config, Nz, Nh):
+    """fp32 with the reference-default hydraulics steps two columns per lane with packed instructions
+    (trm_packed_f32.hpp): every operation is the scalar kernel's, so the results are the scalar kernel's bit for bit --
+    odd column counts, partly filled waves, flux boundary conditions, the saturation repair and LandModel included."""
+    lat, lon = small_columns(max(Nh, 2))
+    lat, lon = lat[:Nh], lon[:Nh]
+    w = W.make_workload(config, lat, lon, Nz, dtype=np.float32)
+    if config == "richards":
+        w["bcs"][("saturation_water_ice", "top")] = ("flux", np.where(np.arange(Nh) % 3 == 0, -3.0e-4, 0.0))
+        w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(Nh, 0.05))
+        w["bcs"][("temperature", "bottom")] = ("value", w["T0"] - 1.0)
+    a, b = W.setup_device(w), W.setup_device(w)
+    assert a.get_option("packed_f32") == 1
+    b.set_option("packed_f32", 0)
+    for nsteps, fin in ((1, False), (7, False), (12, True)):
+        a.step(w["dt"], nsteps, fin)
+        b.step(w["dt"], nsteps, fin)
+        for n in W.compared_fields(w):
+            x, y = a.get(n), b.get(n)
+            assert np.array_equal(x, y, equal_nan=True), (n, nsteps, np.argwhere(x != y)[:4])
+    assert a.status() == b.status() and a.clock() == b.clock()
