@@ -10,19 +10,22 @@
 // (trm_upload / trm_download) converts from / to the reference's x-fastest interior layout.
 //
 // Why lane = level: the global N145 grid has only 56 951 columns.  One lane per column gives
-// 890 wavefronts for 1024 SIMDs, and the step is bound by dependent fp64 arithmetic (about
-// 300 instructions and 6 divides per cell), not by HBM: measured 64 us per step with a rolling
+// 890 wavefronts for 1024 SIMDs, and the step is bound by instruction issue (about 300 fp64
+// instructions and 4 divides per cell), not by HBM: measured 64 us per step with a rolling
 // register stencil.  Spreading the vertical axis over the lanes gives 28 000+ independent
-// waves, the vertical stencil becomes wavefront shuffles, the water table a ballot, and the
-// sequential saturation repair a ballot-guarded lane-serial loop.  (An intermediate version kept
-// the x-fastest layout and transposed 32-column tiles through LDS: 57-82 us, limited by the
-// load -> barrier -> compute -> barrier -> store phases at one workgroup per CU.  See DESIGN.md.)
+// waves, the vertical stencil becomes DPP wave shifts, the water table a ballot, and the
+// sequential saturation repair a ballot-guarded, range-limited lane-serial loop: 30 us.  (An
+// intermediate version kept the x-fastest layout and transposed 32-column tiles through LDS:
+// 57-82 us, limited by the load -> barrier -> compute -> barrier -> store phases.  See DESIGN.md.)
 //
-// Two implementations sit behind the same C ABI:
-//   * k_step_wave -- ONE launch per time step (update_state! + explicit_step! + closure!).
+// Implementations behind the same C ABI:
+//   * k_step_wave -- ONE launch per time step (update_state! + explicit_step! + closure!), or two
+//     for Heun (predictor into the stage buffers, corrector from the stage's tendencies);
+//   * k_step_pk (trm_packed_f32.hpp) -- the same step in fp32 with two columns per lane and packed math;
 //   * k_* (unfused) -- one launch per reference kernel in the reference's order:
-//     the stand-alone compute_* / closure entry points, Heun, Nz > 64, and the A/B comparator
-//     for what fusion buys.
+//     the stand-alone compute_* / closure entry points, Nz > 64, and the A/B comparator for what
+//     fusion buys;
+//   * k_surface (LandModel's 0-D surface energy balance), k_interp_series (time series inputs).
 #pragma once
 #include "trm_device.hpp"
 
