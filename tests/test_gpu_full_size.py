@@ -101,3 +101,32 @@ def test_c5_shard_fp32_properties():
     for n in ("temperature", "saturation_water_ice", "internal_energy", "skin_temperature"):
         a, b = dev.get(n)[..., sel].astype(np.float64), orc.get(n).astype(np.float64)
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-4, n
+
+
+def test_bench_contract_json_line():
+    """bench.py prints ONE JSON line with the driver's keys, the roofline object and the CPU baseline."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--cpu-seconds", "2"],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "column-steps/sec" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3
+    assert d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f64" and d["scaling"] == "weak"
+    assert "N145" in d["config"]["workload"] and d["config"]["status_flags"] == 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
+    assert r["traffic"] is None or r["traffic"] > 1e8
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
+    # value = whole-job columns x steps / wall time
+    assert abs(d["value"] - 56951 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-6
