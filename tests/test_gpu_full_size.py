@@ -86,13 +86,23 @@ def test_n145_fused_equals_unfused_and_conserves_water():
         assert np.array_equal(r.get(n)[..., ::-1], a.get(n)), n
 
 
-def test_c5_shard_fp32_properties():
-    """0.1-degree-sized shard (fp32, 64 levels); 203 125 columns = a quarter of one GPU's C5 share."""
+@pytest.mark.parametrize("hydraulics", ["vg", "default"])
+def test_c5_shard_fp32_properties(hydraulics):
+    """0.1-degree-sized shard (fp32, 64 levels); 203 125 columns (odd) = a quarter of one GPU's C5 share.  With the
+    default hydraulics the step runs in the packed two-columns-per-lane kernel: it must equal the scalar kernel bit for
+    bit at this size too."""
     lat, lon = W.synthetic_columns(203125)
-    w = W.make_workload("land", lat, lon, 64, dtype=np.float32, hydraulics="vg")
+    w = W.make_workload("land", lat, lon, 64, dtype=np.float32, hydraulics=hydraulics)
     dev = W.setup_device(w)
     dev.step(w["dt"], 10, finalize=True)
     assert dev.status() == 0
+    if hydraulics == "default":
+        ref = W.setup_device(w)
+        ref.set_option("packed_f32", 0)
+        ref.step(w["dt"], 10, finalize=True)
+        for n in W.compared_fields(w):
+            assert np.array_equal(dev.get(n), ref.get(n), equal_nan=True), n
+        del ref
     for n in ("temperature", "saturation_water_ice", "pressure_head", "skin_temperature", "ground_heat_flux"):
         assert np.all(np.isfinite(dev.get(n))), n
     sel = np.arange(0, 203125, 2031)
