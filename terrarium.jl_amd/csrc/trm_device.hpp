@@ -100,6 +100,7 @@ template <class NF> TRM_HD NF pow_int(NF x, int n) {
     if (n == 0) return NF(1);
     NF y = NF(1), xnlo = NF(0), ynlo = NF(0);
     if (n == 3) return x * x * x;
+    if (n == 2) return x * x;   // pow_body(x, 2): the compensation term is the exact residual of x * x, so RN(hi + lo) = hi
     if (n < 0) {
         NF rx = NF(1) / x;
         if (n == -2) return rx * rx;
@@ -303,7 +304,11 @@ template <class NF> TRM_DEV NF conductivity_linear(const DevParams<NF>& p, const
     NF theta_sat = f.water + f.ice + f.air;
     return p.K_sat * f.water / theta_sat;
 }
-template <class NF> TRM_DEV NF conductivity_vg(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
+// COMPLEX_FALLBACK = false (the fused step): a state outside 0 <= x <= 1 is an illegal composition -- the reference's
+// CPU path stops at its SoilVolume @assert (soil_volume.jl:26-28) before K is ever evaluated, here it is reported through
+// TRM_STATUS_COMPOSITION_OUT_OF_RANGE -- and K is NaN instead of the complex magnitude.  Keeping the out-of-line
+// complex path callable from the step kernel costs 29 VGPRs (96 vs 67, 5 vs 7 waves per SIMD) and 8 % of its time.
+template <class NF, bool COMPLEX_FALLBACK = true> TRM_DEV NF conductivity_vg(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
     NF x = f.water / p.por;
     // I_ice = 10^(-Omega (1 - f)): Base.:^ takes the integer path when the exponent is integer-valued
     NF y = -p.impedance * (NF(1) - liq);
@@ -321,12 +326,13 @@ template <class NF> TRM_DEV NF conductivity_vg(const DevParams<NF>& p, NF liq, c
         NF t = NF(1) - jl_pow(inner, p.vgk_e2);
         return fabs_(p.K_sat * I_ice * sqrt_(x) * (t * t));
     }
+    if (!COMPLEX_FALLBACK) return Limits<NF>::nan();
     return vg_conductivity_complex(x, p.K_sat * I_ice, p.vgk_e1.y, p.vgk_e2.y);
 }
-template <class NF, int HYD> TRM_DEV NF conductivity_hydraulic(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
+template <class NF, int HYD, bool COMPLEX_FALLBACK = true> TRM_DEV NF conductivity_hydraulic(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
     if (HYD == HYD_BC_LINEAR) return conductivity_linear(p, f);
-    if (HYD == HYD_VG_VG) return conductivity_vg(p, liq, f);
-    return p.unsat_k == 0 ? conductivity_linear(p, f) : conductivity_vg(p, liq, f);
+    if (HYD == HYD_VG_VG) return conductivity_vg<NF, COMPLEX_FALLBACK>(p, liq, f);
+    return p.unsat_k == 0 ? conductivity_linear(p, f) : conductivity_vg<NF, COMPLEX_FALLBACK>(p, liq, f);
 }
 
 // Free-water energy closure (soil_energy_closures.jl:99-159): (U, sat) -> (liq, T)

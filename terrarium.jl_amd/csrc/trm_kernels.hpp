@@ -120,7 +120,7 @@ template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __
     NF Kf_top;
     if (FROM_STATE) {
         const NF liq_top = TOP_ARRAYS ? v.top_liq[i] : v.liq[top];
-        Kf_top = conductivity_hydraulic<NF, HYD>(p, liq_top, fractions(p, sat_top, liq_top, viol));
+        Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));   // (in front of the fused step)
     } else {
         Kf_top = v.Kf[top];
     }
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
     uint32_t viol_old = 0;
     const Frac<NF> f = fractions(p, sat, liq, viol_old);
     const NF kap = conductivity(p, f);
-    const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD>(p, liq, f) : NF(0);
+    const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD, false>(p, liq, f) : NF(0);
 
     // ---- neighbours by DPP row shifts (executed by all lanes, never inside a divergent select) -----------
     const NF T_sh = shfl_up1<NF, LPC>(T), kap_sh = shfl_up1<NF, LPC>(kap);
@@ -754,7 +754,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
     const NF psin = RICHARDS ? pressure_head<NF, HYD>(p, snew, L.zC, L.psiz, z0) : NF(0);
     NF Kf_out = Kf_lo, Kf_out_top = Kc;
     if (finalize && write_kf) {
-        const NF Kc_new = conductivity_hydraulic<NF, HYD>(p, ln, fractions(p, snew, ln, viol));
+        const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(p, ln, fractions(p, snew, ln, viol));
         const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
         const NF Kmin_new = jl_min(Kc_new, Kc_new_m);
         Kf_out = (is_bot || is_top) ? Kc_new : Kmin_new;
