@@ -211,6 +211,29 @@ def test_ragged_and_tiny_shapes(Nh, Nz, kernel):
     assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, f"Nh={Nh} Nz={Nz} ")
 
 
+@pytest.mark.parametrize("Nz", [17, 31, 33, 50, 63])
+@pytest.mark.parametrize("config,dtype", [("richards", np.float64), ("land", np.float64), ("land", np.float32)])
+def test_partly_filled_lane_groups(config, dtype, Nz):
+    """Level counts that do not fill their 32- / 64-lane group (the reference's own tests use N = 50): the idle lanes
+    sit next to the top level in the wave-shift stencil, in the ballots of the repair / water table, and -- for fp32 --
+    in the packed two-column kernel.  Euler and Heun, against the oracle."""
+    lat, lon = small_columns(45)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype)
+    if config == "richards":
+        w["bcs"][("saturation_water_ice", "top")] = ("flux", np.where(np.arange(45) % 2 == 0, -3.0e-4, 0.0))
+    exact = bit_exact_config(config, "default", dtype)
+    tol = TOL64 if dtype == np.float64 else TOL32
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    orc.run(w["dt"], 12)
+    dev.step(w["dt"], 12, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), exact, tol, f"Nz={Nz} euler ")
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    for n in range(4):
+        orc.timestep_heun(w["dt"], n == 3)
+    dev.step_heun(w["dt"], 4, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), exact, tol, f"Nz={Nz} heun ")
+
+
 def test_bc_kinds_parity():
     """Value / Flux / Gradient boundary conditions on every variable that carries them."""
     lat, lon = small_columns(80)
