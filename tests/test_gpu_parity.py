@@ -518,3 +518,31 @@ def test_packed_fp32_equals_scalar_bitwise(config, Nz, Nh):
             x, y = a.get(n), b.get(n)
             assert np.array_equal(x, y, equal_nan=True), (n, nsteps, np.argwhere(x != y)[:4])
     assert a.status() == b.status() and a.clock() == b.clock()
+
+
+def test_external_stream_and_async_option():
+    """trm_set_stream (a torch / HIP stream owned by the caller) + TRM_OPT_ASYNC: the launches are only enqueued, the
+    caller synchronises; results equal the synchronous run on the context's own stream."""
+    import torch
+    lat, lon = small_columns(300)
+    w = W.make_workload("land", lat, lon, 32)
+    a, b = W.setup_device(w), W.setup_device(w)
+    stream = torch.cuda.Stream()
+    b.set_stream(stream.cuda_stream)
+    b.set_option("asynchronous", 1)
+    a.step(w["dt"], 20, True)
+    b.step(w["dt"], 20, True)          # returns after enqueueing
+    stream.synchronize()
+    for n in W.compared_fields(w):
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    # events recorded on that stream see the library's kernels (what bench.py relies on)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(stream):
+        e0.record()
+        b.step(w["dt"], 20, False)
+        e1.record()
+    e1.synchronize()
+    assert e0.elapsed_time(e1) > 0.05   # 40 launches cannot take less than this; 0 would mean the events saw nothing
+    b.set_stream(None)
+    b.set_option("asynchronous", 0)
+    b.step(w["dt"], 1, True)
