@@ -28,7 +28,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 import numpy as np
 
-STABLE_STEPS = 100   # see main(): longest stretch the explicit Richards scheme is stepped from one state
+STABLE_STEPS = 150   # see main(): longest stretch the explicit Richards scheme is stepped from one state (W <= 100 before it)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 WORKLOADS = {
@@ -136,12 +136,12 @@ def main():
     # warmup (untimed)
     heun = args.integrator == "heun"
     if args.warmup > 0:
-        (dev.step_heun if heun else dev.step)(dt, min(args.warmup, STABLE_STEPS), finalize=False)
+        (dev.step_heun if heun else dev.step)(dt, min(args.warmup, 100), finalize=False)
     # The explicit Richards scheme at dt = 60 s dries the top cells of this synthetic state to sat = 0 (psi = -Inf, then
     # NaN) after ~270 steps -- in the reference as well.  Runs longer than STABLE_STEPS therefore go back to a device-side
     # snapshot of the warmed-up state every STABLE_STEPS steps (a D2D copy inside the timed wall clock, no host data):
     # every step still does its full work on a valid state.
-    chunked = config != "heat" and args.steps + args.warmup > 2 * STABLE_STEPS
+    chunked = config != "heat" and args.steps > STABLE_STEPS
     if chunked or args.spinup_ms > 0:
         dev.save_state()
     # Clock spin-up (untimed, part of the warm-up): an MI355X that comes out of idle needs ~30 ms of sustained load before
