@@ -91,9 +91,12 @@ def _lib(omp=False):
         lib.trm_oracle_update_inputs.argtypes = [C.c_void_p]
         lib.trm_oracle_time_indices.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]
         lib.trm_oracle_set_land_model.argtypes = [C.c_void_p, C.c_int]
+        lib.trm_oracle_set_et_coupled.argtypes = [C.c_void_p, C.c_int]
         lib.trm_oracle_grid.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         for f in ("fill_halo_regions", "initialize", "reset_tendencies", "compute_auxiliary", "compute_tendencies",
-                  "closure", "invclosure", "adjust_saturation_profile", "compute_water_table"):
+                  "closure", "invclosure", "adjust_saturation_profile", "compute_water_table", "compute_evaporation",
+                  "compute_runoff", "compute_hydraulics", "compute_surface_energy_fluxes", "update_skin_temperature",
+                  "seb_fluxes_only"):
             getattr(lib, "trm_oracle_" + f).argtypes = [C.c_void_p]
         lib.trm_oracle_update_state.argtypes = [C.c_void_p, C.c_int]
         lib.trm_oracle_explicit_step.argtypes = [C.c_void_p, C.c_double]
@@ -113,13 +116,12 @@ def _lib(omp=False):
             energy_to_temperature=[D, D, D], liquid_water_fraction=[D, D], stefan_boltzmann=[P, D, D],
             net_radiation=[D, D, D, D], longwave_up=[P, D, D, D], saturation_vapor_pressure=[D], pow=[D, D],
             safediv=[D, D], expmodel=[C.c_int, D, D, D, C.c_int],
+            surface_drainage=[P, D], infiltration=[D, D, D], surface_runoff=[D, D, D],
         ).items():
             fn = getattr(lib, "trm_oracle_" + name)
             fn.restype = D
             fn.argtypes = args
         lib.trm_oracle_volumetric_fractions.argtypes = [D, D, D, D, C.c_void_p]
-        lib.trm_oracle_skin_temperature_iterations.restype = D
-        lib.trm_oracle_skin_temperature_iterations.argtypes = [P] + [D] * 8 + [C.c_int, C.POINTER(D)]
         _libs[omp] = lib
     return _libs[omp]
 
@@ -148,13 +150,6 @@ def volumetric_fractions(por, sat, liq, org=0.0):
     out = np.zeros(5)
     _lib().trm_oracle_volumetric_fractions(por, sat, liq, org, out.ctypes.data)
     return dict(zip(("water", "ice", "air", "mineral", "organic"), out))
-
-
-def skin_temperature_iterations(params, sw_down, lw_down, q_air, pres, T_air, T_ground, windspeed, dz_top, iterations):
-    ts = C.c_double()
-    resid = _lib().trm_oracle_skin_temperature_iterations(C.byref(params), sw_down, lw_down, q_air, pres, T_air,
-                                                          T_ground, windspeed, dz_top, iterations, C.byref(ts))
-    return resid, ts.value
 
 
 class Oracle:
@@ -256,6 +251,14 @@ class Oracle:
     def invclosure(self): self.lib.trm_oracle_invclosure(self.h)
     def adjust_saturation_profile(self): self.lib.trm_oracle_adjust_saturation_profile(self.h)
     def compute_water_table(self): self.lib.trm_oracle_compute_water_table(self.h)
+    # surface-process passes of compute_auxiliary!, one at a time
+    def set_et_coupled(self, on=True): self.lib.trm_oracle_set_et_coupled(self.h, int(on))
+    def compute_hydraulics(self): self.lib.trm_oracle_compute_hydraulics(self.h)
+    def compute_evaporation(self): self.lib.trm_oracle_compute_evaporation(self.h)
+    def compute_runoff(self): self.lib.trm_oracle_compute_runoff(self.h)
+    def compute_surface_energy_fluxes(self): self.lib.trm_oracle_compute_surface_energy_fluxes(self.h)
+    def update_skin_temperature(self): self.lib.trm_oracle_update_skin_temperature(self.h)
+    def seb_fluxes_only(self): self.lib.trm_oracle_seb_fluxes_only(self.h)
     def timestep(self, dt, finalize=True): self.lib.trm_oracle_timestep(self.h, float(dt), int(finalize))
     def timestep_heun(self, dt, finalize=True): self.lib.trm_oracle_timestep_heun(self.h, float(dt), int(finalize))
     def run(self, dt, steps): self.lib.trm_oracle_run(self.h, float(dt), int(steps))

@@ -173,44 +173,18 @@ double trm_oracle_expmodel(int heun, double u, double v, double dt, int steps) {
     return u;
 }
 
-}  // extern "C"
+// direct_surface_runoff.jl scalar functions (test/surface_hydrology/surface_runoff_tests.jl)
+double trm_oracle_surface_drainage(const ParamsD* pd, double S) { return compute_surface_drainage(Params<double>(*pd), S); }
+double trm_oracle_infiltration(double influx, double sat_top, double max_infil) { return compute_infiltration(influx, sat_top, max_infil); }
+double trm_oracle_surface_runoff(double rain, double drainage, double infil) { return compute_surface_runoff(rain, drainage, infil); }
+// surface-process passes of compute_auxiliary!, one at a time (unit known-answer tests)
+void trm_oracle_set_et_coupled(OracleHandle* h, int on) { DISPATCH(h, o->et_coupled = on != 0); }
+void trm_oracle_compute_evaporation(OracleHandle* h) { DISPATCH(h, o->compute_evaporation()); }
+void trm_oracle_compute_runoff(OracleHandle* h) { DISPATCH(h, o->compute_runoff()); }
+void trm_oracle_compute_hydraulics(OracleHandle* h) { DISPATCH(h, o->compute_hydraulics()); }
+void trm_oracle_compute_surface_energy_fluxes(OracleHandle* h) { DISPATCH(h, o->compute_surface_energy_fluxes()); }
+// compute_surface_energy_fluxes!(out, i, j, ...) once per column, skin temperature as it is (surface_energy_balance.jl:119-144)
+void trm_oracle_seb_fluxes_only(OracleHandle* h) { DISPATCH(h, { for (long i = 0; i < o->Nh; ++i) o->seb_fluxes(i); }); }
+void trm_oracle_update_skin_temperature(OracleHandle* h) { DISPATCH(h, o->update_skin_temperature()); }
 
-// Standalone surface-energy-balance fixed-point iteration used by the
-// reference's skin-temperature test (test/surface_energy/skin_temperature.jl:
-// 16-47): SurfaceEnergyModel without an ET scheme, so the latent heat flux is
-// diagnosed from the humidity deficit at the skin temperature
-// (turbulent_fluxes.jl:110-126).  Each iteration = fused SEB kernel
-// (fluxes -> T_s -> fluxes, surface_energy_balance.jl:95-110) followed by
-// update_skin_temperature! (skin_temperature.jl:104-109).  Returns the last
-// residual max|T_s - T_s_old| and writes the final skin temperature.
-extern "C" double trm_oracle_skin_temperature_iterations(const trm_oracle::ParamsD* pd, double sw_down, double lw_down,
-                                                          double q_air, double pres, double T_air, double T_ground,
-                                                          double windspeed, double dz_top, int iterations,
-                                                          double* Ts_out) {
-    using namespace trm_oracle;
-    Params<double> p(*pd);
-    double Ts = 0.0, G = 0.0, resid = 0.0;
-    auto fluxes = [&]() {
-        double swu = p.albedo * sw_down;
-        double lwu = stefan_boltzmann(p, Ts + p.Tref, p.emissivity) + (1.0 - p.emissivity) * lw_down;
-        double rnet = swu - sw_down + lwu - lw_down;
-        double V = jl_max(jl_max(windspeed, p.min_windspeed), 1.0e-6);
-        double ra = 1.0 / (p.C_h * V);
-        double Hs = p.c_a * p.rho_a * ((Ts - T_air) / ra);
-        double dq = p.eps_mw * compute_vpd(p, pres, q_air, Ts) / pres;
-        double Hl = p.Llg * p.rho_a * (dq / ra);
-        G = rnet - Hs - Hl;
-    };
-    auto update = [&]() { Ts = T_ground - G * dz_top / (2.0 * p.kappa_s); };
-    double old = Ts;
-    for (int it = 0; it < iterations; ++it) {
-        fluxes();
-        update();
-        fluxes();
-        update();
-        resid = std::fabs(Ts - old);
-        old = Ts;
-    }
-    if (Ts_out) *Ts_out = Ts;
-    return resid;
-}
+}  // extern "C"

@@ -310,6 +310,28 @@ template <class NF> inline NF stefan_boltzmann(const Params<NF>& p, NF T, NF emi
     return emis * p.sigma * jl_pow_int(T, 4);
 }
 
+// direct_surface_runoff.jl:27-33 compute_surface_drainage
+template <class NF> inline NF compute_surface_drainage(const Params<NF>& p, NF surface_excess_water) {
+    NF S = jl_max(surface_excess_water, NF(0));
+    return S / p.tau_r;
+}
+// direct_surface_runoff.jl:41-47 compute_infiltration: min(influx, max_infil) * is_unsaturated
+template <class NF> inline NF compute_infiltration(NF influx, NF sat_top, NF max_infil) {
+    bool is_unsaturated = sat_top < NF(1);
+    return jl_boolmul(is_unsaturated, jl_min(influx, max_infil));
+}
+// direct_surface_runoff.jl:54-62 compute_surface_runoff: P + dS/dt - I
+template <class NF> inline NF compute_surface_runoff(NF rain, NF surface_drainage, NF infil) {
+    return rain + surface_drainage - infil;
+}
+// turbulent_fluxes.jl:36-50 compute_sensible_heat_flux(tur, Q_T, rho_a, c_a), compute_latent_heat_flux(tur, Q_h, rho_a, L)
+template <class NF> inline NF sensible_heat_flux(const Params<NF>& p, NF Q_T) { return p.c_a * p.rho_a * Q_T; }
+template <class NF> inline NF latent_heat_flux(const Params<NF>& p, NF Q_h) { return p.Llg * p.rho_a * Q_h; }
+// skin_temperature.jl:62-68 compute_skin_temperature(skinT, Tg, G, dz)
+template <class NF> inline NF compute_skin_temperature(const Params<NF>& p, NF Tg, NF G, NF dz) {
+    return Tg - G * dz / (NF(2) * p.kappa_s);
+}
+
 // ---------------------------------------------------------------------------
 // Column grid (column_grid.jl:20-34 + Oceananigans generate_coordinate)
 // ---------------------------------------------------------------------------
@@ -683,18 +705,21 @@ template <class NF> class Oracle {
             NF k_unsat = Kf[C(Nz, i)];
             NF sat_top = sat[C(Nz, i)];
             NF drainage, inf;
-            bool unsat = sat_top < NF(1);
             if (excess > NF(0)) {
-                drainage = jl_max(excess, NF(0)) / p.tau_r;
-                inf = jl_boolmul(unsat, jl_min(drainage, k_unsat));
+                drainage = compute_surface_drainage(p, excess);
+                inf = compute_infiltration(drainage, sat_top, k_unsat);
             } else {
                 drainage = NF(0);
-                inf = jl_boolmul(unsat, jl_min(rainfall, k_unsat));
+                inf = compute_infiltration(rainfall, sat_top, k_unsat);
             }
             infil[i] = inf;
-            runoff[i] = rainfall + drainage - inf;
+            runoff[i] = compute_surface_runoff(rainfall, drainage, inf);
         }
     }
+    // LandModel couples the latent heat flux to the ET scheme (turbulent_fluxes.jl:130-143); the standalone
+    // SurfaceEnergyModel of the reference's unit tests has no ET scheme and diagnoses it from the humidity deficit at
+    // the skin temperature (turbulent_fluxes.jl:110-126, surface_energy_balance.jl:133-139).
+    bool et_coupled = true;
     void seb_fluxes(long i) {  // surface_energy_balance.jl:119-144
         NF Tsurf = Ts[i];
         swu[i] = p.albedo * swd[i];
@@ -703,9 +728,9 @@ template <class NF> class Oracle {
         rnet[i] = swu[i] - swd[i] + lwu[i] - lwd[i];
         NF ra = aerodynamic_resistance(i);
         NF Q_T = (Tsurf - Tair[i]) / ra;
-        Hs[i] = p.c_a * p.rho_a * Q_T;
-        NF Q_h = evap[i];  // coupled to the ET scheme (turbulent_fluxes.jl:130-143)
-        Hl[i] = p.Llg * p.rho_a * Q_h;
+        Hs[i] = sensible_heat_flux(p, Q_T);
+        NF Q_h = et_coupled ? evap[i] : humidity_vpd(i, Tsurf) / ra;
+        Hl[i] = latent_heat_flux(p, Q_h);
         ghf[i] = rnet[i] - Hs[i] - Hl[i];
     }
     void compute_surface_energy_fluxes() {  // surface_energy_balance.jl:95-110
@@ -714,9 +739,13 @@ template <class NF> class Oracle {
         for (long i = 0; i < Nh; ++i) {
             seb_fluxes(i);
             NF Tg = T[C(Nz, i)];  // ground_temperature = view of the top soil layer (soil_energy.jl:52-57)
-            Ts[i] = Tg - ghf[i] * dz1 / (NF(2) * p.kappa_s);
+            Ts[i] = compute_skin_temperature(p, Tg, ghf[i], dz1);
             seb_fluxes(i);
         }
+    }
+    void update_skin_temperature() {  // skin_temperature.jl:104-109
+        NF dz1 = g.dzc[Nz];
+        for (long i = 0; i < Nh; ++i) Ts[i] = compute_skin_temperature(p, T[C(Nz, i)], ghf[i], dz1);
     }
 
     // ---- compute_auxiliary!(state, model) -----------------------------------

@@ -86,12 +86,12 @@ def test_n145_fused_equals_unfused_and_conserves_water():
         assert np.array_equal(r.get(n)[..., ::-1], a.get(n)), n
 
 
-@pytest.mark.parametrize("hydraulics", ["vg", "default"])
-def test_c5_shard_fp32_properties(hydraulics):
-    """0.1-degree-sized shard (fp32, 64 levels); 203 125 columns (odd) = a quarter of one GPU's C5 share.  With the
-    default hydraulics the step runs in the packed two-columns-per-lane kernel: it must equal the scalar kernel bit for
-    bit at this size too."""
-    lat, lon = W.synthetic_columns(203125)
+@pytest.mark.parametrize("hydraulics,num_columns", [("vg", 203125), ("default", 203125), ("default", 812500)])
+def test_c5_shard_fp32_properties(hydraulics, num_columns):
+    """0.1-degree-sized shard (fp32, 64 levels): 812 500 columns = one GPU's full C5 share (BASELINE config 5:
+    ~6.5 M columns over 8 GPUs), and an odd quarter of it (203 125).  With the default hydraulics the step runs in the
+    packed two-columns-per-lane kernel: it must equal the scalar kernel bit for bit at this size too."""
+    lat, lon = W.synthetic_columns(num_columns)
     w = W.make_workload("land", lat, lon, 64, dtype=np.float32, hydraulics=hydraulics)
     dev = W.setup_device(w)
     dev.step(w["dt"], 10, finalize=True)
@@ -102,15 +102,17 @@ def test_c5_shard_fp32_properties(hydraulics):
         ref.step(w["dt"], 10, finalize=True)
         for n in W.compared_fields(w):
             assert np.array_equal(dev.get(n), ref.get(n), equal_nan=True), n
+        ref.close()
         del ref
     for n in ("temperature", "saturation_water_ice", "pressure_head", "skin_temperature", "ground_heat_flux"):
         assert np.all(np.isfinite(dev.get(n))), n
-    sel = np.arange(0, 203125, 2031)
+    sel = np.unique(np.concatenate([[0, 1, 63, 64, 65, num_columns - 2, num_columns - 1], np.arange(0, num_columns, num_columns // 100)]))
     orc = _oracle_with_dx(sample_workload(w, sel), 1.0 / lat.size)
     orc.run(w["dt"], 10)
-    for n in ("temperature", "saturation_water_ice", "internal_energy", "skin_temperature"):
+    for n in ("temperature", "saturation_water_ice", "internal_energy", "skin_temperature", "pressure_head", "ground_heat_flux"):
         a, b = dev.get(n)[..., sel].astype(np.float64), orc.get(n).astype(np.float64)
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-4, n
+    dev.close()
 
 
 def test_bench_contract_json_line():

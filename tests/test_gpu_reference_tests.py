@@ -198,3 +198,116 @@ def test_example_soil_heat_global_matches_oracle():
         assert np.array_equal(integ.state.get(name), orc.get(name)), name
     full = grid.scatter(integ.state.get("temperature")[-1])
     assert full.shape == (144, 288) and np.isnan(full[~grid.mask]).all()
+
+
+# ---- known answers the reference holds on the surface processes (row a10) and explicit_step! (row a7) -----------
+def _land_state(Nh=1, N=10, **params):
+    """LandModel(vegetation = nothing) context on ExponentialSpacing(N), default hydraulics, through the C ABI."""
+    p = trm._capi.default_params()
+    p.flow, p.seb = 1, 1
+    for k, v in params.items():
+        setattr(p, k, v)
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=N), Nh)
+    return trm.DeviceState(grid, p), p
+
+
+# test/surface_hydrology/surface_runoff_tests.jl:10-58 through compute_auxiliary! (direct_surface_runoff.jl:87-117)
+@pytest.mark.parametrize("tau_r", [3600.0, 24 * 3600.0])
+def test_surface_runoff_known_answers(tau_r):
+    import oracle
+    st, p = _land_state(Nh=6, K_sat=1.0, tau_r=tau_r)   # K_sat large: max_infil = K(top face) caps nothing unless stated
+    sat = np.full((10, 6), 0.5)
+    sat[-1, 3] = 1.0                                     # column 3: saturated top cell => infiltration 0
+    st.set("saturation_water_ice", sat)
+    st.set("temperature", 5.0)
+    st.initialize()
+    S = np.array([0.0, 0.1, -0.1, 0.1, 0.0, 0.0])
+    rain = np.array([1.0e-6, 1.0e-6, 1.0e-6, 1.0e-6, 0.0, 3.0])   # column 4: no flux; column 5: flux above the cap
+    st.set("surface_excess_water", S)
+    st.set_forcing("rainfall", rain)
+    st.compute_auxiliary()
+    I, R, K = st.infiltration, st.surface_runoff, st.hydraulic_conductivity[-1]
+    D = np.where(S > 0, np.maximum(S, 0) / tau_r, 0.0)
+    assert I[0] == rain[0] and R[0] == 0.0               # no excess water: rain is routed to infiltration
+    assert I[1] == pytest.approx(0.1 / tau_r, rel=1e-15) and R[1] == rain[1] + D[1] - I[1]   # drainage = S / tau_r
+    assert I[2] == rain[2] and R[2] == 0.0               # negative excess water: drainage stays zero
+    assert I[3] == 0.0 and R[3] == rain[3] + D[3]        # saturated soil: zero infiltration
+    assert I[4] == 0.0 and R[4] == 0.0                   # zero influx: zero infiltration, zero runoff
+    assert I[5] == K[5] and R[5] == rain[5] - K[5]       # infiltration capped at the hydraulic conductivity
+    # and bit for bit what the oracle's compute_runoff pass (pinned by K21) gives
+    o = oracle.Oracle(6, st.grid.thickness, oracle.default_params(flow=1, seb=1, K_sat=1.0, tau_r=tau_r))
+    o.set("saturation_water_ice", sat); o.set("temperature", 5.0); o.initialize()
+    o.set("surface_excess_water", S); o.set("rainfall", rain)
+    o.compute_auxiliary()
+    assert np.array_equal(I, o.get("infiltration")) and np.array_equal(R, o.get("surface_runoff"))
+
+
+# test/surface_energy/turbulent_fluxes.jl:19-39: sign of the sensible heat flux (positive up)
+def test_diagnosed_turbulent_fluxes_sign():
+    st, p = _land_state(Nh=2)
+    st.set("saturation_water_ice", 0.5)
+    st.set("temperature", np.array([30.0, -30.0])[None, :] * np.ones((10, 1)))   # ground far warmer / colder than the air
+    st.initialize()
+    st.set("skin_temperature", np.array([30.0, -30.0]))
+    st.set_forcing("air_temperature", np.array([5.0, 10.0]))
+    st.set_forcing("specific_humidity", np.array([1.0e-3, 0.5]))
+    st.compute_auxiliary()
+    Hs, Ts, Ta = st.sensible_heat_flux, st.skin_temperature, np.array([5.0, 10.0])
+    assert Ts[0] > Ta[0] and Hs[0] > 0        # air colder than skin: positive (up)
+    assert Ts[1] < Ta[1] and Hs[1] < 0        # air warmer than skin: negative (down)
+    ra = 1.0 / (p.C_h * max(max(0.1, p.min_windspeed), 1e-6))
+    assert np.allclose(Hs, p.c_a * p.rho_a * ((Ts - Ta) / ra), rtol=1e-14, atol=0)   # turbulent_fluxes.jl:36-39,85-100
+
+
+# test/surface_energy/albedo.jl:8-13 (ConstantAlbedo) and its use in radiative_fluxes.jl:85-100
+def test_constant_albedo_known_answers():
+    st, p = _land_state(Nh=1, albedo=0.4, emissivity=0.8)
+    assert st.params.albedo == 0.4 and st.params.emissivity == 0.8
+    st.set("saturation_water_ice", 0.5)
+    st.set("temperature", 3.0)
+    st.initialize()
+    st.set_forcing("surface_shortwave_down", 250.0)
+    st.set_forcing("surface_longwave_down", 80.0)
+    st.compute_auxiliary()
+    Ts = st.skin_temperature[0]
+    assert st.surface_shortwave_up[0] == 0.4 * 250.0
+    assert st.surface_longwave_up[0] == pytest.approx(0.8 * p.sigma * (Ts + 273.15) ** 4 + (1 - 0.8) * 80.0, rel=1e-14)
+    assert st.surface_net_radiation[0] == pytest.approx(st.surface_shortwave_up[0] - 250.0 + st.surface_longwave_up[0] - 80.0, rel=1e-14)
+
+
+# test/surface_energy/skin_temperature.jl:24-46: the implicit skin temperature converges under repeated
+# compute_auxiliary! (each = evaporation, runoff, fused SEB kernel twice: land_model.jl:79-88)
+def test_implicit_skin_temperature_converges():
+    st, p = _land_state(Nh=1)
+    T = np.zeros((10, 1)); T[-1] = 2.0
+    st.set("saturation_water_ice", 0.5)
+    st.set("temperature", T)
+    st.initialize()
+    for name, v in dict(surface_shortwave_down=300.0, surface_longwave_down=50.0, specific_humidity=0.002,
+                        air_pressure=101325.0, air_temperature=10.0, windspeed=1.0).items():
+        st.set_forcing(name, v)
+    old, resid = st.skin_temperature.copy(), None
+    for _ in range(5):
+        st.compute_auxiliary()
+        ts = st.skin_temperature
+        resid = np.max(np.abs(ts - old))
+        old = ts.copy()
+    assert np.all(np.isfinite(old)) and resid < math.sqrt(np.finfo(float).eps)
+
+
+# test/timestepping/explicit_step.jl:8-53 incl. the nested-namespace prognostic: every prognostic / tendency pair is
+# advanced (3-D and 2-D kernels), closure variables untouched
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_explicit_step_all_prognostics(dtype):
+    p = trm._capi.default_params()
+    p.flow = 1
+    st = trm.DeviceState(trm.ColumnGrid(trm.ExponentialSpacing(N=10), 3, dtype=dtype), p)
+    dt, dxdt, dydt = 10.0, 0.1, 0.2
+    st.set("tend_internal_energy", dxdt)
+    st.set("tend_saturation_water_ice", dydt)
+    st.set("tend_surface_excess_water", dxdt * 2)
+    st.explicit_step(dt)
+    assert np.allclose(st.internal_energy, dt * dxdt)
+    assert np.allclose(st.saturation_water_ice, dt * dydt)
+    assert np.allclose(st.surface_excess_water, dt * dxdt * 2)
+    assert np.all(st.temperature == 0) and np.all(st.pressure_head == 0)   # (inverse) closure not evaluated

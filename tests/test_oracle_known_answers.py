@@ -243,16 +243,23 @@ def test_k12_expmodel_euler_heun_exact():
     assert heun > 0.1 * dt
 
 
-# K13  test/timestepping/explicit_step.jl:43-53
+# K13  test/timestepping/explicit_step.jl:8-53: top-level prognostics x, y (3-D) and a prognostic x of a nested
+# namespace carrying its own tendency 2*dxdt.  The path's analogue of the nested namespace is the 2-D prognostic
+# surface_excess_water (soil_hydrology_rre.jl:22): explicit_step! must reach every prognostic/tendency pair, 3-D
+# (explicit_step_xyz_kernel!) and 2-D (explicit_step_xy_kernel!), and leave the closure variables alone.
 def test_k13_explicit_step():
     o = Oracle(2, trm.ExponentialSpacing(N=10).get_spacing(), default_params(flow=1))
     dt = 10.0
-    o.set("tend_internal_energy", 0.1)
-    o.set("tend_saturation_water_ice", 0.2)
+    dxdt, dydt = 0.1, 0.2
+    o.set("tend_internal_energy", dxdt)
+    o.set("tend_saturation_water_ice", dydt)
+    o.set("tend_surface_excess_water", dxdt * 2)
     o.explicit_step(dt)
-    assert np.allclose(o.get("internal_energy"), dt * 0.1)
-    assert np.allclose(o.get("saturation_water_ice"), dt * 0.2)
+    assert np.allclose(o.get("internal_energy"), dt * dxdt)
+    assert np.allclose(o.get("saturation_water_ice"), dt * dydt)
+    assert np.allclose(o.get("surface_excess_water"), dt * dxdt * 2)
     assert np.all(o.get("temperature") == 0)  # closure not evaluated by explicit_step!
+    assert np.all(o.get("pressure_head") == 0)
 
 
 # K14  test/boundary_conditions.jl:16-19 (exact)
@@ -279,13 +286,114 @@ def test_k15_radiative_fluxes():
     assert scalar("stefan_boltzmann", p, 273.15, 0.9) == pytest.approx(0.9 * 5.6704e-8 * 273.15 ** 4, rel=1e-14)
 
 
-# K16  test/surface_energy/skin_temperature.jl:16-47
+def _surface_energy_column(**inputs):
+    """SurfaceEnergyModel(grid, seb) of the reference's unit tests on ExponentialSpacing(N = 10): the surface processes
+    of the oracle without an ET scheme (latent heat from the humidity deficit at the skin temperature)."""
+    o = Oracle(1, trm.ExponentialSpacing(N=10).get_spacing(), default_params(seb=1))
+    o.set_et_coupled(False)
+    for name, v in inputs.items():
+        o.set(name, v)
+    return o
+
+
+# K16  test/surface_energy/skin_temperature.jl:16-47 -- drives Oracle::compute_surface_energy_fluxes (the fused
+# fluxes -> T_s -> fluxes kernel) and update_skin_temperature!, the code the GPU is compared with
 def test_k16_implicit_skin_temperature_converges():
-    dz_top = trm.ExponentialSpacing(N=10).get_spacing()[0]
-    resid, ts = oracle.skin_temperature_iterations(default_params(), 300.0, 50.0, 0.002, 101325.0, 10.0, 2.0, 1.0,
-                                                   dz_top, 5)
-    assert math.isfinite(ts)
+    o = _surface_energy_column(surface_shortwave_down=300.0, surface_longwave_down=50.0, specific_humidity=0.002,
+                               air_pressure=101325.0, air_temperature=10.0, windspeed=1.0)
+    T = np.zeros((10, 1))
+    T[-1] = 2.0                                  # ground_temperature = top soil cell
+    o.set("temperature", T)
+    old = o.get("skin_temperature").copy()
+    resid = None
+    for _ in range(5):
+        o.compute_surface_energy_fluxes()
+        o.update_skin_temperature()
+        ts = o.get("skin_temperature")
+        resid = np.max(np.abs(ts - old))
+        old = ts.copy()
+    assert np.all(np.isfinite(old))
     assert resid < math.sqrt(np.finfo(float).eps)
+
+
+# K19  test/surface_energy/turbulent_fluxes.jl:19-39 (DiagnosedTurbulentFluxes: sign of the sensible heat flux)
+def test_k19_diagnosed_turbulent_fluxes_sign():
+    o = _surface_energy_column(air_temperature=5.0)
+    o.set("skin_temperature", 10.0)
+    o.seb_fluxes_only()
+    assert np.all(o.get("sensible_heat_flux") > 0)      # air colder than skin: positive up
+    o.set("skin_temperature", 5.0)
+    o.set("air_temperature", 10.0)
+    o.set("specific_humidity", 0.5)
+    o.seb_fluxes_only()
+    assert np.all(o.get("sensible_heat_flux") < 0)      # air warmer than skin: negative (down)
+    # the formula itself, turbulent_fluxes.jl:36-39,85-100: H_s = c_a rho_a (T_s - T_a) / r_a
+    p = default_params()
+    ra = 1.0 / (p.C_h * max(max(0.1, p.min_windspeed), 1e-6))       # default windspeed 0.1 m/s
+    assert o.get("sensible_heat_flux")[0] == p.c_a * p.rho_a * ((5.0 - 10.0) / ra)
+
+
+# K20  test/surface_energy/albedo.jl:8-13 (ConstantAlbedo: the parameters come back unchanged) and their use in
+# radiative_fluxes.jl:85-100: SW_up = albedo * SW_down, LW_up = eps sigma T^4 + (1 - eps) LW_down
+def test_k20_constant_albedo():
+    p = default_params(seb=1, albedo=0.4, emissivity=0.8)
+    assert p.albedo == 0.4 and p.emissivity == 0.8
+    o = Oracle(1, trm.ExponentialSpacing().get_spacing(), p)
+    o.set_et_coupled(False)
+    o.set("surface_shortwave_down", 250.0)
+    o.set("surface_longwave_down", 80.0)
+    o.set("skin_temperature", 3.0)
+    o.seb_fluxes_only()
+    assert o.get("surface_shortwave_up")[0] == 0.4 * 250.0
+    assert o.get("surface_longwave_up")[0] == pytest.approx(0.8 * p.sigma * (3.0 + 273.15) ** 4 + (1 - 0.8) * 80.0, rel=1e-14)
+
+
+# K21  test/surface_hydrology/surface_runoff_tests.jl:10-58
+def test_k21_surface_drainage():
+    p = default_params()
+    assert scalar("surface_drainage", p, 0.0) == 0.0
+    assert scalar("surface_drainage", p, -0.1) == 0.0           # negative excess water: still zero
+    assert scalar("surface_drainage", p, 0.1) == pytest.approx(0.1 / p.tau_r)
+    p = default_params(tau_r=24 * 3600.0)
+    assert scalar("surface_drainage", p, 0.1) == pytest.approx(0.1 / p.tau_r)
+
+
+def test_k21_infiltration():
+    sat_top, max_infil = 0.5, 1.0e-5
+    assert scalar("infiltration", 0.0, sat_top, max_infil) == 0.0
+    assert scalar("infiltration", max_infil, sat_top, max_infil) == pytest.approx(max_infil)
+    assert scalar("infiltration", 2 * max_infil, sat_top, max_infil) == pytest.approx(max_infil)   # capped
+    assert scalar("infiltration", 2 * max_infil, 1.0, max_infil) == 0.0                             # saturated soil
+
+
+def test_k21_surface_runoff():
+    assert scalar("surface_runoff", 0.0, 0.0, 0.0) == 0.0
+    precip, drainage, infil = 1.0e-6, 1.0e-7, 1.0e-5
+    assert scalar("surface_runoff", precip, drainage, infil) == pytest.approx(precip + drainage - infil)
+
+
+def test_k21_runoff_kernel_cases():
+    """compute_surface_runoff! (direct_surface_runoff.jl:87-117) through the oracle's compute_runoff pass: the two
+    cases of the kernel, built from the scalar functions pinned above."""
+    p = default_params(flow=1, seb=1, K_sat=1.0)         # K_sat large: the hydraulic conductivity never caps
+    o = Oracle(4, trm.ExponentialSpacing(N=10).get_spacing(), p)
+    sat = np.full((10, 4), 0.5)
+    sat[-1, 3] = 1.0                                       # column 3: saturated top cell
+    o.set("saturation_water_ice", sat)
+    o.set("temperature", 5.0)
+    o.initialize()
+    S = np.array([0.0, 0.1, -0.1, 0.1])
+    rain = np.array([1.0e-6, 1.0e-6, 1.0e-6, 1.0e-6])
+    o.set("surface_excess_water", S)
+    o.set("rainfall", rain)
+    o.compute_hydraulics()
+    o.compute_runoff()
+    I, R = o.get("infiltration"), o.get("surface_runoff")
+    D = np.array([0.0, 0.1 / p.tau_r, 0.0, 0.1 / p.tau_r])
+    assert I[0] == rain[0] and R[0] == 0.0                 # no excess water: rain infiltrates
+    assert I[1] == D[1] and R[1] == rain[1] + D[1] - I[1]  # excess water: drainage infiltrates, rain runs off
+    assert I[2] == rain[2]                                 # negative excess water counts as none
+    assert I[3] == 0.0 and R[3] == rain[3] + D[3]          # saturated top cell: nothing infiltrates
 
 
 # K17  test/coupled_models/land_model_tests.jl:6-36
