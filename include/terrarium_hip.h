@@ -36,12 +36,13 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 2
+#define TRM_ABI_VERSION 3
 
 typedef struct trm_ctx trm_ctx;
 
 /* ---- status codes ------------------------------------------------------- */
-enum { TRM_OK = 0, TRM_EINVAL = 1, TRM_EHIP = 2, TRM_ENOMEM = 3, TRM_EUNSUPPORTED = 4 };
+enum { TRM_OK = 0, TRM_EINVAL = 1, TRM_EHIP = 2, TRM_ENOMEM = 3, TRM_EUNSUPPORTED = 4,
+       TRM_ESTALE = 5 /* the field asked for is not materialised at this point (see trm_step) */ };
 
 /* ---- number format NF (every reference struct is parameterised by it) ---- */
 enum { TRM_F64 = 0, TRM_F32 = 1 };
@@ -236,7 +237,15 @@ int trm_invclosure(trm_ctx* ctx);
 
 /* `nsteps` x timestep!(integrator, ForwardEuler, dt; finalize = false), then compute_auxiliary! once
  * if `finalize` (forward_euler.jl:19-31, model_integrator.jl:72-88,124-131).  nsteps = 1, finalize = 1
- * is the reference's timestep!(integrator, dt); finalize = 1 with nsteps = n is run!(steps = n). */
+ * is the reference's timestep!(integrator, dt); finalize = 1 with nsteps = n is run!(steps = n).
+ *
+ * Tendency fields (TRM_FIELD_TEND_*): the reference leaves the last step's tendencies -- compute_tendencies! plus the
+ * flux-boundary term compute_z_bcs! adds inside explicit_step!, averaged over the two stages for Heun -- in
+ * state.tendencies.  The fused kernels (TRM_KERNEL_FUSED) keep tendencies in registers and store them only from the
+ * launch that finalizes: after a call with finalize = 1 the tendency fields hold exactly what the reference's would;
+ * after a call with finalize = 0 they are NOT materialised and trm_download / trm_reduce / trm_field_device_ptr of a
+ * TRM_FIELD_TEND_* field fail with TRM_ESTALE until trm_update_state(ctx, 1), trm_reset_tendencies or a finalizing
+ * step has run.  TRM_KERNEL_UNFUSED materialises them at every step. */
 int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* Same for Heun (heun.jl:37-71): with TRM_KERNEL_FUSED two launches per step (predictor into the stage buffers,
  * corrector from the stage's tendencies), otherwise the reference-order kernels on a second copy of the state. */

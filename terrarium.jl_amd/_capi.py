@@ -30,6 +30,7 @@ REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4)
 KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
+TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE = range(6)
 
 EXPORTS = (
     "trm_abi_version trm_default_params trm_create trm_destroy trm_last_error trm_field_rows trm_get_grid "
@@ -58,7 +59,7 @@ class TrmParams(C.Structure):
 
 
 class TerrariumHipError(RuntimeError):
-    pass
+    code = None
 
 
 _lib = None
@@ -119,7 +120,9 @@ def lib():
 def check(ctx, rc, what):
     if rc != 0:
         msg = lib().trm_last_error(ctx)
-        raise TerrariumHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+        err = TerrariumHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+        err.code = rc
+        raise err
 
 
 def default_params() -> TrmParams:

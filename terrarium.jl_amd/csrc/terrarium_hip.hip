@@ -37,6 +37,7 @@ struct trm_ctx {
     double saved_time = 0.0;
     int64_t saved_iteration = 0;
     uint32_t saved_status = 0;
+    bool saved_tend_valid = true;
     void* bc_value[TRM_BCV_COUNT][2] = {};
     int bc_kind[TRM_BCV_COUNT][2] = {};
     void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr, *d_lvl = nullptr;
@@ -55,13 +56,22 @@ struct trm_ctx {
     void* d_top3 = nullptr;  // LandModel: [3][Nh] (T, sat, liq) of the top cell as left by the last fused step
     bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)
     bool top_escaped = false;  // a device pointer to T / sat / liq was handed out: never trust the copies again
+    bool tend_valid = true;    // the tendency fields hold what the reference would (false after a fused step that did not finalize)
     void* d_zero = nullptr;  // [Nh] zeros: stands in for the value array of every unset boundary condition
     double* d_reduce = nullptr;  // scratch for trm_reduce
     size_t reduce_cap = 0;
+    void* d_io = nullptr;        // staging buffer of trm_upload / trm_download (host layout [rows][Nh])
+    size_t io_cap = 0;
     double time = 0.0;
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
+    // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
+    // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
+    // `args_valid` and the next launch rebuilds them.
+    bool args_valid = false;
+    void* args = nullptr;   // LaunchArgs<NF>*, owned
+    void (*args_free)(void*) = nullptr;
     std::string err;
 };
 
@@ -273,6 +283,32 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     return v;
 }
 
+template <class NF> StageView<NF> make_stage_view(const trm_ctx* c);
+template <class NF> struct LaunchArgs {
+    DevParams<NF> p;
+    View<NF> state, stage;
+    StageView<NF> w;
+};
+template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
+    if (!c->args) {
+        c->args = new LaunchArgs<NF>();
+        c->args_free = [](void* q) { delete (LaunchArgs<NF>*)q; };
+    }
+    LaunchArgs<NF>* a = (LaunchArgs<NF>*)c->args;
+    if (!c->args_valid) {
+        a->p = make_dev_params<NF>(c->params);
+        a->state = make_view<NF>(c, c->state);
+        a->stage = make_view<NF>(c, c->stage);
+        a->w = make_stage_view<NF>(c);
+        c->args_valid = true;
+    }
+    return *a;
+}
+template <class NF> const View<NF>& cached_view(trm_ctx* c, const FieldSet& s) {
+    const LaunchArgs<NF>& a = launch_args<NF>(c);
+    return &s == &c->stage ? a.stage : a.state;
+}
+
 dim3 cell_grid(const trm_ctx* c, long /*rows*/ = 0) { return dim3((unsigned)(((size_t)c->Nh * c->Nzp + 255) / 256), 1, 1); }
 dim3 col_grid(const trm_ctx* c) { return dim3((unsigned)((c->Nh + 255) / 256), 1, 1); }
 // lane = level kernels: one column per LPC lanes, 4 waves per workgroup
@@ -324,6 +360,27 @@ void series_time_indices(const std::vector<double>& times, int indexing, double 
     }
 }
 
+template <class NF> StageView<NF> make_stage_view(const trm_ctx* c) {
+    StageView<NF> w{};
+    if (!c->has_stage) return w;
+    auto F = [&](int id) { return (NF*)c->stage.f[id]; };
+    w.U = F(TRM_FIELD_INTERNAL_ENERGY);
+    w.sat = F(TRM_FIELD_SATURATION_WATER_ICE);
+    w.T = F(TRM_FIELD_TEMPERATURE);
+    w.liq = F(TRM_FIELD_LIQUID_WATER_FRACTION);
+    w.psi = F(TRM_FIELD_PRESSURE_HEAD);
+    w.S = F(TRM_FIELD_SURFACE_EXCESS_WATER);
+    w.wt = F(TRM_FIELD_WATER_TABLE);
+    w.Ts = F(TRM_FIELD_SKIN_TEMPERATURE);
+    auto bc = [&](int side) {
+        void* q = c->bc_value_stage[TRM_BCV_TEMPERATURE][side] ? c->bc_value_stage[TRM_BCV_TEMPERATURE][side] : c->bc_value[TRM_BCV_TEMPERATURE][side];
+        return (const NF*)(q ? q : c->d_zero);
+    };
+    w.bcT_bot = bc(0);
+    w.bcT_top = bc(1);
+    return w;
+}
+
 template <class NF> struct Ops {
     static bool richards(const trm_ctx* c) { return c->params.flow == TRM_FLOW_RICHARDS; }
 
@@ -348,7 +405,10 @@ template <class NF> struct Ops {
             NF* dst;
             if (sr.is_bc) {
                 void*& slot = stage ? c->bc_value_stage[sr.var][sr.side] : c->bc_value[sr.var][sr.side];
-                if (!slot) TRM_HIP(c, hipMalloc(&slot, (size_t)c->Nh * sizeof(NF)));
+                if (!slot) {
+                    TRM_HIP(c, hipMalloc(&slot, (size_t)c->Nh * sizeof(NF)));
+                    c->args_valid = false;
+                }
                 dst = (NF*)slot;
             } else {
                 dst = (NF*)s.f[sr.field];
@@ -374,15 +434,15 @@ template <class NF> struct Ops {
     }
 
     static int hydraulics(trm_ctx* c, const FieldSet& s) {
-        auto v = make_view<NF>(c, s);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         TRM_BY_HYD(c, hipLaunchKernelGGL((k_hydraulics<NF, H>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p));
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
     static int surface(trm_ctx* c, const FieldSet& s, bool from_state = false) {
-        auto v = make_view<NF>(c, s);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         if (from_state && c->top_valid && &s == &c->state) {
             if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
             else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
@@ -403,8 +463,8 @@ template <class NF> struct Ops {
         return rc;
     }
     static int compute_tendencies(trm_ctx* c, const FieldSet& s) {
-        auto v = make_view<NF>(c, s);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         if (richards(c)) hipLaunchKernelGGL((k_tendencies<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
         else hipLaunchKernelGGL((k_tendencies<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
         TRM_HIP(c, hipGetLastError());
@@ -422,8 +482,8 @@ template <class NF> struct Ops {
         return rc;
     }
     static int explicit_step(trm_ctx* c, const FieldSet& s, double dt) {
-        auto v = make_view<NF>(c, s);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         if (richards(c)) hipLaunchKernelGGL((k_explicit_step<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
         else hipLaunchKernelGGL((k_explicit_step<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
         TRM_HIP(c, hipGetLastError());
@@ -436,8 +496,8 @@ template <class NF> struct Ops {
         else hipLaunchKernelGGL((k_closure_hydrology_seq<NF, PSI, H, ADJ>), col_grid(c), dim3(256), 0, c->stream, v, p);
     }
     static int closure_hydrology(trm_ctx* c, const FieldSet& s, bool with_psi, bool with_adjust = true) {
-        auto v = make_view<NF>(c, s);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         if (with_psi) {
             TRM_BY_HYD(c, (launch_closure_hydrology<true, true, H>(c, v, p)));
         } else if (with_adjust) {
@@ -449,8 +509,8 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     static int closure(trm_ctx* c, const FieldSet& s) {
-        auto v = make_view<NF>(c, s);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         if (richards(c)) {
             int rc = closure_hydrology(c, s, true);
             if (rc) return rc;
@@ -460,8 +520,8 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     static int invclosure(trm_ctx* c, const FieldSet& s) {
-        auto v = make_view<NF>(c, s);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         if (richards(c)) {
             hipLaunchKernelGGL(k_pressure_to_saturation<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
             TRM_HIP(c, hipGetLastError());
@@ -473,8 +533,8 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     static int initialize(trm_ctx* c) {
-        auto v = make_view<NF>(c, c->state);
-        auto p = make_dev_params<NF>(c->params);
+        const View<NF>& v = cached_view<NF>(c, c->state);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
         if (richards(c)) {  // soil_hydrology_rre.jl:33-47
             int rc = closure_hydrology(c, c->state, true);
             if (!rc) rc = hydraulics(c, c->state);
@@ -501,36 +561,16 @@ template <class NF> struct Ops {
         }
         return generic;
     }
-    static StageView<NF> make_stage_view(const trm_ctx* c) {
-        StageView<NF> w{};
-        if (!c->has_stage) return w;
-        auto F = [&](int id) { return (NF*)c->stage.f[id]; };
-        w.U = F(TRM_FIELD_INTERNAL_ENERGY);
-        w.sat = F(TRM_FIELD_SATURATION_WATER_ICE);
-        w.T = F(TRM_FIELD_TEMPERATURE);
-        w.liq = F(TRM_FIELD_LIQUID_WATER_FRACTION);
-        w.psi = F(TRM_FIELD_PRESSURE_HEAD);
-        w.S = F(TRM_FIELD_SURFACE_EXCESS_WATER);
-        w.wt = F(TRM_FIELD_WATER_TABLE);
-        w.Ts = F(TRM_FIELD_SKIN_TEMPERATURE);
-        auto bc = [&](int side) {
-            void* q = c->bc_value_stage[TRM_BCV_TEMPERATURE][side] ? c->bc_value_stage[TRM_BCV_TEMPERATURE][side] : c->bc_value[TRM_BCV_TEMPERATURE][side];
-            return (const NF*)(q ? q : c->d_zero);
-        };
-        w.bcT_bot = bc(0);
-        w.bcT_top = bc(1);
-        return w;
-    }
     // ---- fused step, column per (half-)wavefront ------------------------------------------------------
     template <bool RICH, int H, int LPC, int MODE> static int launch_wave(trm_ctx* c, double dt, int finalize) {
-        auto v = make_view<NF>(c, c->state);
-        auto w = make_stage_view(c);
-        auto p = make_dev_params<NF>(c->params);
+        const LaunchArgs<NF>& la = launch_args<NF>(c);
+        const View<NF>& v = la.state;
+        const StageView<NF>& w = la.w;
+        const DevParams<NF>& p = la.p;
         dim3 grid = wave_grid(c, LPC);
         grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
         const int wkf = MODE == STEP_HEUN_FINAL ? finalize : ((c->opt_write_kf || finalize) ? 1 : 0);
-        // tuning knob: unused dynamic LDS per workgroup caps the resident workgroups per CU (occupancy sweeps)
-        static const unsigned lds = getenv("TRM_EXP_LDS_BYTES") ? (unsigned)atoi(getenv("TRM_EXP_LDS_BYTES")) : 0u;
+        const unsigned lds = 0u;
         if constexpr (std::is_same<NF, float>::value && H == HYD_BC_LINEAR && MODE == STEP_EULER) {
             // fp32, reference-default hydraulics: two columns per lane with packed math (trm_packed_f32.hpp)
             const auto& spec = p.bc_neg_inv_lambda;
@@ -578,12 +618,14 @@ template <class NF> struct Ops {
             if (rc) return rc;
             if (!fused) {
                 c->top_valid = false;
+                c->tend_valid = true;
                 rc = unfused_step(c, dt, fin);
             } else {
                 // LandModel: the 0-D surface processes run as their own small launch in front of the fused
                 // column kernel (and once more after it when finalizing)
                 if (c->params.seb) rc = surface(c, c->state, true);
                 if (!rc) rc = wave_step(c, dt, fin);
+                c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
                 c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             }
@@ -618,6 +660,7 @@ template <class NF> struct Ops {
         if (!rc) rc = wave_step_mode<STEP_HEUN_STAGE>(c, dt, 0);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock
         if (!rc) rc = wave_step_mode<STEP_HEUN_FINAL>(c, dt, finalize);
+        c->tend_valid = finalize != 0;
         c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
@@ -625,9 +668,11 @@ template <class NF> struct Ops {
     static int heun_step(trm_ctx* c, double dt, int finalize) {
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c)) return heun_step_fused(c, dt, finalize);
         c->top_valid = false;
+        c->tend_valid = true;
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_state(c, c->state, true);
         if (!rc) rc = copy_state_to_stage(c);
+        if (!rc) rc = update_inputs(c, c->stage, c->time);   // the stage's clock is still t for its predictor step (heun.jl:47-50)
         if (!rc) rc = explicit_step(c, c->stage, dt);
         if (!rc) rc = closure(c, c->stage);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // the stage's clock has ticked (heun.jl:52)
@@ -702,6 +747,9 @@ template <class NF> int fill_row(trm_ctx* c, int field, double value) {
 }
 
 // ---- reductions ------------------------------------------------------------------------------------
+// minimum / maximum as Julia's Base.minimum / maximum: a NaN anywhere gives NaN
+__host__ __device__ inline double nan_min(double a, double b) { return (a != a || b != b) ? (a + b) : (a < b ? a : b); }
+__host__ __device__ inline double nan_max(double a, double b) { return (a != a || b != b) ? (a + b) : (a > b ? a : b); }
 // element (row r, column i) of a field sits at base[r] + i * stride[r]
 template <class NF, int OP> __global__ void k_reduce_rows(const NF* f3, const NF* ftop, long Nh, int Nzp, int Nz, int is3d,
                                                           const NF* weight, double* partial) {
@@ -713,15 +761,15 @@ template <class NF, int OP> __global__ void k_reduce_rows(const NF* f3, const NF
         double x = (double)base[i * stride];
         if (OP == TRM_REDUCE_SUM) acc += x;
         else if (OP == TRM_REDUCE_VOLUME_INTEGRAL_Z) acc += x * (double)weight[row];
-        else if (OP == TRM_REDUCE_MIN) acc = fmin(acc, x);
-        else if (OP == TRM_REDUCE_MAX) acc = fmax(acc, x);
+        else if (OP == TRM_REDUCE_MIN) acc = nan_min(acc, x);
+        else if (OP == TRM_REDUCE_MAX) acc = nan_max(acc, x);
         else acc += (x != x) ? 1.0 : 0.0;
     }
     __shared__ double sm[4];
     for (int off = 32; off > 0; off >>= 1) {
         double o = __shfl_down(acc, off, 64);
-        if (OP == TRM_REDUCE_MIN) acc = fmin(acc, o);
-        else if (OP == TRM_REDUCE_MAX) acc = fmax(acc, o);
+        if (OP == TRM_REDUCE_MIN) acc = nan_min(acc, o);
+        else if (OP == TRM_REDUCE_MAX) acc = nan_max(acc, o);
         else acc += o;
     }
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
@@ -729,8 +777,8 @@ template <class NF, int OP> __global__ void k_reduce_rows(const NF* f3, const NF
     if (threadIdx.x == 0) {
         double r = sm[0];
         for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
-            if (OP == TRM_REDUCE_MIN) r = fmin(r, sm[w]);
-            else if (OP == TRM_REDUCE_MAX) r = fmax(r, sm[w]);
+            if (OP == TRM_REDUCE_MIN) r = nan_min(r, sm[w]);
+            else if (OP == TRM_REDUCE_MAX) r = nan_max(r, sm[w]);
             else r += sm[w];
         }
         partial[(long)row * gridDim.x + blockIdx.x] = r;
@@ -774,8 +822,8 @@ template <class NF> int reduce_impl(trm_ctx* c, int field, int op, double* out) 
         double acc = (op == TRM_REDUCE_MIN) ? HUGE_VAL : (op == TRM_REDUCE_MAX ? -HUGE_VAL : 0.0);
         for (int b = 0; b < nblocks; ++b) {
             double x = part[(size_t)r * nblocks + b];
-            if (op == TRM_REDUCE_MIN) acc = std::fmin(acc, x);
-            else if (op == TRM_REDUCE_MAX) acc = std::fmax(acc, x);
+            if (op == TRM_REDUCE_MIN) acc = nan_min(acc, x);
+            else if (op == TRM_REDUCE_MAX) acc = nan_max(acc, x);
             else acc += x;
         }
         if (op == TRM_REDUCE_VOLUME_INTEGRAL_Z) total += acc;
@@ -787,7 +835,50 @@ template <class NF> int reduce_impl(trm_ctx* c, int field, int op, double* out) 
 }
 
 // Host arrays are the reference's interior layout [rows][Nh] (column fastest); the device keeps 3-D fields
-// z-fastest [Nh][Nzp].  The transposition happens here, on the host, off the hot path.
+// z-fastest [Nh][Nzp].  The transposition runs on the device (32 x 32 tiles through LDS, both sides coalesced): the host
+// array crosses PCIe once, as it is, through a staging buffer the context keeps.
+template <class NF, bool TO_DEVICE_LAYOUT>
+__global__ void __launch_bounds__(256) k_transpose(const NF* __restrict__ src, NF* __restrict__ dst, long Nh, int Nz, int Nzp) {
+    __shared__ NF tile[32][33];
+    const long i0 = (long)blockIdx.x * 32;
+    const int k0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    if (TO_DEVICE_LAYOUT) {   // src [Nz][Nh] -> dst [Nh][Nzp]; levels Nz..Nzp-1 are padding (0)
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r;
+            const long i = i0 + tx;
+            tile[r][tx] = (k < Nz && i < Nh) ? src[(size_t)k * Nh + i] : NF(0);
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const long i = i0 + r;
+            const int k = k0 + tx;
+            if (i < Nh && k < Nzp) dst[(size_t)i * Nzp + k] = tile[tx][r];
+        }
+    } else {                  // src [Nh][Nzp] -> dst [Nz][Nh]
+        for (int r = ty; r < 32; r += 8) {
+            const long i = i0 + r;
+            const int k = k0 + tx;
+            tile[r][tx] = (i < Nh && k < Nzp) ? src[(size_t)i * Nzp + k] : NF(0);
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r;
+            const long i = i0 + tx;
+            if (k < Nz && i < Nh) dst[(size_t)k * Nh + i] = tile[tx][r];
+        }
+    }
+}
+int io_buffer(trm_ctx* c, size_t bytes) {
+    if (bytes > c->io_cap) {
+        if (c->d_io) TRM_HIP(c, hipFree(c->d_io));
+        c->d_io = nullptr;
+        c->io_cap = 0;
+        TRM_HIP(c, hipMalloc(&c->d_io, bytes));
+        c->io_cap = bytes;
+    }
+    return TRM_OK;
+}
 template <class NF> int upload_impl(trm_ctx* c, int field, const NF* host) {
     const long Nh = c->Nh, rows = field_rows(c, field);
     if (!is_3d(field)) {
@@ -795,12 +886,14 @@ template <class NF> int upload_impl(trm_ctx* c, int field, const NF* host) {
         TRM_HIP(c, hipStreamSynchronize(c->stream));
         return TRM_OK;
     }
-    std::vector<NF> tmp((size_t)Nh * c->Nzp, NF(0));
-    for (int k = 0; k < c->Nz; ++k)
-        for (long i = 0; i < Nh; ++i) tmp[(size_t)i * c->Nzp + k] = host[(size_t)k * Nh + i];
-    TRM_HIP(c, hipMemcpyAsync(c->state.f[field], tmp.data(), tmp.size() * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+    int rc = io_buffer(c, (size_t)rows * Nh * sizeof(NF));
+    if (rc) return rc;
+    TRM_HIP(c, hipMemcpyAsync(c->d_io, host, (size_t)rows * Nh * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+    dim3 grid((unsigned)((Nh + 31) / 32), (unsigned)((c->Nzp + 31) / 32));
+    hipLaunchKernelGGL((k_transpose<NF, true>), grid, dim3(256), 0, c->stream, (const NF*)c->d_io, (NF*)c->state.f[field], Nh, c->Nz, c->Nzp);
+    TRM_HIP(c, hipGetLastError());
     if (rows == c->Nz + 1)  // Face field: the top face lives in its own [Nh] buffer
-        TRM_HIP(c, hipMemcpyAsync(c->state.kf_top, host + (size_t)c->Nz * Nh, (size_t)Nh * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+        TRM_HIP(c, hipMemcpyAsync(c->state.kf_top, (const NF*)c->d_io + (size_t)c->Nz * Nh, (size_t)Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
     return TRM_OK;
 }
@@ -811,13 +904,15 @@ template <class NF> int download_impl(trm_ctx* c, int field, NF* host) {
         TRM_HIP(c, hipStreamSynchronize(c->stream));
         return TRM_OK;
     }
-    std::vector<NF> tmp((size_t)Nh * c->Nzp);
-    TRM_HIP(c, hipMemcpyAsync(tmp.data(), c->state.f[field], tmp.size() * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
+    int rc = io_buffer(c, (size_t)rows * Nh * sizeof(NF));
+    if (rc) return rc;
+    dim3 grid((unsigned)((Nh + 31) / 32), (unsigned)((c->Nzp + 31) / 32));
+    hipLaunchKernelGGL((k_transpose<NF, false>), grid, dim3(256), 0, c->stream, (const NF*)c->state.f[field], (NF*)c->d_io, Nh, c->Nz, c->Nzp);
+    TRM_HIP(c, hipGetLastError());
     if (rows == c->Nz + 1)
-        TRM_HIP(c, hipMemcpyAsync(host + (size_t)c->Nz * Nh, c->state.kf_top, (size_t)Nh * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
+        TRM_HIP(c, hipMemcpyAsync((NF*)c->d_io + (size_t)c->Nz * Nh, c->state.kf_top, (size_t)Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+    TRM_HIP(c, hipMemcpyAsync(host, c->d_io, (size_t)rows * Nh * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < c->Nz; ++k)
-        for (long i = 0; i < Nh; ++i) host[(size_t)k * Nh + i] = tmp[(size_t)i * c->Nzp + k];
     return TRM_OK;
 }
 
@@ -934,11 +1029,12 @@ int trm_destroy(trm_ctx* c) {
         }
     for (auto& sr : c->series)
         if (sr.d_values) (void)hipFree(sr.d_values);
-    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, c->d_top3, (void*)c->d_status, (void*)c->d_reduce})
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, c->d_top3, (void*)c->d_status, (void*)c->d_reduce, c->d_io})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->args && c->args_free) c->args_free(c->args);
     delete c;
     return TRM_OK;
 }
@@ -962,19 +1058,33 @@ int trm_upload(trm_ctx* c, int field, const void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_upload: bad argument");
     TRM_HIP(c, hipSetDevice(c->device));
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
-    if (!rc && field == TRM_FIELD_VWC_FORCING) c->opt_vwc_field = 1;
+    if (!rc && field == TRM_FIELD_VWC_FORCING) {
+        c->opt_vwc_field = 1;
+        c->args_valid = false;
+    }
     c->top_valid = false;
+    if (!rc && (field == TRM_FIELD_TEND_INTERNAL_ENERGY || field == TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_TEND_SURFACE_EXCESS_WATER))
+        c->tend_valid = true;   // (a caller that sets one tendency field owns all of them)
     return rc;
 }
 
+static bool is_tendency(int f) {
+    return f == TRM_FIELD_TEND_INTERNAL_ENERGY || f == TRM_FIELD_TEND_SATURATION_WATER_ICE || f == TRM_FIELD_TEND_SURFACE_EXCESS_WATER;
+}
+static const char* kStaleTendencies =
+    "the tendency fields are not materialised by a fused step that does not finalize (finalize = 0): call trm_step / "
+    "trm_step_heun with finalize = 1, or trm_update_state(ctx, 1), before reading them";
+
 int trm_download(trm_ctx* c, int field, void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_download: bad argument");
+    if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     TRM_HIP(c, hipSetDevice(c->device));
     return c->precision == TRM_F64 ? download_impl<double>(c, field, (double*)host) : download_impl<float>(c, field, (float*)host);
 }
 
 int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems) {
     if (!c || !dev || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_field_device_ptr: bad argument");
+    if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     *dev = c->state.f[field];
     if (pitch_elems) *pitch_elems = is_3d(field) ? c->Nzp : 1;
     // the caller may write the state behind the library's back from now on: stop trusting the top-cell copies
@@ -989,7 +1099,17 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
         return fail(c, TRM_EINVAL, "trm_set_bc: bad argument");
     TRM_HIP(c, hipSetDevice(c->device));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
+    // a constant replaces an earlier time series of the same boundary value (which would otherwise overwrite it at the next step)
+    for (size_t n = 0; n < c->series.size(); ++n) {
+        auto& o = c->series[n];
+        if (o.is_bc && o.var == var && o.side == side) {
+            if (o.d_values) (void)hipFree(o.d_values);
+            c->series.erase(c->series.begin() + (long)n);
+            break;
+        }
+    }
     c->bc_kind[var][side] = kind;
+    c->args_valid = false;
     if (kind == TRM_BC_NOFLUX) return TRM_OK;
     size_t bytes = (size_t)c->Nh * c->esize;
     if (!c->bc_value[var][side]) TRM_HIP(c, hipMalloc(&c->bc_value[var][side], bytes));
@@ -1060,6 +1180,7 @@ int trm_set_bc_series(trm_ctx* c, int var, int side, int kind, int nt, const dou
     int rc = add_series(c, std::move(sr), nt, times, values, "trm_set_bc_series");
     if (rc) return rc;
     c->bc_kind[var][side] = kind;
+    c->args_valid = false;
     if (!c->bc_value[var][side]) {
         TRM_HIP(c, hipMalloc(&c->bc_value[var][side], (size_t)c->Nh * c->esize));
         TRM_HIP(c, hipMemset(c->bc_value[var][side], 0, (size_t)c->Nh * c->esize));
@@ -1092,6 +1213,7 @@ int trm_update_inputs(trm_ctx* c) {
 }
 int trm_update_state(trm_ctx* c, int compute_tendencies) {
     TRM_ENTER(c);
+    c->tend_valid = true;
     int rc = DISPATCH(c, update_inputs(c, c->state, c->time));
     if (rc) return rc;
     return finish(c, DISPATCH(c, update_state(c, c->state, compute_tendencies != 0)));
@@ -1106,6 +1228,7 @@ int trm_compute_tendencies(trm_ctx* c) {
 }
 int trm_reset_tendencies(trm_ctx* c) {
     TRM_ENTER(c);
+    c->tend_valid = true;
     return finish(c, DISPATCH(c, reset_tendencies(c, c->state)));
 }
 int trm_explicit_step(trm_ctx* c, double dt) {
@@ -1149,6 +1272,7 @@ int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
         int rc = alloc_fields(c, c->stage);
         if (rc) return rc;
         c->has_stage = true;
+        c->args_valid = false;
     }
     for (int n = 0; n < nsteps; ++n) {
         int fin = (finalize && n == nsteps - 1) ? 1 : 0;
@@ -1174,6 +1298,7 @@ int trm_save_state(trm_ctx* c) {
     TRM_HIP(c, hipStreamSynchronize(c->stream));
     c->saved_time = c->time;
     c->saved_iteration = c->iteration;
+    c->saved_tend_valid = c->tend_valid;
     return TRM_OK;
 }
 int trm_restore_state(trm_ctx* c) {
@@ -1185,6 +1310,7 @@ int trm_restore_state(trm_ctx* c) {
     TRM_HIP(c, hipMemcpyAsync(c->d_status, &c->saved_status, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     c->time = c->saved_time;
     c->iteration = c->saved_iteration;
+    c->tend_valid = c->saved_tend_valid;
     c->top_valid = false;
     return finish(c, TRM_OK);
 }
@@ -1205,6 +1331,7 @@ int trm_set_clock(trm_ctx* c, double time, int64_t iteration) {
 int trm_reduce(trm_ctx* c, int field, int op, double* out) {
     TRM_ENTER(c);
     if (!out || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_reduce: bad argument");
+    if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     return c->precision == TRM_F64 ? reduce_impl<double>(c, field, op, out) : reduce_impl<float>(c, field, op, out);
 }
 
@@ -1213,17 +1340,12 @@ int trm_status(trm_ctx* c, uint32_t* flags) {
     if (!flags) return TRM_EINVAL;
     TRM_HIP(c, hipMemcpyAsync(flags, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
-#ifdef TRM_EXP_CONCURRENCY
-    unsigned long long h[4];
-    hipMemcpyFromSymbol(h, HIP_SYMBOL(trm::trm_exp_conc), sizeof(h));
-    fprintf(stderr, "[exp] waves in flight: now %llu  peak %llu  mean-at-start %.1f  (%llu wave starts)\n", h[0], h[1],
-            h[3] ? (double)h[2] / (double)h[3] : 0.0, h[3]);
-#endif
     return TRM_OK;
 }
 
 int trm_set_option(trm_ctx* c, int option, int value) {
     if (!c) return TRM_EINVAL;
+    c->args_valid = false;
     switch (option) {
         case TRM_OPT_ASYNC: c->opt_async = value != 0; return TRM_OK;
         case TRM_OPT_STEP_KERNEL:

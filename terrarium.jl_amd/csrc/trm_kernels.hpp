@@ -498,11 +498,8 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 // examples set up); it is handled without a single branch.  Any other kind (Gradient, Value on liquid
 // fraction / saturation / pressure head) takes the GENERIC_BC = true instantiation.
 //
-// Diagnostic builds (never shipped): -DTRM_EXP_MEMORY_ONLY (same traffic, no
-// arithmetic), -DTRM_EXP_COMPUTE_ONLY (no global traffic), -DTRM_EXP_EXTRA_VALU=N (N extra fp64 FMAs per lane).
-#ifdef TRM_EXP_CONCURRENCY   // diagnostic: waves in flight (current, peak, sum over wave starts, starts)
-__device__ unsigned long long trm_exp_conc[4];
-#endif
+// Diagnostic variants (memory-only, compute-only, extra VALU, per-wave time stamps) are NOT in
+// this translation unit: profiles/tools/make_diag_variants.py derives them from this source into build/diag/.
 //
 // MODE selects the integrator stage (heun.jl:37-71); `w` holds the Heun stage's buffers:
 //   STEP_EULER        v -> v                                   (forward_euler.jl:19-31)
@@ -520,17 +517,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
     static_assert(!(GENERIC_BC && MODE != STEP_EULER), "the Heun stages use the branch-free boundary path");
     constexpr int CPW = 64 / LPC;   // columns per wave
     const int lane = threadIdx.x & 63;
-#ifdef TRM_EXP_STAMPS   // diagnostic: per-wave start / end time stamps + HW_ID into the (unused) energy tendency buffer
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef TRM_EXP_CONCURRENCY
-    if (lane == 0) {
-        unsigned long long cur = atomicAdd(&trm_exp_conc[0], 1ull) + 1ull;
-        atomicMax(&trm_exp_conc[1], cur);
-        atomicAdd(&trm_exp_conc[2], cur);
-        atomicAdd(&trm_exp_conc[3], 1ull);
-    }
-#endif
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int k = lane % LPC, sub = lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
@@ -548,25 +534,12 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
 
     // (U, sat, T, liq, psi): the state the tendencies are evaluated at -- the stage's in STEP_HEUN_FINAL
     const bool from_stage = MODE == STEP_HEUN_FINAL;
-#ifdef TRM_EXP_COMPUTE_ONLY   // plausible register inputs, no global loads
-    const NF U = NF(1.0e6) + NF(cb) * NF(3.0), sat = NF(0.5) + NF(cb & 31) * NF(0.01), T = NF(2) + NF(cb & 7);
-    const NF liq = NF(1), psi = NF(-1) - NF(cb & 15) * NF(0.1);
-#else
     // (without Richards flow the saturation is not prognostic: the stage never gets a copy, the state's is read)
     const NF U = ldg(from_stage ? w.U : v.U, cb), sat = ldg((from_stage && RICHARDS) ? w.sat : v.sat, cb);
     const NF T = ldg(from_stage ? w.T : v.T, cb), liq = ldg(from_stage ? w.liq : v.liq, cb);
     const NF psi = RICHARDS ? ldg(from_stage ? w.psi : v.psi, cb) : NF(0);
-#endif
     // (U0, sat0): the state that is advanced
     const NF U0 = from_stage ? ldg(v.U, cb) : U, sat0 = from_stage ? ldg(v.sat, cb) : sat;
-#ifdef TRM_EXP_MEMORY_ONLY
-    if (act) {
-        stg(v.U, cb, U + dt); stg(v.T, cb, T + dt); stg(v.liq, cb, liq + dt);
-        if (RICHARDS) { stg(v.sat, cb, sat + dt); stg(v.psi, cb, psi + dt); }
-        if (write_kf) stg(v.Kf, cb, U + sat);
-    }
-    return;
-#endif
 
     // (composition bounds of the incoming state were flagged by the launch that produced it)
     uint32_t viol_old = 0;
@@ -730,6 +703,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
             NF GS = NF(0) + jl_min(NF(0), MODE == STEP_HEUN_FINAL ? ldg(w.S, ib) : S);
             if (MODE == STEP_HEUN_STAGE) stg(v.G_S, ib, GS);
             if (MODE == STEP_HEUN_FINAL) GS = (ldg(v.G_S, ib) + GS) / NF(2);
+            if (MODE != STEP_HEUN_STAGE && finalize) stg(v.G_S, ib, GS);
             S = S + GS * dt;
             stg(MODE == STEP_HEUN_STAGE ? w.S : v.S, ib, S + over);
             stg(MODE == STEP_HEUN_STAGE ? w.wt : v.wt, ib, z0);
@@ -739,15 +713,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         const unsigned ib = block_local(ib0);
         stg(MODE == STEP_HEUN_STAGE ? w.Ts : v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
     }
-#ifdef TRM_EXP_EXTRA_VALU
-    NF xa = U, xb = sat, xc = T, xd = liq;
-#pragma unroll
-    for (int j = 0; j < TRM_EXP_EXTRA_VALU / 4; ++j) {
-        xa = fma_(xa, NF(1.0000001), NF(1e-9)); xb = fma_(xb, NF(0.9999999), NF(1e-9));
-        xc = fma_(xc, NF(1.0000002), NF(1e-9)); xd = fma_(xd, NF(0.9999998), NF(1e-9));
-    }
-    if (xa + xb + xc + xd == NF(-12345.678)) bad = true;
-#endif
     // ---- closures: (U, sat) -> (T, liq, psi) ------------------------------------------------------------------
     NF ln, Tn;
     energy_closure(p, Unew, snew, ln, Tn, viol);
@@ -760,11 +725,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         Kf_out = (is_bot || is_top) ? Kc_new : Kmin_new;
         Kf_out_top = Kc_new;
     }
-#ifdef TRM_EXP_COMPUTE_ONLY
-    if (act && Unew == NF(-12345.678)) {   // never true: keeps the arithmetic alive without the stores
-#else
     if (act) {
-#endif
         const unsigned cb = block_local(cb0), ib = block_local(ib0);
         const bool to_stage = MODE == STEP_HEUN_STAGE;
         stg(to_stage ? w.U : v.U, cb, Unew);
@@ -774,6 +735,11 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         if (MODE == STEP_HEUN_STAGE) {
             stg(v.G_U, cb, gU_stage);
             if (RICHARDS) stg(v.G_sat, cb, gS_stage);
+        } else if (finalize) {
+            // state.tendencies as the reference leaves them after its last step: compute_tendencies! (averaged for
+            // Heun) plus the compute_z_bcs! term explicit_step! added.  Only the finalizing launch stores them.
+            stg(v.G_U, cb, gU);
+            if (RICHARDS) stg(v.G_sat, cb, gS);
         }
         if (MODE != STEP_HEUN_STAGE && is_top && p.seb) {   // the next surface energy balance reads these
             stg(v.top_T, ib, Tn);
@@ -788,23 +754,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         viol |= bad ? 1u : 0u;
     }
     if (viol) atomicOr(v.status, viol);
-#ifdef TRM_EXP_STAMPS
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_ID, all 32 bits
-        if (lane == 0 && wave * 4 + 3 < Nh * v.Nzp) {
-            v.G_U[wave * 4 + 0] = (NF)(double)t_start;
-            v.G_U[wave * 4 + 1] = (NF)(double)(t_end - t_start);
-            v.G_U[wave * 4 + 2] = (NF)(double)hw;
-            v.G_U[wave * 4 + 3] = (NF)(double)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);   // XCC_ID
-        }
-    }
-#endif
-#ifdef TRM_EXP_CONCURRENCY
-    __builtin_amdgcn_s_waitcnt(0);
-    if (lane == 0) atomicAdd(&trm_exp_conc[0], ~0ull);
-#endif
 }
 
 }  // namespace trm

@@ -233,13 +233,17 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevPa
         if (is_top && k < Nz) {
             if (act0) {
                 float S = ldg(v.S, ib0);
-                S = S + (0.0f + jl_min(0.0f, S)) * dt;
+                const float GS = 0.0f + jl_min(0.0f, S);
+                if (finalize) stg(v.G_S, ib0, GS);
+                S = S + GS * dt;
                 stg(v.S, ib0, S + over0);
                 stg(v.wt, ib0, z0.x);
             }
             if (act1) {
                 float S = ldg(v.S, ib1);
-                S = S + (0.0f + jl_min(0.0f, S)) * dt;
+                const float GS = 0.0f + jl_min(0.0f, S);
+                if (finalize) stg(v.G_S, ib1, GS);
+                S = S + GS * dt;
                 stg(v.S, ib1, S + over1);
                 stg(v.wt, ib1, z0.y);
             }
@@ -260,9 +264,13 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevPa
         Kf_out = sel(is_bot || is_top, Kc_new, Kmin_new);
         Kf_out_top = Kc_new;
     }
-    auto store = [&](bool act, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft) {
+    auto store = [&](bool act, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft, float gu, float gs) {
         if (!act) return;
         const unsigned cb = block_local(cb_), ib = block_local(ib_);   // keeps the saddr form inside this block
+        if (finalize) {   // state.tendencies of the last step (k_step_wave)
+            stg(v.G_U, cb, gu);
+            if (RICHARDS) stg(v.G_sat, cb, gs);
+        }
         stg(v.U, cb, u);
         stg(v.T, cb, t);
         stg(v.liq, cb, l);
@@ -273,8 +281,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevPa
             if (is_top) stg(v.Kf_top, ib, kft);
         }
     };
-    store(act0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x);
-    store(act1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y);
+    store(act0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x);
+    store(act1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y, gU.y, gS.y);
     // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
     if (act0 || act1) viol |= bad ? 1u : 0u;
     if (viol && (act0 || act1)) atomicOr(v.status, viol);

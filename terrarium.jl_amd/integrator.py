@@ -312,17 +312,28 @@ class ModelIntegrator:
     def clock(self):
         return self.state.clock()
 
-    def _apply_time_dependent(self, t):
+    def _apply_time_dependent(self, t, dt=None):
         """update_inputs! + BC functions, evaluated at the pre-tick time (the reference fills halos
-        before tick!, forward_euler.jl:19-31)."""
+        before tick!, forward_euler.jl:19-31).
+
+        Heun evaluates its stage at the ticked stage clock (heun.jl:52-59: tick!(stage.clock) then update_state!(stage)),
+        so under Heun a function f is handed over as the two-node series [(t, f(t)), (t + dt, f(t + dt))]: the library
+        evaluates it at t for the state and at t + dt for the stage (both nodes are hit exactly)."""
         dyn = False
+        heun = isinstance(self.timestepper, Heun) and dt is not None
         for (var, side), (kind, value) in self.boundary_conditions.items():
             if callable(value):
-                self.state.set_bc(var, side, kind, value(t))
+                if heun:
+                    self.state.set_bc_series(var, side, kind, [t, t + dt], np.stack([np.broadcast_to(np.asarray(value(tt), dtype=np.float64), (self.state.grid.Nh,)) for tt in (t, t + dt)]))
+                else:
+                    self.state.set_bc(var, side, kind, value(t))
                 dyn = True
         for name, value in self.inputs.items():
             if callable(value):
-                self.state.set_forcing(name, value(t))
+                if heun:
+                    self.state.set_forcing_series(name, [t, t + dt], np.stack([np.broadcast_to(np.asarray(value(tt), dtype=np.float64), (self.state.grid.Nh,)) for tt in (t, t + dt)]))
+                else:
+                    self.state.set_forcing(name, value(t))
                 dyn = True
         return dyn
 
@@ -402,7 +413,7 @@ def initialize_integrator(integ: ModelIntegrator):
 def timestep(integ: ModelIntegrator, dt: Optional[float] = None, finalize: bool = True):
     """timestep!(integrator, dt; finalize) (model_integrator.jl:124-131)"""
     dt = integ.timestepper.dt if dt is None else float(dt)
-    integ._apply_time_dependent(current_time(integ))
+    integ._apply_time_dependent(current_time(integ), dt)
     if isinstance(integ.timestepper, Heun):
         integ.state.step_heun(dt, 1, finalize)
     else:
@@ -422,7 +433,7 @@ def run(integ: ModelIntegrator, steps: Optional[int] = None, period: Optional[fl
     stepper = integ.state.step_heun if heun else integ.state.step
     if integ._has_time_dependence():
         for n in range(steps):
-            integ._apply_time_dependent(current_time(integ))
+            integ._apply_time_dependent(current_time(integ), dt)
             stepper(dt, 1, finalize=(n == steps - 1))
     elif steps > 0:
         stepper(dt, steps, finalize=True)

@@ -147,3 +147,38 @@ def test_integrator_with_field_time_series():
     # np.interp and the device formula round differently in the last place; the trajectories agree to 1e-12
     assert np.allclose(a.state.get("temperature"), b.state.get("temperature"), rtol=0, atol=1e-11)
     assert np.ptp(a.state.get("temperature")[-1]) == 0 and abs(a.state.get("temperature")[-1, 0] - 1.0) > 0.1
+
+
+@pytest.mark.parametrize("kernel", ["fused", "unfused"])
+def test_heun_with_time_dependent_boundary_function(kernel):
+    """under Heun a functional boundary value is evaluated at t for the state and at t + dt for the stage
+    (heun.jl:52-59).  The integrator hands f over as a two-node series per step; the oracle steps the same function
+    sampled on the step grid (every evaluation hits a node)."""
+    import oracle
+    Nh, Nz, dt, nsteps = 40, 20, 300.0, 12
+    lon = np.linspace(0, 2 * np.pi, Nh, endpoint=False)
+    f = lambda t: 2.0 + 8.0 * np.sin(2 * np.pi * t / 7200.0 - lon)
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
+    integ = trm.initialize(trm.SoilModel(grid), trm.Heun(dt=dt), boundary_conditions=trm.PrescribedSurfaceTemperature("Ts", f),
+                           initializers=dict(temperature=1.0, saturation_water_ice=0.7))
+    integ.state.set_option("step_kernel", kernel)
+    for _ in range(nsteps):
+        trm.timestep(integ)
+    orc = oracle.Oracle(Nh, grid.thickness, oracle.default_params())
+    orc.set("temperature", 1.0)
+    orc.set("saturation_water_ice", 0.7)
+    nodes = dt * np.arange(nsteps + 2)
+    orc.set_bc_series("temperature", "top", "value", nodes, np.stack([f(t) for t in nodes]))
+    orc.update_inputs()
+    orc.initialize()
+    for _ in range(nsteps):
+        orc.timestep_heun(dt, True)
+    for name in ("temperature", "internal_energy", "liquid_water_fraction"):
+        assert np.array_equal(integ.state.get(name), orc.get(name)), name
+    # and it differs from holding f(t) over both stages (what round 1 did)
+    held = trm.initialize(trm.SoilModel(grid), trm.Heun(dt=dt), boundary_conditions={("temperature", "top"): ("value", f(0.0))},
+                          initializers=dict(temperature=1.0, saturation_water_ice=0.7))
+    for n in range(nsteps):
+        held.state.set_bc("temperature", "top", "value", f(n * dt))
+        held.state.step_heun(dt, 1, True)
+    assert not np.array_equal(held.state.get("temperature"), integ.state.get("temperature"))

@@ -546,3 +546,81 @@ def test_external_stream_and_async_option():
     b.set_stream(None)
     b.set_option("asynchronous", 0)
     b.step(w["dt"], 1, True)
+
+
+# ---- state.tendencies after a step (the fused step must not leave stale tendency fields) -----------------
+@pytest.mark.parametrize("integrator", ["euler", "heun"])
+@pytest.mark.parametrize("config,hydraulics,dtype", [("heat", "default", np.float64), ("richards", "default", np.float64),
+                                                     ("land", "vg", np.float64), ("land", "default", np.float32)])
+def test_tendency_fields_after_finalizing_step(config, hydraulics, dtype, integrator):
+    """After timestep!(integrator, dt) the reference's state.tendencies hold the last step's tendencies incl. the
+    compute_z_bcs! term (averaged over the stages for Heun).  Fused (finalize = 1) == unfused == oracle."""
+    lat, lon = small_columns(130)
+    w = W.make_workload(config, lat, lon, 64 if np.dtype(dtype) == np.float32 else 32, dtype=dtype, hydraulics=hydraulics)
+    if config == "heat":   # a flux condition at the bottom as well, so that compute_z_bcs! has something to add
+        w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(lat.size, 0.05))
+    a, b, orc = W.setup_device(w), W.setup_device(w), W.setup_oracle(w)
+    b.set_option("step_kernel", "unfused")
+    names = ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else [])
+    for d in (a, b):
+        (d.step_heun if integrator == "heun" else d.step)(w["dt"], 7, finalize=True)
+    for _ in range(7):
+        (orc.timestep_heun if integrator == "heun" else orc.timestep)(w["dt"], True)
+    for n in names:
+        assert np.array_equal(a.get(n), b.get(n)), n
+        assert np.any(a.get(n) != 0) or n == "tend_surface_excess_water", n
+    exact = bit_exact_config(config, hydraulics, dtype)
+    assert_fields_match(a, orc, names, exact, TOL64 if np.dtype(dtype) == np.float64 else TOL32)
+
+
+def test_tendency_fields_are_refused_when_not_materialised():
+    lat, lon = small_columns(70)
+    w = W.make_workload("richards", lat, lon, 32)
+    d = W.setup_device(w)
+    d.step(w["dt"], 3, finalize=False)
+    for call in (lambda: d.get("tend_internal_energy"), lambda: d.reduce("tend_saturation_water_ice", "sum")):
+        with pytest.raises(trm.TerrariumHipError) as e:
+            call()
+        assert e.value.code == trm._capi.TRM_ESTALE
+    d.update_state(True)            # materialises them again
+    assert np.all(np.isfinite(d.get("tend_internal_energy")))
+    d.step(w["dt"], 1, finalize=True)
+    assert np.all(np.isfinite(d.get("tend_saturation_water_ice")))
+    d.set_option("step_kernel", "unfused")
+    d.step(w["dt"], 1, finalize=False)
+    assert np.all(np.isfinite(d.get("tend_internal_energy")))
+
+
+def test_set_bc_replaces_a_series_and_nan_propagating_minmax():
+    lat, lon = small_columns(65)
+    w = W.make_workload("heat", lat, lon, 20)
+    d, orc = W.setup_device(w), W.setup_oracle(w)
+    times = np.array([0.0, 1.0e6])
+    d.set_bc_series("temperature", "top", "value", times, np.stack([np.full(65, -30.0), np.full(65, -30.0)]))
+    d.set_bc("temperature", "top", "value", w["bcs"][("temperature", "top")][1])   # the constant wins from now on
+    d.step(w["dt"], 20, finalize=True)
+    orc.run(w["dt"], 20)
+    assert np.array_equal(d.get("temperature"), orc.get("temperature"))
+    # minimum / maximum propagate NaN as Julia's do
+    T = d.get("temperature")
+    T[3, 7] = np.nan
+    d.set("temperature", T)
+    mn, mx = d.reduce("temperature", "min"), d.reduce("temperature", "max")
+    assert np.isnan(mn[3]) and np.isnan(mx[3])
+    keep = np.arange(20) != 3
+    assert np.array_equal(mn[keep], T[keep].min(axis=1)) and np.array_equal(mx[keep], T[keep].max(axis=1))
+
+
+def test_upload_download_round_trip_layouts():
+    """trm_upload / trm_download transpose on the device: every field kind, ragged sizes, both precisions."""
+    rng = np.random.default_rng(5)
+    for dtype, Nh, Nz in ((np.float64, 1, 2), (np.float64, 333, 20), (np.float32, 65, 64), (np.float64, 31, 70), (np.float32, 1000, 33)):
+        p = trm._capi.default_params()
+        p.flow = 1
+        d = trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=Nz), Nh, dtype=dtype), p)
+        for name in ("temperature", "hydraulic_conductivity", "surface_excess_water", "tend_saturation_water_ice"):
+            a = rng.standard_normal((d.rows(name), Nh)).astype(dtype)
+            d.set(name, a)
+            b = d.get(name)
+            assert np.array_equal(b if b.ndim == 2 else b[None, :], a), (name, dtype, Nh, Nz)
+        d.close()

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"libterrarium_hip.so does not export {n}"
     assert sorted(trm._capi.EXPORTS) == names  # the Python binding covers the whole ABI, nothing more
-    assert lib.trm_abi_version() == 2
+    header = open(os.path.join(ROOT, "include", "terrarium_hip.h")).read()
+    assert lib.trm_abi_version() == int(re.search(r"#define\s+TRM_ABI_VERSION\s+(\d+)", header).group(1))
 
 
 def test_default_params_match_reference_defaults():
