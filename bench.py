@@ -12,12 +12,20 @@ levels, coupled heat + Richards water transport, fp64.  With --gpus N every rank
 holds a full N145-sized shard (weak scaling: columns are independent, there is no
 collective on the step path).  Rank 0 prints ONE JSON line.
 
+Launching N > 1: the driver's form is
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+(one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE from the environment).  A bare `python bench.py --gpus N` with
+no WORLD_SIZE in the environment starts those N ranks itself (fresh child processes, before anything touches the
+GPU in the parent) and relays rank 0's line.  --gpus that disagrees with WORLD_SIZE is an error.
+
 The CPU oracle is used here ONLY for the `cpu_baseline` leg (a timed, bounded
 sample of the same workload on the host cores) -- never for the measured path.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,19 +36,23 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 import numpy as np
 
-STABLE_STEPS = 150   # see main(): longest stretch the explicit Richards scheme is stepped from one state (W <= 100 before it)
+STABLE_STEPS = 150   # see run_timed(): longest stretch the explicit Richards scheme is stepped from one state
+MAX_WARMUP = 100     # ... and the warm-up steps executed before it (config.warmup_executed reports the count)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+PROFILE_ROUND = "r02"
 
 WORKLOADS = {
-    # name: (description, config, hydraulics, mask/columns, Nz, dtype)
-    "c2": ("C2: N72 ERA5-land mask (14017 columns) x 30 levels, soil heat conduction only, fp64", "heat", "default", "N72", 30, "f64"),
-    "c2n145": ("C2 physics on the N145 mask (56951 columns) x 30 levels: soil heat conduction only, fp64", "heat", "default", "N145", 30, "f64"),
-    "c3": ("C3: N145 ERA5-land mask (56951 columns) x 32 levels, coupled heat + Richards (BrooksCorey SWRC, linear K), fp64", "richards", "default", "N145", 32, "f64"),
-    "c3vg": ("C3-VG: N145 mask x 32 levels, heat + Richards (VanGenuchten SWRC + Mualem K with ice impedance), fp64", "richards", "vg", "N145", 32, "f64"),
-    "c4": ("C4: N145 mask x 32 levels, full bare-ground LandModel (heat + Richards + surface energy balance, PrescribedAtmosphere), default hydraulics (BrooksCorey SWRC, linear K), fp64", "land", "default", "N145", 32, "f64"),
-    "c4vg": ("C4-VG: as C4 with the land-model test's hydraulics (VanGenuchten(alpha=2, n=2) SWRC + Mualem K with ice impedance), fp64", "land", "vg", "N145", 32, "f64"),
-    "c5": ("C5: synthetic 0.1-degree grid, 812500 columns per GPU x 64 levels, heat + Richards + SEB, default hydraulics, fp32", "land", "default", 812500, 64, "f32"),
-    "c5vg": ("C5-VG: as C5 with VanGenuchten SWRC + Mualem K, fp32", "land", "vg", 812500, 64, "f32"),
+    # name: (description, config, hydraulics, mask/columns, Nz, dtype, replicas)
+    "c2": ("C2: N72 ERA5-land mask (14017 columns) x 30 levels, soil heat conduction only, fp64", "heat", "default", "N72", 30, "f64", 1),
+    "c2n145": ("C2 physics on the N145 mask (56951 columns) x 30 levels: soil heat conduction only, fp64", "heat", "default", "N145", 30, "f64", 1),
+    "c3": ("C3: N145 ERA5-land mask (56951 columns) x 32 levels, coupled heat + Richards (BrooksCorey SWRC, linear K), fp64", "richards", "default", "N145", 32, "f64", 1),
+    "c3x8": ("C3 physics on 8 copies of the N145 columns (455608 columns x 32 levels, fp64): 0.93 GB of state per step, "
+             "3.6x the 256 MiB Infinity Cache -- the same kernel as C3 with every access served by HBM", "richards", "default", "N145", 32, "f64", 8),
+    "c3vg": ("C3-VG: N145 mask x 32 levels, heat + Richards (VanGenuchten SWRC + Mualem K with ice impedance), fp64", "richards", "vg", "N145", 32, "f64", 1),
+    "c4": ("C4: N145 mask x 32 levels, full bare-ground LandModel (heat + Richards + surface energy balance, PrescribedAtmosphere), default hydraulics (BrooksCorey SWRC, linear K), fp64", "land", "default", "N145", 32, "f64", 1),
+    "c4vg": ("C4-VG: as C4 with the land-model test's hydraulics (VanGenuchten(alpha=2, n=2) SWRC + Mualem K with ice impedance), fp64", "land", "vg", "N145", 32, "f64", 1),
+    "c5": ("C5: synthetic 0.1-degree grid, 812500 columns per GPU x 64 levels, heat + Richards + SEB, default hydraulics, fp32", "land", "default", 812500, 64, "f32", 1),
+    "c5vg": ("C5-VG: as C5 with VanGenuchten SWRC + Mualem K, fp32", "land", "vg", 812500, 64, "f32", 1),
 }
 
 
@@ -52,6 +64,121 @@ def algorithmic_bytes_per_column_step(config, Nz, wordsize):
     if config == "land":
         b += wordsize * 18                      # 7 forcing reads, T_s r+w, 9 flux/diagnostic writes
     return b
+
+
+def state_bytes_per_step(config, Nz, Nh, wordsize):
+    """Bytes of distinct state the fused step touches per launch (what has to fit a cache for it to help)."""
+    fields = 3 if config == "heat" else 6       # U, T, liq (+ sat read) / U, sat, T, liq, psi, K
+    return (fields + (1 if config == "heat" else 0)) * Nz * Nh * wordsize
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (nothing has touched the GPU in this process)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def build_workload(W, parallel, name, world, rank, scaling):
+    desc, config, hydraulics, columns, Nz, dt_name, replicas = WORKLOADS[name]
+    dtype = np.float64 if dt_name == "f64" else np.float32
+    if isinstance(columns, str):
+        lat, lon = W.columns_from_mask(columns)
+    else:
+        lat, lon = W.synthetic_columns(columns)
+    if replicas > 1:
+        lat, lon = np.tile(lat, replicas), np.tile(lon, replicas)
+    if os.environ.get("TRM_BENCH_SHARD_OF"):    # rehearsal: the shard one rank of an N-way strong-scaling run would hold
+        lo, hi = parallel.shard_range(lat.size, int(os.environ["TRM_BENCH_SHARD_OF"]), 0)
+        lat, lon = lat[lo:hi], lon[lo:hi]
+    if scaling == "strong" and world > 1:
+        lo, hi = parallel.shard_range(lat.size, world, rank)
+        lat, lon = lat[lo:hi], lon[lo:hi]
+    return W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics), desc, config, Nz, dt_name
+
+
+def run_timed(dev, w, config, steps, warmup, spinup_ms, heun, sync, barrier=None):
+    """W untimed warm-up steps, an untimed clock spin-up, then exactly `steps` timed steps (one launch each).
+    Returns (wall seconds of the timed region, device ms of its launches by HIP events on the library's stream,
+    warm-up steps executed)."""
+    dt = w["dt"]
+    warm = min(warmup, MAX_WARMUP)
+    if warm > 0:
+        (dev.step_heun if heun else dev.step)(dt, warm, finalize=False)
+    # The explicit Richards scheme at dt = 60 s dries the top cells of this synthetic state to sat = 0 (psi = -Inf, then
+    # NaN) after ~270 steps -- in the reference as well.  Runs longer than STABLE_STEPS therefore go back to a device-side
+    # snapshot of the warmed-up state every STABLE_STEPS steps (a D2D copy inside the timed wall clock, no host data):
+    # every step still does its full work on a valid state.
+    chunked = config != "heat" and steps > STABLE_STEPS
+    if chunked or spinup_ms > 0:
+        dev.save_state()
+    # Clock spin-up (untimed, part of the warm-up): an MI355X that comes out of idle needs ~30 ms of sustained load before
+    # its clocks settle (profiles/tools/ramp.py).  A land-surface run is hours of sustained stepping, so the timed region
+    # should see the settled clocks: the warmed-up state is stepped and restored until the device has been busy for
+    # --spinup-ms, then restored once more.  The timed K steps start from exactly the state the W steps produced.
+    spun = 0.0
+    while spun < spinup_ms:
+        if heun:
+            t1 = time.perf_counter()
+            dev.step_heun(dt, STABLE_STEPS, finalize=False)
+            sync()
+            spun += (time.perf_counter() - t1) * 1e3
+        else:
+            spun += dev.step_timed(dt, STABLE_STEPS, finalize=False)
+        dev.restore_state()
+    (barrier or sync)()
+    t0 = time.perf_counter()
+    ms, done = 0.0, 0
+    while done < steps:
+        n = min(steps - done, STABLE_STEPS) if chunked else steps
+        if chunked and done > 0:
+            dev.restore_state()
+        if heun:    # no event-timed entry point for Heun: the wall clock of the synchronous call stands in
+            t1 = time.perf_counter()
+            dev.step_heun(dt, n, finalize=False)
+            sync()
+            ms += (time.perf_counter() - t1) * 1e3
+        else:
+            ms += dev.step_timed(dt, n, finalize=False)  # n steps = n launches, HIP events on the library's stream
+        done += n
+    sync()
+    (barrier or sync)()
+    return time.perf_counter() - t0, ms, warm, chunked
+
+
+def roofline_object(config, Nz, Nh, wordsize, kernel_s, kernel_name, pmc_name=None, workload=None):
+    bytes_per_colstep = algorithmic_bytes_per_column_step(config, Nz, wordsize)
+    achieved = bytes_per_colstep * Nh / kernel_s / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": None, "kernel": kernel_name, "kernel_ms": kernel_s * 1e3,
+         "algorithmic_bytes_per_column_step": bytes_per_colstep, "columns_per_launch": Nh,
+         "state_bytes_per_launch": state_bytes_per_step(config, Nz, Nh, wordsize)}
+    if workload:
+        r["workload"] = workload
+    # HBM traffic of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of this
+    # command by profiles/collect.sh (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), summary committed under
+    # profiles/<round>/ together with the commit of the kernel it was measured on.  Never measured in this run.
+    if pmc_name:
+        pmc = os.path.join(ROOT, "profiles", PROFILE_ROUND, pmc_name)
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                d = json.load(f)
+            if d.get("columns") == Nh and d.get("levels") == Nz:
+                r["traffic"] = d["hbm_traffic_bytes_per_launch"]
+                r["traffic_source"] = (f"from the committed profile profiles/{PROFILE_ROUND}/{pmc_name} (bytes per launch, rocprofv3 --pmc "
+                                       f"passes of this command; kernel source at commit {d.get('commit', '?')}), not from this run")
+    return r
 
 
 def main():
@@ -67,15 +194,22 @@ def main():
     ap.add_argument("--skip-kf", action="store_true", help="store hydraulic_conductivity only when finalizing")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-resident", action="store_true", help="skip the HBM-resident companion measurements (c3x8, c5)")
+    ap.add_argument("--multistep", type=int, default=0, help="also time the resident-column multi-step kernel with this many steps per launch (temporal blocking; reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))     # before torch / the library are touched in this process
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (see the module docstring)")
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
     # Rehearsal knobs (not used by the driver): TRM_BENCH_BACKEND=gloo + TRM_BENCH_SHARE_DEVICE=1 run the N > 1 code
@@ -96,20 +230,9 @@ def main():
     import terrarium_jl_amd as trm
     from terrarium_jl_amd import parallel
 
-    desc, config, hydraulics, columns, Nz, dt_name = WORKLOADS[args.workload]
-    dtype = np.float64 if dt_name == "f64" else np.float32
-    if isinstance(columns, str):
-        lat, lon = W.columns_from_mask(columns)
-    else:
-        lat, lon = W.synthetic_columns(columns)
-    if os.environ.get("TRM_BENCH_SHARD_OF"):    # rehearsal: the shard one rank of an N-way strong-scaling run would hold
-        lo, hi = parallel.shard_range(lat.size, int(os.environ["TRM_BENCH_SHARD_OF"]), 0)
-        lat, lon = lat[lo:hi], lon[lo:hi]
-    if args.scaling == "strong" and world > 1:
-        lo, hi = parallel.shard_range(lat.size, world, rank)
-        lat, lon = lat[lo:hi], lon[lo:hi]
-    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    w, desc, config, Nz, dt_name = build_workload(W, parallel, args.workload, world, rank, args.scaling)
     Nh = w["Nh"]
+    wordsize = 8 if dt_name == "f64" else 4
 
     dev = W.setup_device(w, device=local_rank)
     dev.set_option("step_kernel", args.kernel)
@@ -125,7 +248,9 @@ def main():
             dev.set_bc_series("temperature", "top", "value", nodes, w["T0"][None, :] + 10.0 * np.sin(ph))
     if args.skip_kf:
         dev.set_option("write_kf_every_step", 0)
-    dt = w["dt"]
+
+    def sync():
+        torch.cuda.synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -133,50 +258,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warmup (untimed)
     heun = args.integrator == "heun"
-    if args.warmup > 0:
-        (dev.step_heun if heun else dev.step)(dt, min(args.warmup, 100), finalize=False)
-    # The explicit Richards scheme at dt = 60 s dries the top cells of this synthetic state to sat = 0 (psi = -Inf, then
-    # NaN) after ~270 steps -- in the reference as well.  Runs longer than STABLE_STEPS therefore go back to a device-side
-    # snapshot of the warmed-up state every STABLE_STEPS steps (a D2D copy inside the timed wall clock, no host data):
-    # every step still does its full work on a valid state.
-    chunked = config != "heat" and args.steps > STABLE_STEPS
-    if chunked or args.spinup_ms > 0:
-        dev.save_state()
-    # Clock spin-up (untimed, part of the warm-up): an MI355X that comes out of idle needs ~30 ms of sustained load before
-    # its clocks settle -- the same 100 steps from the same state take 30.1 us/step right after start-up and 27.4 us/step
-    # from the tenth repetition on (profiles/tools/ramp.py).  A land-surface run is hours of sustained stepping, so the
-    # timed region should see the settled clocks: the warmed-up state is stepped and restored until the device has
-    # been busy for --spinup-ms, then restored once more.  The timed K steps start from exactly the state W steps produced.
-    spun = 0.0
-    while spun < args.spinup_ms:
-        if heun:
-            t1 = time.perf_counter()
-            dev.step_heun(dt, STABLE_STEPS, finalize=False)
-            torch.cuda.synchronize()
-            spun += (time.perf_counter() - t1) * 1e3
-        else:
-            spun += dev.step_timed(dt, STABLE_STEPS, finalize=False)
-        dev.restore_state()
-    barrier()
-    t0 = time.perf_counter()
-    ms, done = 0.0, 0
-    while done < args.steps:
-        n = min(args.steps - done, STABLE_STEPS) if chunked else args.steps
-        if chunked and done > 0:
-            dev.restore_state()
-        if heun:    # no event-timed entry point for Heun: the wall clock of the synchronous call stands in
-            t1 = time.perf_counter()
-            dev.step_heun(dt, n, finalize=False)
-            torch.cuda.synchronize()
-            ms += (time.perf_counter() - t1) * 1e3
-        else:
-            ms += dev.step_timed(dt, n, finalize=False)  # n steps = n launches, HIP events on the library's stream
-        done += n
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, ms, warm, chunked = run_timed(dev, w, config, args.steps, args.warmup, args.spinup_ms, heun, sync, barrier)
     status = dev.status()
 
     # max over ranks, total columns over ranks
@@ -191,11 +274,11 @@ def main():
     else:
         total_columns = float(Nh)
         nan_flag = status
-    wordsize = 8 if dtype == np.float64 else 4
-    bytes_per_colstep = algorithmic_bytes_per_column_step(config, Nz, wordsize)
     kernel_s = ms * 1e-3 / max(args.steps, 1)            # average duration of one step launch on this GPU
-    achieved_gbs = bytes_per_colstep * Nh / kernel_s / 1e9
     value = total_columns * args.steps / elapsed
+    packed = dt_name == "f32" and WORKLOADS[args.workload][2] == "default" and args.kernel == "fused" and not heun
+    kernel_name = ("k_step_pk" if packed else "k_step_wave") if args.kernel == "fused" else "unfused sequence"
+    pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series) else None
 
     out = {
         "metric": "column-steps/sec",
@@ -210,24 +293,23 @@ def main():
         "vs_baseline": None,
         "dtype": dt_name,
         "data": "synthetic forcing and initial state on the reference's ERA5-land mask columns (SURVEY 8(d)); seeded",
-        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": dt, "kernel": args.kernel, "integrator": args.integrator, "series": bool(args.series), "state_restored_every": STABLE_STEPS if chunked else None,
-                   "clock_spinup_ms": args.spinup_ms,
+        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": w["dt"], "kernel": args.kernel, "integrator": args.integrator, "series": bool(args.series), "state_restored_every": STABLE_STEPS if chunked else None,
+                   "warmup_executed": warm, "clock_spinup_ms": args.spinup_ms,
                    "parallelism": f"columns block-sharded over {n_gpus} GPU(s), no data-path collective",
                    "status_flags": int(nan_flag)},
-        "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_step_wave" if args.kernel == "fused" else "unfused sequence",
-                     "kernel_ms": kernel_s * 1e3, "algorithmic_bytes_per_column_step": bytes_per_colstep},
+        "roofline": roofline_object(config, Nz, Nh, wordsize, kernel_s, kernel_name, pmc_name),
     }
+    if world > 1:
+        # global diagnostics through the library's own RCCL path (trm_comm_init / trm_reduce_global), beside torch's
+        out["config"]["abi_global_status"] = abi_global_status(dev, dist, rank, world, local_rank, backend, status)
+    dev.close()
 
-    # HBM traffic of the dominant kernel from the PMC counters: collected in separate rocprofv3 --pmc passes of
-    # this same command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), summary committed under profiles/
-    pmc = os.path.join(ROOT, "profiles", "r01", "pmc_summary_c3_fused.json")
-    if args.workload == "c3" and args.kernel == "fused" and os.path.exists(pmc):
-        with open(pmc) as f:
-            out["roofline"]["traffic"] = json.load(f)["hbm_traffic_bytes_per_launch"]
-        out["roofline"]["traffic_source"] = "profiles/r01/pmc_summary_c3_fused.json (bytes per launch)"
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    single = rank == 0 and n_gpus == 1
+    if single and args.multistep > 0:
+        out["multistep"] = multistep_leg(W, w, desc, config, Nz, Nh, wordsize, args, sync, local_rank)
+    if single and not args.no_hbm_resident and args.workload == "c3" and args.kernel == "fused" and not heun:
+        out["roofline_hbm_resident"] = hbm_resident_leg(W, parallel, args, sync, local_rank)
+    if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, w, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
@@ -235,43 +317,121 @@ def main():
         dist.destroy_process_group()
 
 
+def abi_global_status(dev, dist, rank, world, local_rank, backend, local_status):
+    """ORs the status word over the ranks inside the library (RCCL, include/terrarium_hip.h: trm_comm_init) and checks it
+    against torch.distributed's answer.  Failures are reported, never fatal: the timed numbers above do not depend on it."""
+    try:
+        if backend != "nccl" or not hasattr(dev, "comm_init"):
+            return "skipped"
+        import torch
+        uid = dev.comm_unique_id() if rank == 0 else bytes(128)
+        t = torch.frombuffer(bytearray(uid), dtype=torch.uint8).cuda()
+        dist.broadcast(t, src=0)
+        dev.comm_init(rank, world, bytes(t.cpu().numpy().tobytes()))
+        flags = dev.status_global()
+        ref = torch.tensor([local_status], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ref, op=dist.ReduceOp.BOR)
+        return "ok" if int(ref[0]) == flags else f"mismatch: library {flags}, torch {int(ref[0])}"
+    except Exception as e:   # noqa: BLE001 -- diagnostic leg
+        return f"failed: {type(e).__name__}: {e}"
+
+
+def hbm_resident_leg(W, parallel, args, sync, device):
+    """The headline C3 state (6 x 14.6 MB) never leaves the 256 MiB Infinity Cache, so its roofline fraction is an
+    algorithmic-bytes fraction of a cache-resident step.  Measured in the same run: the SAME kernel on 8 copies of the
+    N145 columns (0.93 GB of state per launch) and the C5 shard (812 500 x 64 fp32, 3.3 GB) -- both far beyond the cache."""
+    legs = []
+    for name, steps in (("c3x8", 60), ("c5", 30)):
+        w, desc, config, Nz, dt_name = build_workload(W, parallel, name, 1, 0, "weak")
+        wordsize = 8 if dt_name == "f64" else 4
+        dev = W.setup_device(w, device=device)
+        elapsed, ms, warm, _ = run_timed(dev, w, config, steps, 5, min(args.spinup_ms, 100.0), False, sync)
+        status = dev.status()
+        dev.close()
+        kernel_s = ms * 1e-3 / steps
+        r = roofline_object(config, Nz, w["Nh"], wordsize, kernel_s, "k_step_pk (+ k_surface)" if name == "c5" else "k_step_wave",
+                            f"pmc_summary_{name}_fused.json", desc)
+        r.update(steps=steps, warmup_executed=warm, column_steps_per_s=w["Nh"] * steps / elapsed, status_flags=int(status))
+        legs.append(r)
+        del w, dev
+    first = legs[0]
+    first["also"] = legs[1:]
+    return first
+
+
+def multistep_leg(W, w, desc, config, Nz, Nh, wordsize, args, sync, device):
+    """Temporal blocking ("report it separately and never as the headline fraction"): columns stay in
+    registers for `m` steps per launch, fields are written once per launch."""
+    m = args.multistep
+    dev = W.setup_device(w, device=device)
+    dev.set_option("steps_per_launch", m)
+    steps = max(m, (args.steps // m) * m)
+    elapsed, ms, warm, _ = run_timed(dev, w, config, steps, args.warmup, args.spinup_ms, False, sync)
+    status = dev.status()
+    dev.close()
+    return {"steps_per_launch": m, "steps": steps, "column_steps_per_s": Nh * steps / elapsed, "us_per_step": ms * 1e3 / steps,
+            "status_flags": int(status),
+            "note": "resident-column multi-step kernel: bit-identical to per-step launches; NOT comparable with the per-step HBM roofline"}
+
+
 def cpu_baseline(W, w, target_seconds):
-    """CPU restatement of the reference path (oracle/, OpenMP over columns, reference kernel order) timed on
-    this box's host cores on the same workload: whole column set, bounded number of steps.  The thread count is
-    auto-tuned over a few candidates (the reference-order passes are memory-bound and stop scaling long before
-    all hardware threads are busy); `cores` reports the count actually used for the quoted number."""
+    """CPU restatement of the reference path (oracle/, reference kernel order) timed on this box's host cores on the same
+    workload: whole column set, bounded number of steps.  Headline `value`: one pass per reference kernel with OpenMP over
+    columns, thread count auto-tuned over a few candidates (the reference-order passes are memory-bound and stop scaling
+    long before all hardware threads are busy).  BASELINE.md 4.2's other legs ride along in `legs`: the same driver on one
+    thread, and the cache-blocked ("fused") driver -- every pass over one block of columns at a time -- on one thread
+    and on the tuned thread count."""
     import oracle
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     candidates = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail} | {min(avail, 8)})
+    dt, Nh = w["dt"], w["Nh"]
+
+    def timed(orc, fn, steps):
+        t0 = time.perf_counter()
+        fn(orc, steps)
+        return time.perf_counter() - t0
+
+    ref_order = lambda o, n: o.steps(dt, n)
+    blocked = lambda o, n: o.steps_blocked(dt, n, 64)
     budget = target_seconds
     best = None
     for threads in candidates:
         oracle.set_threads(threads)
         orc = W.setup_oracle(w, omp=True)
-        orc.steps(w["dt"], 2)  # touch pages / spin up the thread pool
-        t0 = time.perf_counter()
-        orc.steps(w["dt"], 10)
-        dt = time.perf_counter() - t0
-        budget -= dt
-        rate = w["Nh"] * 10 / dt
+        ref_order(orc, 2)  # touch pages / spin up the thread pool
+        sec = timed(orc, ref_order, 10)
+        budget -= sec
+        rate = Nh * 10 / sec
         if best is None or rate > best[1]:
             best = (threads, rate)
-        if budget < target_seconds * 0.5:
+        if budget < target_seconds * 0.6:
             break
     threads = best[0]
+    legs = {}
+    # single thread: a few steps are enough (seconds each at N145 size)
+    for label, fn, thr, n in (("reference_order_1_thread", ref_order, 1, 3), ("cache_blocked_1_thread", blocked, 1, 3),
+                              (f"cache_blocked_{threads}_threads", blocked, threads, 20)):
+        oracle.set_threads(thr)
+        orc = W.setup_oracle(w, omp=True)
+        fn(orc, 1)
+        sec = timed(orc, fn, n)
+        legs[label] = {"value": Nh * n / sec, "steps": n, "seconds": round(sec, 2)}
+        budget -= sec
     oracle.set_threads(threads)
-    orc = W.setup_oracle(w, omp=True)
-    orc.steps(w["dt"], 2)
-    chunk, done, spent = 10, 0, 0.0
-    while spent < max(budget, 2.0) and done < 80:
-        t0 = time.perf_counter()
-        orc.steps(w["dt"], chunk)
-        spent += time.perf_counter() - t0
+    chunk, done, spent = 50, 0, 0.0
+    while spent < max(budget, 2.0) and done < 5000:
+        if done % STABLE_STEPS == 0:      # a fresh state every 150 steps (the explicit Richards scheme dries cells out later)
+            orc = W.setup_oracle(w, omp=True)
+            ref_order(orc, 2)
+        spent += timed(orc, ref_order, chunk)
         done += chunk
-    return {"value": w["Nh"] * done / spent, "unit": "column-steps/s", "cores": threads, "kind": "port",
-            "sample": f"all {w['Nh']} columns x {done} steps of the same workload; CPU restatement of the Terrarium.jl "
+    legs[f"reference_order_{threads}_threads"] = {"value": Nh * done / spent, "steps": done, "seconds": round(spent, 2)}
+    return {"value": Nh * done / spent, "unit": "column-steps/s", "cores": threads, "kind": "port",
+            "sample": f"all {Nh} columns x {done} steps of the same workload; CPU restatement of the Terrarium.jl "
                       f"path (not Terrarium.jl itself: Julia is not installed), one pass per reference kernel, OpenMP "
-                      f"over columns with {threads} of {avail} hardware threads (best of {candidates}); {spent:.1f} s"}
+                      f"over columns with {threads} of {avail} hardware threads (best of {candidates}); {spent:.1f} s; "
+                      f"other legs (column-steps/s): " + ", ".join(f"{k} {v['value']:.3g}" for k, v in legs.items()),
+            "legs": legs}
 
 
 if __name__ == "__main__":

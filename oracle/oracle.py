@@ -104,6 +104,7 @@ def _lib(omp=False):
         lib.trm_oracle_timestep_heun.argtypes = [C.c_void_p, C.c_double, C.c_int]
         lib.trm_oracle_run.argtypes = [C.c_void_p, C.c_double, C.c_long]
         lib.trm_oracle_steps.argtypes = [C.c_void_p, C.c_double, C.c_long]
+        lib.trm_oracle_steps_blocked.argtypes = [C.c_void_p, C.c_double, C.c_long, C.c_long]
         lib.trm_oracle_clock.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         lib.trm_oracle_set_clock.argtypes = [C.c_void_p, C.c_double, C.c_longlong]
         lib.trm_oracle_status.restype = C.c_uint
@@ -263,6 +264,7 @@ class Oracle:
     def timestep_heun(self, dt, finalize=True): self.lib.trm_oracle_timestep_heun(self.h, float(dt), int(finalize))
     def run(self, dt, steps): self.lib.trm_oracle_run(self.h, float(dt), int(steps))
     def steps(self, dt, steps): self.lib.trm_oracle_steps(self.h, float(dt), int(steps))
+    def steps_blocked(self, dt, steps, block=64): self.lib.trm_oracle_steps_blocked(self.h, float(dt), int(steps), int(block))
 
     def clock(self):
         t, it = C.c_double(), C.c_longlong()

@@ -111,6 +111,8 @@ void trm_oracle_run(OracleHandle* h, double dt, long steps) { DISPATCH(h, o->run
 void trm_oracle_steps(OracleHandle* h, double dt, long steps) {
     DISPATCH(h, { for (long s = 0; s < steps; ++s) o->timestep_euler(dt, false); });
 }
+// the same, cache-blocked over `block` columns at a time (BASELINE.md 4.2 "fused driver")
+void trm_oracle_steps_blocked(OracleHandle* h, double dt, long steps, long block) { DISPATCH(h, o->steps_blocked(dt, steps, block)); }
 void trm_oracle_clock(OracleHandle* h, double* time, long long* iteration) {
     DISPATCH(h, { *time = o->time; *iteration = o->iteration; });
 }

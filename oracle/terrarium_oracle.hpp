@@ -408,6 +408,12 @@ template <class NF> class Oracle {
     double time = 0.0;
     long long iteration = 0;
     uint32_t status = 0;  // bit0 NaN seen (unused here), bit1 composition out of [0,1]
+    // Column range the passes below work on: the whole grid by default; the cache-blocked driver (steps_blocked)
+    // narrows it per thread to one block of columns at a time.
+    static long& range_lo() { static thread_local long v = 0; return v; }
+    static long& range_hi() { static thread_local long v = -1; return v; }
+    long col_lo() const { return range_lo(); }
+    long col_hi() const { long h = range_hi(); return h < 0 ? Nh : h; }
 
     // 3-D centre fields with z halos: (Nz+2) x Nh
     std::vector<NF> U, sat, T, liq, psi, G_U, G_sat;
@@ -605,7 +611,7 @@ template <class NF> class Oracle {
             std::vector<NF>* dst = sr.is_bc ? &bc[sr.var][sr.top].value : field2(sr.field);
             const NF* v1 = &sr.values[(size_t)n1 * Nh];
             const NF* v2 = &sr.values[(size_t)n2 * Nh];
-            for (long i = 0; i < Nh; ++i)
+            for (long i = col_lo(); i < col_hi(); ++i)
                 (*dst)[i] = (n1 == n2) ? v1[i] : (NF)((double)v2[i] * f + (double)v1[i] * (1.0 - f));
         }
     }
@@ -619,7 +625,7 @@ template <class NF> class Oracle {
         const Bc<NF>& bb = bc[var][0];
         NF dtop = g.dzf[Nz + 1], dbot = g.dzf[1];
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             NF cN = c[C(Nz, i)], c1 = c[C(1, i)];
             if (bt.kind == BC_VALUE) {
                 NF grad = (bt.value[i] - cN) / (dtop / NF(2));
@@ -651,7 +657,7 @@ template <class NF> class Oracle {
         if (!richards() && p.halo_policy == HALO_MIRROR) {
             // policy switch for SURVEY Appendix C-1: under NoFlow the reference
             // never fills the halos of the auxiliary saturation field.
-            for (long i = 0; i < Nh; ++i) { sat[C(0, i)] = sat[C(1, i)]; sat[C(Nz + 1, i)] = sat[C(Nz, i)]; }
+            for (long i = col_lo(); i < col_hi(); ++i) { sat[C(0, i)] = sat[C(1, i)]; sat[C(Nz + 1, i)] = sat[C(Nz, i)]; }
         }
     }
 
@@ -664,7 +670,7 @@ template <class NF> class Oracle {
     void compute_hydraulics() {
         NF por = porosity(p), org = organic_fraction(p);
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             auto Kc = [&](int k) { return hydraulic_conductivity_cell(p, por, liq[C(k, i)], fractions_at(k, i, por, org)); };
             for (int k = 1; k <= Nz; ++k) {
                 if (k <= 1) {
@@ -691,7 +697,7 @@ template <class NF> class Oracle {
     }
     void compute_evaporation() {  // bare_ground_evaporation.jl:49-62
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             NF ra = aerodynamic_resistance(i);
             NF dq = humidity_vpd(i, Ts[i]);
             evap[i] = p.beta_evap * dq / ra;
@@ -699,7 +705,7 @@ template <class NF> class Oracle {
     }
     void compute_runoff() {  // direct_surface_runoff.jl:87-117
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             NF rainfall = rain[i];
             NF excess = richards() ? S[i] : NF(0);
             NF k_unsat = Kf[C(Nz, i)];
@@ -736,7 +742,7 @@ template <class NF> class Oracle {
     void compute_surface_energy_fluxes() {  // surface_energy_balance.jl:95-110
         NF dz1 = g.dzc[Nz];
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             seb_fluxes(i);
             NF Tg = T[C(Nz, i)];  // ground_temperature = view of the top soil layer (soil_energy.jl:52-57)
             Ts[i] = compute_skin_temperature(p, Tg, ghf[i], dz1);
@@ -745,7 +751,7 @@ template <class NF> class Oracle {
     }
     void update_skin_temperature() {  // skin_temperature.jl:104-109
         NF dz1 = g.dzc[Nz];
-        for (long i = 0; i < Nh; ++i) Ts[i] = compute_skin_temperature(p, T[C(Nz, i)], ghf[i], dz1);
+        for (long i = col_lo(); i < col_hi(); ++i) Ts[i] = compute_skin_temperature(p, T[C(Nz, i)], ghf[i], dz1);
     }
 
     // ---- compute_auxiliary!(state, model) -----------------------------------
@@ -765,7 +771,7 @@ template <class NF> class Oracle {
         // hydrology first (soil_coupled.jl:80-90)
         if (richards()) {
             TRM_OMP_FOR
-            for (long i = 0; i < Nh; ++i) {
+            for (long i = col_lo(); i < col_hi(); ++i) {
                 auto darcy = [&](int k) {  // soil_hydrology_rre.jl:115-131
                     NF grad = (psi[C(k, i)] - psi[C(k - 1, i)]) * g.rdzf[k];
                     NF Kk = jl_boolmul(grad < NF(0), jl_min(Kf[C(k - 1, i)], Kf[C(k, i)])) +
@@ -785,7 +791,7 @@ template <class NF> class Oracle {
         }
         // energy (soil_energy.jl:112-149)
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             auto kappa = [&](int k) { return thermal_conductivity(p, fractions_at(k, i, por, org)); };
             auto q = [&](int k) {
                 NF kf = NF(0.5) * (kappa(k) + kappa(k - 1));
@@ -800,14 +806,15 @@ template <class NF> class Oracle {
 
     // ---- update_state! (state_variables.jl:72-80) ---------------------------
     void reset_tendencies() {
+        const long i0_ = col_lo(), i1_ = col_hi();
         TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
-            for (long i = 0; i < Nh; ++i) { G_U[C(k, i)] = NF(0); G_sat[C(k, i)] = NF(0); }
-        std::fill(G_S.begin(), G_S.end(), NF(0));
+            for (long i = i0_; i < i1_; ++i) { G_U[C(k, i)] = NF(0); G_sat[C(k, i)] = NF(0); }
+        std::fill(G_S.begin() + i0_, G_S.begin() + i1_, NF(0));
     }
-    void update_state(bool tendencies = true) {
+    void update_state(bool tendencies = true, bool inputs = true) {
         reset_tendencies();
-        update_inputs();  // constant inputs are set by the harness before the call; series are evaluated at `time`
+        if (inputs) update_inputs();  // constant inputs are set by the harness before the call; series are evaluated at `time`
         fill_halo_regions();
         compute_auxiliary();
         if (tendencies) compute_tendencies();
@@ -821,7 +828,7 @@ template <class NF> class Oracle {
         const Bc<NF>& bt = bc[var][1];
         const Bc<NF>& bb = bc[var][0];
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             if (bb.kind == BC_FLUX) G[C(1, i)] += bb.value[i] * Az / Vbot;
             if (top_field) {
                 NF F = negate_top ? -(*top_field)[i] : (*top_field)[i];
@@ -835,24 +842,25 @@ template <class NF> class Oracle {
         // prognostic order: soil (energy, hydrology) then SEB's skin_temperature
         // (zero tendency); each prognostic is independent of the others here.
         apply_z_flux_bcs(G_U, BCV_INTERNAL_ENERGY, land_model ? &ghf : nullptr, false);  // land_model.jl:56-58
+        const long i0_ = col_lo(), i1_ = col_hi();
         TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
-            for (long i = 0; i < Nh; ++i) U[C(k, i)] = U[C(k, i)] + G_U[C(k, i)] * dt;
+            for (long i = i0_; i < i1_; ++i) U[C(k, i)] = U[C(k, i)] + G_U[C(k, i)] * dt;
         if (richards()) {
             apply_z_flux_bcs(G_sat, BCV_SATURATION, land_model ? &infil : nullptr, true);  // land_model.jl:57-61
             TRM_OMP_FOR2
             for (int k = 1; k <= Nz; ++k)
-                for (long i = 0; i < Nh; ++i) sat[C(k, i)] = sat[C(k, i)] + G_sat[C(k, i)] * dt;
-            for (long i = 0; i < Nh; ++i) S[i] = S[i] + G_S[i] * dt;
+                for (long i = i0_; i < i1_; ++i) sat[C(k, i)] = sat[C(k, i)] + G_sat[C(k, i)] * dt;
+            for (long i = col_lo(); i < col_hi(); ++i) S[i] = S[i] + G_S[i] * dt;
         }
         if (p.seb)
-            for (long i = 0; i < Nh; ++i) Ts[i] = Ts[i] + NF(0) * dt;  // skin_temperature: prognostic, zero tendency
+            for (long i = col_lo(); i < col_hi(); ++i) Ts[i] = Ts[i] + NF(0) * dt;  // skin_temperature: prognostic, zero tendency
     }
 
     // ---- hydrology closure (soil_hydraulic_closures.jl:23-44) ---------------
     void adjust_saturation_profile() {  // soil_hydrology.jl:185-219
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             for (int k = 1; k <= Nz - 1; ++k) {
                 NF excess = jl_max(sat[C(k, i)] - NF(1), NF(0));
                 sat[C(k, i)] -= excess;
@@ -872,7 +880,7 @@ template <class NF> class Oracle {
     void compute_water_table() {  // soil_hydrology.jl:170-175, kernel_utils.jl:7-16
         int n = Nz + 1;           // znodes(Center, Center, Face): Nz+1 faces; index Nz+1 reads the top halo cell
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             int idx = -1;
             for (int k = 1; k <= n; ++k)
                 if (idx < 0 && sat[C(k, i)] < NF(1)) idx = k;
@@ -883,7 +891,7 @@ template <class NF> class Oracle {
         NF por = porosity(p);
         NF z_ref = g.zF[Nz + 1];
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             NF z0 = wt[i];
             for (int k = 1; k <= Nz; ++k) {
                 NF z = g.zC[k];
@@ -898,7 +906,7 @@ template <class NF> class Oracle {
         NF por = porosity(p);
         NF z_ref = g.zF[Nz + 1];
         TRM_OMP_FOR
-        for (long i = 0; i < Nh; ++i) {
+        for (long i = col_lo(); i < col_hi(); ++i) {
             NF z0 = wt[i];
             for (int k = 1; k <= Nz; ++k) {
                 NF z = g.zC[k];
@@ -913,9 +921,10 @@ template <class NF> class Oracle {
     void energy_to_temperature_all() {
         NF por = porosity(p), org = organic_fraction(p);
         NF L = p.rho_w * p.Lsl;
+        const long i0_ = col_lo(), i1_ = col_hi();
         TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
-            for (long i = 0; i < Nh; ++i) {
+            for (long i = i0_; i < i1_; ++i) {
                 NF u = U[C(k, i)], s = sat[C(k, i)];
                 NF Ltheta = L * s * por;
                 NF l = liquid_water_fraction(u, Ltheta);
@@ -927,9 +936,10 @@ template <class NF> class Oracle {
     void temperature_to_energy_all() {
         NF por = porosity(p), org = organic_fraction(p);
         NF L = p.rho_w * p.Lsl;
+        const long i0_ = col_lo(), i1_ = col_hi();
         TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
-            for (long i = 0; i < Nh; ++i) {
+            for (long i = i0_; i < i1_; ++i) {
                 NF t = T[C(k, i)], s = sat[C(k, i)];
                 NF l = (t >= NF(0)) ? NF(1) : NF(0);
                 liq[C(k, i)] = l;
@@ -978,6 +988,26 @@ template <class NF> class Oracle {
         closure();
         tick(dt);
         if (finalize) compute_auxiliary();
+    }
+    // The same step, cache-blocked ("fused driver" of BASELINE.md section 4.2): every pass of the step runs over one
+    // block of columns while that block's rows sit in cache, blocks spread over the OpenMP threads.  Same passes, same
+    // arithmetic, same order per column: results are identical to timestep_euler (tests/test_oracle_known_answers.py).
+    void steps_blocked(double dt, long nsteps, long block) {
+        const long nb = (Nh + block - 1) / block;
+        for (long s = 0; s < nsteps; ++s) {
+            update_inputs();
+            TRM_OMP_FOR
+            for (long b = 0; b < nb; ++b) {
+                range_lo() = b * block;
+                range_hi() = std::min(Nh, (b + 1) * block);
+                update_state(true, false);
+                explicit_step(NF(dt));
+                closure();
+                range_lo() = 0;
+                range_hi() = -1;
+            }
+            tick(dt);
+        }
     }
     void run(double dt, long steps) {  // model_integrator.jl:72-88
         for (long s = 0; s < steps; ++s) timestep_euler(dt, false);

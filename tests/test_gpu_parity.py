@@ -564,8 +564,8 @@ def test_tendency_fields_after_finalizing_step(config, hydraulics, dtype, integr
     names = ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else [])
     for d in (a, b):
         (d.step_heun if integrator == "heun" else d.step)(w["dt"], 7, finalize=True)
-    for _ in range(7):
-        (orc.timestep_heun if integrator == "heun" else orc.timestep)(w["dt"], True)
+    for n in range(7):   # run!(steps = 7): compute_auxiliary! once, after the last step (it advances the skin temperature)
+        (orc.timestep_heun if integrator == "heun" else orc.timestep)(w["dt"], n == 6)
     for n in names:
         assert np.array_equal(a.get(n), b.get(n)), n
         assert np.any(a.get(n) != 0) or n == "tend_surface_excess_water", n

@@ -536,3 +536,22 @@ def test_update_inputs_from_series():
     o.update_inputs()
     o.fill_halo_regions()
     assert o.halo("temperature", 1) == pytest.approx(2 * 40.0)   # clamped
+
+
+@pytest.mark.parametrize("config,hydraulics", [("heat", "default"), ("richards", "default"), ("land", "vg")])
+@pytest.mark.parametrize("omp", [False, True])
+def test_cache_blocked_driver_equals_reference_order_driver(config, hydraulics, omp):
+    """The CPU baseline's cache-blocked ("fused") driver runs the same passes over one block of columns at a time:
+    it must reproduce the reference-order driver bit for bit (ragged last block, several OpenMP threads)."""
+    import workloads as W
+    lat, lon = W.columns_from_mask("N72")
+    sel = np.linspace(0, lat.size - 1, 203).astype(int)
+    w = W.make_workload(config, lat[sel], lon[sel], 20, hydraulics=hydraulics)
+    if omp:
+        oracle.set_threads(3)
+    a, b = W.setup_oracle(w, omp=omp), W.setup_oracle(w, omp=omp)
+    a.steps(w["dt"], 12)
+    b.steps_blocked(w["dt"], 12, block=16)
+    for name in W.compared_fields(w) + ["tend_internal_energy"]:
+        assert np.array_equal(a.get(name), b.get(name), equal_nan=True), name
+    assert a.clock() == b.clock()
