@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 3
+#define TRM_ABI_VERSION 4
 
 typedef struct trm_ctx trm_ctx;
 
@@ -120,8 +120,18 @@ enum {
     TRM_OPT_WRITE_KF_EVERY_STEP = 2,/* 1 (default): hydraulic_conductivity is stored by every step launch;   */
                                     /* 0: only by launches that finalize (it is never an input of a step)   */
     TRM_OPT_VWC_FORCING_FIELD = 3,  /* 1 after TRM_FIELD_VWC_FORCING was uploaded: per-cell vwc_forcing; 0: scalar */
-    TRM_OPT_PACKED_F32 = 4          /* 1 (default): fp32 contexts with the reference-default hydraulics step two       */
+    TRM_OPT_PACKED_F32 = 4,         /* 1 (default): fp32 contexts with the reference-default hydraulics step two       */
                                     /* columns per lane with packed fp32 instructions (bit-identical results); 0: off */
+    TRM_OPT_DERIVE_CLOSURE_FIELDS = 5, /* 1 (default): when the stored temperature / liquid_water_fraction are known to be */
+                                    /* the energy closure of the stored internal_energy / saturation (the library wrote   */
+                                    /* them), a fused step re-derives them in registers instead of reading them: 2 of 5   */
+                                    /* field reads less, bit-identical results; 0: always read them                        */
+    TRM_OPT_LEGACY_STEP_KERNEL = 6, /* 1: round-1 step kernel (k_step_wave) for the branch-free boundary kinds -- the A/B  */
+                                    /* comparator of the column programs; Heun then runs on the reference-order kernels    */
+    TRM_OPT_STEPS_PER_LAUNCH = 7    /* m >= 1 (default 1): trm_step keeps every column in registers for up to m steps per   */
+                                    /* launch and writes the fields once per launch (temporal blocking of run!'s loop;     */
+                                    /* bit-identical to m = 1).  Applies while no time series is attached and the boundary  */
+                                    /* kinds are the branch-free ones; otherwise one step per launch as usual               */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
@@ -247,8 +257,8 @@ int trm_invclosure(trm_ctx* ctx);
  * TRM_FIELD_TEND_* field fail with TRM_ESTALE until trm_update_state(ctx, 1), trm_reset_tendencies or a finalizing
  * step has run.  TRM_KERNEL_UNFUSED materialises them at every step. */
 int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
-/* Same for Heun (heun.jl:37-71): with TRM_KERNEL_FUSED two launches per step (predictor into the stage buffers,
- * corrector from the stage's tendencies), otherwise the reference-order kernels on a second copy of the state. */
+/* Same for Heun (heun.jl:37-71): with TRM_KERNEL_FUSED ONE launch per step (both stages on the column held in
+ * registers; the stage never touches memory), otherwise the reference-order kernels on a second copy of the state. */
 int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
 int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);

@@ -3,6 +3,7 @@
 #include "../../include/terrarium_hip.h"
 #include "trm_kernels.hpp"
 #include "trm_packed_f32.hpp"
+#include "trm_column.hpp"
 
 #include <cmath>
 #include <type_traits>
@@ -57,6 +58,10 @@ struct trm_ctx {
     bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)
     bool top_escaped = false;  // a device pointer to T / sat / liq was handed out: never trust the copies again
     bool tend_valid = true;    // the tendency fields hold what the reference would (false after a fused step that did not finalize)
+    // the stored (temperature, liquid_water_fraction) ARE the energy closure of the stored (internal_energy, saturation):
+    // true after a fused step / closure!, false after anything else wrote one of the four fields.  Lets the step derive
+    // them in registers instead of reading them (k_column<DERIVE>).
+    bool closure_consistent = false, closure_escaped = false, saved_closure_consistent = false;
     void* d_zero = nullptr;  // [Nh] zeros: stands in for the value array of every unset boundary condition
     double* d_reduce = nullptr;  // scratch for trm_reduce
     size_t reduce_cap = 0;
@@ -66,6 +71,7 @@ struct trm_ctx {
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
+    int opt_derive = 1, opt_legacy = 0, opt_steps_per_launch = 1;
     // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
     // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
     // `args_valid` and the next launch rebuilds them.
@@ -283,6 +289,7 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     return v;
 }
 
+template <class NF> struct StageView { const NF *bcT_bot, *bcT_top; };
 template <class NF> StageView<NF> make_stage_view(const trm_ctx* c);
 template <class NF> struct LaunchArgs {
     DevParams<NF> p;
@@ -361,17 +368,8 @@ void series_time_indices(const std::vector<double>& times, int indexing, double 
 }
 
 template <class NF> StageView<NF> make_stage_view(const trm_ctx* c) {
+    // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
     StageView<NF> w{};
-    if (!c->has_stage) return w;
-    auto F = [&](int id) { return (NF*)c->stage.f[id]; };
-    w.U = F(TRM_FIELD_INTERNAL_ENERGY);
-    w.sat = F(TRM_FIELD_SATURATION_WATER_ICE);
-    w.T = F(TRM_FIELD_TEMPERATURE);
-    w.liq = F(TRM_FIELD_LIQUID_WATER_FRACTION);
-    w.psi = F(TRM_FIELD_PRESSURE_HEAD);
-    w.S = F(TRM_FIELD_SURFACE_EXCESS_WATER);
-    w.wt = F(TRM_FIELD_WATER_TABLE);
-    w.Ts = F(TRM_FIELD_SKIN_TEMPERATURE);
     auto bc = [&](int side) {
         void* q = c->bc_value_stage[TRM_BCV_TEMPERATURE][side] ? c->bc_value_stage[TRM_BCV_TEMPERATURE][side] : c->bc_value[TRM_BCV_TEMPERATURE][side];
         return (const NF*)(q ? q : c->d_zero);
@@ -402,6 +400,7 @@ template <class NF> struct Ops {
             int n1, n2;
             double f;
             series_time_indices(sr.times, sr.indexing, time, n1, n2, f);
+            if (!sr.is_bc && stage && !c->has_stage) continue;   // (fused Heun: the stage's surface processes are never evaluated)
             NF* dst;
             if (sr.is_bc) {
                 void*& slot = stage ? c->bc_value_stage[sr.var][sr.side] : c->bc_value[sr.var][sr.side];
@@ -562,45 +561,93 @@ template <class NF> struct Ops {
         return generic;
     }
     // ---- fused step, column per (half-)wavefront ------------------------------------------------------
-    template <bool RICH, int H, int LPC, int MODE> static int launch_wave(trm_ctx* c, double dt, int finalize) {
+    // ---- fused step, column per (half-)wavefront ------------------------------------------------------
+    static dim3 column_grid(const trm_ctx* c, int lpc) {
+        dim3 grid = wave_grid(c, lpc);
+        grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
+        return grid;
+    }
+    // k_step_wave: the generic boundary kinds (and the legacy comparator of the branch-free path), Euler only
+    template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         const View<NF>& v = la.state;
-        const StageView<NF>& w = la.w;
         const DevParams<NF>& p = la.p;
-        dim3 grid = wave_grid(c, LPC);
-        grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
-        const int wkf = MODE == STEP_HEUN_FINAL ? finalize : ((c->opt_write_kf || finalize) ? 1 : 0);
-        const unsigned lds = 0u;
-        if constexpr (std::is_same<NF, float>::value && H == HYD_BC_LINEAR && MODE == STEP_EULER) {
-            // fp32, reference-default hydraulics: two columns per lane with packed math (trm_packed_f32.hpp)
-            const auto& spec = p.bc_neg_inv_lambda;
-            if (c->opt_packed && !generic_bcs(c) && spec.kind == POW_INT && spec.n == -5) {
-                const long pairs = (c->Nh + 1) / 2;
-                const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
-                dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-                hipLaunchKernelGGL((k_step_pk<RICH, LPC>), pg, dim3(TRM_STEP_BLOCK), lds, c->stream, v, p, (float)dt, finalize, wkf);
-                TRM_HIP(c, hipGetLastError());
-                return TRM_OK;
-            }
-        }
-        if (MODE == STEP_EULER && generic_bcs(c))
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true, STEP_EULER>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, w, p, (NF)dt, finalize, wkf);
+        const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+        if (generic_bcs(c))
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
         else
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false, MODE>), grid, dim3(TRM_STEP_BLOCK), lds, c->stream, v, w, p, (NF)dt, finalize, wkf);
+            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
-    template <bool RICH, int H, int MODE> static int wave_lpc(trm_ctx* c, double dt, int finalize) {
-        if (c->Nz <= 32) return launch_wave<RICH, H, 32, MODE>(c, dt, finalize);
-        return launch_wave<RICH, H, 64, MODE>(c, dt, finalize);
+    // fp32, reference-default hydraulics: two columns per lane with packed math (trm_packed_f32.hpp)
+    static bool packed_path(trm_ctx* c) {
+        if (!std::is_same<NF, float>::value || !c->opt_packed || generic_bcs(c) || hyd(c) != HYD_BC_LINEAR) return false;
+        const auto& spec = launch_args<NF>(c).p.bc_neg_inv_lambda;
+        return spec.kind == POW_INT && spec.n == -5;
     }
-    template <int MODE> static int wave_step_mode(trm_ctx* c, double dt, int finalize) {
+    template <bool RICH, int LPC> static int launch_packed(trm_ctx* c, double dt, int finalize) {
+        if constexpr (std::is_same<NF, float>::value) {
+            const LaunchArgs<NF>& la = launch_args<NF>(c);
+            const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+            const long pairs = (c->Nh + 1) / 2;
+            const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
+            dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
+            hipLaunchKernelGGL((k_step_pk<RICH, LPC>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, (float)dt, finalize, wkf);
+            TRM_HIP(c, hipGetLastError());
+        }
+        return TRM_OK;
+    }
+    // k_column: the register-resident column programs (trm_column.hpp)
+    template <bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
+        const LaunchArgs<NF>& la = launch_args<NF>(c);
+        const View<NF>& v = la.state;
+        const DevParams<NF>& p = la.p;
+        ColumnArgs<NF> a;
+        a.dt = (NF)dt;
+        a.finalize = finalize;
+        a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
+        a.nsteps = nsteps;
+        a.bcT_bot_stage = la.w.bcT_bot;
+        a.bcT_top_stage = la.w.bcT_top;
+        const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
+        const bool derive = c->opt_derive && c->closure_consistent && !c->closure_escaped;
+        if constexpr (PROG == PROG_MULTI) {
+            if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true>), grid, block, 0, c->stream, v, p, a);
+            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false>), grid, block, 0, c->stream, v, p, a);
+        } else {
+            if (derive) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, true, PROG, false>), grid, block, 0, c->stream, v, p, a);
+            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG, false>), grid, block, 0, c->stream, v, p, a);
+        }
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    template <int PROG> static int column_program(trm_ctx* c, double dt, int finalize, int nsteps) {
         int rc = TRM_OK;
-        if (richards(c)) { TRM_BY_HYD(c, rc = (wave_lpc<true, H, MODE>(c, dt, finalize))); }
-        else { TRM_BY_HYD(c, rc = (wave_lpc<false, H, MODE>(c, dt, finalize))); }
+        const bool deep = c->Nz > 32;
+        if (richards(c)) {
+            TRM_BY_HYD(c, rc = deep ? (launch_column<true, H, 64, PROG>(c, dt, finalize, nsteps)) : (launch_column<true, H, 32, PROG>(c, dt, finalize, nsteps)));
+        } else {
+            TRM_BY_HYD(c, rc = deep ? (launch_column<false, H, 64, PROG>(c, dt, finalize, nsteps)) : (launch_column<false, H, 32, PROG>(c, dt, finalize, nsteps)));
+        }
         return rc;
     }
-    static int wave_step(trm_ctx* c, double dt, int finalize) { return wave_step_mode<STEP_EULER>(c, dt, finalize); }
+    // one fused ForwardEuler step (the state's surface processes have run)
+    static int wave_step(trm_ctx* c, double dt, int finalize) {
+        int rc = TRM_OK;
+        const bool deep = c->Nz > 32;
+        if (packed_path(c)) {
+            if (richards(c)) rc = deep ? launch_packed<true, 64>(c, dt, finalize) : launch_packed<true, 32>(c, dt, finalize);
+            else rc = deep ? launch_packed<false, 64>(c, dt, finalize) : launch_packed<false, 32>(c, dt, finalize);
+        } else if (generic_bcs(c) || c->opt_legacy) {
+            if (richards(c)) { TRM_BY_HYD(c, rc = deep ? (launch_wave<true, H, 64>(c, dt, finalize)) : (launch_wave<true, H, 32>(c, dt, finalize))); }
+            else { TRM_BY_HYD(c, rc = deep ? (launch_wave<false, H, 64>(c, dt, finalize)) : (launch_wave<false, H, 32>(c, dt, finalize))); }
+        } else {
+            rc = column_program<PROG_EULER>(c, dt, finalize, 1);
+        }
+        if (!rc) c->closure_consistent = true;
+        return rc;
+    }
     static int unfused_step(trm_ctx* c, double dt, int finalize) {
         int rc = update_state(c, c->state, true);
         if (!rc) rc = explicit_step(c, c->state, dt);
@@ -609,17 +656,28 @@ template <class NF> struct Ops {
         return rc;
     }
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
-        for (int n = 0; n < nsteps; ++n) {
-            int fin = (finalize && n == nsteps - 1) ? 1 : 0;
-            // the fused kernel maps one soil level to one lane: columns deeper than 64 levels take the
-            // reference-order kernels
-            const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
+        // the fused kernels map one soil level to one lane: columns deeper than 64 levels take the reference-order kernels
+        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
+        // Resident-column multi-step program (TRM_OPT_STEPS_PER_LAUNCH > 1): legal when nothing the host evaluates changes
+        // between the steps of a launch -- no time series -- and the branch-free boundary kinds apply.
+        const int spl = (fused && c->series.empty() && !generic_bcs(c) && !c->opt_legacy) ? c->opt_steps_per_launch : 1;
+        int n = 0;
+        while (n < nsteps) {
+            const int m = std::min(spl, nsteps - n);
+            const int fin = (finalize && n + m == nsteps) ? 1 : 0;
             int rc = update_inputs(c, c->state, c->time);
             if (rc) return rc;
             if (!fused) {
                 c->top_valid = false;
                 c->tend_valid = true;
                 rc = unfused_step(c, dt, fin);
+                if (!rc) c->closure_consistent = true;   // closure! has just run
+            } else if (m > 1) {
+                rc = column_program<PROG_MULTI>(c, dt, fin, m);
+                if (!rc) c->closure_consistent = true;
+                c->tend_valid = fin != 0;
+                c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+                if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             } else {
                 // LandModel: the 0-D surface processes run as their own small launch in front of the fused
                 // column kernel (and once more after it when finalizing)
@@ -630,8 +688,9 @@ template <class NF> struct Ops {
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             }
             if (rc) return rc;
-            c->time += dt;
-            c->iteration += 1;
+            for (int j = 0; j < m; ++j) c->time += dt;   // tick! per step: the same sequence of sums as per-step calls
+            c->iteration += m;
+            n += m;
         }
         return TRM_OK;
     }
@@ -650,25 +709,25 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
-    // Heun in two fused launches (TRM_KERNEL_FUSED, Nz <= 64, no generic boundary kinds): predictor into the stage
-    // buffers with G1 kept in the state's tendency fields, then the corrector from the stage's tendencies.  The
-    // stage's surface energy balance is not evaluated: its fluxes would only enter through compute_z_bcs!, which
-    // the reference runs for the state alone (heun.jl:54-69).
+    // Heun in ONE launch (TRM_KERNEL_FUSED, Nz <= 64, branch-free boundary kinds): both stages on the column in registers
+    // (k_column<PROG_HEUN>), the stage never touches memory.  The stage's surface energy balance is not evaluated: its
+    // fluxes would only enter through compute_z_bcs!, which the reference runs for the state alone (heun.jl:54-69).
     static int heun_step_fused(trm_ctx* c, double dt, int finalize) {
         int rc = update_inputs(c, c->state, c->time);
+        if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
         if (!rc && c->params.seb) rc = surface(c, c->state, true);
-        if (!rc) rc = wave_step_mode<STEP_HEUN_STAGE>(c, dt, 0);
-        if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock
-        if (!rc) rc = wave_step_mode<STEP_HEUN_FINAL>(c, dt, finalize);
+        if (!rc) rc = column_program<PROG_HEUN>(c, dt, finalize, 1);
+        if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
         c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
     }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
-        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c)) return heun_step_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !c->opt_legacy) return heun_step_fused(c, dt, finalize);
         c->top_valid = false;
         c->tend_valid = true;
+        c->closure_consistent = true;   // (ends with closure!)
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_state(c, c->state, true);
         if (!rc) rc = copy_state_to_stage(c);
@@ -1058,6 +1117,7 @@ int trm_upload(trm_ctx* c, int field, const void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_upload: bad argument");
     TRM_HIP(c, hipSetDevice(c->device));
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
+    if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_consistent = false;
     if (!rc && field == TRM_FIELD_VWC_FORCING) {
         c->opt_vwc_field = 1;
         c->args_valid = false;
@@ -1090,6 +1150,7 @@ int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems
     // the caller may write the state behind the library's back from now on: stop trusting the top-cell copies
     if (field == TRM_FIELD_TEMPERATURE || field == TRM_FIELD_SATURATION_WATER_ICE || field == TRM_FIELD_LIQUID_WATER_FRACTION)
         c->top_escaped = true;
+    if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_escaped = true;   // U, sat, T, liq may change behind the library's back
     c->top_valid = false;
     return TRM_OK;
 }
@@ -1205,6 +1266,7 @@ int trm_clear_series(trm_ctx* c) {
 int trm_initialize(trm_ctx* c) {
     TRM_ENTER(c);
     c->top_valid = false;
+    c->closure_consistent = false;   // temperature is the user's, internal_energy follows from it
     return finish(c, DISPATCH(c, initialize(c)));
 }
 int trm_update_inputs(trm_ctx* c) {
@@ -1234,16 +1296,19 @@ int trm_reset_tendencies(trm_ctx* c) {
 int trm_explicit_step(trm_ctx* c, double dt) {
     TRM_ENTER(c);
     c->top_valid = false;
+    c->closure_consistent = false;
     return finish(c, DISPATCH(c, explicit_step(c, c->state, dt)));
 }
 int trm_closure(trm_ctx* c) {
     TRM_ENTER(c);
     c->top_valid = false;
+    c->closure_consistent = true;
     return finish(c, DISPATCH(c, closure(c, c->state)));
 }
 int trm_invclosure(trm_ctx* c) {
     TRM_ENTER(c);
     c->top_valid = false;
+    c->closure_consistent = false;
     return finish(c, DISPATCH(c, invclosure(c, c->state)));
 }
 
@@ -1268,7 +1333,9 @@ int trm_step_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
 int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
     TRM_ENTER(c);
     if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step_heun: nsteps < 0");
-    if (!c->has_stage) {
+    const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !c->opt_legacy &&
+                            !(c->precision == TRM_F64 ? Ops<double>::generic_bcs(c) : Ops<float>::generic_bcs(c));
+    if (!fused_heun && !c->has_stage) {   // the reference-order kernels work on a second copy of the state
         int rc = alloc_fields(c, c->stage);
         if (rc) return rc;
         c->has_stage = true;
@@ -1299,6 +1366,7 @@ int trm_save_state(trm_ctx* c) {
     c->saved_time = c->time;
     c->saved_iteration = c->iteration;
     c->saved_tend_valid = c->tend_valid;
+    c->saved_closure_consistent = c->closure_consistent;
     return TRM_OK;
 }
 int trm_restore_state(trm_ctx* c) {
@@ -1311,6 +1379,7 @@ int trm_restore_state(trm_ctx* c) {
     c->time = c->saved_time;
     c->iteration = c->saved_iteration;
     c->tend_valid = c->saved_tend_valid;
+    c->closure_consistent = c->saved_closure_consistent;
     c->top_valid = false;
     return finish(c, TRM_OK);
 }
@@ -1355,6 +1424,12 @@ int trm_set_option(trm_ctx* c, int option, int value) {
         case TRM_OPT_WRITE_KF_EVERY_STEP: c->opt_write_kf = value != 0; return TRM_OK;
         case TRM_OPT_VWC_FORCING_FIELD: c->opt_vwc_field = value != 0; return TRM_OK;
         case TRM_OPT_PACKED_F32: c->opt_packed = value != 0; return TRM_OK;
+        case TRM_OPT_DERIVE_CLOSURE_FIELDS: c->opt_derive = value != 0; return TRM_OK;
+        case TRM_OPT_LEGACY_STEP_KERNEL: c->opt_legacy = value != 0; return TRM_OK;
+        case TRM_OPT_STEPS_PER_LAUNCH:
+            if (value < 1 || value > 100000) break;
+            c->opt_steps_per_launch = value;
+            return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -1367,6 +1442,9 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_WRITE_KF_EVERY_STEP: *value = c->opt_write_kf; return TRM_OK;
         case TRM_OPT_VWC_FORCING_FIELD: *value = c->opt_vwc_field; return TRM_OK;
         case TRM_OPT_PACKED_F32: *value = c->opt_packed; return TRM_OK;
+        case TRM_OPT_DERIVE_CLOSURE_FIELDS: *value = c->opt_derive; return TRM_OK;
+        case TRM_OPT_LEGACY_STEP_KERNEL: *value = c->opt_legacy; return TRM_OK;
+        case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

@@ -1,0 +1,326 @@
+// trm_column.hpp -- the register-resident column program (lane = soil level).
+//
+// A soil column lives in the registers of LPC = 32 / 64 lanes for the whole launch.  The three building blocks --
+//   column_tendencies   compute_auxiliary! + compute_tendencies! of the state held in registers (reference a4-a6)
+//   column_advance      compute_z_bcs! + explicit_step! + hydrology closure (repair, water table)  (a7, a9)
+//   column_closure      energy closure + saturation_to_pressure!                                   (a8, a9)
+// are composed into three programs by k_column:
+//   PROG_EULER   one ForwardEuler step                                 (forward_euler.jl:19-31)
+//   PROG_HEUN    one Heun step, both stages in registers: the stage never touches memory       (heun.jl:37-71)
+//   PROG_MULTI   `nsteps` ForwardEuler steps on the resident column, fields written once per launch (temporal
+//                blocking of run!'s loop, model_integrator.jl:72-88; legal because columns are independent)
+// Every operation is the one the per-step kernels perform, in the same order: results are bit-identical to them
+// (tests/test_gpu_column_programs.py).
+//
+// DERIVE: temperature and liquid fraction of the incoming state are re-derived from (U, sat) by the energy closure
+// instead of being read -- legal only when the stored (T, liq) ARE the closure of the stored (U, sat), which the host
+// tracks (trm_ctx::closure_consistent): 2 of the 5 field reads disappear.  The kernel is bound by the bytes it moves
+// (profiles/tools/microbench/memfloor.hip: every access pattern reaches the same floor), so bytes are what counts.
+//
+// Boundary conditions: the branch-free kinds only (Value on temperature, Flux on the prognostics, LandModel wiring);
+// anything else takes k_step_wave<GENERIC_BC = true>.
+#pragma once
+#include "trm_kernels.hpp"
+
+namespace trm {
+
+enum { PROG_EULER = 0, PROG_HEUN = 1, PROG_MULTI = 2 };
+
+template <class NF> struct Cell { NF U, sat, T, liq, psi; };
+// what one lane knows about its place in the column
+struct LaneInfo { int lane, k; bool is_bot, is_top, act; };
+// boundary inputs of this lane's column (every lane of a column holds the same values)
+template <class NF> struct ColumnBC {
+    NF bTb, bTt;            // temperature boundary values (used when the Value condition is set)
+    NF eU_b, eU_t;          // compute_z_bcs! terms of internal_energy at the bottom / top cell (flux * Az / V, signed)
+    NF eS_b, eS_t;          // ... of saturation_water_ice
+};
+template <class NF> struct Tendency { NF gU, gS, Kf_lo, Kc; };
+
+// Energy closure (soil_energy_closures.jl:99-159) for a whole wave: same results as energy_closure(), but the
+// liquid-fraction divide U / (-L_theta + eps) is skipped when no lane needs its value.  For a frozen cell
+// (U < -L_theta) the reference's `false * (1 - x)` is a zero carrying the sign of 1 - x; with L_theta > eps the
+// quotient x of two distinct floats of the same sign and |U| > |denominator| rounds to >= 1 + 2^-52, so 1 - x < 0
+// and the result is -0.0 without dividing.  Cells in phase change (and L_theta <= eps, sat below 1.4e-24) take the
+// divide -- decided per wave by one ballot.
+template <class NF> TRM_DEV void energy_closure_wave(const DevParams<NF>& p, NF U, NF sat, NF& liq, NF& T, uint32_t& viol) {
+    const NF Lth = p.L * sat * p.por;
+    const NF nLth = -Lth;
+    const bool thawed = U >= NF(0), frozen = U < nLth;
+    const bool need_div = !thawed && !(frozen && Lth > Limits<NF>::eps());   // phase change, NaN, vanishing L_theta
+    if (__ballot(need_div) == 0ull) {
+        liq = thawed ? NF(1) : NF(-0.0);
+    } else {
+        liq = thawed ? NF(1) : boolmul(U >= nLth, NF(1) - safediv(U, nLth));
+    }
+    const NF C = heat_capacity(p, fractions(p, sat, liq, viol));
+    const NF num = frozen ? (U + Lth) : U;
+    const NF quo = div_nr(num, C);
+    T = (frozen || thawed) ? quo : NF(0);
+}
+
+// compute_auxiliary! + compute_tendencies! of the column in registers, WITHOUT the compute_z_bcs! terms.
+template <class NF, bool RICHARDS, int HYD, int LPC>
+TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p, const LevelGeom<NF>& L, const LaneInfo& ln,
+                                       const Cell<NF>& c, NF bTb, NF bTt, bool need_kc, uint32_t& viol) {
+    const bool is_bot = ln.is_bot, is_top = ln.is_top;
+    uint32_t viol_old = 0;   // (composition bounds of an incoming state were flagged by the launch / program step that produced it)
+    const Frac<NF> f = fractions(p, c.sat, c.liq, viol_old);
+    const NF kap = conductivity(p, f);
+    const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD, false>(p, c.liq, f) : NF(0);
+    // neighbours by DPP shifts (executed by all lanes, never inside a divergent select)
+    const NF T_sh = shfl_up1<NF, LPC>(c.T), kap_sh = shfl_up1<NF, LPC>(kap);
+    // temperature halos: every condition that is not set costs one wave-uniform branch, every condition that is set is
+    // computed by all lanes and kept by the edge lane
+    NF T_ext_b = c.T, T_ext_t = c.T;
+    if (v.bc.kind[2][0] == 1) T_ext_b = c.T + div_const(c.T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
+    if (v.bc.kind[2][1] == 1) T_ext_t = c.T + div_const(bTt - c.T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
+    const NF T_m = is_bot ? T_ext_b : T_sh;
+    const NF T_h = T_ext_t;
+    // liquid fraction / saturation / pressure head carry the default condition (halo = edge cell): the halo cell's
+    // conductivity is the edge cell's, bit for bit -- except under NoFlow with the reference's never-filled saturation
+    // halo (SURVEY C-1), where the halo cell is dry
+    NF kap_halo = kap;
+    if (!RICHARDS && p.halo_policy != 1) kap_halo = conductivity(p, fractions(p, NF(0), c.liq, viol));
+    const NF kap_m = is_bot ? kap_halo : kap_sh;
+    const NF kap_h = kap_halo;
+    // heat: every lane forms its lower face, the top lane also the boundary face (soil_energy.jl:112-149)
+    const NF qT_lo = -(NF(0.5) * (kap + kap_m)) * ((c.T - T_m) * L.rdzf_lo);
+    const NF qT_sh = shfl_dn1<NF, LPC>(qT_lo);
+    const NF qT_hi = is_top ? -(NF(0.5) * (kap_h + kap)) * ((T_h - c.T) * L.rdzf_hi) : qT_sh;
+    Tendency<NF> t;
+    t.gU = NF(0) + (-((qT_hi - qT_lo) * L.rdzc));
+    t.gS = NF(0);
+    t.Kf_lo = NF(0);
+    t.Kc = Kc;
+    if (need_kc) {   // face conductivities (soil_hydrology.jl:145-163)
+        const NF Kc_m = shfl_up1<NF, LPC>(Kc);
+        const NF Kmin = jl_min(Kc, Kc_m);
+        t.Kf_lo = (is_bot || is_top) ? Kc : Kmin;
+    }
+    if (RICHARDS) {  // Darcy fluxes (soil_hydrology_rre.jl:95-131)
+        const NF Kf_lo = t.Kf_lo;
+        const NF Kf_up = shfl_up1<NF, LPC>(Kf_lo), Kf_dn = shfl_dn1<NF, LPC>(Kf_lo), psi_sh = shfl_up1<NF, LPC>(c.psi);
+        const NF Kf_m = is_bot ? NF(0) : Kf_up;   // halo face below: never written (0)
+        const NF Kf_p = is_top ? Kc : Kf_dn;      // face Nz repeats the top cell's value
+        const NF psi_m = is_bot ? c.psi : psi_sh;
+        const NF g_lo = (c.psi - psi_m) * L.rdzf_lo;
+        const NF Ks_lo = upwind_conductivity(g_lo, Kf_m, Kf_lo, Kf_p);
+        const NF qW_lo = -Ks_lo * g_lo;
+        const NF qW_sh = shfl_dn1<NF, LPC>(qW_lo);
+        // boundary face above the top cell, default condition: the halo cell repeats psi, so the head difference is +0
+        // (NaN for a non-finite psi), never negative: K* = min(K, K_halo_face = 0)
+        const NF zero_or_nan = c.psi - c.psi;
+        const NF qW_t = -jl_min(Kc, NF(0)) * zero_or_nan;
+        const NF qW_hi = is_top ? qW_t : qW_sh;
+        const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
+        t.gS = NF(0) + div_const(dtheta, p.por, p.rpor);
+    }
+    return t;
+}
+
+// compute_z_bcs! + explicit_step! + the hydrology closure's repair and water table for the column in registers.
+// (gU, gS): tendencies WITHOUT the boundary flux terms (they are added here); S_GS: tendency of surface_excess_water
+// (top lane).  S is owned by the top lane.  Returns the new (U, sat) in `n`, the water table in z0.
+template <class NF, bool RICHARDS, int LPC>
+TRM_DEV void column_advance(const View<NF>& v, const LevelGeom<NF>& L, const LaneInfo& ln, int Nz, const ColumnBC<NF>& bc,
+                            NF U0, NF sat0, NF& gU, NF& gS, NF dt, NF& S, NF GS, Cell<NF>& n, NF& z0, bool& bad) {
+    const NF flux_U = ln.is_bot ? bc.eU_b : (ln.is_top ? bc.eU_t : NF(0));
+    gU += flux_U;
+    n.U = U0 + gU * dt;
+    bad = bad || (ln.act && is_nan(n.U));
+    n.sat = sat0;
+    z0 = NF(0);
+    if (RICHARDS) {
+        const NF flux_S = ln.is_bot ? bc.eS_b : (ln.is_top ? bc.eS_t : NF(0));
+        gS += flux_S;
+        NF snew = sat0 + gS * dt;
+        bad = bad || (ln.act && is_nan(snew));
+        const NF over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.act, ln.is_bot, ln.is_top, L);
+        z0 = water_table<NF, LPC>(snew, ln.act, ln.lane, L);
+        n.sat = snew;
+        S = (S + GS * dt) + over;   // (meaningful in the top lane only)
+    }
+}
+
+template <class NF, bool RICHARDS, int HYD>
+TRM_DEV void column_closure(const DevParams<NF>& p, const LevelGeom<NF>& L, NF z0, Cell<NF>& n, uint32_t& viol) {
+    energy_closure_wave(p, n.U, n.sat, n.liq, n.T, viol);
+    n.psi = RICHARDS ? pressure_head<NF, HYD>(p, n.sat, L.zC, L.psiz, z0) : NF(0);
+}
+
+// LandModel inside the program (PROG_MULTI): the 0-D surface processes of the column, evaluated by its top lane from
+// the registers (land_model.jl:79-88) -- what k_surface<FROM_STATE> does in front of a per-step launch.
+template <class NF> struct SurfaceRegs {
+    SebIn<NF> in;
+    SebOut<NF> out;   // out.Ts is the prognostic skin temperature
+};
+
+template <class NF> struct ColumnArgs {
+    NF dt;
+    int finalize, write_kf, nsteps;
+    // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
+    const NF *bcT_bot_stage, *bcT_top_stage;
+};
+
+template <class NF, bool RICHARDS, int HYD, int LPC, bool DERIVE, int PROG, bool SEB_INLINE>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column(View<NF> v, DevParams<NF> p, ColumnArgs<NF> a) {
+    static_assert(!SEB_INLINE || PROG == PROG_MULTI, "the in-kernel surface energy balance belongs to the multi-step program");
+    constexpr int CPW = 64 / LPC;
+    LaneInfo ln;
+    ln.lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    ln.k = ln.lane % LPC;
+    const int sub = ln.lane / LPC;
+    const int Nz = v.Nz, Nh = (int)v.Nh;
+    ln.is_bot = ln.k == 0;
+    ln.is_top = ln.k == Nz - 1;
+    const LevelGeom<NF> L = level_geom(v, ln.k);
+    const NF dt = a.dt;
+    const int finalize = a.finalize, write_kf = a.write_kf;
+    const bool need_kc = RICHARDS || write_kf;
+
+    const int i = wave * CPW + sub;
+    const bool colok = i < Nh;
+    ln.act = colok && ln.k < Nz;
+    const int ii = colok ? i : Nh - 1;
+    const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
+    const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);
+    uint32_t viol = 0;
+    bool bad = false;
+
+    // ---- the column comes in: 5 (3 with DERIVE) coalesced reads -------------------------------------------------------
+    Cell<NF> c;
+    c.U = ldg(v.U, cb0);
+    c.sat = ldg(v.sat, cb0);
+    c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
+    if (DERIVE) {
+        uint32_t viol_in = 0;
+        energy_closure_wave(p, c.U, c.sat, c.liq, c.T, viol_in);
+    } else {
+        c.T = ldg(v.T, cb0);
+        c.liq = ldg(v.liq, cb0);
+    }
+    // ---- boundary inputs of the column --------------------------------------------------------------------------------
+    const bool seb = p.seb != 0;
+    const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
+    ColumnBC<NF> bc;
+    bc.bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0);
+    bc.bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
+    bc.eU_b = bc.eU_t = bc.eS_b = bc.eS_t = NF(0);
+    if (v.bc.kind[0][0] == 2) bc.eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib0), v.g);
+    if (RICHARDS && v.bc.kind[1][0] == 2) bc.eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib0), v.g);
+    if (!SEB_INLINE) {
+        // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this
+        // launch.  Top terms enter with a minus sign.
+        if (seb || v.bc.kind[0][1] == 2) bc.eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib0), v.g);
+        if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
+            const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
+            bc.eS_t = -flux_term_top(seb ? -fS : fS, v.g);
+        }
+    }
+    // column scalars owned by the top lane (every lane loads them: same address within a column)
+    NF S = RICHARDS ? ldg(v.S, ib0) : NF(0);
+    SurfaceRegs<NF> sf;
+    if (SEB_INLINE) {
+        sf.in = SebIn<NF>{ldg(v.Tair, ib0), ldg(v.pres, ib0), ldg(v.wind, ib0), ldg(v.qair, ib0), ldg(v.rain, ib0), ldg(v.swd, ib0), ldg(v.lwd, ib0)};
+        sf.out.Ts = ldg(v.Ts, ib0);
+    }
+
+    Cell<NF> n = c;          // the state after the program's last step
+    Tendency<NF> t{};        // tendencies of the last evaluation at the STATE (hydraulic_conductivity comes from here)
+    NF gU_out = NF(0), gS_out = NF(0), GS_out = NF(0), z0 = NF(0);
+
+    if (PROG == PROG_HEUN) {
+        // stage 1: tendencies at the state, Euler predictor (with the state's boundary fluxes) and its closures
+        t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
+        const NF G1U = t.gU, G1S = t.gS;
+        const NF GS1 = NF(0) + jl_min(NF(0), S);
+        NF gU = G1U, gS = G1S, S_stage = S, z0s;
+        Cell<NF> s;
+        column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, S_stage, GS1, s, z0s, bad);
+        column_closure<NF, RICHARDS, HYD>(p, L, z0s, s, viol);
+        // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
+        const NF bTb2 = vTb ? ldg(a.bcT_bot_stage, ib0) : NF(0), bTt2 = vTt ? ldg(a.bcT_top_stage, ib0) : NF(0);
+        uint32_t viol_stage = 0;
+        const Tendency<NF> t2 = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, s, bTb2, bTt2, RICHARDS, viol_stage);
+        viol |= viol_stage;
+        // average_tendencies! (heun.jl:27-35), then the step of the STATE with its own boundary fluxes
+        gU = (G1U + t2.gU) / NF(2);
+        gS = RICHARDS ? (G1S + t2.gS) / NF(2) : NF(0);
+        const NF GS = (GS1 + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
+        column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, S, GS, n, z0, bad);
+        column_closure<NF, RICHARDS, HYD>(p, L, z0, n, viol);
+        gU_out = gU; gS_out = gS; GS_out = GS;
+    } else {
+        const int nsteps = PROG == PROG_MULTI ? a.nsteps : 1;
+        for (int step = 0; step < nsteps; ++step) {
+            if (PROG == PROG_MULTI && step > 0) c = n;
+            if (SEB_INLINE) {
+                // compute_auxiliary! of the surface processes from the top cell in registers (k_surface<FROM_STATE>)
+                uint32_t viol_s = 0;
+                const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, c.liq, fractions(p, c.sat, c.liq, viol_s));
+                const NF Ts_in = sf.out.Ts;
+                surface_processes(p, sf.in, Ts_in, c.T, c.sat, Kf_top, S, RICHARDS, v.g.dzc_top, sf.out);
+                bc.eU_t = -flux_term_top(sf.out.ghf, v.g);
+                if (RICHARDS) bc.eS_t = -flux_term_top(-sf.out.infil, v.g);
+                sf.out.Ts = sf.out.Ts + NF(0) * dt;   // zero-tendency prognostic skin_temperature
+            }
+            t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
+            NF gU = t.gU, gS = t.gS;
+            const NF GS = NF(0) + jl_min(NF(0), S);
+            column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, S, GS, n, z0, bad);
+            column_closure<NF, RICHARDS, HYD>(p, L, z0, n, viol);
+            gU_out = gU; gS_out = gS; GS_out = GS;
+        }
+    }
+
+    // ---- hydraulic_conductivity of the state: K(state the last tendencies saw), K(new state) when finalizing -----------
+    NF Kf_out = t.Kf_lo, Kf_out_top = t.Kc;
+    if (finalize && write_kf) {
+        const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(p, n.liq, fractions(p, n.sat, n.liq, viol));
+        const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
+        const NF Kmin_new = jl_min(Kc_new, Kc_new_m);
+        Kf_out = (ln.is_bot || ln.is_top) ? Kc_new : Kmin_new;
+        Kf_out_top = Kc_new;
+    }
+    // ---- the column goes out: 6 coalesced stores ---------------------------------------------------------------------------
+    if (ln.act) {
+        const unsigned cb = block_local(cb0), ib = block_local(ib0);
+        stg(v.U, cb, n.U);
+        stg(v.T, cb, n.T);
+        stg(v.liq, cb, n.liq);
+        if (RICHARDS) { stg(v.sat, cb, n.sat); stg(v.psi, cb, n.psi); }
+        if (finalize) {   // state.tendencies as the reference leaves them after its last step
+            stg(v.G_U, cb, gU_out);
+            if (RICHARDS) stg(v.G_sat, cb, gS_out);
+        }
+        if (write_kf) {
+            stg(v.Kf, cb, Kf_out);
+            if (ln.is_top) stg(v.Kf_top, ib, Kf_out_top);
+        }
+        if (ln.is_top) {
+            if (RICHARDS) {
+                stg(v.S, ib, S);
+                stg(v.wt, ib, z0);
+                if (finalize) stg(v.G_S, ib, GS_out);
+            }
+            if (seb) {   // the next surface energy balance reads these
+                stg(v.top_T, ib, n.T);
+                stg(v.top_sat, ib, n.sat);
+                stg(v.top_liq, ib, n.liq);
+                if (SEB_INLINE) {
+                    const SebOut<NF>& o = sf.out;
+                    stg(v.Ts, ib, o.Ts); stg(v.ghf, ib, o.ghf); stg(v.swu, ib, o.swu); stg(v.lwu, ib, o.lwu); stg(v.rnet, ib, o.rnet);
+                    stg(v.Hs, ib, o.Hs); stg(v.Hl, ib, o.Hl); stg(v.evap, ib, o.evap); stg(v.infil, ib, o.infil); stg(v.runoff, ib, o.runoff);
+                } else {
+                    stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);   // zero-tendency prognostic skin_temperature
+                }
+            }
+        }
+        viol |= bad ? 1u : 0u;
+    }
+    if (viol) atomicOr(v.status, viol);
+}
+
+}  // namespace trm

@@ -66,6 +66,31 @@ template <class NF> TRM_HD NF div_const(NF a, NF b, NF rb) {
     NF q2 = fma_(r, rb, q);
     return (q == NF(0)) ? q : q2;  // keeps the sign of a zero quotient
 }
+// n / d for VARIABLE operands in fp64 without the scaling steps of the full IEEE sequence.  The compiler expands `/` to
+// v_div_scale x2, v_rcp, two Newton steps on the reciprocal, q = n * y, the residual fma, v_div_fmas, v_div_fixup.
+// v_div_scale leaves its operand unchanged (and v_div_fmas is a plain fma) unless the divisor is denormal or beyond
+// 2^1021, the numerator is below 2^-969, or the quotient leaves the normal range; v_div_fixup supplies the zero /
+// infinity / NaN cases from the original operands.  Every divide of the step has a divisor that is normal and bounded
+// for any legal composition -- heat capacity C >= 1e3, theta_sat ~ porosity, -L_theta + eps in [4.9e-32, 2e8],
+// r = theta / span in (0, 1] -- and numerators (energies, water contents, 1) far above 2^-969, so the sequence below
+// IS the hardware divide with its no-op steps removed: bit-identical (tests/test_gpu_parity.py::test_divide_sequences).
+// Outside those ranges (|numerator| < 2e-292, saturation below 4.5e-308) the last bit / the overflow case may differ.
+TRM_HD double div_nr(double n, double d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    q = __builtin_fma(r, y, q);
+    return __builtin_amdgcn_div_fixup(q, d, n);
+#else
+    return n / d;
+#endif
+}
+TRM_HD float div_nr(float n, float d) { return n / d; }
 // Bool * Float: `false` is a strong zero carrying the sign of x.
 template <class NF> TRM_HD NF boolmul(bool b, NF x) { return b ? x : copysign_(NF(0), x); }
 
@@ -93,7 +118,7 @@ template <class NF> TRM_DEV NF upwind_conductivity(NF g, NF Kdn, NF Kmid, NF Kup
 }
 
 // src/utils/utils.jl:25
-template <class NF> TRM_HD NF safediv(NF x, NF y) { return (y == NF(0)) ? Limits<NF>::inf() : x / (y + Limits<NF>::eps()); }
+template <class NF> TRM_HD NF safediv(NF x, NF y) { return (y == NF(0)) ? Limits<NF>::inf() : div_nr(x, y + Limits<NF>::eps()); }
 
 // Base.Math.pow_body(x, n::Integer): compensated power by squaring.
 template <class NF> TRM_HD NF pow_int(NF x, int n) {
@@ -177,7 +202,7 @@ TRM_DEV float fabs_(float x) { return fabsf(x); }
 // finite x (x * 0 and 1 * x folded; they are exact), i.e. bit-identical -- the BrooksCorey default
 // lambda = 0.2 evaluates r^(-1/lambda) = r^(-5.0) for every cell and step.
 template <class NF> TRM_HD NF pow_int_m5(NF x) {
-    const NF rx = NF(1) / x;
+    const NF rx = div_nr(NF(1), x);
     const NF l0 = -fma_(x, rx, NF(-1)) * rx;     // low part of 1/x
     // n = 5 (odd): y = rx, ynlo = 0 + l0
     const NF ynlo = NF(0) + (l0 + NF(0));
@@ -302,7 +327,7 @@ template <class NF> __device__ __noinline__ NF vg_conductivity_complex(NF x, NF 
 // hydraulic_conductivity at a cell centre (soil_hydraulic_properties.jl:170-181, 203-221)
 template <class NF> TRM_DEV NF conductivity_linear(const DevParams<NF>& p, const Frac<NF>& f) {
     NF theta_sat = f.water + f.ice + f.air;
-    return p.K_sat * f.water / theta_sat;
+    return div_nr(p.K_sat * f.water, theta_sat);
 }
 // COMPLEX_FALLBACK = false (the fused step): a state outside 0 <= x <= 1 is an illegal composition -- the reference's
 // CPU path stops at its SoilVolume @assert (soil_volume.jl:26-28) before K is ever evaluated, here it is reported through
@@ -342,7 +367,7 @@ template <class NF> TRM_DEV void energy_closure(const DevParams<NF>& p, NF U, NF
     NF C = heat_capacity(p, fractions(p, sat, liq, viol));
     // (U < -Lth) ? (U + Lth) / C : (U >= 0 ? U / C : 0): one divide, operands selected first
     NF num = (U < -Lth) ? (U + Lth) : U;
-    NF quo = num / C;
+    NF quo = div_nr(num, C);
     T = (U < -Lth || U >= NF(0)) ? quo : NF(0);
 }
 // inverse (initialisation only, soil_energy_closures.jl:64-97): (T, sat) -> (liq, U)

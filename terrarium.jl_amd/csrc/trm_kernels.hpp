@@ -501,20 +501,10 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 // Diagnostic variants (memory-only, compute-only, extra VALU, per-wave time stamps) are NOT in
 // this translation unit: profiles/tools/make_diag_variants.py derives them from this source into build/diag/.
 //
-// MODE selects the integrator stage (heun.jl:37-71); `w` holds the Heun stage's buffers:
-//   STEP_EULER        v -> v                                   (forward_euler.jl:19-31)
-//   STEP_HEUN_STAGE   reads the state v, keeps its tendencies G1 in v's tendency fields, writes the Euler
-//                     predictor (+ closure) into the stage w                         (heun.jl:41-52)
-//   STEP_HEUN_FINAL   tendencies G2 of the stage w, G = (G1 + G2) / 2, boundary fluxes of the state (the stage's
-//                     boundary fluxes never enter: compute_z_bcs! runs inside explicit_step! only), v -> v   (heun.jl:54-69)
-enum { STEP_EULER = 0, STEP_HEUN_STAGE = 1, STEP_HEUN_FINAL = 2 };
-template <class NF> struct StageView {
-    NF *U, *sat, *T, *liq, *psi, *S, *wt, *Ts;
-    const NF *bcT_bot, *bcT_top;   // the stage's temperature boundary values (evaluated at t + dt for a series)
-};
-template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC, int MODE>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageView<NF> w, DevParams<NF> p, NF dt, int finalize, int write_kf) {
-    static_assert(!(GENERIC_BC && MODE != STEP_EULER), "the Heun stages use the branch-free boundary path");
+// This kernel serves the GENERIC boundary kinds (and the legacy A/B comparator of the branch-free path); the branch-free
+// Euler step, Heun and the multi-step program live in trm_column.hpp (k_column).
+template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
     constexpr int CPW = 64 / LPC;   // columns per wave
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
@@ -532,14 +522,10 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(k < Nz ? k : Nz - 1)) * (unsigned)sizeof(NF), cb = cb0;
     uint32_t viol = 0;
 
-    // (U, sat, T, liq, psi): the state the tendencies are evaluated at -- the stage's in STEP_HEUN_FINAL
-    const bool from_stage = MODE == STEP_HEUN_FINAL;
-    // (without Richards flow the saturation is not prognostic: the stage never gets a copy, the state's is read)
-    const NF U = ldg(from_stage ? w.U : v.U, cb), sat = ldg((from_stage && RICHARDS) ? w.sat : v.sat, cb);
-    const NF T = ldg(from_stage ? w.T : v.T, cb), liq = ldg(from_stage ? w.liq : v.liq, cb);
-    const NF psi = RICHARDS ? ldg(from_stage ? w.psi : v.psi, cb) : NF(0);
-    // (U0, sat0): the state that is advanced
-    const NF U0 = from_stage ? ldg(v.U, cb) : U, sat0 = from_stage ? ldg(v.sat, cb) : sat;
+    const NF U = ldg(v.U, cb), sat = ldg(v.sat, cb);
+    const NF T = ldg(v.T, cb), liq = ldg(v.liq, cb);
+    const NF psi = RICHARDS ? ldg(v.psi, cb) : NF(0);
+    const NF U0 = U, sat0 = sat;
 
     // (composition bounds of the incoming state were flagged by the launch that produced it)
     uint32_t viol_old = 0;
@@ -597,11 +583,11 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
         NF T_ext_b = T, T_ext_t = T;
         if (vTb) {
-            const NF bTb = ldg(from_stage ? w.bcT_bot : bcval(v, 2, 0), ib);
+            const NF bTb = ldg(bcval(v, 2, 0), ib);
             T_ext_b = T + div_const(T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
         }
         if (vTt) {
-            const NF bTt = ldg(from_stage ? w.bcT_top : bcval(v, 2, 1), ib);
+            const NF bTt = ldg(bcval(v, 2, 1), ib);
             T_ext_t = T + div_const(bTt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
         }
         T_m = is_bot ? T_ext_b : T_sh;
@@ -678,12 +664,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + F_user;
         gS = NF(0) + div_const(dtheta, p.por, p.rpor);
     }
-    // ---- Heun: keep G1 (stage launch) / average with G1 (final launch), average_tendencies! heun.jl:27-35 ----
-    const NF gU_stage = gU, gS_stage = gS;
-    if (MODE == STEP_HEUN_FINAL) {
-        gU = (ldg(v.G_U, cb) + gU) / NF(2);
-        if (RICHARDS) gS = (ldg(v.G_sat, cb) + gS) / NF(2);
-    }
     // ---- compute_z_bcs!: flux BCs into the boundary cells (x + 0 is exact for the interior lanes) -------
     gU += flux_U;
     if (RICHARDS) gS += flux_S;
@@ -700,18 +680,16 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
             // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler update, overflow
             const unsigned ib = block_local(ib0);
             NF S = ldg(v.S, ib);
-            NF GS = NF(0) + jl_min(NF(0), MODE == STEP_HEUN_FINAL ? ldg(w.S, ib) : S);
-            if (MODE == STEP_HEUN_STAGE) stg(v.G_S, ib, GS);
-            if (MODE == STEP_HEUN_FINAL) GS = (ldg(v.G_S, ib) + GS) / NF(2);
-            if (MODE != STEP_HEUN_STAGE && finalize) stg(v.G_S, ib, GS);
+            const NF GS = NF(0) + jl_min(NF(0), S);
+            if (finalize) stg(v.G_S, ib, GS);
             S = S + GS * dt;
-            stg(MODE == STEP_HEUN_STAGE ? w.S : v.S, ib, S + over);
-            stg(MODE == STEP_HEUN_STAGE ? w.wt : v.wt, ib, z0);
+            stg(v.S, ib, S + over);
+            stg(v.wt, ib, z0);
         }
     }
     if (act && is_top && p.seb) {   // zero-tendency prognostic skin_temperature
         const unsigned ib = block_local(ib0);
-        stg(MODE == STEP_HEUN_STAGE ? w.Ts : v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
+        stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
     }
     // ---- closures: (U, sat) -> (T, liq, psi) ------------------------------------------------------------------
     NF ln, Tn;
@@ -727,27 +705,23 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, StageV
     }
     if (act) {
         const unsigned cb = block_local(cb0), ib = block_local(ib0);
-        const bool to_stage = MODE == STEP_HEUN_STAGE;
-        stg(to_stage ? w.U : v.U, cb, Unew);
-        stg(to_stage ? w.T : v.T, cb, Tn);
-        stg(to_stage ? w.liq : v.liq, cb, ln);
-        if (RICHARDS) { stg(to_stage ? w.sat : v.sat, cb, snew); stg(to_stage ? w.psi : v.psi, cb, psin); }
-        if (MODE == STEP_HEUN_STAGE) {
-            stg(v.G_U, cb, gU_stage);
-            if (RICHARDS) stg(v.G_sat, cb, gS_stage);
-        } else if (finalize) {
+        stg(v.U, cb, Unew);
+        stg(v.T, cb, Tn);
+        stg(v.liq, cb, ln);
+        if (RICHARDS) { stg(v.sat, cb, snew); stg(v.psi, cb, psin); }
+        if (finalize) {
             // state.tendencies as the reference leaves them after its last step: compute_tendencies! (averaged for
             // Heun) plus the compute_z_bcs! term explicit_step! added.  Only the finalizing launch stores them.
             stg(v.G_U, cb, gU);
             if (RICHARDS) stg(v.G_sat, cb, gS);
         }
-        if (MODE != STEP_HEUN_STAGE && is_top && p.seb) {   // the next surface energy balance reads these
+        if (is_top && p.seb) {   // the next surface energy balance reads these
             stg(v.top_T, ib, Tn);
             stg(v.top_sat, ib, snew);
             stg(v.top_liq, ib, ln);
         }
-        // hydraulic_conductivity of the state: K(old state) from the Euler / stage launch, K(new state) when finalizing
-        if (write_kf && (MODE != STEP_HEUN_FINAL || finalize)) {
+        // hydraulic_conductivity of the state: K(old state), K(new state) when finalizing
+        if (write_kf) {
             stg(v.Kf, block_local(cb0), Kf_out);
             if (is_top) stg(v.Kf_top, block_local(ib0), Kf_out_top);
         }

@@ -1,0 +1,180 @@
+"""The register-resident column programs (csrc/trm_column.hpp: k_column) against the per-step kernels they replace
+and against the oracle: ForwardEuler with temperature / liquid fraction derived in registers, Heun in one launch, and
+`m` steps per launch with the column held in registers.  All three must be BIT-IDENTICAL to the round-1 step kernel /
+the reference-order kernels -- they perform the same operations in the same order."""
+import numpy as np
+import pytest
+
+import workloads as W
+import terrarium_jl_amd as trm
+
+pytestmark = pytest.mark.gpu
+
+
+def small_columns(n, name="N72"):
+    lat, lon = W.columns_from_mask(name)
+    sel = np.linspace(0, lat.size - 1, n).astype(int)
+    return lat[sel], lon[sel]
+
+
+def all_fields(w):
+    return W.compared_fields(w)
+
+
+CONFIGS = [("heat", "default", np.float64, 30), ("richards", "default", np.float64, 32), ("richards", "vg", np.float64, 20),
+           ("land", "default", np.float64, 32), ("land", "vg", np.float64, 50), ("richards", "vg", np.float32, 64),
+           ("land", "vg", np.float32, 40), ("heat", "default", np.float32, 20)]
+
+
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz", CONFIGS)
+def test_euler_program_equals_legacy_kernel_bitwise(config, hydraulics, dtype, Nz):
+    """k_column<PROG_EULER>, reading T / liq on its first step and deriving them from (U, sat) afterwards, against the
+    round-1 k_step_wave and against the same program with the derivation switched off."""
+    lat, lon = small_columns(203)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    if config == "heat":
+        w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(lat.size, 0.05))
+        w["bcs"][("temperature", "bottom")] = ("value", np.full(lat.size, 1.5))
+    new, noderive, legacy = W.setup_device(w), W.setup_device(w), W.setup_device(w)
+    noderive.set_option("derive_closure_fields", 0)
+    legacy.set_option("legacy_step_kernel", 1)
+    for d in (new, noderive, legacy):
+        d.set_option("packed_f32", 0)
+        d.step(w["dt"], 1, finalize=False)      # first step: stored T / liq are the user's
+        d.step(w["dt"], 23, finalize=False)
+        d.step(w["dt"], 1, finalize=True)
+    for n in all_fields(w) + ["tend_internal_energy"]:
+        a = legacy.get(n)
+        assert np.array_equal(new.get(n), a, equal_nan=True), n
+        assert np.array_equal(noderive.get(n), a, equal_nan=True), n
+    assert new.status() == legacy.status()
+
+
+def test_derivation_is_dropped_when_the_state_is_touched():
+    """An upload of T between steps makes the stored (T, liq) the user's again: the next step must read them."""
+    lat, lon = small_columns(100)
+    w = W.make_workload("richards", lat, lon, 32)
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("legacy_step_kernel", 1)
+    for d in (a, b):
+        d.step(w["dt"], 5, finalize=False)
+        T = d.get("temperature")
+        d.set("temperature", T + 0.25)          # inconsistent with U on purpose
+        d.step(w["dt"], 5, finalize=True)
+    for n in all_fields(w):
+        assert np.array_equal(a.get(n), b.get(n)), n
+    # save / restore keeps the bookkeeping straight
+    a.save_state(); b.save_state()
+    for d in (a, b):
+        d.set("internal_energy", d.get("internal_energy") * 1.01)
+        d.restore_state()
+        d.step(w["dt"], 3, finalize=True)
+    for n in all_fields(w):
+        assert np.array_equal(a.get(n), b.get(n)), n
+
+
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz", CONFIGS)
+def test_heun_single_launch_equals_reference_order_kernels_bitwise(config, hydraulics, dtype, Nz):
+    lat, lon = small_columns(131)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    if config == "heat":
+        w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(lat.size, 0.05))
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("step_kernel", "unfused")
+    for d in (a, b):
+        d.step_heun(w["dt"], 12, finalize=False)
+        d.step_heun(w["dt"], 1, finalize=True)
+    for n in all_fields(w) + ["tend_internal_energy"]:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+
+
+@pytest.mark.parametrize("m", [2, 7, 50])
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz", CONFIGS)
+def test_multistep_program_equals_per_step_launches_bitwise(config, hydraulics, dtype, Nz, m):
+    """TRM_OPT_STEPS_PER_LAUNCH = m: the column stays in registers for m steps (LandModel: with the surface energy
+    balance evaluated in the kernel) -- same state, diagnostics, tendencies, clock and status as one launch per step."""
+    lat, lon = small_columns(131)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("steps_per_launch", m)
+    for d in (a, b):
+        d.set_option("packed_f32", 0)
+        d.step(w["dt"], 23, finalize=False)     # 23 = q * m + r: full launches and a shorter last one
+        d.step(w["dt"], 10, finalize=True)
+    assert a.clock() == b.clock()
+    for n in all_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else []):
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status()
+
+
+def test_multistep_with_repair_and_overflow_matches_oracle():
+    """Columns that overflow into surface_excess_water and cells that the repair touches, 40 steps in launches of 8."""
+    lat, lon = small_columns(64)
+    w = W.make_workload("richards", lat, lon, 32)
+    sat = w["fields"]["saturation_water_ice"].copy()
+    sat[-3:, ::3] = 0.999                        # nearly saturated top cells over a wetting profile
+    sat[5:9, 1::4] = 1.0
+    w["fields"]["saturation_water_ice"] = sat
+    w["bcs"][("saturation_water_ice", "top")] = ("flux", np.full(lat.size, -2.0e-6))   # infiltration into a full column
+    d, o = W.setup_device(w), W.setup_oracle(w)
+    d.set_option("steps_per_launch", 8)
+    d.step(w["dt"], 40, finalize=True)
+    o.run(w["dt"], 40)
+    assert np.any(d.get("surface_excess_water") > 0)
+    for n in all_fields(w):
+        assert np.array_equal(d.get(n), o.get(n)), n
+
+
+def test_multistep_falls_back_with_series_and_generic_bcs():
+    lat, lon = small_columns(70)
+    w = W.make_workload("heat", lat, lon, 20)
+    a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("steps_per_launch", 10)
+    times = np.array([0.0, 3000.0, 9000.0])
+    vals = np.stack([w["T0"] + x for x in (0.0, 4.0, -3.0)])
+    for d in (a, b):
+        d.set_bc_series("temperature", "top", "value", times, vals)
+        d.step(w["dt"], 25, finalize=True)
+    assert np.array_equal(a.get("temperature"), b.get("temperature"))
+    for d in (a, b):
+        d.set_bc("temperature", "bottom", "gradient", 0.01)
+        d.step(w["dt"], 25, finalize=True)
+    assert np.array_equal(a.get("temperature"), b.get("temperature"))
+
+
+def test_divide_sequences():
+    """div_nr (trm_device.hpp): the step's variable-divisor divides without v_div_scale / v_div_fmas.  Through the C ABI:
+    the energy closure T = U / C and the linear hydraulic conductivity K_sat * water / theta_sat over sweeps of operands
+    (random mantissas, edge exponents of the legal ranges, zeros) must equal numpy's IEEE division bit for bit."""
+    rng = np.random.default_rng(7)
+    Nh, Nz = 4096, 32
+    p = trm._capi.default_params()
+    p.flow = 1
+    d = trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=Nz), Nh), p)
+    por = 0.49
+    sat = rng.uniform(1e-6, 1.0, (Nz, Nh))
+    sat[0] = np.ldexp(rng.uniform(0.5, 1.0, Nh), rng.integers(-60, 0, Nh))      # tiny saturations
+    U = np.concatenate([rng.uniform(0.0, 1e9, (Nz // 2, Nh)), np.ldexp(rng.uniform(0.5, 1, (Nz // 2, Nh)), rng.integers(-200, 30, (Nz // 2, Nh)))])
+    U[3, :7] = 0.0
+    frozen = rng.random((Nz, Nh)) < 0.4
+    L = p.rho_w * p.Lsl
+    Lth = L * sat * por
+    U = np.where(frozen, -Lth - U, U)            # thawed (U >= 0) or fully frozen (U < -L_theta)
+    d.set("internal_energy", U)
+    d.set("saturation_water_ice", sat)
+    d.closure()
+    liq = np.where(U >= 0, 1.0, 0.0)
+    wi = sat * por
+    water, ice, air = wi * liq, wi * (1.0 - liq), (1.0 - sat) * por
+    C = p.c_water * water
+    C = C + p.c_ice * ice
+    C = C + p.c_air * air
+    C = C + p.c_mineral * ((1.0 - por) * 1.0)
+    C = C + p.c_organic * ((1.0 - por) * 0.0)
+    T_expected = np.where(U >= 0, U, U + Lth) / C
+    assert np.array_equal(d.get("temperature"), T_expected)
+    d.compute_auxiliary()
+    K_expected = (p.K_sat * water) / (water + ice + air)
+    Kc = d.get("hydraulic_conductivity")
+    assert np.array_equal(Kc[0], K_expected[0]) and np.array_equal(Kc[-1], K_expected[-1])
+    assert np.array_equal(Kc[1:-2], np.minimum(K_expected[1:-1], K_expected[:-2]))
