@@ -122,10 +122,11 @@ enum {
     TRM_OPT_VWC_FORCING_FIELD = 3,  /* 1 after TRM_FIELD_VWC_FORCING was uploaded: per-cell vwc_forcing; 0: scalar */
     TRM_OPT_PACKED_F32 = 4,         /* 1 (default): fp32 contexts with the reference-default hydraulics step two       */
                                     /* columns per lane with packed fp32 instructions (bit-identical results); 0: off */
-    TRM_OPT_DERIVE_CLOSURE_FIELDS = 5, /* 1 (default): when the stored temperature / liquid_water_fraction are known to be */
-                                    /* the energy closure of the stored internal_energy / saturation (the library wrote   */
-                                    /* them), a fused step re-derives them in registers instead of reading them: 2 of 5   */
-                                    /* field reads less, bit-identical results; 0: always read them                        */
+    TRM_OPT_DERIVE_CLOSURE_FIELDS = 5, /* When the stored temperature / liquid_water_fraction are known to be the energy     */
+                                    /* closure of the stored internal_energy / saturation (the library wrote them), a fused   */
+                                    /* Euler step can re-derive them in registers instead of reading them: 2 of 5 field reads */
+                                    /* less, bit-identical results.  0: never; 1: whenever legal; 2 (default): when the state  */
+                                    /* one step touches exceeds the 256 MiB Infinity Cache (it loses below that)  */
     TRM_OPT_LEGACY_STEP_KERNEL = 6, /* 1: round-1 step kernel (k_step_wave) for the branch-free boundary kinds -- the A/B  */
                                     /* comparator of the column programs; Heun then runs on the reference-order kernels    */
     TRM_OPT_STEPS_PER_LAUNCH = 7    /* m >= 1 (default 1): trm_step keeps every column in registers for up to m steps per   */

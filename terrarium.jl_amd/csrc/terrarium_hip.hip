@@ -71,7 +71,7 @@ struct trm_ctx {
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
-    int opt_derive = 1, opt_legacy = 0, opt_steps_per_launch = 1;
+    int opt_derive = 2, opt_legacy = 0, opt_steps_per_launch = 1;
     // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
     // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
     // `args_valid` and the next launch rebuilds them.
@@ -611,13 +611,20 @@ template <class NF> struct Ops {
         a.bcT_bot_stage = la.w.bcT_bot;
         a.bcT_top_stage = la.w.bcT_top;
         const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
-        const bool derive = c->opt_derive && c->closure_consistent && !c->closure_escaped;
+        // Deriving T and liq in registers saves 2 of 11 field accesses and costs ~35 instructions per cell.  Measured on
+        // MI355X it loses while the step's state sits in the 256 MiB Infinity Cache (N145: 30.9 vs 28.4 us) and wins once
+        // the state streams from HBM (8 x N145: 244 vs 258 us): AUTO switches on the bytes one step touches.
+        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
+        const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && state_bytes > ((size_t)256 << 20));
+        const bool derive = want && c->closure_consistent && !c->closure_escaped;
         if constexpr (PROG == PROG_MULTI) {
             if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true>), grid, block, 0, c->stream, v, p, a);
             else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false>), grid, block, 0, c->stream, v, p, a);
+        } else if constexpr (PROG == PROG_EULER) {
+            if (derive) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, true, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
         } else {
-            if (derive) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, true, PROG, false>), grid, block, 0, c->stream, v, p, a);
-            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG, false>), grid, block, 0, c->stream, v, p, a);
+            hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG, false>), grid, block, 0, c->stream, v, p, a);
         }
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
@@ -1424,7 +1431,10 @@ int trm_set_option(trm_ctx* c, int option, int value) {
         case TRM_OPT_WRITE_KF_EVERY_STEP: c->opt_write_kf = value != 0; return TRM_OK;
         case TRM_OPT_VWC_FORCING_FIELD: c->opt_vwc_field = value != 0; return TRM_OK;
         case TRM_OPT_PACKED_F32: c->opt_packed = value != 0; return TRM_OK;
-        case TRM_OPT_DERIVE_CLOSURE_FIELDS: c->opt_derive = value != 0; return TRM_OK;
+        case TRM_OPT_DERIVE_CLOSURE_FIELDS:
+            if (value < 0 || value > 2) break;
+            c->opt_derive = value;
+            return TRM_OK;
         case TRM_OPT_LEGACY_STEP_KERNEL: c->opt_legacy = value != 0; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH:
             if (value < 1 || value > 100000) break;

@@ -32,8 +32,7 @@ struct LaneInfo { int lane, k; bool is_bot, is_top, act; };
 // boundary inputs of this lane's column (every lane of a column holds the same values)
 template <class NF> struct ColumnBC {
     NF bTb, bTt;            // temperature boundary values (used when the Value condition is set)
-    NF eU_b, eU_t;          // compute_z_bcs! terms of internal_energy at the bottom / top cell (flux * Az / V, signed)
-    NF eS_b, eS_t;          // ... of saturation_water_ice
+    NF flux_U, flux_S;      // compute_z_bcs! term of this lane's cell (flux * Az / V, signed; 0 in the interior)
 };
 template <class NF> struct Tendency { NF gU, gS, Kf_lo, Kc; };
 
@@ -120,27 +119,26 @@ TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p
 }
 
 // compute_z_bcs! + explicit_step! + the hydrology closure's repair and water table for the column in registers.
-// (gU, gS): tendencies WITHOUT the boundary flux terms (they are added here); S_GS: tendency of surface_excess_water
-// (top lane).  S is owned by the top lane.  Returns the new (U, sat) in `n`, the water table in z0.
+// (gU, gS): tendencies WITHOUT the boundary flux terms (they are added here).  Returns the new (U, sat) in `n`, the
+// water table in z0 and, in the top lane, the column's overflow into surface_excess_water (0 elsewhere).
 template <class NF, bool RICHARDS, int LPC>
-TRM_DEV void column_advance(const View<NF>& v, const LevelGeom<NF>& L, const LaneInfo& ln, int Nz, const ColumnBC<NF>& bc,
-                            NF U0, NF sat0, NF& gU, NF& gS, NF dt, NF& S, NF GS, Cell<NF>& n, NF& z0, bool& bad) {
-    const NF flux_U = ln.is_bot ? bc.eU_b : (ln.is_top ? bc.eU_t : NF(0));
-    gU += flux_U;
+TRM_DEV NF column_advance(const View<NF>& v, const LevelGeom<NF>& L, const LaneInfo& ln, int Nz, const ColumnBC<NF>& bc,
+                          NF U0, NF sat0, NF& gU, NF& gS, NF dt, Cell<NF>& n, NF& z0, bool& bad) {
+    gU += bc.flux_U;
     n.U = U0 + gU * dt;
     bad = bad || (ln.act && is_nan(n.U));
     n.sat = sat0;
     z0 = NF(0);
+    NF over = NF(0);
     if (RICHARDS) {
-        const NF flux_S = ln.is_bot ? bc.eS_b : (ln.is_top ? bc.eS_t : NF(0));
-        gS += flux_S;
+        gS += bc.flux_S;
         NF snew = sat0 + gS * dt;
         bad = bad || (ln.act && is_nan(snew));
-        const NF over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.act, ln.is_bot, ln.is_top, L);
+        over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.act, ln.is_bot, ln.is_top, L);
         z0 = water_table<NF, LPC>(snew, ln.act, ln.lane, L);
         n.sat = snew;
-        S = (S + GS * dt) + over;   // (meaningful in the top lane only)
     }
+    return over;
 }
 
 template <class NF, bool RICHARDS, int HYD>
@@ -163,8 +161,26 @@ template <class NF> struct ColumnArgs {
     const NF *bcT_bot_stage, *bcT_top_stage;
 };
 
+// Kernel arguments re-read through an opaque pointer into the kernarg segment.  A loop around the step makes every
+// scalar of View / DevParams loop-invariant: the optimiser hoists ~250 scalar loads out of the loop, runs out of SGPRs
+// and parks them in VGPR lanes (196 VGPRs, 2 waves per SIMD).  Read through a pointer it cannot see through, they are
+// fetched where they are used (s_load from the constant cache, as in the straight-line programs).
+template <class T> TRM_DEV const T& kernarg_reload(unsigned offset) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const T*)(kp + offset);
+}
+constexpr unsigned round_up_to(unsigned x, unsigned a) { return (x + a - 1) / a * a; }
+
 template <class NF, bool RICHARDS, int HYD, int LPC, bool DERIVE, int PROG, bool SEB_INLINE>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column(View<NF> v, DevParams<NF> p, ColumnArgs<NF> a) {
+__global__ void __launch_bounds__(TRM_STEP_BLOCK)
+    __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? 7 : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
+    k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
+    // (kernarg layout: the arguments in order, each at its natural alignment)
+    constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+    const View<NF>& v = v_arg;
+    const DevParams<NF>& p = p_arg;
     static_assert(!SEB_INLINE || PROG == PROG_MULTI, "the in-kernel surface energy balance belongs to the multi-step program");
     constexpr int CPW = 64 / LPC;
     LaneInfo ln;
@@ -207,38 +223,46 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column(View<NF> v, DevParams
     ColumnBC<NF> bc;
     bc.bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0);
     bc.bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
-    bc.eU_b = bc.eU_t = bc.eS_b = bc.eS_t = NF(0);
-    if (v.bc.kind[0][0] == 2) bc.eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib0), v.g);
-    if (RICHARDS && v.bc.kind[1][0] == 2) bc.eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib0), v.g);
-    if (!SEB_INLINE) {
-        // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this
-        // launch.  Top terms enter with a minus sign.
-        if (seb || v.bc.kind[0][1] == 2) bc.eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib0), v.g);
-        if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
-            const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
-            bc.eS_t = -flux_term_top(seb ? -fS : fS, v.g);
+    {   // flux conditions: edge terms, 0 unless a condition is set; kept by the edge lanes
+        NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
+        if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib0), v.g);
+        if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib0), v.g);
+        if (!SEB_INLINE) {
+            // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before
+            // this launch.  Top terms enter with a minus sign.
+            if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib0), v.g);
+            if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
+                const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
+                eS_t = -flux_term_top(seb ? -fS : fS, v.g);
+            }
         }
+        bc.flux_U = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
+        bc.flux_S = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
     }
-    // column scalars owned by the top lane (every lane loads them: same address within a column)
-    NF S = RICHARDS ? ldg(v.S, ib0) : NF(0);
+    // surface_excess_water (and LandModel's surface state) is owned by the column's top lane.  The one-step programs
+    // touch it in one short top-lane block at the end; the multi-step program carries it in a register.
+    NF S = NF(0);
     SurfaceRegs<NF> sf;
-    if (SEB_INLINE) {
-        sf.in = SebIn<NF>{ldg(v.Tair, ib0), ldg(v.pres, ib0), ldg(v.wind, ib0), ldg(v.qair, ib0), ldg(v.rain, ib0), ldg(v.swd, ib0), ldg(v.lwd, ib0)};
-        sf.out.Ts = ldg(v.Ts, ib0);
+    if (PROG == PROG_MULTI) {
+        if (RICHARDS) S = ldg(v.S, ib0);
+        if (SEB_INLINE) {
+            sf.in = SebIn<NF>{ldg(v.Tair, ib0), ldg(v.pres, ib0), ldg(v.wind, ib0), ldg(v.qair, ib0), ldg(v.rain, ib0), ldg(v.swd, ib0), ldg(v.lwd, ib0)};
+            sf.out.Ts = ldg(v.Ts, ib0);
+        }
     }
 
     Cell<NF> n = c;          // the state after the program's last step
     Tendency<NF> t{};        // tendencies of the last evaluation at the STATE (hydraulic_conductivity comes from here)
     NF gU_out = NF(0), gS_out = NF(0), GS_out = NF(0), z0 = NF(0);
 
+    NF over = NF(0), over_stage = NF(0);   // (top lane) overflow of the column into surface_excess_water
     if (PROG == PROG_HEUN) {
         // stage 1: tendencies at the state, Euler predictor (with the state's boundary fluxes) and its closures
         t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
         const NF G1U = t.gU, G1S = t.gS;
-        const NF GS1 = NF(0) + jl_min(NF(0), S);
-        NF gU = G1U, gS = G1S, S_stage = S, z0s;
+        NF gU = G1U, gS = G1S, z0s;
         Cell<NF> s;
-        column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, S_stage, GS1, s, z0s, bad);
+        over_stage = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, s, z0s, bad);
         column_closure<NF, RICHARDS, HYD>(p, L, z0s, s, viol);
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
         const NF bTb2 = vTb ? ldg(a.bcT_bot_stage, ib0) : NF(0), bTt2 = vTt ? ldg(a.bcT_top_stage, ib0) : NF(0);
@@ -248,13 +272,15 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column(View<NF> v, DevParams
         // average_tendencies! (heun.jl:27-35), then the step of the STATE with its own boundary fluxes
         gU = (G1U + t2.gU) / NF(2);
         gS = RICHARDS ? (G1S + t2.gS) / NF(2) : NF(0);
-        const NF GS = (GS1 + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
-        column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, S, GS, n, z0, bad);
+        over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
         column_closure<NF, RICHARDS, HYD>(p, L, z0, n, viol);
-        gU_out = gU; gS_out = gS; GS_out = GS;
+        gU_out = gU; gS_out = gS;
     } else {
         const int nsteps = PROG == PROG_MULTI ? a.nsteps : 1;
         for (int step = 0; step < nsteps; ++step) {
+            // (the multi-step loop reads its kernel arguments afresh every iteration, see kernarg_reload)
+            const View<NF>& v = PROG == PROG_MULTI ? kernarg_reload<View<NF>>(0) : v_arg;
+            const DevParams<NF>& p = PROG == PROG_MULTI ? kernarg_reload<DevParams<NF>>(off_p) : p_arg;
             if (PROG == PROG_MULTI && step > 0) c = n;
             if (SEB_INLINE) {
                 // compute_auxiliary! of the surface processes from the top cell in registers (k_surface<FROM_STATE>)
@@ -262,16 +288,21 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column(View<NF> v, DevParams
                 const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, c.liq, fractions(p, c.sat, c.liq, viol_s));
                 const NF Ts_in = sf.out.Ts;
                 surface_processes(p, sf.in, Ts_in, c.T, c.sat, Kf_top, S, RICHARDS, v.g.dzc_top, sf.out);
-                bc.eU_t = -flux_term_top(sf.out.ghf, v.g);
-                if (RICHARDS) bc.eS_t = -flux_term_top(-sf.out.infil, v.g);
+                if (ln.is_top) {
+                    bc.flux_U = -flux_term_top(sf.out.ghf, v.g);
+                    if (RICHARDS) bc.flux_S = -flux_term_top(-sf.out.infil, v.g);
+                }
                 sf.out.Ts = sf.out.Ts + NF(0) * dt;   // zero-tendency prognostic skin_temperature
             }
             t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
             NF gU = t.gU, gS = t.gS;
-            const NF GS = NF(0) + jl_min(NF(0), S);
-            column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, S, GS, n, z0, bad);
+            over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
+            if (PROG == PROG_MULTI && RICHARDS) {   // surface_excess_water carried in the top lane's register
+                GS_out = NF(0) + jl_min(NF(0), S);
+                S = (S + GS_out * dt) + over;
+            }
             column_closure<NF, RICHARDS, HYD>(p, L, z0, n, viol);
-            gU_out = gU; gS_out = gS; GS_out = GS;
+            gU_out = gU; gS_out = gS;
         }
     }
 
@@ -301,6 +332,16 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column(View<NF> v, DevParams
         }
         if (ln.is_top) {
             if (RICHARDS) {
+                // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler / Heun update, overflow
+                if (PROG != PROG_MULTI) {
+                    S = ldg(v.S, ib);
+                    GS_out = NF(0) + jl_min(NF(0), S);
+                    if (PROG == PROG_HEUN) {
+                        const NF S_stage = (S + GS_out * dt) + over_stage;
+                        GS_out = (GS_out + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
+                    }
+                    S = (S + GS_out * dt) + over;
+                }
                 stg(v.S, ib, S);
                 stg(v.wt, ib, z0);
                 if (finalize) stg(v.G_S, ib, GS_out);

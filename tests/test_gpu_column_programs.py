@@ -36,7 +36,7 @@ def test_euler_program_equals_legacy_kernel_bitwise(config, hydraulics, dtype, N
         w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(lat.size, 0.05))
         w["bcs"][("temperature", "bottom")] = ("value", np.full(lat.size, 1.5))
     new, noderive, legacy = W.setup_device(w), W.setup_device(w), W.setup_device(w)
-    noderive.set_option("derive_closure_fields", 0)
+    new.set_option("derive_closure_fields", 1)
     legacy.set_option("legacy_step_kernel", 1)
     for d in (new, noderive, legacy):
         d.set_option("packed_f32", 0)
@@ -55,6 +55,7 @@ def test_derivation_is_dropped_when_the_state_is_touched():
     lat, lon = small_columns(100)
     w = W.make_workload("richards", lat, lon, 32)
     a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("derive_closure_fields", 1)
     b.set_option("legacy_step_kernel", 1)
     for d in (a, b):
         d.step(w["dt"], 5, finalize=False)
