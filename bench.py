@@ -195,7 +195,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the HBM-resident companion measurements (c3x8, c5)")
-    ap.add_argument("--multistep", type=int, default=0, help="also time the resident-column multi-step kernel with this many steps per launch (temporal blocking; reported separately)")
+    ap.add_argument("--multistep", type=int, default=50, help="also time the resident-column multi-step kernel with this many steps per launch (temporal blocking; reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -277,7 +277,7 @@ def main():
     kernel_s = ms * 1e-3 / max(args.steps, 1)            # average duration of one step launch on this GPU
     value = total_columns * args.steps / elapsed
     packed = dt_name == "f32" and WORKLOADS[args.workload][2] == "default" and args.kernel == "fused" and not heun
-    kernel_name = ("k_step_pk" if packed else "k_step_wave") if args.kernel == "fused" else "unfused sequence"
+    kernel_name = ("k_step_pk" if packed else "k_column") if args.kernel == "fused" else "unfused sequence"
     pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series) else None
 
     out = {
@@ -305,7 +305,7 @@ def main():
     dev.close()
 
     single = rank == 0 and n_gpus == 1
-    if single and args.multistep > 0:
+    if single and args.multistep > 1 and args.kernel == "fused" and not heun and not args.series:
         out["multistep"] = multistep_leg(W, w, desc, config, Nz, Nh, wordsize, args, sync, local_rank)
     if single and not args.no_hbm_resident and args.workload == "c3" and args.kernel == "fused" and not heun:
         out["roofline_hbm_resident"] = hbm_resident_leg(W, parallel, args, sync, local_rank)
@@ -349,7 +349,7 @@ def hbm_resident_leg(W, parallel, args, sync, device):
         status = dev.status()
         dev.close()
         kernel_s = ms * 1e-3 / steps
-        r = roofline_object(config, Nz, w["Nh"], wordsize, kernel_s, "k_step_pk (+ k_surface)" if name == "c5" else "k_step_wave",
+        r = roofline_object(config, Nz, w["Nh"], wordsize, kernel_s, "k_step_pk (+ k_surface)" if name == "c5" else "k_column",
                             f"pmc_summary_{name}_fused.json", desc)
         r.update(steps=steps, warmup_executed=warm, column_steps_per_s=w["Nh"] * steps / elapsed, status_flags=int(status))
         legs.append(r)

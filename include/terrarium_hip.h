@@ -127,9 +127,7 @@ enum {
                                     /* Euler step can re-derive them in registers instead of reading them: 2 of 5 field reads */
                                     /* less, bit-identical results.  0: never; 1: whenever legal; 2 (default): when the state  */
                                     /* one step touches exceeds the 256 MiB Infinity Cache (it loses below that)  */
-    TRM_OPT_LEGACY_STEP_KERNEL = 6, /* 1: round-1 step kernel (k_step_wave) for the branch-free boundary kinds -- the A/B  */
-                                    /* comparator of the column programs; Heun then runs on the reference-order kernels    */
-    TRM_OPT_STEPS_PER_LAUNCH = 7    /* m >= 1 (default 1): trm_step keeps every column in registers for up to m steps per   */
+    TRM_OPT_STEPS_PER_LAUNCH = 6    /* m >= 1 (default 1): trm_step keeps every column in registers for up to m steps per   */
                                     /* launch and writes the fields once per launch (temporal blocking of run!'s loop;     */
                                     /* bit-identical to m = 1).  Applies while no time series is attached and the boundary  */
                                     /* kinds are the branch-free ones; otherwise one step per launch as usual               */

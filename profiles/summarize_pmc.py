@@ -1,58 +1,66 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 --pmc csv output of profiles/collect.sh into the per-launch summary of the fused
-step kernel (profiles/<round>/pmc_summary_c3_fused.json).
+"""Turns the rocprofv3 --pmc csv output of profiles/collect.sh into the per-launch summary of the dominant step kernel
+(profiles/<round>/pmc_summary_<workload>_fused.json):  summarize_pmc.py <dir> <workload> <commit>
 
-HBM traffic per MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are reported in KiB... on gfx950 FETCH_SIZE counts
-half of the bytes actually fetched, so reads = FETCH_SIZE * 1024 * 2; writes = WRITE_SIZE * 1024.
-SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are in quad-cycles (x4 for cycles), summed over all SIMDs."""
+HBM traffic per MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE counts half of the
+bytes of a coalesced streaming read, so reads = FETCH_SIZE * 1024 * 2; writes = WRITE_SIZE * 1024.  Infinity-Cache hits
+are counted (the counters sit on the L2's fabric side).  SQ_*_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* are in quad-cycles, summed
+over all SIMDs."""
 import csv
 import glob
 import json
 import os
 import sys
 
-KERNEL = "k_step_wave"
-COLUMNS, LEVELS, WORD = 56951, 32, 8
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (workload table and the algorithmic-bytes formula)
+
+SIZES = {"c3": 56951, "c3x8": 455608, "c5": 812500, "c4": 56951, "c2": 14017}
 
 
-def collect(directory):
-    sums, counts = {}, {}
+def collect(directory, kernel):
+    sums = {}
+    names = set()
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
             for row in csv.DictReader(f):
-                if KERNEL not in row.get("Kernel_Name", ""):
+                if kernel not in row.get("Kernel_Name", ""):
                     continue
-                name = row["Counter_Name"]
-                key = (name, row["Dispatch_Id"])
+                names.add(row["Kernel_Name"].split("(")[0])
+                key = (row["Counter_Name"], row["Dispatch_Id"])
                 sums[key] = sums.get(key, 0.0) + float(row["Counter_Value"])
     per_counter = {}
     for (name, _), v in sums.items():
         per_counter.setdefault(name, []).append(v)
-    return {n: sum(v) / len(v) for n, v in per_counter.items()}, {n: len(v) for n, v in per_counter.items()}
+    return {n: sum(v) / len(v) for n, v in per_counter.items()}, {n: len(v) for n, v in per_counter.items()}, sorted(names)
 
 
-def main(out):
-    counters, ndisp = {}, {}
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
-        c, n = collect(os.path.join(out, sub))
+def main(out, wl, commit):
+    desc, config, hydraulics, columns, Nz, dt_name, replicas = bench.WORKLOADS[wl]
+    kernel = "k_step_pk" if (dt_name == "f32" and hydraulics == "default") else "k_column"
+    Nh = SIZES[wl]
+    word = 8 if dt_name == "f64" else 4
+    counters, ndisp, names = {}, {}, []
+    for sub in ("fetch", "write", "sq1", "sq2"):
+        c, n, nm = collect(os.path.join(out, sub), kernel)
         counters.update(c)
         ndisp.update(n)
-    cells = COLUMNS * LEVELS
+        names = nm or names
+    cells = Nh * Nz
     read = counters.get("FETCH_SIZE", 0.0) * 1024 * 2
     write = counters.get("WRITE_SIZE", 0.0) * 1024
     waves = counters.get("SQ_WAVES", 0.0) or 1.0
+    alg = bench.algorithmic_bytes_per_column_step(config, Nz, word)
     summary = {
-        "kernel": "trm::k_step_wave<double, true, 0, 32, false>",
-        "workload": "C3 N145 x 32, heat + Richards, fp64",
-        "columns": COLUMNS, "levels": LEVELS,
+        "kernel": names, "workload": desc, "commit": commit, "columns": Nh, "levels": Nz,
         "hbm_read_bytes_per_launch_corrected": read,
         "hbm_write_bytes_per_launch": write,
         "hbm_traffic_bytes_per_launch": read + write,
         "traffic_bytes_per_cell": (read + write) / cells,
-        "algorithmic_bytes_per_launch": COLUMNS * WORD * (8 * LEVELS + 4),
-        "algorithmic_bytes_per_cell": WORD * (8 * LEVELS + 4) / LEVELS,
-        "note": "the kernel reads U, sat, T, liq, psi (5 words) and writes U, sat, T, liq, psi, K (6 words) per cell = 88 B; "
-                "the SURVEY's algorithmic figure (65 B) counts only U, sat reads and the 6 writes",
+        "algorithmic_bytes_per_launch": Nh * alg,
+        "algorithmic_bytes_per_cell": alg / Nz,
+        "traffic_over_algorithmic": (read + write) / (Nh * alg),
         "per_wave": {k[9:].lower(): counters[k] / waves for k in counters if k.startswith("SQ_INSTS_")},
         "counters": counters,
         "dispatches_averaged": ndisp,
@@ -61,4 +69,4 @@ def main(out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "unknown")

@@ -9,15 +9,15 @@ import workloads as W
 from terrarium_jl_amd import parallel
 
 def variants(dev, name):
-    if name == "legacy": dev.set_option("legacy_step_kernel", 1)
-    elif name == "column": pass
+    if name == "legacy": dev.set_option("step_kernel", "unfused")
+    elif name == "column": dev.set_option("derive_closure_fields", 0)
     elif name == "column+derive": dev.set_option("derive_closure_fields", 1)
     elif name.startswith("multi"): dev.set_option("steps_per_launch", int(name[5:]))
 
 for wl in (sys.argv[1:] or ["c3", "c3x8"]):
     w, desc, config, Nz, dt_name = bench.build_workload(W, parallel, wl, 1, 0, "weak")
     devs = {}
-    for name in ("legacy", "column", "column+derive", "multi10", "multi50"):
+    for name in ("column", "column+derive", "multi10", "multi50"):
         devs[name] = W.setup_device(w)
         variants(devs[name], name)
         devs[name].step(w["dt"], 10, finalize=False)

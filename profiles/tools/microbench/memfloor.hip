@@ -58,6 +58,27 @@ template <int G> __global__ void __launch_bounds__(256) k_c(Ptrs p, int Nh, doub
     }
 }
 
+// D: as A with only U, sat, psi read (T and liq derived in registers): 3 reads + 6 writes
+__global__ void __launch_bounds__(256) k_d(Ptrs p, int Nh, double dt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int i = wave * 2 + (lane >> 5), k = lane & 31;
+    if (i >= Nh) return;
+    const size_t c = (size_t)i * 32 + k;
+    double a0 = p.f[0][c], a1 = p.f[1][c], a4 = p.f[4][c];
+    p.f[0][c] = a0 + dt; p.f[1][c] = a1 + dt; p.f[2][c] = a0 * dt; p.f[3][c] = a1 * dt; p.f[4][c] = a4 + dt; p.f[5][c] = a0 + a1;
+}
+// E: 2 reads + 6 writes (psi derived as well)
+__global__ void __launch_bounds__(256) k_e(Ptrs p, int Nh, double dt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int i = wave * 2 + (lane >> 5), k = lane & 31;
+    if (i >= Nh) return;
+    const size_t c = (size_t)i * 32 + k;
+    double a0 = p.f[0][c], a1 = p.f[1][c];
+    p.f[0][c] = a0 + dt; p.f[1][c] = a1 + dt; p.f[2][c] = a0 * dt; p.f[3][c] = a1 * dt; p.f[4][c] = a0 - a1; p.f[5][c] = a0 + a1;
+}
+
 int main(int argc, char** argv) {
     const int Nh = argc > 1 ? atoi(argv[1]) : 56951;
     const size_t n = (size_t)Nh * 32;
@@ -82,6 +103,8 @@ int main(int argc, char** argv) {
     };
     const int wavesA = (Nh + 1) / 2, wavesB = (Nh + 7) / 8;
     run("A lane=level 8B/lane", [&] { hipLaunchKernelGGL(k_a, dim3((wavesA + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
+    run("D 3 reads 6 writes (x9/11)", [&] { hipLaunchKernelGGL(k_d, dim3((wavesA + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
+    run("E 2 reads 6 writes (x8/11)", [&] { hipLaunchKernelGGL(k_e, dim3((wavesA + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
     run("B 4 levels/lane 2x16B", [&] { hipLaunchKernelGGL(k_b, dim3((wavesB + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
     run("C2 two groups per wave", [&] { hipLaunchKernelGGL(k_c<2>, dim3(((wavesA + 1) / 2 + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
     run("C4 four groups per wave", [&] { hipLaunchKernelGGL(k_c<4>, dim3(((wavesA + 3) / 4 + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });

@@ -8,8 +8,10 @@ from terrarium_jl_amd import parallel
 w, desc, config, Nz, dt_name = bench.build_workload(W, parallel, sys.argv[1] if len(sys.argv) > 1 else "c3", 1, 0, "weak")
 d = W.setup_device(w)
 v = os.environ.get("TRM_AB_VARIANT", "column")
-if v == "legacy": d.set_option("legacy_step_kernel", 1)
+if v == "legacy": d.set_option("step_kernel", "unfused")
 elif v == "derive": d.set_option("derive_closure_fields", 1)
+elif v == "column": d.set_option("derive_closure_fields", 0)
 elif v.startswith("multi"): d.set_option("steps_per_launch", int(v[5:]))
-d.step(w["dt"], int(os.environ.get("TRM_AB_STEPS", "20")), finalize=False)
+d.step(w["dt"], 1, finalize=False)
+d.step(w["dt"], int(os.environ.get("TRM_AB_STEPS", "50")), finalize=False)
 print(d.status())

@@ -28,7 +28,7 @@ INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidi
                 "surface_shortwave_down", "surface_longwave_down")
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4,
-              derive_closure_fields=5, legacy_step_kernel=6, steps_per_launch=7)
+              derive_closure_fields=5, steps_per_launch=6)
 KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
 TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE = range(6)

@@ -71,7 +71,7 @@ struct trm_ctx {
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
-    int opt_derive = 2, opt_legacy = 0, opt_steps_per_launch = 1;
+    int opt_derive = 2, opt_steps_per_launch = 1;
     // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
     // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
     // `args_valid` and the next launch rebuilds them.
@@ -567,16 +567,13 @@ template <class NF> struct Ops {
         grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
         return grid;
     }
-    // k_step_wave: the generic boundary kinds (and the legacy comparator of the branch-free path), Euler only
+    // k_step_wave: the generic boundary kinds, Euler
     template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         const View<NF>& v = la.state;
         const DevParams<NF>& p = la.p;
         const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
-        if (generic_bcs(c))
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, true>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
-        else
-            hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC, false>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
+        hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
@@ -646,7 +643,7 @@ template <class NF> struct Ops {
         if (packed_path(c)) {
             if (richards(c)) rc = deep ? launch_packed<true, 64>(c, dt, finalize) : launch_packed<true, 32>(c, dt, finalize);
             else rc = deep ? launch_packed<false, 64>(c, dt, finalize) : launch_packed<false, 32>(c, dt, finalize);
-        } else if (generic_bcs(c) || c->opt_legacy) {
+        } else if (generic_bcs(c)) {
             if (richards(c)) { TRM_BY_HYD(c, rc = deep ? (launch_wave<true, H, 64>(c, dt, finalize)) : (launch_wave<true, H, 32>(c, dt, finalize))); }
             else { TRM_BY_HYD(c, rc = deep ? (launch_wave<false, H, 64>(c, dt, finalize)) : (launch_wave<false, H, 32>(c, dt, finalize))); }
         } else {
@@ -667,7 +664,7 @@ template <class NF> struct Ops {
         const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
         // Resident-column multi-step program (TRM_OPT_STEPS_PER_LAUNCH > 1): legal when nothing the host evaluates changes
         // between the steps of a launch -- no time series -- and the branch-free boundary kinds apply.
-        const int spl = (fused && c->series.empty() && !generic_bcs(c) && !c->opt_legacy) ? c->opt_steps_per_launch : 1;
+        const int spl = (fused && c->series.empty() && !generic_bcs(c)) ? c->opt_steps_per_launch : 1;
         int n = 0;
         while (n < nsteps) {
             const int m = std::min(spl, nsteps - n);
@@ -731,7 +728,7 @@ template <class NF> struct Ops {
         return rc;
     }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
-        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !c->opt_legacy) return heun_step_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c)) return heun_step_fused(c, dt, finalize);
         c->top_valid = false;
         c->tend_valid = true;
         c->closure_consistent = true;   // (ends with closure!)
@@ -1340,7 +1337,7 @@ int trm_step_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
 int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
     TRM_ENTER(c);
     if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step_heun: nsteps < 0");
-    const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !c->opt_legacy &&
+    const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 &&
                             !(c->precision == TRM_F64 ? Ops<double>::generic_bcs(c) : Ops<float>::generic_bcs(c));
     if (!fused_heun && !c->has_stage) {   // the reference-order kernels work on a second copy of the state
         int rc = alloc_fields(c, c->stage);
@@ -1435,7 +1432,6 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             if (value < 0 || value > 2) break;
             c->opt_derive = value;
             return TRM_OK;
-        case TRM_OPT_LEGACY_STEP_KERNEL: c->opt_legacy = value != 0; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH:
             if (value < 1 || value > 100000) break;
             c->opt_steps_per_launch = value;
@@ -1453,7 +1449,6 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_VWC_FORCING_FIELD: *value = c->opt_vwc_field; return TRM_OK;
         case TRM_OPT_PACKED_F32: *value = c->opt_packed; return TRM_OK;
         case TRM_OPT_DERIVE_CLOSURE_FIELDS: *value = c->opt_derive; return TRM_OK;
-        case TRM_OPT_LEGACY_STEP_KERNEL: *value = c->opt_legacy; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         default: return TRM_EINVAL;
     }

@@ -18,7 +18,7 @@
 // (profiles/tools/microbench/memfloor.hip: every access pattern reaches the same floor), so bytes are what counts.
 //
 // Boundary conditions: the branch-free kinds only (Value on temperature, Flux on the prognostics, LandModel wiring);
-// anything else takes k_step_wave<GENERIC_BC = true>.
+// anything else takes k_step_wave (trm_kernels.hpp).
 #pragma once
 #include "trm_kernels.hpp"
 
@@ -161,21 +161,12 @@ template <class NF> struct ColumnArgs {
     const NF *bcT_bot_stage, *bcT_top_stage;
 };
 
-// Kernel arguments re-read through an opaque pointer into the kernarg segment.  A loop around the step makes every
-// scalar of View / DevParams loop-invariant: the optimiser hoists ~250 scalar loads out of the loop, runs out of SGPRs
-// and parks them in VGPR lanes (196 VGPRs, 2 waves per SIMD).  Read through a pointer it cannot see through, they are
-// fetched where they are used (s_load from the constant cache, as in the straight-line programs).
-template <class T> TRM_DEV const T& kernarg_reload(unsigned offset) {
-    typedef const __attribute__((address_space(4))) char* kptr;
-    kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    return *(const T*)(kp + offset);
-}
-constexpr unsigned round_up_to(unsigned x, unsigned a) { return (x + a - 1) / a * a; }
-
+#ifndef TRM_COLUMN_WAVES_EULER
+#define TRM_COLUMN_WAVES_EULER 1
+#endif
 template <class NF, bool RICHARDS, int HYD, int LPC, bool DERIVE, int PROG, bool SEB_INLINE>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
-    __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? 7 : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
+    __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
     // (kernarg layout: the arguments in order, each at its natural alignment)
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
@@ -263,17 +254,17 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
         NF gU = G1U, gS = G1S, z0s;
         Cell<NF> s;
         over_stage = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, s, z0s, bad);
-        column_closure<NF, RICHARDS, HYD>(p, L, z0s, s, viol);
+        column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0s, s, viol);
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
         const NF bTb2 = vTb ? ldg(a.bcT_bot_stage, ib0) : NF(0), bTt2 = vTt ? ldg(a.bcT_top_stage, ib0) : NF(0);
         uint32_t viol_stage = 0;
-        const Tendency<NF> t2 = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, s, bTb2, bTt2, RICHARDS, viol_stage);
+        const Tendency<NF> t2 = column_tendencies<NF, RICHARDS, HYD, LPC>(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), L, ln, s, bTb2, bTt2, RICHARDS, viol_stage);
         viol |= viol_stage;
         // average_tendencies! (heun.jl:27-35), then the step of the STATE with its own boundary fluxes
         gU = (G1U + t2.gU) / NF(2);
         gS = RICHARDS ? (G1S + t2.gS) / NF(2) : NF(0);
         over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
-        column_closure<NF, RICHARDS, HYD>(p, L, z0, n, viol);
+        column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
         gU_out = gU; gS_out = gS;
     } else {
         const int nsteps = PROG == PROG_MULTI ? a.nsteps : 1;
@@ -292,6 +283,14 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
                     bc.flux_U = -flux_term_top(sf.out.ghf, v.g);
                     if (RICHARDS) bc.flux_S = -flux_term_top(-sf.out.infil, v.g);
                 }
+                if (step == nsteps - 1 && ln.act && ln.is_top) {
+                    // the diagnostics of the surface processes as the last step saw them (what k_surface leaves behind);
+                    // stored here so that they do not occupy registers across the rest of the step
+                    const SebOut<NF>& o = sf.out;
+                    const unsigned ib = block_local(ib0);
+                    stg(v.ghf, ib, o.ghf); stg(v.swu, ib, o.swu); stg(v.lwu, ib, o.lwu); stg(v.rnet, ib, o.rnet);
+                    stg(v.Hs, ib, o.Hs); stg(v.Hl, ib, o.Hl); stg(v.evap, ib, o.evap); stg(v.infil, ib, o.infil); stg(v.runoff, ib, o.runoff);
+                }
                 sf.out.Ts = sf.out.Ts + NF(0) * dt;   // zero-tendency prognostic skin_temperature
             }
             t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
@@ -301,7 +300,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
                 GS_out = NF(0) + jl_min(NF(0), S);
                 S = (S + GS_out * dt) + over;
             }
-            column_closure<NF, RICHARDS, HYD>(p, L, z0, n, viol);
+            // (second half of the step: parameters fetched afresh instead of being kept in SGPRs across the first half --
+            // the kernel is short of scalar registers, and what does not fit is parked in VGPR lanes at a VALU move each)
+            column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
             gU_out = gU; gS_out = gS;
         }
     }
@@ -309,6 +310,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     // ---- hydraulic_conductivity of the state: K(state the last tendencies saw), K(new state) when finalizing -----------
     NF Kf_out = t.Kf_lo, Kf_out_top = t.Kc;
     if (finalize && write_kf) {
+        const DevParams<NF>& p = kernarg_reload<DevParams<NF>>(off_p);
         const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(p, n.liq, fractions(p, n.sat, n.liq, viol));
         const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
         const NF Kmin_new = jl_min(Kc_new, Kc_new_m);
@@ -317,6 +319,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     }
     // ---- the column goes out: 6 coalesced stores ---------------------------------------------------------------------------
     if (ln.act) {
+        const View<NF>& v = kernarg_reload<View<NF>>(0);
         const unsigned cb = block_local(cb0), ib = block_local(ib0);
         stg(v.U, cb, n.U);
         stg(v.T, cb, n.T);
@@ -351,9 +354,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
                 stg(v.top_sat, ib, n.sat);
                 stg(v.top_liq, ib, n.liq);
                 if (SEB_INLINE) {
-                    const SebOut<NF>& o = sf.out;
-                    stg(v.Ts, ib, o.Ts); stg(v.ghf, ib, o.ghf); stg(v.swu, ib, o.swu); stg(v.lwu, ib, o.lwu); stg(v.rnet, ib, o.rnet);
-                    stg(v.Hs, ib, o.Hs); stg(v.Hl, ib, o.Hl); stg(v.evap, ib, o.evap); stg(v.infil, ib, o.infil); stg(v.runoff, ib, o.runoff);
+                    stg(v.Ts, ib, sf.out.Ts);
                 } else {
                     stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);   // zero-tendency prognostic skin_temperature
                 }

@@ -493,18 +493,33 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 #define TRM_STEP_BLOCK 256
 #endif
 
-// GENERIC_BC = false is the common case -- the only boundary conditions are Value conditions on
-// temperature and Flux conditions on the prognostic variables (everything the reference's models and
-// examples set up); it is handled without a single branch.  Any other kind (Gradient, Value on liquid
-// fraction / saturation / pressure head) takes the GENERIC_BC = true instantiation.
+// k_step_wave serves every boundary kind -- Gradient conditions, Value conditions on liquid fraction / saturation /
+// pressure head, a per-cell vwc_forcing field -- with the halo values formed by the edge lanes.  The common case (Value
+// on temperature, Flux on the prognostics: everything the reference's models and examples set up) takes the branch-free
+// column programs of trm_column.hpp (k_column), which also hold Heun and the multi-step program.
 //
-// Diagnostic variants (memory-only, compute-only, extra VALU, per-wave time stamps) are NOT in
-// this translation unit: profiles/tools/make_diag_variants.py derives them from this source into build/diag/.
-//
-// This kernel serves the GENERIC boundary kinds (and the legacy A/B comparator of the branch-free path); the branch-free
-// Euler step, Heun and the multi-step program live in trm_column.hpp (k_column).
-template <class NF, bool RICHARDS, int HYD, int LPC, bool GENERIC_BC>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevParams<NF> p, NF dt, int finalize, int write_kf) {
+// Diagnostic variants (memory-only, compute-only) are NOT in this translation unit:
+// profiles/tools/make_diag_variants.py derives them from the shipped sources into build/diag/.
+// Kernel arguments re-read through an opaque pointer into the kernarg segment.  The step kernels are short of scalar
+// registers: View + DevParams hold ~200 scalars, and a value used both early and late in the kernel (or, in a loop, in
+// every iteration) is kept in an SGPR throughout -- what does not fit is parked in VGPR lanes at a v_writelane /
+// v_readlane (VALU) each: 57-150 extra VALU per wave were measured.  Read through a pointer the optimiser cannot see
+// through, the second half of the kernel fetches its scalars afresh (s_load from the constant cache), the first half's
+// die early, and nothing spills.
+template <class T> TRM_DEV const T& kernarg_reload(unsigned offset) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return *(const T*)(kp + offset);
+}
+constexpr unsigned round_up_to(unsigned x, unsigned a) { return (x + a - 1) / a * a; }
+
+template <class NF, bool RICHARDS, int HYD, int LPC>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v_arg, DevParams<NF> p_arg, NF dt, int finalize, int write_kf) {
+    // (kernarg layout: the arguments in order, each at its natural alignment)
+    constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+    const View<NF>& v = v_arg;
+    const DevParams<NF>& p = p_arg;
     constexpr int CPW = 64 / LPC;   // columns per wave
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
@@ -538,87 +553,44 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
     // halo cells below the bottom / above the top cell
     NF T_m = T_sh, kap_m = kap_sh, T_h = NF(0), kap_h = NF(0), psi_hb = NF(0), psi_ht = NF(0);
     NF flux_U = NF(0), flux_S = NF(0);  // compute_z_bcs! term of this lane's cell (0 in the interior)
-    if (GENERIC_BC) {
-        // With the default (no-flux) conditions on liquid fraction and saturation the halo cell has the edge
-        // cell's composition, hence bit for bit its conductivity: nothing to recompute.
-        const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 &&
-                              (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
-        const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 &&
-                              (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
-        if (is_bot) {
-            T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
-            kap_m = kap;
-            if (!same_bot) {
-                NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq, v.g);
-                NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat);
-                kap_m = conductivity(p, fractions(p, sh, lh, viol));
-            }
-            if (RICHARDS) psi_hb = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), ii, psi, v.g);
-            if (v.bc.kind[0][0] == 2) flux_U = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
-            if (RICHARDS && v.bc.kind[1][0] == 2) flux_S = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
+    {
+    // With the default (no-flux) conditions on liquid fraction and saturation the halo cell has the edge
+    // cell's composition, hence bit for bit its conductivity: nothing to recompute.
+    const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 &&
+                          (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
+    const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 &&
+                          (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
+    if (is_bot) {
+        T_m = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T, v.g);
+        kap_m = kap;
+        if (!same_bot) {
+            NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq, v.g);
+            NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat);
+            kap_m = conductivity(p, fractions(p, sh, lh, viol));
         }
-        if (is_top) {
-            T_h = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), ii, T, v.g);
-            kap_h = kap;
-            if (!same_top) {
-                NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, liq, v.g);
-                NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sat);
-                kap_h = conductivity(p, fractions(p, sh, lh, viol));
-            }
-            if (RICHARDS) psi_ht = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), ii, psi, v.g);
-            // top flux BCs enter with a minus sign; LandModel wires ground_heat_flux / -infiltration
-            // (land_model.jl:56-61), produced by k_surface just before this launch
-            if (p.seb) {
-                flux_U = -flux_term_top(v.ghf[ii], v.g);
-                if (RICHARDS) flux_S = -flux_term_top(-v.infil[ii], v.g);
-            } else {
-                if (v.bc.kind[0][1] == 2) flux_U = -flux_term_top(bcval(v, 0, 1)[ii], v.g);
-                if (RICHARDS && v.bc.kind[1][1] == 2) flux_S = -flux_term_top(bcval(v, 1, 1)[ii], v.g);
-            }
+        if (RICHARDS) psi_hb = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), ii, psi, v.g);
+        if (v.bc.kind[0][0] == 2) flux_U = flux_term_bottom(bcval(v, 0, 0)[ii], v.g);
+        if (RICHARDS && v.bc.kind[1][0] == 2) flux_S = flux_term_bottom(bcval(v, 1, 0)[ii], v.g);
+    }
+    if (is_top) {
+        T_h = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), ii, T, v.g);
+        kap_h = kap;
+        if (!same_top) {
+            NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, liq, v.g);
+            NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sat);
+            kap_h = conductivity(p, fractions(p, sh, lh, viol));
         }
-    } else {
-        // Boundary handling without divergence: every condition that is not set costs one wave-uniform branch
-        // (the kinds are launch constants), every condition that is set is computed by all lanes and kept by the
-        // edge lane (all lanes of a column read the same boundary value).
-        const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
-        NF T_ext_b = T, T_ext_t = T;
-        if (vTb) {
-            const NF bTb = ldg(bcval(v, 2, 0), ib);
-            T_ext_b = T + div_const(T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
+        if (RICHARDS) psi_ht = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), ii, psi, v.g);
+        // top flux BCs enter with a minus sign; LandModel wires ground_heat_flux / -infiltration
+        // (land_model.jl:56-61), produced by k_surface just before this launch
+        if (p.seb) {
+            flux_U = -flux_term_top(v.ghf[ii], v.g);
+            if (RICHARDS) flux_S = -flux_term_top(-v.infil[ii], v.g);
+        } else {
+            if (v.bc.kind[0][1] == 2) flux_U = -flux_term_top(bcval(v, 0, 1)[ii], v.g);
+            if (RICHARDS && v.bc.kind[1][1] == 2) flux_S = -flux_term_top(bcval(v, 1, 1)[ii], v.g);
         }
-        if (vTt) {
-            const NF bTt = ldg(bcval(v, 2, 1), ib);
-            T_ext_t = T + div_const(bTt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
-        }
-        T_m = is_bot ? T_ext_b : T_sh;
-        T_h = T_ext_t;
-        // liquid fraction / saturation / pressure head carry the default condition: halo = edge cell, so the halo
-        // cell's conductivity is the edge cell's, bit for bit -- except under NoFlow with the reference's
-        // never-filled saturation halo (SURVEY C-1), where the halo cell is dry
-        NF kap_halo = kap;
-        if (!RICHARDS && p.halo_policy != 1) kap_halo = conductivity(p, fractions(p, NF(0), liq, viol));
-        kap_m = is_bot ? kap_halo : kap_sh;
-        kap_h = kap_halo;
-        psi_hb = psi;
-        psi_ht = psi;
-        // flux conditions; LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by
-        // k_surface just before this launch.  Top terms enter with a minus sign.
-        const bool seb = p.seb != 0;
-        const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
-        NF eU_b = NF(0), eU_t = NF(0);   // edge terms: 0 unless a flux condition is set
-        if (fUb) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib), v.g);
-        if (fUt) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib), v.g);
-        flux_U = is_bot ? eU_b : (is_top ? eU_t : NF(0));
-        if (RICHARDS) {
-            const bool fSb = v.bc.kind[1][0] == 2, fSt = seb || v.bc.kind[1][1] == 2;
-            NF eS_b = NF(0), eS_t = NF(0);
-            if (fSb) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib), v.g);
-            if (fSt) {
-                const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib);
-                eS_t = -flux_term_top(seb ? -fS : fS, v.g);
-            }
-            flux_S = is_bot ? eS_b : (is_top ? eS_t : NF(0));
-        }
+    }
     }
     // ---- heat: every lane forms its lower face, the top lane also the boundary face -------------------
     const NF qT_lo = -(NF(0.5) * (kap + kap_m)) * ((T - T_m) * L.rdzf_lo);
@@ -644,23 +616,15 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
         const NF qW_sh = shfl_dn1<NF, LPC>(qW_lo);
         NF qW_hi = qW_sh;
         {   // boundary face above the top cell (computed by every lane, kept by the top lane)
-            NF qW_t;
-            if (GENERIC_BC) {
-                const NF g_t = (psi_ht - psi) * L.rdzf_hi;
-                const NF Ks_t = upwind_conductivity(g_t, Kf_lo, Kc, NF(0));
-                qW_t = -Ks_t * g_t;
-            } else {
-                // default condition: the halo cell repeats psi, so the head difference is +0 (NaN for a non-finite
-                // psi), never negative: K* = min(K, K_halo_face = 0), and (x * rdzf) keeps a zero / NaN as it is
-                const NF zero_or_nan = psi - psi;
-                qW_t = -jl_min(Kc, NF(0)) * zero_or_nan;
-            }
+            const NF g_t = (psi_ht - psi) * L.rdzf_hi;
+            const NF Ks_t = upwind_conductivity(g_t, Kf_lo, Kc, NF(0));
+            const NF qW_t = -Ks_t * g_t;
             qW_hi = is_top ? qW_t : qW_sh;
         }
         // (+ 0: the evapotranspiration forcing, never passed for bare ground, soil_coupled.jl:86) + user forcing
         // (the per-cell field is served by the generic instance only: its pointer test costs the van Genuchten
         // instances 5 % through register pressure, and a spatially varying user forcing is the rare case)
-        const NF F_user = (GENERIC_BC && v.Fvwc) ? ldg(v.Fvwc, cb) : p.vwc_forcing;
+        const NF F_user = v.Fvwc ? ldg(v.Fvwc, cb) : p.vwc_forcing;
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + F_user;
         gS = NF(0) + div_const(dtheta, p.por, p.rpor);
     }
@@ -691,10 +655,11 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v, DevPar
         const unsigned ib = block_local(ib0);
         stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
     }
-    // ---- closures: (U, sat) -> (T, liq, psi) ------------------------------------------------------------------
+    // ---- closures: (U, sat) -> (T, liq, psi), parameters fetched afresh (see kernarg_reload) ----------------------
     NF ln, Tn;
-    energy_closure(p, Unew, snew, ln, Tn, viol);
-    const NF psin = RICHARDS ? pressure_head<NF, HYD>(p, snew, L.zC, L.psiz, z0) : NF(0);
+    const DevParams<NF>& p2 = kernarg_reload<DevParams<NF>>(off_p);
+    energy_closure(p2, Unew, snew, ln, Tn, viol);
+    const NF psin = RICHARDS ? pressure_head<NF, HYD>(p2, snew, L.zC, L.psiz, z0) : NF(0);
     NF Kf_out = Kf_lo, Kf_out_top = Kc;
     if (finalize && write_kf) {
         const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(p, ln, fractions(p, snew, ln, viol));

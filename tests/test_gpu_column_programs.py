@@ -1,7 +1,7 @@
 """The register-resident column programs (csrc/trm_column.hpp: k_column) against the per-step kernels they replace
 and against the oracle: ForwardEuler with temperature / liquid fraction derived in registers, Heun in one launch, and
-`m` steps per launch with the column held in registers.  All three must be BIT-IDENTICAL to the round-1 step kernel /
-the reference-order kernels -- they perform the same operations in the same order."""
+`m` steps per launch with the column held in registers.  All three must be BIT-IDENTICAL to the reference-order
+kernels (one launch per reference kernel) -- they perform the same operations in the same order."""
 import numpy as np
 import pytest
 
@@ -27,27 +27,28 @@ CONFIGS = [("heat", "default", np.float64, 30), ("richards", "default", np.float
 
 
 @pytest.mark.parametrize("config,hydraulics,dtype,Nz", CONFIGS)
-def test_euler_program_equals_legacy_kernel_bitwise(config, hydraulics, dtype, Nz):
+def test_euler_program_equals_reference_order_kernels_bitwise(config, hydraulics, dtype, Nz):
     """k_column<PROG_EULER>, reading T / liq on its first step and deriving them from (U, sat) afterwards, against the
-    round-1 k_step_wave and against the same program with the derivation switched off."""
+    reference-order kernels and against the same program with the derivation switched off."""
     lat, lon = small_columns(203)
     w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
     if config == "heat":
         w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(lat.size, 0.05))
         w["bcs"][("temperature", "bottom")] = ("value", np.full(lat.size, 1.5))
-    new, noderive, legacy = W.setup_device(w), W.setup_device(w), W.setup_device(w)
+    new, noderive, ref = W.setup_device(w), W.setup_device(w), W.setup_device(w)
     new.set_option("derive_closure_fields", 1)
-    legacy.set_option("legacy_step_kernel", 1)
-    for d in (new, noderive, legacy):
+    noderive.set_option("derive_closure_fields", 0)
+    ref.set_option("step_kernel", "unfused")
+    for d in (new, noderive, ref):
         d.set_option("packed_f32", 0)
         d.step(w["dt"], 1, finalize=False)      # first step: stored T / liq are the user's
         d.step(w["dt"], 23, finalize=False)
         d.step(w["dt"], 1, finalize=True)
     for n in all_fields(w) + ["tend_internal_energy"]:
-        a = legacy.get(n)
+        a = ref.get(n)
         assert np.array_equal(new.get(n), a, equal_nan=True), n
         assert np.array_equal(noderive.get(n), a, equal_nan=True), n
-    assert new.status() == legacy.status()
+    assert new.status() == ref.status()
 
 
 def test_derivation_is_dropped_when_the_state_is_touched():
@@ -56,7 +57,7 @@ def test_derivation_is_dropped_when_the_state_is_touched():
     w = W.make_workload("richards", lat, lon, 32)
     a, b = W.setup_device(w), W.setup_device(w)
     a.set_option("derive_closure_fields", 1)
-    b.set_option("legacy_step_kernel", 1)
+    b.set_option("step_kernel", "unfused")
     for d in (a, b):
         d.step(w["dt"], 5, finalize=False)
         T = d.get("temperature")

@@ -138,6 +138,11 @@ def test_bench_contract_json_line():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and 0.2 < r["frac"] < 1.0
     assert r["traffic"] is None or r["traffic"] > 1e8
+    h = d["roofline_hbm_resident"]      # the same kernel on a state 3.6x the Infinity Cache, and the C5 shard, in the same run
+    assert h["columns_per_launch"] == 8 * 56951 and h["state_bytes_per_launch"] > 2 * 256 * 2**20 and 0.2 < h["frac"] < 1.0
+    assert h["also"][0]["columns_per_launch"] == 812500 and 0.2 < h["also"][0]["frac"] < 1.0
+    m = d["multistep"]                  # temporal blocking, reported separately from the per-step roofline
+    assert m["steps_per_launch"] == 50 and m["status_flags"] == 0 and m["column_steps_per_s"] > d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
     # value = whole-job columns x steps / wall time
