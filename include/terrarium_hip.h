@@ -36,13 +36,14 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 4
+#define TRM_ABI_VERSION 5
 
 typedef struct trm_ctx trm_ctx;
 
 /* ---- status codes ------------------------------------------------------- */
 enum { TRM_OK = 0, TRM_EINVAL = 1, TRM_EHIP = 2, TRM_ENOMEM = 3, TRM_EUNSUPPORTED = 4,
-       TRM_ESTALE = 5 /* the field asked for is not materialised at this point (see trm_step) */ };
+       TRM_ESTALE = 5, /* the field asked for is not materialised at this point (see trm_step) */
+       TRM_ECOMM = 6   /* RCCL could not be loaded / a collective failed */ };
 
 /* ---- number format NF (every reference struct is parameterised by it) ---- */
 enum { TRM_F64 = 0, TRM_F32 = 1 };
@@ -215,8 +216,11 @@ int trm_set_forcing(trm_ctx* ctx, int input_field, const void* per_column);
  *   TRM_TIME_CLAMP     linear interpolation, end values outside                         (`Clamp`)
  *   TRM_TIME_CYCLICAL  periodic with period (t_nt - t_1) + (t_nt - t_{nt-1})            (`Cyclical`)
  * Between nodes n1 < n2: value = v[n2] * f + v[n1] * (1 - f), f = (1 / (t[n2] - t[n1])) * (t - t[n1]), evaluated in
- * double and rounded once to the context precision; on an interior node the node's values are copied. */
-enum { TRM_TIME_LINEAR = 0, TRM_TIME_CLAMP = 1, TRM_TIME_CYCLICAL = 2 };
+ * double and rounded once to the context precision; on an interior node the node's values are copied.
+ *   TRM_TIME_RASTER    the Raster input source of ext/TerrariumRastersExt (lines 96-121): between nodes
+ *                      v[n1] + (t - t[n1]) * (v[n2] - v[n1]) / (t[n2] - t[n1]) with (v[n2] - v[n1]) formed in the context
+ *                      precision and the rest in double, the node's values on a node, the end values beyond the ends */
+enum { TRM_TIME_LINEAR = 0, TRM_TIME_CLAMP = 1, TRM_TIME_CYCLICAL = 2, TRM_TIME_RASTER = 3 };
 /* `values`: [nt][Nh] in the context precision.  Replaces any earlier series or constant of the same input. */
 int trm_set_forcing_series(trm_ctx* ctx, int input_field, int nt, const double* times, const void* values, int time_indexing);
 /* Boundary value series for (bc_var, side) with the given kind (VALUE / FLUX / GRADIENT). */
@@ -271,10 +275,30 @@ int trm_clock(const trm_ctx* ctx, double* time, int64_t* iteration);
 int trm_set_clock(trm_ctx* ctx, double time, int64_t iteration);
 
 /* Local (this device's columns) reduction of a field.  SUM/MIN/MAX/HASNAN give one value per row in
- * out[rows]; VOLUME_INTEGRAL_Z gives one value (sum over columns of sum_k f*dz).  The host side
- * combines ranks with one RCCL all-reduce (terrarium.jl_amd/parallel.py). */
+ * out[rows]; VOLUME_INTEGRAL_Z gives one value (sum over columns of sum_k f*dz).  trm_reduce_global (below)
+ * combines the devices' results. */
 int trm_reduce(trm_ctx* ctx, int field, int op, double* out);
 int trm_status(trm_ctx* ctx, uint32_t* flags);
+
+/* ---- multi-device diagnostics ----------------------------------------------------------------------------------------
+ * The global grid of laterally independent columns is block-sharded over the devices of a node, one context (and one
+ * host process or thread) per device; the step path has NO collective.  Diagnostics that span the shards -- the
+ * reference's `sum(field)`, `minimum`, `maximum`, `any(isnan, ...)` on a whole Field, the CPU-side @assert scans -- are
+ * combined inside the library with one RCCL all-reduce of <= 2 * (Nz + 1) doubles on the context's side stream (xGMI:
+ * latency-bound, link bandwidth irrelevant), so a host in any language gets global values without a communication
+ * layer of its own.  RCCL is opened lazily (dlopen) by the first of these calls.
+ *   rank 0:      trm_comm_unique_id(id);  broadcast the 128 bytes to the other ranks by any means (MPI, a file, a pipe)
+ *   every rank:  trm_comm_init(ctx, rank, world, id);    -- collective: returns once every rank has called it
+ *                trm_reduce_global / trm_status_global   -- collective, same arguments on every rank
+ * trm_reduce_global gives what trm_reduce would give on the unsharded grid: SUM / VOLUME_INTEGRAL_Z sums over ranks
+ * (in RCCL's deterministic ring order), MIN / MAX / HASNAN exactly, a NaN on any rank propagating into MIN / MAX. */
+int trm_comm_unique_id(void* id128);
+int trm_comm_init(trm_ctx* ctx, int rank, int world_size, const void* id128);
+int trm_comm_destroy(trm_ctx* ctx);
+/* *world_size = 0 while the context has no communicator */
+int trm_comm_info(const trm_ctx* ctx, int* rank, int* world_size);
+int trm_reduce_global(trm_ctx* ctx, int field, int op, double* out);
+int trm_status_global(trm_ctx* ctx, uint32_t* flags);
 
 int trm_set_option(trm_ctx* ctx, int option, int value);
 int trm_get_option(const trm_ctx* ctx, int option, int* value);

@@ -23,7 +23,7 @@ FIELDS = dict(
 )
 BC_VARS = dict(internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4)
 BC_KINDS = dict(noflux=0, value=1, flux=2, gradient=3)
-TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2)
+TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2, raster=3)
 
 
 class ParamsD(C.Structure):

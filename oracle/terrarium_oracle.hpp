@@ -547,7 +547,7 @@ template <class NF> class Oracle {
         std::vector<NF> values;  // [nt][Nh]
     };
     std::vector<Series> series;
-    enum { TIME_LINEAR = 0, TIME_CLAMP = 1, TIME_CYCLICAL = 2 };
+    enum { TIME_LINEAR = 0, TIME_CLAMP = 1, TIME_CYCLICAL = 2, TIME_RASTER = 3 };
 
     static void find_time_index(const std::vector<double>& times, double t, double& f, long& n1, long& n2) {
         long Nt = (long)times.size();
@@ -611,6 +611,24 @@ template <class NF> class Oracle {
             std::vector<NF>* dst = sr.is_bc ? &bc[sr.var][sr.top].value : field2(sr.field);
             const NF* v1 = &sr.values[(size_t)n1 * Nh];
             const NF* v2 = &sr.values[(size_t)n2 * Nh];
+            if (sr.indexing == TIME_RASTER) {
+                // update_from_raster! (ext/TerrariumRastersExt/TerrariumRastersExt.jl:96-121), numeric time axis
+                const std::vector<double>& tt = sr.times;
+                const long nt = (long)tt.size();
+                const long right = (long)(std::lower_bound(tt.begin(), tt.end(), time) - tt.begin());   // first(searchsorted) - 1
+                const long left = (long)(std::upper_bound(tt.begin(), tt.end(), time) - tt.begin()) - 1; // last(searchsorted) - 1
+                if (left >= 0 && right <= nt - 1) {
+                    const NF* x1 = &sr.values[(size_t)left * Nh];
+                    const NF* x2 = &sr.values[(size_t)right * Nh];
+                    const double dT = tt[right] - tt[left], eps = time - tt[left];
+                    for (long i = col_lo(); i < col_hi(); ++i)
+                        (*dst)[i] = dT > 0 ? (NF)((double)x1[i] + eps * (double)(NF)(x2[i] - x1[i]) / dT) : x2[i];
+                } else {
+                    const NF* x = &sr.values[(size_t)std::min(right, nt - 1) * Nh];
+                    for (long i = col_lo(); i < col_hi(); ++i) (*dst)[i] = x[i];
+                }
+                continue;
+            }
             for (long i = col_lo(); i < col_hi(); ++i)
                 (*dst)[i] = (n1 == n2) ? v1[i] : (NF)((double)v2[i] * f + (double)v1[i] * (1.0 - f));
         }

@@ -9,6 +9,7 @@ include/terrarium_hip.h; there is no CPU fallback.
 """
 from .grids import (AbstractVerticalSpacing, UniformSpacing, ExponentialSpacing, PrescribedSpacing, ColumnGrid,
                     ColumnRingGrid)
+from . import io
 from . import masks
 from . import parallel
 from . import _capi
@@ -26,3 +27,4 @@ from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, Presc
                          timestep, run, current_time, compute_auxiliary, compute_tendencies, closure, invclosure,
                          update_state)
 from ._capi import TerrariumHipError
+from .io import Hdf5File, RasterInputSource

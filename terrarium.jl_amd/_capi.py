@@ -31,7 +31,7 @@ OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_
               derive_closure_fields=5, steps_per_launch=6)
 KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
-TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE = range(6)
+TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE, TRM_ECOMM = range(7)
 
 EXPORTS = (
     "trm_abi_version trm_default_params trm_create trm_destroy trm_last_error trm_field_rows trm_get_grid "
@@ -39,8 +39,9 @@ EXPORTS = (
     "trm_compute_auxiliary trm_compute_tendencies trm_reset_tendencies trm_explicit_step trm_closure trm_invclosure "
     "trm_step trm_step_heun trm_step_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_option "
     "trm_get_option trm_set_stream trm_synchronize "
-    "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs trm_save_state trm_restore_state").split()
-TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2)
+    "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs trm_save_state trm_restore_state "
+    "trm_comm_unique_id trm_comm_init trm_comm_destroy trm_comm_info trm_reduce_global trm_status_global").split()
+TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2, raster=3)
 
 
 class TrmGrid(C.Structure):
@@ -111,6 +112,12 @@ def lib():
     L.trm_set_option.argtypes = [vp, i32, i32]
     L.trm_get_option.argtypes = [vp, i32, C.POINTER(i32)]
     L.trm_set_stream.argtypes = [vp, vp]
+    L.trm_comm_unique_id.argtypes = [vp]
+    L.trm_comm_init.argtypes = [vp, i32, i32, vp]
+    L.trm_comm_destroy.argtypes = [vp]
+    L.trm_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.trm_reduce_global.argtypes = [vp, i32, i32, vp]
+    L.trm_status_global.argtypes = [vp, C.POINTER(C.c_uint32)]
     for name in EXPORTS:
         if name not in ("trm_last_error",):
             getattr(L, name).restype = i32

@@ -5,6 +5,9 @@
 #include "trm_packed_f32.hpp"
 #include "trm_column.hpp"
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types only: the library is opened lazily by trm_comm_init (no link-time dependency)
+
 #include <cmath>
 #include <type_traits>
 #include <cstdio>
@@ -75,6 +78,11 @@ struct trm_ctx {
     // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
     // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
     // `args_valid` and the next launch rebuilds them.
+    // multi-device diagnostics: one RCCL communicator per context, collectives on a side stream (never on the step path)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    hipStream_t comm_stream = nullptr;
+    double* d_comm = nullptr;   // [2 * (Nz + 1) + 8] doubles: send | recv
     bool args_valid = false;
     void* args = nullptr;   // LaunchArgs<NF>*, owned
     void (*args_free)(void*) = nullptr;
@@ -327,11 +335,27 @@ dim3 wave_grid(const trm_ctx* c, int lpc) {
 // Time interpolation indices of a series at time t -- Oceananigans' FieldTimeSeries indexing (Linear / Clamp /
 // Cyclical), restated; that package is not part of the reference tree (parity unpinned).
 // Returns 0-based nodes n1, n2 and the fraction f: value = v[n2] * f + v[n1] * (1 - f); n1 == n2 means "copy".
-void series_time_indices(const std::vector<double>& times, int indexing, double t, int& n1, int& n2, double& f) {
+void series_time_indices(const std::vector<double>& times, int indexing, double t, int& n1, int& n2, double& f, double& g) {
     const int nt = (int)times.size();
     n1 = n2 = 0;
-    f = 0.0;
+    f = g = 0.0;
     if (nt == 1) return;
+    if (indexing == TRM_TIME_RASTER) {
+        // update_from_raster! (TerrariumRastersExt.jl:96-121): searchsorted brackets t; on a node or beyond either end the
+        // node's values are taken as they are (flat extrapolation), in between x1 + eps * (x2 - x1) / dt
+        const int right = (int)(std::lower_bound(times.begin(), times.end(), t) - times.begin());       // first(indexes) - 1
+        const int left = (int)(std::upper_bound(times.begin(), times.end(), t) - times.begin()) - 1;    // last(indexes) - 1
+        if (left >= 0 && right <= nt - 1) {
+            n1 = left;
+            n2 = right;
+            g = times[right] - times[left];
+            f = t - times[left];
+            if (!(g > 0)) n1 = n2 = right;   // (on a node)
+        } else {
+            n1 = n2 = std::min(right, nt - 1);
+        }
+        return;
+    }
     auto find = [&](double tq) {
         // binary search for the bracketing interval; an interior node hit returns (n, n); outside the range the
         // first / last interval is returned (linear extrapolation)
@@ -398,8 +422,8 @@ template <class NF> struct Ops {
         };
         for (auto& sr : c->series) {
             int n1, n2;
-            double f;
-            series_time_indices(sr.times, sr.indexing, time, n1, n2, f);
+            double f, g;
+            series_time_indices(sr.times, sr.indexing, time, n1, n2, f, g);
             if (!sr.is_bc && stage && !c->has_stage) continue;   // (fused Heun: the stage's surface processes are never evaluated)
             NF* dst;
             if (sr.is_bc) {
@@ -413,7 +437,7 @@ template <class NF> struct Ops {
                 dst = (NF*)s.f[sr.field];
             }
             const NF* base = (const NF*)sr.d_values;
-            jobs.job[nj++] = SeriesJob<NF>{dst, base + (size_t)n1 * c->Nh, base + (size_t)n2 * c->Nh, f};
+            jobs.job[nj++] = SeriesJob<NF>{dst, base + (size_t)n1 * c->Nh, base + (size_t)n2 * c->Nh, f, g, sr.indexing == TRM_TIME_RASTER ? 1 : 0};
             if (nj == 16) { int rc = flush(); if (rc) return rc; }
         }
         return flush();
@@ -979,6 +1003,51 @@ template <class NF> int download_impl(trm_ctx* c, int field, NF* host) {
     return TRM_OK;
 }
 
+// ---- RCCL, opened on first use ------------------------------------------------------------------------
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+Rccl* rccl() {
+    static Rccl r;
+    if (r.handle || !r.error.empty()) return &r;
+    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) {
+        r.error = std::string("librccl.so could not be loaded: ") + dlerror();
+        return &r;
+    }
+    auto sym = [&](const char* n) { void* p = dlsym(r.handle, n); if (!p && r.error.empty()) r.error = std::string("librccl.so lacks ") + n; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    return &r;
+}
+#define TRM_NCCL(ctx, call)                                                                                   \
+    do {                                                                                                      \
+        ncclResult_t e__ = (call);                                                                            \
+        if (e__ != ncclSuccess) return fail(ctx, TRM_ECOMM, std::string(#call) + ": " + rccl()->GetErrorString(e__)); \
+    } while (0)
+
+// one all-reduce of `n` doubles over the context's communicator, on the side stream, after the context stream's work
+int comm_allreduce(trm_ctx* c, double* host, int n, ncclRedOp_t op) {
+    if (!c->comm) return fail(c, TRM_EINVAL, "no communicator: call trm_comm_init first");
+    TRM_HIP(c, hipMemcpyAsync(c->d_comm, host, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
+    TRM_NCCL(c, rccl()->AllReduce(c->d_comm, c->d_comm + n, (size_t)n, ncclDouble, op, c->comm, c->comm_stream));
+    TRM_HIP(c, hipMemcpyAsync(host, c->d_comm + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+    TRM_HIP(c, hipStreamSynchronize(c->comm_stream));
+    return TRM_OK;
+}
+
 }  // namespace
 
 // ======================================================================================================
@@ -1075,6 +1144,7 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
 int trm_destroy(trm_ctx* c) {
     if (!c) return TRM_OK;
     (void)hipSetDevice(c->device);
+    (void)trm_comm_destroy(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
         if (c->state.f[f]) (void)hipFree(c->state.f[f]);
@@ -1203,7 +1273,7 @@ int add_series(trm_ctx* c, trm_ctx::Series&& sr, int nt, const double* times, co
     if (nt < 1 || !times || !values) return fail(c, TRM_EINVAL, std::string(who) + ": nt >= 1, times and values are required");
     for (int n = 1; n < nt; ++n)
         if (!(times[n] > times[n - 1])) return fail(c, TRM_EINVAL, std::string(who) + ": times must be strictly increasing");
-    if (sr.indexing < TRM_TIME_LINEAR || sr.indexing > TRM_TIME_CYCLICAL) return fail(c, TRM_EINVAL, std::string(who) + ": bad time_indexing");
+    if (sr.indexing < TRM_TIME_LINEAR || sr.indexing > TRM_TIME_RASTER) return fail(c, TRM_EINVAL, std::string(who) + ": bad time_indexing");
     TRM_HIP(c, hipSetDevice(c->device));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
     // replace an earlier series with the same target
@@ -1406,6 +1476,99 @@ int trm_reduce(trm_ctx* c, int field, int op, double* out) {
     if (!out || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_reduce: bad argument");
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     return c->precision == TRM_F64 ? reduce_impl<double>(c, field, op, out) : reduce_impl<float>(c, field, op, out);
+}
+
+// ---- multi-device diagnostics --------------------------------------------------------
+int trm_comm_unique_id(void* id128) {
+    if (!id128) return TRM_EINVAL;
+    Rccl* r = rccl();
+    if (!r->error.empty()) return fail(nullptr, TRM_ECOMM, r->error);
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    ncclResult_t e = r->GetUniqueId(&id);
+    if (e != ncclSuccess) return fail(nullptr, TRM_ECOMM, std::string("ncclGetUniqueId: ") + r->GetErrorString(e));
+    std::memcpy(id128, &id, sizeof(id));
+    return TRM_OK;
+}
+
+int trm_comm_init(trm_ctx* c, int rank, int world, const void* id128) {
+    TRM_ENTER(c);
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(c, TRM_EINVAL, "trm_comm_init: bad argument");
+    if (c->comm) return fail(c, TRM_EINVAL, "trm_comm_init: the context already has a communicator");
+    Rccl* r = rccl();
+    if (!r->error.empty()) return fail(c, TRM_ECOMM, r->error);
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof(id));
+    TRM_NCCL(c, r->CommInitRank(&c->comm, world, id, rank));
+    c->comm_rank = rank;
+    c->comm_world = world;
+    TRM_HIP(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    TRM_HIP(c, hipMalloc((void**)&c->d_comm, (size_t)(4 * (c->Nz + 1) + 16) * sizeof(double)));
+    return TRM_OK;
+}
+
+int trm_comm_destroy(trm_ctx* c) {
+    if (!c || !c->comm) return TRM_OK;
+    (void)hipSetDevice(c->device);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    (void)rccl()->CommDestroy(c->comm);
+    c->comm = nullptr;
+    if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
+    c->comm_stream = nullptr;
+    if (c->d_comm) (void)hipFree(c->d_comm);
+    c->d_comm = nullptr;
+    c->comm_world = 1;
+    c->comm_rank = 0;
+    return TRM_OK;
+}
+
+int trm_comm_info(const trm_ctx* c, int* rank, int* world) {
+    if (!c) return TRM_EINVAL;
+    if (rank) *rank = c->comm_rank;
+    if (world) *world = c->comm ? c->comm_world : 0;
+    return TRM_OK;
+}
+
+int trm_reduce_global(trm_ctx* c, int field, int op, double* out) {
+    int rc = trm_reduce(c, field, op, out);     // this device's columns (synchronous)
+    if (rc) return rc;
+    if (!c->comm) return fail(c, TRM_EINVAL, "trm_reduce_global: call trm_comm_init first");
+    const int rows = op == TRM_REDUCE_VOLUME_INTEGRAL_Z ? 1 : (int)field_rows(c, field);
+    std::vector<double> buf((size_t)2 * rows);
+    if (op == TRM_REDUCE_MIN || op == TRM_REDUCE_MAX) {
+        // a NaN on any rank must reach every rank (Base.minimum / maximum): RCCL's min / max do not promise that,
+        // so the values travel NaN-free next to a flag that travels with the same operator
+        const double sentinel = op == TRM_REDUCE_MIN ? HUGE_VAL : -HUGE_VAL, yes = op == TRM_REDUCE_MIN ? -1.0 : 1.0;
+        for (int r = 0; r < rows; ++r) {
+            const bool nan = out[r] != out[r];
+            buf[r] = nan ? sentinel : out[r];
+            buf[rows + r] = nan ? yes : 0.0;
+        }
+        rc = comm_allreduce(c, buf.data(), 2 * rows, op == TRM_REDUCE_MIN ? ncclMin : ncclMax);
+        if (rc) return rc;
+        for (int r = 0; r < rows; ++r) out[r] = buf[rows + r] != 0.0 ? std::nan("") : buf[r];
+        return TRM_OK;
+    }
+    for (int r = 0; r < rows; ++r) buf[r] = out[r];
+    rc = comm_allreduce(c, buf.data(), rows, op == TRM_REDUCE_HASNAN ? ncclMax : ncclSum);
+    if (rc) return rc;
+    for (int r = 0; r < rows; ++r) out[r] = buf[r];
+    return TRM_OK;
+}
+
+int trm_status_global(trm_ctx* c, uint32_t* flags) {
+    uint32_t local = 0;
+    int rc = trm_status(c, &local);
+    if (rc) return rc;
+    if (!flags) return TRM_EINVAL;
+    if (!c->comm) return fail(c, TRM_EINVAL, "trm_status_global: call trm_comm_init first");
+    double bits[8];
+    for (int b = 0; b < 8; ++b) bits[b] = (double)((local >> b) & 1u);
+    rc = comm_allreduce(c, bits, 8, ncclMax);    // OR of the flag bits
+    if (rc) return rc;
+    *flags = 0;
+    for (int b = 0; b < 8; ++b) *flags |= bits[b] != 0.0 ? (1u << b) : 0u;
+    return TRM_OK;
 }
 
 int trm_status(trm_ctx* c, uint32_t* flags) {

@@ -362,7 +362,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
         }
         viol |= bad ? 1u : 0u;
     }
-    if (viol) atomicOr(v.status, viol);
+    // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
+    if (viol && ln.act) atomicOr(v_arg.status, viol);
 }
 
 }  // namespace trm

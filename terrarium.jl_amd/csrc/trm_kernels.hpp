@@ -245,7 +245,9 @@ template <class NF> __global__ void k_invclosure_energy(View<NF> v, DevParams<NF
 // update_inputs! for time series sources (input_sources.jl:162-168): dst = v2 * f + v1 * (1 - f) in double,
 // rounded once to NF; f == 0 with v1 == v2 (same node) is the plain copy.  Up to 16 series per launch
 // (blockIdx.y = series).
-template <class NF> struct SeriesJob { NF* dst; const NF* v1; const NF* v2; double f; };
+// raster: the Raster input source's rule x1 + eps * (x2 - x1) / dt (ext/TerrariumRastersExt.jl:96-121) with f = eps,
+// g = dt [s]; (x2 - x1) is formed in NF as the reference's array expression does, the rest in double.
+template <class NF> struct SeriesJob { NF* dst; const NF* v1; const NF* v2; double f, g; int raster; };
 template <class NF> struct SeriesJobs { SeriesJob<NF> job[16]; };
 template <class NF> __global__ void k_interp_series(SeriesJobs<NF> jobs, long Nh) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,7 +257,8 @@ template <class NF> __global__ void k_interp_series(SeriesJobs<NF> jobs, long Nh
         j.dst[i] = j.v1[i];
     } else {
         const double a = (double)j.v1[i], b = (double)j.v2[i];
-        j.dst[i] = (NF)(b * j.f + a * (1.0 - j.f));
+        if (j.raster) j.dst[i] = (NF)(a + j.f * (double)(NF)(j.v2[i] - j.v1[i]) / j.g);
+        else j.dst[i] = (NF)(b * j.f + a * (1.0 - j.f));
     }
 }
 
@@ -692,7 +695,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v_arg, De
         }
         viol |= bad ? 1u : 0u;
     }
-    if (viol) atomicOr(v.status, viol);
+    // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
+    if (viol && act) atomicOr(v.status, viol);
 }
 
 }  // namespace trm

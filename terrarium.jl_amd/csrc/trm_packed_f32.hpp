@@ -45,9 +45,11 @@ TRM_DEV v2f div_const2(v2f a, float b, float rb) {
 
 struct Frac2 { v2f water, ice, air; };
 TRM_DEV Frac2 fractions2(const DevParams<float>& p, v2f sat, v2f liq, uint32_t& viol) {
+    // (bit 1: component x out of bounds, bit 2: component y -- folded into the status flag by the caller, for the
+    // components that are real cells only: the copy a tail lane carries is not repaired and may be out of bounds)
     const bool okx = (0.0f <= sat.x && sat.x <= 1.0f) && (0.0f <= liq.x && liq.x <= 1.0f);
     const bool oky = (0.0f <= sat.y && sat.y <= 1.0f) && (0.0f <= liq.y && liq.y <= 1.0f);
-    viol |= (okx && oky) ? 0u : 2u;
+    viol |= (okx ? 0u : 2u) | (oky ? 0u : 4u);
     Frac2 f;
     const v2f wi = sat * p.por;
     f.water = wi * liq;
@@ -284,8 +286,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevPa
     store(act0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x);
     store(act1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y, gU.y, gS.y);
     // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
-    if (act0 || act1) viol |= bad ? 1u : 0u;
-    if (viol && (act0 || act1)) atomicOr(v.status, viol);
+    const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u);
+    if (flags) atomicOr(v.status, flags);
 }
 
 }  // namespace trm

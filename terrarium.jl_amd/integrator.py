@@ -15,6 +15,7 @@ import numpy as np
 
 from . import _capi
 from . import models as M
+from .io import RasterInputSource
 from .grids import ColumnGrid
 
 
@@ -99,9 +100,10 @@ class FieldTimeSeries:
         return cls(times, np.stack([np.asarray(f(float(t)), dtype=np.float64) for t in times]), time_indexing)
 
 
-def InputSource(source, name):
-    """InputSource(field | fts; name) (input_sources.jl:104-160): a (name, source) pair for `initialize(...; inputs)`."""
-    return (name, source)
+def InputSource(source, name=None):
+    """InputSource(field | fts | raster; name) (input_sources.jl:104-160, ext/TerrariumRastersExt:45-52): a (name, source)
+    pair for `initialize(...; inputs)`.  A `RasterInputSource` carries its own name."""
+    return (name or source.name, source)
 
 
 def InputSources(*sources):
@@ -274,6 +276,32 @@ class DeviceState:
         self._check(self._lib.trm_reduce(self._ctx, _capi.FIELD[name], _capi.REDUCE[op], out.ctypes.data), "trm_reduce")
         return out
 
+    # -- multi-device diagnostics (RCCL inside the library) ---------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        _capi.check(None, self._lib.trm_comm_unique_id(buf), "trm_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank: int, world_size: int, unique_id: bytes):
+        assert len(unique_id) == 128
+        self._check(self._lib.trm_comm_init(self._ctx, int(rank), int(world_size), C.c_char_p(unique_id)), "trm_comm_init")
+
+    def comm_world(self) -> int:
+        r, w = C.c_int(), C.c_int()
+        self._check(self._lib.trm_comm_info(self._ctx, C.byref(r), C.byref(w)), "trm_comm_info")
+        return int(w.value)
+
+    def reduce_global(self, name, op) -> np.ndarray:
+        rows = 1 if op == "volume_integral_z" else self.rows(name)
+        out = np.zeros(rows, dtype=np.float64)
+        self._check(self._lib.trm_reduce_global(self._ctx, _capi.FIELD[name], _capi.REDUCE[op], out.ctypes.data), "trm_reduce_global")
+        return out
+
+    def status_global(self) -> int:
+        f = C.c_uint32()
+        self._check(self._lib.trm_status_global(self._ctx, C.byref(f)), "trm_status_global")
+        return int(f.value)
+
     def status(self) -> int:
         f = C.c_uint32()
         self._check(self._lib.trm_status(self._ctx, C.byref(f)), "trm_status")
@@ -394,7 +422,10 @@ def initialize_integrator(integ: ModelIntegrator):
         else:
             st.set_bc(var, side, kind, value(0.0) if callable(value) else value)
     for name, value in integ.inputs.items():
-        if isinstance(value, FieldTimeSeries):
+        if isinstance(value, RasterInputSource):
+            value.name = name
+            value.attach(st)      # static raster: set once; time-indexed: device-resident series (ext/TerrariumRastersExt)
+        elif isinstance(value, FieldTimeSeries):
             st.set_forcing_series(name, value.times, value.values, value.time_indexing)
         else:
             st.set_forcing(name, value(0.0) if callable(value) else value)

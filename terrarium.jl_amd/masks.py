@@ -1,21 +1,34 @@
 """Land-sea masks on full Gaussian grids (the reference's `inputs/*.nc`).
 
-The masks ship as packed-bit fixtures (tests/golden/era5_land_mask_N*.npz,
-generated by tests/golden/make_mask_fixtures.py from the reference's NetCDF
-inputs with the `> 0.5` threshold of examples/simulations/soil_heat_global.jl:37).
+The two masks the reference ships are packaged as packed bits (terrarium.jl_amd/data/era5_land_mask_N*.npz, made by
+data/make_mask_data.py from the reference's NetCDF inputs with the `> 0.5` threshold of
+examples/simulations/soil_heat_global.jl:37); any other mask is read straight from its NetCDF-4 file
+(`land_mask_from_netcdf`, through the package's own reader in io.py).
 Ring order = row-major flatten of [lat N->S][lon 0->360).
 """
 import os
 
 import numpy as np
 
-_REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GOLDEN_DIR = os.path.join(_REPO, "tests", "golden")
+from . import io as _io
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def land_mask_from_netcdf(path: str, variable: str = "lsm", threshold: float = 0.5) -> np.ndarray:
+    """`Raster(path; name = :lsm)[Ti(1)] .> 0.5` (examples/simulations/soil_heat_global.jl:30-37): boolean [nlat][nlon]."""
+    lsm = _io.Hdf5File(path)[variable].read()
+    while lsm.ndim > 2:
+        lsm = lsm[0]            # the leading time axis has one entry
+    return lsm > threshold
 
 
 def load_land_mask(name: str = "N145", path: str = None) -> np.ndarray:
-    """Boolean land mask [nlat][nlon]; N72 -> 14 017 land points, N145 -> 56 951."""
-    path = path or os.path.join(GOLDEN_DIR, f"era5_land_mask_{name}.npz")
+    """Boolean land mask [nlat][nlon]; N72 -> 14 017 land points, N145 -> 56 951.  `path` may name a NetCDF-4 file
+    (read directly) or a packed .npz."""
+    if path is not None and not path.endswith(".npz"):
+        return land_mask_from_netcdf(path)
+    path = path or os.path.join(DATA_DIR, f"era5_land_mask_{name}.npz")
     with np.load(path) as f:
         nlat, nlon = (int(v) for v in f["shape"])
         mask = np.unpackbits(f["packed"])[: nlat * nlon].astype(bool).reshape(nlat, nlon)

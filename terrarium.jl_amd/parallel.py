@@ -58,8 +58,26 @@ def combine(local: np.ndarray, op: str) -> np.ndarray:
     return t.cpu().numpy()
 
 
+def init_library_communicator(state):
+    """Gives `state`'s context an RCCL communicator over the ranks of the torch.distributed group (trm_comm_init): the
+    128-byte id travels through the existing process group, everything after that happens inside the library."""
+    import torch
+    dist = _dist()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if dist is not None else (1, 0)
+    uid = bytearray(state.comm_unique_id() if rank == 0 else bytes(128))
+    if world > 1:
+        t = torch.frombuffer(uid, dtype=torch.uint8).clone().to(_device())
+        dist.broadcast(t, src=0)
+        uid = bytearray(t.cpu().numpy().tobytes())
+    state.comm_init(rank, world, bytes(uid))
+
+
 def global_reduce(state, field: str, op: str) -> np.ndarray:
-    """Global diagnostic over all ranks' columns: local GPU reduction (trm_reduce) + one all-reduce."""
+    """Global diagnostic over all ranks' columns.  With a library communicator (init_library_communicator): local GPU
+    reduction + one RCCL all-reduce inside libterrarium_hip.so (trm_reduce_global); otherwise the local reduction
+    (trm_reduce) combined by one torch.distributed all-reduce."""
+    if hasattr(state, "comm_world") and state.comm_world() > 0:
+        return state.reduce_global(field, op)
     return combine(state.reduce(field, op), op)
 
 

@@ -182,3 +182,53 @@ def test_heun_with_time_dependent_boundary_function(kernel):
         held.state.set_bc("temperature", "top", "value", f(n * dt))
         held.state.step_heun(dt, 1, True)
     assert not np.array_equal(held.state.get("temperature"), integ.state.get("temperature"))
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_raster_input_source_on_the_device(dtype):
+    """RasterInputSource (ext/TerrariumRastersExt): a time-indexed raster on the full grid, gathered through the mask's
+    index map and interpolated on the device by every step with the extension's rule (nodes exactly, linear in between,
+    flat beyond the ends) -- device == oracle == the rule evaluated in numpy."""
+    import oracle
+    from terrarium_jl_amd.io import RasterInputSource
+    rng = np.random.default_rng(8)
+    mask = rng.random((12, 20)) > 0.5
+    grid = trm.ColumnRingGrid(trm.ExponentialSpacing(N=10), mask, dtype=dtype)
+    Nh = grid.num_columns
+    times = 3600.0 * np.arange(4)
+    Tair = (5.0 + 10.0 * rng.random((4, 12, 20))).astype(dtype)
+    sw = (400.0 * rng.random((4, 12, 20))).astype(dtype)
+    land = trm.LandModel(grid)
+    inits = dict(temperature=2.0, saturation_water_ice=0.6)
+    integ = trm.initialize(land, trm.ForwardEuler(dt=450.0), initializers=inits,
+                           inputs=trm.InputSources(trm.InputSource(RasterInputSource(grid, Tair, "air_temperature", times=times)),
+                                                   trm.InputSource(RasterInputSource(grid, sw[0], "surface_shortwave_down")),
+                                                   trm.InputSource(RasterInputSource(grid, sw, "surface_longwave_down", times=times, reftime=-1800.0))))
+    st = integ.state
+    cols = grid.gather(Tair)
+    lw = grid.gather(sw)
+
+    def rule(t, tt, x):
+        if t <= tt[0]: return x[0]
+        if t >= tt[-1]: return x[-1]
+        r = int(np.searchsorted(tt, t, side="left")); l = int(np.searchsorted(tt, t, side="right")) - 1
+        if l == r: return x[r]
+        return (x[l].astype(np.float64) + (t - tt[l]) * (x[r] - x[l]).astype(np.float64) / (tt[r] - tt[l])).astype(dtype)
+
+    assert np.array_equal(st.air_temperature, cols[0]) and np.array_equal(st.surface_shortwave_down, grid.gather(sw[0]))
+    o = oracle.Oracle(Nh, grid.thickness, oracle.default_params(flow=0, seb=1), dtype=dtype, dx=grid.dx)
+    o.set("temperature", 2.0); o.set("saturation_water_ice", 0.6)
+    o.set_forcing_series("air_temperature", times, cols, "raster")
+    o.set_forcing_series("surface_longwave_down", times + 1800.0, lw, "raster")
+    o.set("surface_shortwave_down", grid.gather(sw[0]))
+    o.update_inputs(); o.initialize()
+    for n in range(30):      # 30 x 450 s: past the last node
+        trm.timestep(integ)
+        o.timestep(450.0, True)
+        t_eval = n * 450.0   # inputs are evaluated at the pre-tick time
+        assert np.array_equal(st.air_temperature, rule(t_eval, times, cols)), n
+        assert np.array_equal(st.surface_longwave_down, rule(t_eval, times + 1800.0, lw)), n
+    tol = 1e-10 if dtype == np.float64 else 1e-4
+    for name in ("temperature", "skin_temperature", "ground_heat_flux", "air_temperature"):
+        a, b = st.get(name).astype(np.float64), o.get(name).astype(np.float64)
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= tol, name

@@ -624,3 +624,22 @@ def test_upload_download_round_trip_layouts():
             b = d.get(name)
             assert np.array_equal(b if b.ndim == 2 else b[None, :], a), (name, dtype, Nh, Nz)
         d.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("Nh", [28476, 28474, 28475])
+def test_no_spurious_status_flags_from_tail_lanes(Nh, dtype):
+    """Lanes beyond the last column carry a clamped copy of it that the saturation repair skips: when that column is
+    oversaturated before the repair, the copy must not raise the composition flag (round-2 regression: shards of 28 476
+    columns reported TRM_STATUS_COMPOSITION_OUT_OF_RANGE while the full grid and the reference-order kernels did not)."""
+    lat, lon = W.columns_from_mask("N145")
+    w = W.make_workload("richards", lat[:Nh], lon[:Nh], 32, dtype=dtype)
+    fused, unfused = W.setup_device(w), W.setup_device(w)
+    unfused.set_option("step_kernel", "unfused")
+    for d in (fused, unfused):
+        d.step(w["dt"], 10, finalize=True)
+    assert unfused.status() == 0 and fused.status() == 0
+    fused.step_heun(w["dt"], 3, finalize=True)
+    fused.set_option("steps_per_launch", 4)
+    fused.step(w["dt"], 8, finalize=True)
+    assert fused.status() == 0
