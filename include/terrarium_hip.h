@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 5
+#define TRM_ABI_VERSION 6
 
 typedef struct trm_ctx trm_ctx;
 
@@ -105,7 +105,11 @@ enum {
      * caller [1/s].  Uploading it switches the Richards tendency from the scalar trm_params.vwc_forcing to this
      * field; TRM_OPT_VWC_FORCING_FIELD = 0 switches back. */
     TRM_FIELD_VWC_FORCING = 28,
-    TRM_FIELD_COUNT = 29
+    /* 2-D inputs of PrescribedAlbedo (src/processes/surface_energy/albedo.jl:8-14): read by the surface energy balance
+     * per column instead of trm_params.albedo / .emissivity when trm_params.prescribed_albedo = 1 */
+    TRM_FIELD_ALBEDO = 29,
+    TRM_FIELD_EMISSIVITY = 30,
+    TRM_FIELD_COUNT = 31
 };
 
 /* ---- diagnostics ---------------------------------------------------------- */
@@ -171,7 +175,8 @@ typedef struct trm_params {
     int32_t unsat_k;          /* TRM_UNSATK_*                                                             */
     int32_t seb;              /* 0: SoilModel; 1: LandModel(vegetation = nothing) coupling (land_model.jl) */
     int32_t halo_policy;      /* TRM_HALO_*                                                               */
-    int32_t reserved;
+    int32_t prescribed_albedo;/* 0: ConstantAlbedo (the two scalars above); 1: PrescribedAlbedo -- per-column inputs
+                                 TRM_FIELD_ALBEDO / TRM_FIELD_EMISSIVITY (albedo.jl:8-14, abstract_types.jl:120-131)   */
 } trm_params;
 
 /* Fill `p` with the reference defaults. */

@@ -20,6 +20,7 @@ FIELDS = dict(
     surface_longwave_up=14, surface_net_radiation=15, sensible_heat_flux=16, latent_heat_flux=17,
     evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
     specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27, vwc_forcing=28,
+    albedo=29, emissivity=30,
 )
 BC_VARS = dict(internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4)
 BC_KINDS = dict(noflux=0, value=1, flux=2, gradient=3)
@@ -33,7 +34,7 @@ class ParamsD(C.Structure):
         "por_mineral por_organic rho_soc rho_org "
         "K_sat theta_res bc_psi_s bc_lambda vg_alpha vg_n impedance vwc_forcing "
         "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap").split()] + [
-        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy reserved".split()]
+        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy prescribed_albedo".split()]
 
 
 def default_params(**overrides):
@@ -47,7 +48,7 @@ def default_params(**overrides):
         K_sat=1.0e-5, theta_res=0.0, bc_psi_s=0.01, bc_lambda=0.2, vg_alpha=1.0, vg_n=2.0, impedance=7.0,
         vwc_forcing=0.0,
         albedo=0.3, emissivity=0.97, kappa_s=2.0, C_h=1.2e-3, min_windspeed=0.01, tau_r=3600.0, beta_evap=1.0,
-        flow=0, swrc=0, unsat_k=0, seb=0, halo_policy=0, reserved=0,
+        flow=0, swrc=0, unsat_k=0, seb=0, halo_policy=0, prescribed_albedo=0,
     )
     for k, v in overrides.items():
         if k not in d:

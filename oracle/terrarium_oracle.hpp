@@ -135,7 +135,7 @@ struct ParamsD {  // plain doubles + ints across the C API
     double K_sat, theta_res, bc_psi_s, bc_lambda, vg_alpha, vg_n, impedance, vwc_forcing;
     // surface energy balance
     double albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap;
-    int32_t flow, swrc, unsat_k, seb, halo_policy, reserved;
+    int32_t flow, swrc, unsat_k, seb, halo_policy, prescribed_albedo;
 };
 
 template <class NF> struct Params {
@@ -145,7 +145,7 @@ template <class NF> struct Params {
     NF por_mineral, por_organic, rho_soc, rho_org;
     NF K_sat, theta_res, bc_psi_s, bc_lambda, vg_alpha, vg_n, impedance, vwc_forcing;
     NF albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap;
-    int flow, swrc, unsat_k, seb, halo_policy;
+    int flow, swrc, unsat_k, seb, halo_policy, prescribed_albedo;
     explicit Params(const ParamsD& d)
         : rho_w(NF(d.rho_w)), rho_i(NF(d.rho_i)), rho_a(NF(d.rho_a)), c_a(NF(d.c_a)), Lsl(NF(d.Lsl)), Llg(NF(d.Llg)),
           Lsg(NF(d.Lsg)), g(NF(d.g)), Tref(NF(d.Tref)), sigma(NF(d.sigma)), kappa_vk(NF(d.kappa_vk)),
@@ -157,7 +157,7 @@ template <class NF> struct Params {
           vg_n(NF(d.vg_n)), impedance(NF(d.impedance)), vwc_forcing(NF(d.vwc_forcing)), albedo(NF(d.albedo)),
           emissivity(NF(d.emissivity)), kappa_s(NF(d.kappa_s)), C_h(NF(d.C_h)), min_windspeed(NF(d.min_windspeed)),
           tau_r(NF(d.tau_r)), beta_evap(NF(d.beta_evap)), flow(d.flow), swrc(d.swrc), unsat_k(d.unsat_k), seb(d.seb),
-          halo_policy(d.halo_policy) {}
+          halo_policy(d.halo_policy), prescribed_albedo(d.prescribed_albedo) {}
 };
 
 // ---------------------------------------------------------------------------
@@ -390,7 +390,7 @@ enum FieldId {
     // inputs (PrescribedAtmosphere)
     F_AIR_TEMPERATURE = 21, F_AIR_PRESSURE = 22, F_WINDSPEED = 23, F_SPECIFIC_HUMIDITY = 24, F_RAINFALL = 25,
     F_SW_DOWN = 26, F_LW_DOWN = 27,
-    F_VWC_FORCING = 28,  // user vwc_forcing evaluated per cell (soil_hydrology.jl:37-38, forcings.jl:13-15)
+    F_VWC_FORCING = 28, F_ALBEDO = 29, F_EMISSIVITY = 30,  // user vwc_forcing evaluated per cell (soil_hydrology.jl:37-38, forcings.jl:13-15)
     F_COUNT = 29
 };
 
@@ -424,6 +424,7 @@ template <class NF> class Oracle {
     // 2-D
     std::vector<NF> S, G_S, wt, Ts, ghf, swu, lwu, rnet, Hs, Hl, evap, infil, runoff;
     std::vector<NF> Tair, pres, wind, qair, rain, swd, lwd;
+    std::vector<NF> albedo_in, emissivity_in;   // PrescribedAlbedo inputs (albedo.jl:8-14)
     Bc<NF> bc[BCV_COUNT][2];  // [var][0 = bottom, 1 = top]
     bool land_model = false;  // LandModel wiring of ground_heat_flux / infiltration flux BCs
 
@@ -441,6 +442,8 @@ template <class NF> class Oracle {
         rain.assign(n2, NF(0));
         swd.assign(n2, NF(300));
         lwd.assign(n2, NF(50));
+        albedo_in.assign(n2, NF(0));
+        emissivity_in.assign(n2, NF(0));
         land_model = p.seb != 0;
     }
 
@@ -484,6 +487,8 @@ template <class NF> class Oracle {
             case F_RAINFALL: return &rain;
             case F_SW_DOWN: return &swd;
             case F_LW_DOWN: return &lwd;
+            case F_ALBEDO: return &albedo_in;
+            case F_EMISSIVITY: return &emissivity_in;
             default: return nullptr;
         }
     }
@@ -746,9 +751,13 @@ template <class NF> class Oracle {
     bool et_coupled = true;
     void seb_fluxes(long i) {  // surface_energy_balance.jl:119-144
         NF Tsurf = Ts[i];
-        swu[i] = p.albedo * swd[i];
+        // albedo(i, j, ...) / emissivity(i, j, ...): ConstantAlbedo's parameters or PrescribedAlbedo's inputs
+        // (albedo.jl:37-44, abstract_types.jl:120-131)
+        const NF alb = p.prescribed_albedo ? albedo_in[i] : p.albedo;
+        const NF emis = p.prescribed_albedo ? emissivity_in[i] : p.emissivity;
+        swu[i] = alb * swd[i];
         NF Tk = Tsurf + p.Tref;
-        lwu[i] = stefan_boltzmann(p, Tk, p.emissivity) + (NF(1) - p.emissivity) * lwd[i];
+        lwu[i] = stefan_boltzmann(p, Tk, emis) + (NF(1) - emis) * lwd[i];
         rnet[i] = swu[i] - swd[i] + lwu[i] - lwd[i];
         NF ra = aerodynamic_resistance(i);
         NF Q_T = (Tsurf - Tair[i]) / ra;

@@ -16,7 +16,8 @@ from . import _capi
 from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapacities, SoilThermalProperties,
                      SoilEnergyBalance, ConstantSoilPorosity, HomogeneousStratigraphy, ConstantSoilCarbonDensity,
                      BrooksCorey, VanGenuchten, UnsatKLinear, UnsatKVanGenuchten, ConstantSoilHydraulics,
-                     SoilHydraulicsSURFEX, NoFlow, RichardsEq, SoilHydrology, SoilEnergyWaterCarbon, ConstantAlbedo,
+                     SoilHydraulicsSURFEX, SoilTexture, NoFlow, RichardsEq, SoilHydrology, SoilEnergyWaterCarbon, ConstantAlbedo,
+                     PrescribedAlbedo,
                      ImplicitSkinTemperature, SurfaceEnergyBalance, ConstantAerodynamics, PrescribedAtmosphere,
                      DirectSurfaceRunoff, BareGroundEvaporation, SurfaceHydrology, DefaultInitializer,
                      ConstantSoilTemperature, QuasiThermalSteadyState, ConstantSaturation, SaturationWaterTable,

@@ -23,9 +23,10 @@ FIELD = dict(
     surface_longwave_up=14, surface_net_radiation=15, sensible_heat_flux=16, latent_heat_flux=17,
     evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
     specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27, vwc_forcing=28,
+    albedo=29, emissivity=30,
 )
 INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidity", "rainfall",
-                "surface_shortwave_down", "surface_longwave_down")
+                "surface_shortwave_down", "surface_longwave_down", "albedo", "emissivity")
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4,
               derive_closure_fields=5, steps_per_launch=6)
@@ -57,7 +58,7 @@ class TrmParams(C.Structure):
         "por_mineral por_organic rho_soc rho_org "
         "K_sat theta_res bc_psi_s bc_lambda vg_alpha vg_n impedance vwc_forcing "
         "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap").split()] + [
-        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy reserved".split()]
+        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy prescribed_albedo".split()]
 
 
 class TerrariumHipError(RuntimeError):

@@ -112,6 +112,9 @@ long field_rows(const trm_ctx* c, int field) {
     return 1;
 }
 bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
+bool is_input_field(int f) {
+    return (f >= TRM_FIELD_AIR_TEMPERATURE && f <= TRM_FIELD_SURFACE_LONGWAVE_DOWN) || f == TRM_FIELD_ALBEDO || f == TRM_FIELD_EMISSIVITY;
+}
 bool is_3d(int field) { return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING; }
 // elements of the device buffer of a field: [Nh][Nzp] for 3-D fields, [Nh] for 2-D fields
 size_t field_elems(const trm_ctx* c, int field) { return is_3d(field) ? (size_t)c->Nh * c->Nzp : (size_t)c->Nh; }
@@ -207,6 +210,8 @@ template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
     p.emissivity = (NF)q.emissivity;
     p.one_minus_emissivity = NF(1) - p.emissivity;
     p.eps_sigma = p.emissivity * (NF)q.sigma;
+    p.sigma = (NF)q.sigma;
+    p.prescribed_albedo = q.prescribed_albedo;
     p.kappa_s2 = NF(2) * (NF)q.kappa_s;
     p.rkappa_s2 = NF(1) / p.kappa_s2;
     p.C_h = (NF)q.C_h;
@@ -265,6 +270,8 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     v.rain = F(TRM_FIELD_RAINFALL);
     v.swd = F(TRM_FIELD_SURFACE_SHORTWAVE_DOWN);
     v.lwd = F(TRM_FIELD_SURFACE_LONGWAVE_DOWN);
+    v.albedo = F(TRM_FIELD_ALBEDO);
+    v.emissivity = F(TRM_FIELD_EMISSIVITY);
     v.zC = (const NF*)c->d_zC;
     v.zF = (const NF*)c->d_zF;
     v.dzc = (const NF*)c->d_dzc;
@@ -1263,7 +1270,7 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
 }
 
 int trm_set_forcing(trm_ctx* c, int input_field, const void* per_column) {
-    if (!c || input_field < TRM_FIELD_AIR_TEMPERATURE || input_field > TRM_FIELD_SURFACE_LONGWAVE_DOWN)
+    if (!c || !is_input_field(input_field))
         return fail(c, TRM_EINVAL, "trm_set_forcing: not an input field");
     return trm_upload(c, input_field, per_column);
 }
@@ -1295,7 +1302,7 @@ int add_series(trm_ctx* c, trm_ctx::Series&& sr, int nt, const double* times, co
 }  // namespace
 
 int trm_set_forcing_series(trm_ctx* c, int input_field, int nt, const double* times, const void* values, int time_indexing) {
-    if (!c || input_field < TRM_FIELD_AIR_TEMPERATURE || input_field > TRM_FIELD_SURFACE_LONGWAVE_DOWN)
+    if (!c || !is_input_field(input_field))
         return fail(c, TRM_EINVAL, "trm_set_forcing_series: not an input field");
     trm_ctx::Series sr;
     sr.is_bc = false;

@@ -237,7 +237,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     if (PROG == PROG_MULTI) {
         if (RICHARDS) S = ldg(v.S, ib0);
         if (SEB_INLINE) {
-            sf.in = SebIn<NF>{ldg(v.Tair, ib0), ldg(v.pres, ib0), ldg(v.wind, ib0), ldg(v.qair, ib0), ldg(v.rain, ib0), ldg(v.swd, ib0), ldg(v.lwd, ib0)};
+            sf.in = SebIn<NF>{ldg(v.Tair, ib0), ldg(v.pres, ib0), ldg(v.wind, ib0), ldg(v.qair, ib0), ldg(v.rain, ib0), ldg(v.swd, ib0), ldg(v.lwd, ib0), NF(0), NF(0), NF(0)};
+            seb_radiation_inputs(p, v.albedo, v.emissivity, ib0, sf.in);
             sf.out.Ts = ldg(v.Ts, ib0);
         }
     }

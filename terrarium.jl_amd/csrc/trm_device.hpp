@@ -274,6 +274,8 @@ template <class NF> struct DevParams {
     NF org, solid_frac, frac_organic, frac_mineral;
     // surface energy balance
     NF albedo, emissivity, one_minus_emissivity, eps_sigma, kappa_s2, rkappa_s2, C_h, min_windspeed, tau_r, rtau_r, beta_evap;
+    NF sigma;
+    int prescribed_albedo;
     NF Tref, eps_mw, one_minus_eps_mw, ca_rhoa, Llg_rhoa;
 };
 
@@ -437,14 +439,30 @@ template <class NF> TRM_DEV NF aerodynamic_resistance(const DevParams<NF>& p, NF
     return NF(1) / (p.C_h * Va);
 }
 
-template <class NF> struct SebIn { NF Tair, pres, wind, qair, rain, swd, lwd; };
+// (albedo, eps_sigma = emissivity * sigma, one_minus_emissivity: ConstantAlbedo's launch constants or PrescribedAlbedo's
+// per-column inputs, see seb_radiation_inputs)
+template <class NF> struct SebIn { NF Tair, pres, wind, qair, rain, swd, lwd, albedo, eps_sigma, one_minus_emissivity; };
 template <class NF> struct SebOut { NF Ts, ghf, swu, lwu, rnet, Hs, Hl, evap, infil, runoff; };
 
+// albedo / emissivity of a column (albedo.jl:37-44, abstract_types.jl:120-131): stefan_boltzmann is eps * sigma * T^4
+template <class NF> TRM_DEV void seb_radiation_inputs(const DevParams<NF>& p, const NF* albedo, const NF* emissivity, unsigned byte_off, SebIn<NF>& in) {
+    if (p.prescribed_albedo) {
+        const NF a = *reinterpret_cast<const NF*>(reinterpret_cast<const char*>(albedo) + byte_off);
+        const NF e = *reinterpret_cast<const NF*>(reinterpret_cast<const char*>(emissivity) + byte_off);
+        in.albedo = a;
+        in.eps_sigma = e * p.sigma;
+        in.one_minus_emissivity = NF(1) - e;
+    } else {
+        in.albedo = p.albedo;
+        in.eps_sigma = p.eps_sigma;
+        in.one_minus_emissivity = p.one_minus_emissivity;
+    }
+}
 template <class NF> TRM_DEV void seb_fluxes(const DevParams<NF>& p, const SebIn<NF>& in, NF ra, SebOut<NF>& o) {
     // surface_energy_balance.jl:119-144 with the ET-coupled latent heat flux (turbulent_fluxes.jl:130-143)
-    o.swu = p.albedo * in.swd;
+    o.swu = in.albedo * in.swd;
     NF Tk = o.Ts + p.Tref;
-    o.lwu = p.eps_sigma * pow_int(Tk, 4) + p.one_minus_emissivity * in.lwd;
+    o.lwu = in.eps_sigma * pow_int(Tk, 4) + in.one_minus_emissivity * in.lwd;
     o.rnet = o.swu - in.swd + o.lwu - in.lwd;
     NF Q_T = (o.Ts - in.Tair) / ra;
     o.Hs = p.ca_rhoa * Q_T;

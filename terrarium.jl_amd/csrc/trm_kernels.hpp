@@ -53,6 +53,7 @@ template <class NF> struct View {
     // (a coalesced read instead of one cache line per column); null without the surface energy balance
     NF *top_T, *top_sat, *top_liq;
     const NF *Tair, *pres, *wind, *qair, *rain, *swd, *lwd;
+    const NF *albedo, *emissivity;   // PrescribedAlbedo inputs, [Nh]
     // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f),
     // psiz[Nz] = zC - z_surface (elevation head)
     const NF *zC, *zF, *dzc, *rdzc, *rdzf, *psiz;
@@ -113,7 +114,8 @@ template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= v.Nh) return;
     const long top = i * v.Nzp + (v.Nz - 1);
-    SebIn<NF> in = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i]};
+    SebIn<NF> in = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i], NF(0), NF(0), NF(0)};
+    seb_radiation_inputs(p, v.albedo, v.emissivity, (unsigned)i * (unsigned)sizeof(NF), in);
     SebOut<NF> o;
     uint32_t viol = 0;
     const NF T_top = TOP_ARRAYS ? v.top_T[i] : v.T[top], sat_top = TOP_ARRAYS ? v.top_sat[i] : v.sat[top];

@@ -70,9 +70,27 @@ class ConstantSoilPorosity:
 
 
 @dataclass
+class SoilTexture:
+    """src/processes/soil/stratigraphy/soil_texture.jl:6-20: fractional mixture of sand, silt and clay."""
+    sand: float = 1.0
+    clay: float = 0.0
+    silt: Optional[float] = None
+
+    def __post_init__(self):
+        if self.silt is None:
+            self.silt = 1 - self.sand - self.clay
+        for name in ("sand", "silt", "clay"):
+            if not (0.0 <= getattr(self, name) <= 1.0):
+                raise AssertionError(f"{name} fraction must lie in [0, 1]")
+        if abs(self.sand + self.silt + self.clay - 1.0) > 1.5e-8:      # Julia's `≈` (rtol = sqrt(eps))
+            raise AssertionError("sand, silt, and clay fractions must sum to unity")
+
+
+@dataclass
 class HomogeneousStratigraphy:
-    """homogeneous_strat.jl:9-15 (texture only matters to SURFEX hydraulics, off-path)."""
+    """homogeneous_strat.jl:9-15 (the texture only matters to SURFEX field capacity / wilting point, off the step path)."""
     porosity: ConstantSoilPorosity = field(default_factory=ConstantSoilPorosity)
+    texture: SoilTexture = field(default_factory=SoilTexture)
 
 
 @dataclass
@@ -112,13 +130,43 @@ class UnsatKVanGenuchten:
 
 @dataclass
 class ConstantSoilHydraulics:
-    """soil_hydraulic_properties.jl:66-97 (SoilHydraulicsSURFEX shares every quantity the step uses)."""
+    """soil_hydraulic_properties.jl:66-97: prescribed saturated conductivity, field capacity and wilting point."""
     swrc: Union[BrooksCorey, VanGenuchten] = field(default_factory=BrooksCorey)
     unsat_hydraulic_cond: Union[UnsatKLinear, UnsatKVanGenuchten] = field(default_factory=UnsatKLinear)
     sat_hydraulic_cond: float = 1.0e-5
+    field_capacity_value: float = 0.25
+    wilting_point_value: float = 0.05
+
+    def saturated_hydraulic_conductivity(self, *args):
+        return self.sat_hydraulic_cond
+
+    def wilting_point(self, *args):
+        return self.wilting_point_value
+
+    def field_capacity(self, *args):
+        return self.field_capacity_value
 
 
-SoilHydraulicsSURFEX = ConstantSoilHydraulics
+@dataclass
+class SoilHydraulicsSURFEX:
+    """soil_hydraulic_properties.jl:112-156: field capacity and wilting point from the clay content (Noilhan & Mahfouf
+    1996, eqs. 28-29).  The step itself reads the SWRC, the unsaturated-K scheme and K_sat, exactly as for
+    ConstantSoilHydraulics; field capacity / wilting point are consumed by the vegetation processes only."""
+    swrc: Union[BrooksCorey, VanGenuchten] = field(default_factory=BrooksCorey)
+    unsat_hydraulic_cond: Union[UnsatKLinear, UnsatKVanGenuchten] = field(default_factory=UnsatKLinear)
+    sat_hydraulic_cond: float = 1.0e-5
+    wilting_point_coef: float = 37.13e-3
+    field_capacity_coef: float = 89.0e-3
+    field_capacity_exp: float = 0.35
+
+    def saturated_hydraulic_conductivity(self, *args):
+        return self.sat_hydraulic_cond
+
+    def wilting_point(self, texture: SoilTexture):
+        return self.wilting_point_coef * (texture.clay * 100) ** 0.5
+
+    def field_capacity(self, texture: SoilTexture):
+        return self.field_capacity_coef * (texture.clay * 100) ** self.field_capacity_exp
 
 
 @dataclass
@@ -137,7 +185,7 @@ class SoilHydrology:
     `[Nz][Nh]` / vertical profile `[Nz]`, or a function (x, z) evaluated once per cell (an Oceananigans `Forcing`
     that depends on position only); forcings that depend on the evolving fields do not cross the C ABI."""
     vertical_flow: Union[NoFlow, RichardsEq] = field(default_factory=NoFlow)
-    hydraulic_properties: ConstantSoilHydraulics = field(default_factory=ConstantSoilHydraulics)
+    hydraulic_properties: Union[ConstantSoilHydraulics, SoilHydraulicsSURFEX] = field(default_factory=ConstantSoilHydraulics)
     vwc_forcing: Optional[object] = None
 
 
@@ -159,6 +207,12 @@ class ConstantAlbedo:
 
 
 @dataclass
+class PrescribedAlbedo:
+    """albedo.jl:8-14: `albedo` and `emissivity` are 2-D inputs, set like any other input (`inputs = dict(albedo = ...,
+    emissivity = ...)`, a number, a per-column array, a FieldTimeSeries or a raster)."""
+
+
+@dataclass
 class ImplicitSkinTemperature:
     """skin_temperature.jl:49-52"""
     kappa_s: float = 2.0
@@ -168,7 +222,7 @@ class ImplicitSkinTemperature:
 class SurfaceEnergyBalance:
     """surface_energy_balance.jl:9-37 (DiagnosedRadiativeFluxes, DiagnosedTurbulentFluxes)."""
     skin_temperature: ImplicitSkinTemperature = field(default_factory=ImplicitSkinTemperature)
-    albedo: ConstantAlbedo = field(default_factory=ConstantAlbedo)
+    albedo: Union[ConstantAlbedo, PrescribedAlbedo] = field(default_factory=ConstantAlbedo)
 
 
 @dataclass
@@ -313,7 +367,10 @@ def flatten(model) -> "_capi.TrmParams":
     if getattr(model, "coupled_surface", False):
         p.seb = 1
         seb = model.surface_energy_balance
-        p.albedo, p.emissivity = seb.albedo.albedo, seb.albedo.emissivity
+        if isinstance(seb.albedo, PrescribedAlbedo):
+            p.prescribed_albedo = 1
+        else:
+            p.albedo, p.emissivity = seb.albedo.albedo, seb.albedo.emissivity
         p.kappa_s = seb.skin_temperature.kappa_s
         p.C_h = model.atmosphere.aerodynamics.C_h
         p.min_windspeed = model.atmosphere.min_windspeed

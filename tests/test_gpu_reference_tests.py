@@ -321,3 +321,32 @@ def test_explicit_step_all_prognostics(dtype):
     assert np.allclose(st.saturation_water_ice, dt * dydt)
     assert np.allclose(st.surface_excess_water, dt * dxdt * 2)
     assert np.all(st.temperature == 0) and np.all(st.pressure_head == 0)   # (inverse) closure not evaluated
+
+
+# test/surface_energy/albedo.jl:15-27 (PrescribedAlbedo): per-column albedo / emissivity inputs drive the radiative fluxes
+@pytest.mark.parametrize("multistep", [1, 5])
+def test_prescribed_albedo_inputs(multistep):
+    import oracle
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10), 70)
+    rng = np.random.default_rng(2)
+    alb, emis = rng.uniform(0.1, 0.6, 70), rng.uniform(0.8, 1.0, 70)
+    land = trm.LandModel(grid, surface_energy_balance=trm.SurfaceEnergyBalance(albedo=trm.PrescribedAlbedo()))
+    integ = trm.initialize(land, trm.ForwardEuler(dt=60.0), initializers=dict(temperature=3.0, saturation_water_ice=0.5),
+                           inputs=dict(albedo=alb, emissivity=emis, surface_shortwave_down=250.0, surface_longwave_down=80.0))
+    st = integ.state
+    assert np.array_equal(st.albedo, alb) and np.array_equal(st.emissivity, emis)
+    st.compute_auxiliary()
+    assert np.array_equal(st.surface_shortwave_up, alb * 250.0)
+    Ts = st.skin_temperature
+    assert np.allclose(st.surface_longwave_up, emis * 5.6704e-8 * (Ts + 273.15) ** 4 + (1 - emis) * 80.0, rtol=1e-13)
+    st.set_option("steps_per_launch", multistep)
+    trm.run(integ, steps=10)
+    o = oracle.Oracle(70, grid.thickness, oracle.default_params(seb=1, prescribed_albedo=1))
+    for k, v in dict(temperature=3.0, saturation_water_ice=0.5, albedo=alb, emissivity=emis, surface_shortwave_down=250.0, surface_longwave_down=80.0).items():
+        o.set(k, v)
+    o.initialize()
+    o.compute_auxiliary()      # (as above: it advances the skin temperature)
+    o.run(60.0, 10)
+    for name in ("temperature", "skin_temperature", "surface_net_radiation", "ground_heat_flux"):
+        a, b = st.get(name), o.get(name)
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-10, name

@@ -112,3 +112,29 @@ def test_graft_entry_build_runs():
     """The driver's build() entry point: compiles (no-op when up to date), imports, checks the exported ABI."""
     import __graft_entry__ as g
     g.build()
+
+
+# src/processes/soil/stratigraphy/soil_texture.jl:6-20, soil_hydraulic_properties.jl:112-156 (parameter structs of a12)
+def test_soil_texture_and_surfex_hydraulics():
+    t = trm.SoilTexture()
+    assert (t.sand, t.clay, t.silt) == (1.0, 0.0, 0.0)
+    t = trm.SoilTexture(sand=0.4, clay=0.25)
+    assert t.silt == pytest.approx(0.35)
+    with pytest.raises(AssertionError):
+        trm.SoilTexture(sand=0.8, clay=0.5)
+    with pytest.raises(AssertionError):
+        trm.SoilTexture(sand=0.5, clay=0.2, silt=0.1)
+    sx = trm.SoilHydraulicsSURFEX()
+    assert sx.wilting_point(t) == pytest.approx(37.13e-3 * (25.0) ** 0.5)
+    assert sx.field_capacity(t) == pytest.approx(89.0e-3 * 25.0 ** 0.35)
+    assert sx.saturated_hydraulic_conductivity() == 1.0e-5
+    ch = trm.ConstantSoilHydraulics()
+    assert (ch.field_capacity(), ch.wilting_point()) == (0.25, 0.05)
+    # both parameterisations flatten to the same step parameters
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10))
+    a = trm.flatten(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq(), hydraulic_properties=sx))))
+    b = trm.flatten(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq(), hydraulic_properties=ch))))
+    for name, _ in trm._capi.TrmParams._fields_:
+        assert getattr(a, name) == getattr(b, name), name
+    land = trm.LandModel(grid, surface_energy_balance=trm.SurfaceEnergyBalance(albedo=trm.PrescribedAlbedo()))
+    assert trm.flatten(land).prescribed_albedo == 1 and trm.flatten(trm.LandModel(grid)).prescribed_albedo == 0

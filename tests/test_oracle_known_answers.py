@@ -555,3 +555,20 @@ def test_cache_blocked_driver_equals_reference_order_driver(config, hydraulics, 
     for name in W.compared_fields(w) + ["tend_internal_energy"]:
         assert np.array_equal(a.get(name), b.get(name), equal_nan=True), name
     assert a.clock() == b.clock()
+
+
+# K20b  test/surface_energy/albedo.jl:15-27 (PrescribedAlbedo: albedo / emissivity are read from the input fields)
+def test_k20_prescribed_albedo():
+    p = default_params(seb=1, prescribed_albedo=1, albedo=0.9, emissivity=0.1)    # the constants must be ignored
+    o = Oracle(2, trm.ExponentialSpacing().get_spacing(), p)
+    o.set_et_coupled(False)
+    o.set("albedo", np.array([0.4, 0.2]))
+    o.set("emissivity", np.array([0.8, 0.95]))
+    assert np.array_equal(o.get("albedo"), [0.4, 0.2]) and np.array_equal(o.get("emissivity"), [0.8, 0.95])
+    o.set("surface_shortwave_down", 250.0)
+    o.set("surface_longwave_down", 80.0)
+    o.set("skin_temperature", 3.0)
+    o.seb_fluxes_only()
+    assert np.array_equal(o.get("surface_shortwave_up"), np.array([0.4, 0.2]) * 250.0)
+    for i, e in enumerate((0.8, 0.95)):
+        assert o.get("surface_longwave_up")[i] == pytest.approx(e * p.sigma * (3.0 + 273.15) ** 4 + (1 - e) * 80.0, rel=1e-14)
