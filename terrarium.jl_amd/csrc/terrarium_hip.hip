@@ -83,6 +83,10 @@ struct trm_ctx {
     int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
     double* d_comm = nullptr;   // [2 * (Nz + 1) + 8] doubles: send | recv
+    // multi-step program with time series: device copies of the slot table and the per-step rows
+    void* d_series_table = nullptr;
+    void* d_series_rows = nullptr;
+    size_t series_rows_cap = 0;
     bool args_valid = false;
     void* args = nullptr;   // LaunchArgs<NF>*, owned
     void (*args_free)(void*) = nullptr;
@@ -627,6 +631,79 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     // k_column: the register-resident column programs (trm_column.hpp)
+    // slot of the multi-step program a series feeds, or -1 when the program cannot take it (the step then runs per launch)
+    static int series_slot(const trm_ctx* c, const trm_ctx::Series& sr) {
+        if (sr.is_bc) {
+            const int kind = c->bc_kind[sr.var][sr.side];
+            if (sr.var == TRM_BCV_TEMPERATURE && kind == TRM_BC_VALUE) return sr.side == TRM_TOP ? SLOT_T_TOP : SLOT_T_BOT;
+            if (sr.var == TRM_BCV_INTERNAL_ENERGY && kind == TRM_BC_FLUX && !(c->params.seb && sr.side == TRM_TOP)) return sr.side == TRM_TOP ? SLOT_FU_TOP : SLOT_FU_BOT;
+            if (sr.var == TRM_BCV_SATURATION_WATER_ICE && kind == TRM_BC_FLUX && richards(c) && !(c->params.seb && sr.side == TRM_TOP)) return sr.side == TRM_TOP ? SLOT_FS_TOP : SLOT_FS_BOT;
+            return -1;
+        }
+        if (!c->params.seb) return -1;     // (inputs nobody reads: leave them to update_inputs!)
+        switch (sr.field) {
+            case TRM_FIELD_AIR_TEMPERATURE: return SLOT_TAIR;
+            case TRM_FIELD_AIR_PRESSURE: return SLOT_PRES;
+            case TRM_FIELD_WINDSPEED: return SLOT_WIND;
+            case TRM_FIELD_SPECIFIC_HUMIDITY: return SLOT_QAIR;
+            case TRM_FIELD_RAINFALL: return SLOT_RAIN;
+            case TRM_FIELD_SURFACE_SHORTWAVE_DOWN: return SLOT_SWD;
+            case TRM_FIELD_SURFACE_LONGWAVE_DOWN: return SLOT_LWD;
+            case TRM_FIELD_ALBEDO: return c->params.prescribed_albedo ? SLOT_ALBEDO : -1;
+            case TRM_FIELD_EMISSIVITY: return c->params.prescribed_albedo ? SLOT_EMISSIVITY : -1;
+            default: return -1;
+        }
+    }
+    static bool series_fit_program(const trm_ctx* c) {
+        for (const auto& sr : c->series)
+            if (series_slot(c, sr) < 0) return false;
+        return true;
+    }
+    // slot table + [nsteps][nseries] rows for a multi-step launch that starts at the context clock
+    static int upload_series_rows(trm_ctx* c, double dt, int nsteps) {
+        const int ns = (int)c->series.size();
+        SeriesTable<NF> tb;
+        std::memset(&tb, 0, sizeof(tb));
+        std::vector<SeriesRow> rows((size_t)nsteps * ns);
+        for (int j = 0; j < ns; ++j) {
+            auto& sr = c->series[j];
+            const int slot = series_slot(c, sr);
+            tb.base[slot] = (const NF*)sr.d_values;
+            tb.row_of[slot] = j;
+            tb.raster[slot] = sr.indexing == TRM_TIME_RASTER ? 1 : 0;
+            if (sr.is_bc) {
+                void*& dst = c->bc_value[sr.var][sr.side];
+                if (!dst) {
+                    TRM_HIP(c, hipMalloc(&dst, (size_t)c->Nh * sizeof(NF)));
+                    c->args_valid = false;
+                }
+                tb.dst[slot] = (NF*)dst;
+            } else {
+                tb.dst[slot] = (NF*)c->state.f[sr.field];
+            }
+            double t = c->time;
+            for (int s = 0; s < nsteps; ++s) {
+                int n1, n2;
+                double f, g;
+                series_time_indices(sr.times, sr.indexing, t, n1, n2, f, g);
+                rows[(size_t)s * ns + j] = SeriesRow{(long long)n1 * c->Nh, (long long)n2 * c->Nh, f, g};
+                t += dt;
+            }
+        }
+        if (!c->d_series_table) TRM_HIP(c, hipMalloc(&c->d_series_table, sizeof(SeriesTable<double>)));
+        if (rows.size() * sizeof(SeriesRow) > c->series_rows_cap) {
+            if (c->d_series_rows) TRM_HIP(c, hipFree(c->d_series_rows));
+            c->d_series_rows = nullptr;
+            c->series_rows_cap = 0;
+            TRM_HIP(c, hipMalloc(&c->d_series_rows, rows.size() * sizeof(SeriesRow)));
+            c->series_rows_cap = rows.size() * sizeof(SeriesRow);
+        }
+        // (synchronous copies from pageable memory: the buffers may be reused as soon as the calls return)
+        TRM_HIP(c, hipMemcpyAsync(c->d_series_table, &tb, sizeof(tb), hipMemcpyHostToDevice, c->stream));
+        TRM_HIP(c, hipMemcpyAsync(c->d_series_rows, rows.data(), rows.size() * sizeof(SeriesRow), hipMemcpyHostToDevice, c->stream));
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        return TRM_OK;
+    }
     template <bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         const View<NF>& v = la.state;
@@ -638,6 +715,9 @@ template <class NF> struct Ops {
         a.nsteps = nsteps;
         a.bcT_bot_stage = la.w.bcT_bot;
         a.bcT_top_stage = la.w.bcT_top;
+        a.series = (const SeriesTable<NF>*)c->d_series_table;
+        a.series_rows = (const SeriesRow*)c->d_series_rows;
+        a.nseries = (int)c->series.size();
         const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
         // Deriving T and liq in registers saves 2 of 11 field accesses and costs ~35 instructions per cell.  Measured on
         // MI355X it loses while the step's state sits in the 256 MiB Infinity Cache (N145: 30.9 vs 28.4 us) and wins once
@@ -646,8 +726,11 @@ template <class NF> struct Ops {
         const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && state_bytes > ((size_t)256 << 20));
         const bool derive = want && c->closure_consistent && !c->closure_escaped;
         if constexpr (PROG == PROG_MULTI) {
-            if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true>), grid, block, 0, c->stream, v, p, a);
-            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false>), grid, block, 0, c->stream, v, p, a);
+            const bool series = !c->series.empty();
+            if (c->params.seb && series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true, true>), grid, block, 0, c->stream, v, p, a);
+            else if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true, false>), grid, block, 0, c->stream, v, p, a);
+            else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
+            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
         } else if constexpr (PROG == PROG_EULER) {
             if (derive) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, true, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
             else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
@@ -694,13 +777,14 @@ template <class NF> struct Ops {
         // the fused kernels map one soil level to one lane: columns deeper than 64 levels take the reference-order kernels
         const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
         // Resident-column multi-step program (TRM_OPT_STEPS_PER_LAUNCH > 1): legal when nothing the host evaluates changes
-        // between the steps of a launch -- no time series -- and the branch-free boundary kinds apply.
-        const int spl = (fused && c->series.empty() && !generic_bcs(c)) ? c->opt_steps_per_launch : 1;
+        // between the steps of a launch -- constants, or device-resident time series the program interpolates itself --
+        // and the branch-free boundary kinds apply.
+        const int spl = (fused && !generic_bcs(c) && series_fit_program(c)) ? c->opt_steps_per_launch : 1;
         int n = 0;
         while (n < nsteps) {
             const int m = std::min(spl, nsteps - n);
             const int fin = (finalize && n + m == nsteps) ? 1 : 0;
-            int rc = update_inputs(c, c->state, c->time);
+            int rc = (m > 1 && !c->series.empty()) ? upload_series_rows(c, dt, m) : update_inputs(c, c->state, c->time);
             if (rc) return rc;
             if (!fused) {
                 c->top_valid = false;
@@ -1169,7 +1253,7 @@ int trm_destroy(trm_ctx* c) {
         }
     for (auto& sr : c->series)
         if (sr.d_values) (void)hipFree(sr.d_values);
-    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, c->d_top3, (void*)c->d_status, (void*)c->d_reduce, c->d_io})
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, c->d_top3, (void*)c->d_status, (void*)c->d_reduce, c->d_io, c->d_series_table, c->d_series_rows})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);

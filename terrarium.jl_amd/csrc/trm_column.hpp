@@ -154,17 +154,44 @@ template <class NF> struct SurfaceRegs {
     SebOut<NF> out;   // out.Ts is the prognostic skin temperature
 };
 
+// Time series inside the multi-step program: update_inputs! (input_sources.jl:162-168) for every step of the launch.
+// What a per-step launch reads from an array that k_interp_series has just filled, the program interpolates itself:
+// the host lays out, per step and series, the bracketing nodes and the fraction (the clock is the host's), the kernel
+// reads the two node values of its column and applies the same formula.
+enum { SLOT_T_BOT = 0, SLOT_T_TOP, SLOT_FU_BOT, SLOT_FU_TOP, SLOT_FS_BOT, SLOT_FS_TOP, SLOT_TAIR, SLOT_PRES, SLOT_WIND, SLOT_QAIR,
+       SLOT_RAIN, SLOT_SWD, SLOT_LWD, SLOT_ALBEDO, SLOT_EMISSIVITY, SLOT_COUNT };
+template <class NF> struct SeriesTable {
+    const NF* base[SLOT_COUNT];   // [nt][Nh] node values of the series feeding the slot, or null
+    NF* dst[SLOT_COUNT];          // where update_inputs! leaves the evaluated values (written back after the last step)
+    int row_of[SLOT_COUNT];       // column of the per-step rows that belongs to the slot
+    int raster[SLOT_COUNT];       // the Raster source's formula instead of FieldTimeSeries' (k_interp_series)
+};
+struct SeriesRow { long long n1, n2; double f, g; };   // element offsets n * Nh of the two nodes, fraction (eps, dt for rasters)
+template <class NF> TRM_DEV NF series_value(const SeriesTable<NF>* tb, const SeriesRow* rows, int slot, int ii) {
+    const SeriesRow r = rows[tb->row_of[slot]];
+    const NF* base = tb->base[slot];
+    const NF x1 = base[r.n1 + ii];
+    if (r.n1 == r.n2) return x1;
+    const NF x2 = base[r.n2 + ii];
+    if (tb->raster[slot]) return (NF)((double)x1 + r.f * (double)(NF)(x2 - x1) / r.g);
+    return (NF)((double)x2 * r.f + (double)x1 * (1.0 - r.f));
+}
+
 template <class NF> struct ColumnArgs {
     NF dt;
     int finalize, write_kf, nsteps;
     // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
     const NF *bcT_bot_stage, *bcT_top_stage;
+    // multi-step program with time series: the slot table and [nsteps][nseries] rows
+    const SeriesTable<NF>* series;
+    const SeriesRow* series_rows;
+    int nseries;
 };
 
 #ifndef TRM_COLUMN_WAVES_EULER
 #define TRM_COLUMN_WAVES_EULER 1
 #endif
-template <class NF, bool RICHARDS, int HYD, int LPC, bool DERIVE, int PROG, bool SEB_INLINE>
+template <class NF, bool RICHARDS, int HYD, int LPC, bool DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
@@ -173,6 +200,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
     static_assert(!SEB_INLINE || PROG == PROG_MULTI, "the in-kernel surface energy balance belongs to the multi-step program");
+    static_assert(!SERIES || PROG == PROG_MULTI, "in-kernel time series belong to the multi-step program");
     constexpr int CPW = 64 / LPC;
     LaneInfo ln;
     ln.lane = threadIdx.x & 63;
@@ -274,6 +302,41 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
             const View<NF>& v = PROG == PROG_MULTI ? kernarg_reload<View<NF>>(0) : v_arg;
             const DevParams<NF>& p = PROG == PROG_MULTI ? kernarg_reload<DevParams<NF>>(off_p) : p_arg;
             if (PROG == PROG_MULTI && step > 0) c = n;
+            if (SERIES) {
+                // update_inputs!(state, clock) of this step, for the slots a series feeds (wave-uniform branches)
+                const SeriesTable<NF>* tb = a.series;
+                const SeriesRow* rows = a.series_rows + (size_t)step * (size_t)a.nseries;
+                if (tb->base[SLOT_T_BOT]) bc.bTb = series_value(tb, rows, SLOT_T_BOT, ii);
+                if (tb->base[SLOT_T_TOP]) bc.bTt = series_value(tb, rows, SLOT_T_TOP, ii);
+                if (tb->base[SLOT_FU_BOT]) { const NF e = flux_term_bottom(series_value(tb, rows, SLOT_FU_BOT, ii), v.g); if (ln.is_bot) bc.flux_U = e; }
+                if (RICHARDS && tb->base[SLOT_FS_BOT]) { const NF e = flux_term_bottom(series_value(tb, rows, SLOT_FS_BOT, ii), v.g); if (ln.is_bot) bc.flux_S = e; }
+                if (!SEB_INLINE) {
+                    if (tb->base[SLOT_FU_TOP]) { const NF e = -flux_term_top(series_value(tb, rows, SLOT_FU_TOP, ii), v.g); if (ln.is_top) bc.flux_U = e; }
+                    if (RICHARDS && tb->base[SLOT_FS_TOP]) { const NF e = -flux_term_top(series_value(tb, rows, SLOT_FS_TOP, ii), v.g); if (ln.is_top) bc.flux_S = e; }
+                } else {
+                    if (tb->base[SLOT_TAIR]) sf.in.Tair = series_value(tb, rows, SLOT_TAIR, ii);
+                    if (tb->base[SLOT_PRES]) sf.in.pres = series_value(tb, rows, SLOT_PRES, ii);
+                    if (tb->base[SLOT_WIND]) sf.in.wind = series_value(tb, rows, SLOT_WIND, ii);
+                    if (tb->base[SLOT_QAIR]) sf.in.qair = series_value(tb, rows, SLOT_QAIR, ii);
+                    if (tb->base[SLOT_RAIN]) sf.in.rain = series_value(tb, rows, SLOT_RAIN, ii);
+                    if (tb->base[SLOT_SWD]) sf.in.swd = series_value(tb, rows, SLOT_SWD, ii);
+                    if (tb->base[SLOT_LWD]) sf.in.lwd = series_value(tb, rows, SLOT_LWD, ii);
+                    if (p.prescribed_albedo && (tb->base[SLOT_ALBEDO] || tb->base[SLOT_EMISSIVITY])) {
+                        const NF al = tb->base[SLOT_ALBEDO] ? series_value(tb, rows, SLOT_ALBEDO, ii) : sf.in.albedo;
+                        if (tb->base[SLOT_ALBEDO]) sf.in.albedo = al;
+                        if (tb->base[SLOT_EMISSIVITY]) {
+                            const NF e = series_value(tb, rows, SLOT_EMISSIVITY, ii);
+                            sf.in.eps_sigma = e * p.sigma;
+                            sf.in.one_minus_emissivity = NF(1) - e;
+                        }
+                    }
+                }
+                if (step == nsteps - 1 && ln.act && ln.is_top) {
+                    // the input fields / boundary value arrays keep what the last step evaluated, as after update_inputs!
+                    for (int s = 0; s < SLOT_COUNT; ++s)
+                        if (tb->base[s]) tb->dst[s][ii] = series_value(tb, rows, s, ii);
+                }
+            }
             if (SEB_INLINE) {
                 // compute_auxiliary! of the surface processes from the top cell in registers (k_surface<FROM_STATE>)
                 uint32_t viol_s = 0;

@@ -127,17 +127,49 @@ def test_multistep_with_repair_and_overflow_matches_oracle():
         assert np.array_equal(d.get(n), o.get(n)), n
 
 
-def test_multistep_falls_back_with_series_and_generic_bcs():
+@pytest.mark.parametrize("m", [3, 16])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_multistep_with_time_series_interpolated_in_the_kernel(dtype, m):
+    """Device-resident series (boundary values, forcing inputs; FieldTimeSeries and raster rules, all indexing modes) are
+    interpolated inside the multi-step program, step by step: identical to update_inputs! + one launch per step, including
+    what the input fields / boundary arrays hold afterwards."""
+    lat, lon = small_columns(101)
+    # heat: a top temperature series (cyclical) and a bottom heat-flux series (clamp)
+    w = W.make_workload("heat", lat, lon, 20, dtype=dtype)
+    a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("steps_per_launch", m)
+    times = np.array([0.0, 2000.0, 5000.0, 9000.0])
+    vals = np.stack([w["T0"] + x for x in (0.0, 4.0, -3.0, 1.0)])
+    flux = np.stack([np.full(lat.size, x) for x in (0.0, 0.08, 0.02, 0.05)])
+    for d in (a, b):
+        d.set_bc_series("temperature", "top", "value", times, vals, "cyclical")
+        d.set_bc_series("internal_energy", "bottom", "flux", times + 300.0, flux, "clamp")
+        d.step(w["dt"], 37, finalize=True)
+    for n in all_fields(w):
+        assert np.array_equal(a.get(n), b.get(n)), n
+    assert a.clock() == b.clock()
+    # land: air temperature (linear), shortwave (raster rule), rainfall (clamp) series + a constant wind
+    w = W.make_workload("land", lat, lon, 32, dtype=dtype, hydraulics="default")
+    a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("steps_per_launch", m)
+    tt = 600.0 * np.arange(6)
+    ph = 2 * np.pi * tt[:, None] / 86400.0 - w["lon"][None, :]
+    for d in (a, b):
+        d.set_option("packed_f32", 0)
+        d.set_forcing_series("air_temperature", tt, w["T0"][None, :] + 5.0 * np.sin(ph), "linear")
+        d.set_forcing_series("surface_shortwave_down", tt + 90.0, np.maximum(0.0, 600.0 * np.sin(ph)), "raster")
+        d.set_forcing_series("rainfall", tt, 1.0e-7 * (1 + np.cos(ph)), "clamp")
+        d.step(w["dt"], 61, finalize=True)       # 61 x 60 s: beyond the last node
+    for n in all_fields(w) + ["air_temperature", "surface_shortwave_down", "rainfall"]:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status()
+
+
+def test_multistep_falls_back_for_generic_boundary_kinds():
     lat, lon = small_columns(70)
     w = W.make_workload("heat", lat, lon, 20)
     a, b = W.setup_device(w), W.setup_device(w)
     a.set_option("steps_per_launch", 10)
-    times = np.array([0.0, 3000.0, 9000.0])
-    vals = np.stack([w["T0"] + x for x in (0.0, 4.0, -3.0)])
-    for d in (a, b):
-        d.set_bc_series("temperature", "top", "value", times, vals)
-        d.step(w["dt"], 25, finalize=True)
-    assert np.array_equal(a.get("temperature"), b.get("temperature"))
     for d in (a, b):
         d.set_bc("temperature", "bottom", "gradient", 0.01)
         d.step(w["dt"], 25, finalize=True)
