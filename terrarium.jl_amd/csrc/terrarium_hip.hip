@@ -612,6 +612,15 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
+    // Deriving T and liq in registers saves 2 of 11 field accesses and costs ~40 instructions per cell.  Measured on MI355X
+    // it does not pay while the step's state sits in the 256 MiB Infinity Cache (N145 fp64: 27.1 vs 26.9 us), wins once an
+    // fp64 state streams from HBM (8 x N145: 223 vs 240 us) and loses in fp32 (C5 van Genuchten: 754 vs 702 us).  AUTO
+    // therefore switches on the number format and the bytes one step touches.
+    template <bool RICH> static bool derive_now(const trm_ctx* c) {
+        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
+        const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && std::is_same<NF, double>::value && state_bytes > ((size_t)256 << 20));
+        return want && c->closure_consistent && !c->closure_escaped;
+    }
     // fp32, reference-default hydraulics: two columns per lane with packed math (trm_packed_f32.hpp)
     static bool packed_path(trm_ctx* c) {
         if (!std::is_same<NF, float>::value || !c->opt_packed || generic_bcs(c) || hyd(c) != HYD_BC_LINEAR) return false;
@@ -719,12 +728,7 @@ template <class NF> struct Ops {
         a.series_rows = (const SeriesRow*)c->d_series_rows;
         a.nseries = (int)c->series.size();
         const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
-        // Deriving T and liq in registers saves 2 of 11 field accesses and costs ~35 instructions per cell.  Measured on
-        // MI355X it loses while the step's state sits in the 256 MiB Infinity Cache (N145: 30.9 vs 28.4 us) and wins once
-        // the state streams from HBM (8 x N145: 244 vs 258 us): AUTO switches on the bytes one step touches.
-        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
-        const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && state_bytes > ((size_t)256 << 20));
-        const bool derive = want && c->closure_consistent && !c->closure_escaped;
+        const bool derive = derive_now<RICH>(c);
         if constexpr (PROG == PROG_MULTI) {
             const bool series = !c->series.empty();
             if (c->params.seb && series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true, true>), grid, block, 0, c->stream, v, p, a);

@@ -231,7 +231,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
     if (DERIVE) {
         uint32_t viol_in = 0;
-        energy_closure_wave(p, c.U, c.sat, c.liq, c.T, viol_in);
+        energy_closure_wave(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat, c.liq, c.T, viol_in);   // (its scalars die right here)
     } else {
         c.T = ldg(v.T, cb0);
         c.liq = ldg(v.liq, cb0);

@@ -90,7 +90,24 @@ TRM_HD double div_nr(double n, double d) {
     return n / d;
 #endif
 }
-TRM_HD float div_nr(float n, float d) { return n / d; }
+// fp32: the compiler's sequence (v_rcp_f32, one Newton step, q = n * y, two residual corrections) without its two
+// v_div_scale steps; they are no-ops unless the divisor is denormal or beyond 2^126, the numerator is below 2^-103 or the
+// quotient leaves the normal range (fp32 denormals are enabled on gfx950, so there is no mode switch around it).
+TRM_HD float div_nr(float n, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float y = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float q = n * y;
+    float r = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(r, y, q);
+    return __builtin_amdgcn_div_fixupf(q, d, n);
+#else
+    return n / d;
+#endif
+}
 // Bool * Float: `false` is a strong zero carrying the sign of x.
 template <class NF> TRM_HD NF boolmul(bool b, NF x) { return b ? x : copysign_(NF(0), x); }
 

@@ -30,7 +30,7 @@ TRM_DEV M2 operator||(M2 a, M2 b) { return M2{a.x || b.x, a.y || b.y}; }
 TRM_DEV v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 TRM_DEV v2f min2(v2f a, v2f b) { return v2f{jl_min(a.x, b.x), jl_min(a.y, b.y)}; }
 TRM_DEV v2f max2(v2f a, v2f b) { return v2f{jl_max(a.x, b.x), jl_max(a.y, b.y)}; }
-TRM_DEV v2f div2(v2f a, v2f b) { return v2f{a.x / b.x, a.y / b.y}; }
+TRM_DEV v2f div2(v2f a, v2f b) { return v2f{div_nr(a.x, b.x), div_nr(a.y, b.y)}; }
 TRM_DEV v2f up2(v2f a) { return v2f{shift_up(a.x), shift_up(a.y)}; }
 TRM_DEV v2f dn2(v2f a) { return v2f{shift_dn(a.x), shift_dn(a.y)}; }
 TRM_DEV v2f ld2(const float* base, unsigned off0, unsigned off1) { return v2f{ldg(base, off0), ldg(base, off1)}; }
@@ -82,12 +82,20 @@ TRM_DEV void energy_closure2(const DevParams<float>& p, v2f U, v2f sat, v2f& liq
     const v2f Lth = sat * p.L * p.por;   // (p.L * sat) * por: multiplication by the scalar commutes bit for bit
     const v2f nLth = -Lth;
     // liq = (U >= 0) ? 1 : boolmul(U >= -Lth, 1 - safediv(U, -Lth))
+    // (energy_closure_wave, trm_column.hpp: the phase-change divide only when a cell of the wave needs it; a frozen cell
+    // with L_theta > eps gets the -0.0 the reference's `false * (1 - x)` gives)
     const float eps = Limits<float>::eps();
-    const v2f den = nLth + eps;
-    const v2f sd = v2f{(nLth.x == 0.0f) ? Limits<float>::inf() : U.x / den.x, (nLth.y == 0.0f) ? Limits<float>::inf() : U.y / den.y};
-    const v2f x = splat(1.0f) - sd;
-    const v2f bm = v2f{(U.x >= nLth.x) ? x.x : copysign_(0.0f, x.x), (U.y >= nLth.y) ? x.y : copysign_(0.0f, x.y)};
-    liq = sel(ge(U, splat(0.0f)), splat(1.0f), bm);
+    const M2 thawed = ge(U, splat(0.0f)), frozen0 = lt(U, nLth);
+    const bool needx = !thawed.x && !(frozen0.x && Lth.x > eps), needy = !thawed.y && !(frozen0.y && Lth.y > eps);
+    if (__ballot(needx || needy) == 0ull) {
+        liq = sel(thawed, splat(1.0f), splat(-0.0f));
+    } else {
+        const v2f den = nLth + eps;
+        const v2f sd = v2f{(nLth.x == 0.0f) ? Limits<float>::inf() : div_nr(U.x, den.x), (nLth.y == 0.0f) ? Limits<float>::inf() : div_nr(U.y, den.y)};
+        const v2f x = splat(1.0f) - sd;
+        const v2f bm = v2f{(U.x >= nLth.x) ? x.x : copysign_(0.0f, x.x), (U.y >= nLth.y) ? x.y : copysign_(0.0f, x.y)};
+        liq = sel(thawed, splat(1.0f), bm);
+    }
     const v2f C = heat_capacity2(p, fractions2(p, sat, liq, viol));
     const M2 frozen = lt(U, nLth);
     const v2f num = sel(frozen, U + Lth, U);
@@ -124,8 +132,13 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 }  // namespace pk
 
 // grid: one wave per 2 * (64 / LPC) columns
+// (Deriving T and liq from (U, sat) instead of reading them, as k_column can, was measured here as well: C5 562 vs 533 us
+// per step -- the packed kernel is not short of bytes -- and is not offered.)
 template <bool RICHARDS, int LPC>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevParams<float> p, float dt, int finalize, int write_kf) {
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
+    constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
+    const View<float>& v = v_arg;
+    const DevParams<float>& p = p_arg;
     using namespace pk;
     typedef float NF;
     constexpr int HYD = HYD_BC_LINEAR;
@@ -146,8 +159,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevPa
     const unsigned cb0 = ((unsigned)j0 * (unsigned)v.Nzp + kk) * 4u, cb1 = ((unsigned)j1 * (unsigned)v.Nzp + kk) * 4u;
     uint32_t viol = 0;
 
-    const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1), T = ld2(v.T, cb0, cb1), liq = ld2(v.liq, cb0, cb1);
+    const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
     const v2f psi = RICHARDS ? ld2(v.psi, cb0, cb1) : splat(0.0f);
+    const v2f T = ld2(v.T, cb0, cb1), liq = ld2(v.liq, cb0, cb1);
 
     uint32_t viol_old = 0;   // (bounds of the incoming state were flagged by the launch that produced it)
     const Frac2 f = fractions2(p, sat, liq, viol_old);
@@ -257,8 +271,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v, DevPa
     }
     // ---- closures
     v2f ln, Tn;
-    energy_closure2(p, Unew, snew, ln, Tn, viol);
-    const v2f psin = RICHARDS ? pressure_head2(p, snew, L.zC, L.psiz, z0) : splat(0.0f);
+    const DevParams<float>& p2 = kernarg_reload<DevParams<float>>(off_p);   // (second half of the step: see kernarg_reload)
+    energy_closure2(p2, Unew, snew, ln, Tn, viol);
+    const v2f psin = RICHARDS ? pressure_head2(p2, snew, L.zC, L.psiz, z0) : splat(0.0f);
     v2f Kf_out = Kf_lo, Kf_out_top = Kc;
     if (finalize && write_kf) {
         const v2f Kc_new = conductivity_linear2(p, fractions2(p, snew, ln, viol));

@@ -212,3 +212,39 @@ def test_divide_sequences():
     Kc = d.get("hydraulic_conductivity")
     assert np.array_equal(Kc[0], K_expected[0]) and np.array_equal(Kc[-1], K_expected[-1])
     assert np.array_equal(Kc[1:-2], np.minimum(K_expected[1:-1], K_expected[:-2]))
+
+
+def test_divide_sequences_fp32():
+    """div_nr(float): through the packed fp32 step's closures (T = U / C, K = K_sat * water / theta_sat) on swept operands,
+    against numpy's float32 division, bit for bit; packed == scalar kernels on the same inputs."""
+    rng = np.random.default_rng(9)
+    Nh, Nz = 2048, 64
+    p = trm._capi.default_params()
+    p.flow = 1
+    d = trm.DeviceState(trm.ColumnGrid(trm.UniformSpacing(dz=0.1, N=Nz), Nh, dtype=np.float32), p)
+    f = np.float32
+    por = f(f(1) - f(0)) * f(0.49) + f(0) * f(0.9)
+    sat = rng.uniform(1e-4, 1.0, (Nz, Nh)).astype(f)
+    U = np.concatenate([rng.uniform(0.0, 1e9, (Nz // 2, Nh)), np.ldexp(rng.uniform(0.5, 1, (Nz // 2, Nh)), rng.integers(-60, 28, (Nz // 2, Nh)))]).astype(f)
+    frozen = rng.random((Nz, Nh)) < 0.4
+    L = f(p.rho_w) * f(p.Lsl)
+    Lth = (L * sat) * por
+    U = np.where(frozen, -Lth - U, U).astype(f)
+    d.set("internal_energy", U)
+    d.set("saturation_water_ice", sat)
+    d.closure()
+    liq = np.where(U >= 0, f(1), f(0)).astype(f)
+    wi = sat * por
+    water, ice, air = wi * liq, wi * (f(1) - liq), (f(1) - sat) * por
+    solid = f(1) - por
+    C = f(p.c_water) * water
+    C = C + f(p.c_ice) * ice
+    C = C + f(p.c_air) * air
+    C = C + f(p.c_mineral) * (solid * f(1))
+    C = C + f(p.c_organic) * (solid * f(0))
+    T_expected = (np.where(U >= 0, U, U + Lth).astype(f) / C).astype(f)
+    assert np.array_equal(d.get("temperature"), T_expected)
+    d.compute_auxiliary()
+    K_expected = ((f(p.K_sat) * water) / ((water + ice) + air)).astype(f)
+    Kc = d.get("hydraulic_conductivity")
+    assert np.array_equal(Kc[0], K_expected[0]) and np.array_equal(Kc[-1], K_expected[-1])
