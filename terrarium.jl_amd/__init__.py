@@ -29,3 +29,4 @@ from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, Presc
                          update_state)
 from ._capi import TerrariumHipError
 from .io import Hdf5File, RasterInputSource
+from .simulation import Simulation, Callback, IterationInterval, TimeInterval, SnapshotWriter, run_simulation

@@ -350,3 +350,39 @@ def test_prescribed_albedo_inputs(multistep):
     for name in ("temperature", "skin_temperature", "surface_net_radiation", "ground_heat_flux"):
         a, b = st.get(name), o.get(name)
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-10, name
+
+
+# examples/simulations/soil_heat_global.jl:117-123, model_integrator.jl:39-66: Simulation(integrator; Δt, stop_time), run!(sim)
+@pytest.mark.parametrize("stepper", [trm.ForwardEuler, trm.Heun])
+def test_simulation_driver_with_callbacks_and_ring_output(tmp_path, stepper):
+    mask = trm.masks.load_land_mask("N72")
+    grid = trm.ColumnRingGrid(trm.ExponentialSpacing(N=20), mask)
+    lat, lon = trm.masks.masked_latlon(mask)
+    T0 = 20.0 - np.abs(40.0 * np.sin(lat))
+    bc = trm.PrescribedSurfaceTemperature("Ts", trm.FieldTimeSeries.from_function(lambda t: T0 + 10 * np.sin(2 * np.pi * t / 86400.0 - lon), 600.0 * np.arange(20)))
+    make = lambda: trm.initialize(trm.SoilModel(grid), stepper(dt=600.0), boundary_conditions=bc, initializers=dict(temperature=T0[None, :] * np.ones((20, 1)), saturation_water_ice=0.7))
+    integ = make()
+    sim = trm.Simulation(integ, dt=600.0, stop_time=2.25 * 3600.0)       # 13.5 steps: the last one is aligned (300 s)
+    seen = []
+    sim.add_callback(lambda s: seen.append((s.iteration, s.time)), trm.IterationInterval(4), name="progress")
+    out = tmp_path / "surface.npz"
+    sim.output_writers["surface"] = trm.SnapshotWriter(["ground_temperature", "temperature"], trm.TimeInterval(1800.0), filename=str(out), ring_grid=grid)
+    trm.run_simulation(sim)
+    assert sim.time == 2.25 * 3600.0 and sim.iteration == 14
+    assert seen == [(0, 0.0), (4, 2400.0), (8, 4800.0), (12, 7200.0)]
+    f = np.load(out)
+    assert list(f["time"]) == [0.0, 1800.0, 3600.0, 5400.0, 7200.0] and f["ground_temperature"].shape == (5, 144, 288)
+    assert np.isnan(f["ground_temperature"][:, ~mask]).all() and np.isfinite(f["ground_temperature"][:, mask]).all()
+    assert f["temperature"].shape == (5, 20, 144, 288)
+    # the same trajectory by hand: 13 steps of 600 s and one of 300 s
+    ref = make()
+    trm.run(ref, steps=13, dt=600.0)
+    trm.timestep(ref, 300.0)
+    assert np.array_equal(ref.state.temperature, integ.state.temperature)
+    assert np.array_equal(grid.gather(f["ground_temperature"][-1]), _state_at(make, 12)[-1])
+
+
+def _state_at(make, nsteps):
+    i = make()
+    trm.run(i, steps=nsteps, dt=600.0)
+    return i.state.temperature

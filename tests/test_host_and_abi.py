@@ -138,3 +138,15 @@ def test_soil_texture_and_surfex_hydraulics():
         assert getattr(a, name) == getattr(b, name), name
     land = trm.LandModel(grid, surface_energy_balance=trm.SurfaceEnergyBalance(albedo=trm.PrescribedAlbedo()))
     assert trm.flatten(land).prescribed_albedo == 1 and trm.flatten(trm.LandModel(grid)).prescribed_albedo == 0
+
+
+def test_simulation_schedules():
+    """IterationInterval / TimeInterval of the Simulation driver (Oceananigans.Utils schedules)."""
+    s = trm.IterationInterval(3)
+    assert [s.actuates(0.0, i) for i in range(7)] == [True, False, False, True, False, False, True]
+    assert s.steps_until_next(0.0, 4, 60.0) == 2 and s.steps_until_next(0.0, 6, 60.0) == 3
+    t = trm.TimeInterval(1800.0)
+    assert t.next_time() == 1800.0 and t.steps_until_next(0.0, 0, 600.0) == 3 and t.steps_until_next(1500.0, 0, 600.0) == 1
+    assert not t.actuates(1200.0, 2)
+    assert t.actuates(1800.0, 3) and t.next_time() == 3600.0
+    assert not t.actuates(3000.0, 5) and t.actuates(3700.0, 6) and t.next_time() == 5400.0
