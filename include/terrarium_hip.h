@@ -170,6 +170,8 @@ typedef struct trm_params {
     /* ConstantAlbedo, ImplicitSkinTemperature, ConstantAerodynamics, PrescribedAtmosphere,
      * DirectSurfaceRunoff, ConstantEvaporationResistanceFactor */
     double albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap;
+    double field_capacity;    /* field_capacity(hydraulic_properties, texture) (soil_hydraulic_properties.jl:93-97,150-155): read by
+                                 the soil-moisture evaporation resistance only                                        */
     int32_t flow;             /* TRM_FLOW_*                                                               */
     int32_t swrc;             /* TRM_SWRC_*                                                               */
     int32_t unsat_k;          /* TRM_UNSATK_*                                                             */
@@ -177,6 +179,10 @@ typedef struct trm_params {
     int32_t halo_policy;      /* TRM_HALO_*                                                               */
     int32_t prescribed_albedo;/* 0: ConstantAlbedo (the two scalars above); 1: PrescribedAlbedo -- per-column inputs
                                  TRM_FIELD_ALBEDO / TRM_FIELD_EMISSIVITY (albedo.jl:8-14, abstract_types.jl:120-131)   */
+    int32_t evap_resistance;  /* ground evaporation resistance factor beta (ground_resistance_factor.jl): 0 = constant
+                                 `beta_evap` (ConstantEvaporationResistanceFactor), 1 = SoilMoistureResistanceFactor:
+                                 (1 - cos(pi * theta_1 / theta_fc))^2 / 4 below field capacity, 1 above (Lee & Pielke 1992) */
+    int32_t reserved;
 } trm_params;
 
 /* Fill `p` with the reference defaults. */

@@ -33,8 +33,8 @@ class ParamsD(C.Structure):
         "k_water k_ice k_air k_mineral k_organic c_water c_ice c_air c_mineral c_organic "
         "por_mineral por_organic rho_soc rho_org "
         "K_sat theta_res bc_psi_s bc_lambda vg_alpha vg_n impedance vwc_forcing "
-        "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap").split()] + [
-        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy prescribed_albedo".split()]
+        "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap field_capacity").split()] + [
+        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy prescribed_albedo evap_resistance reserved".split()]
 
 
 def default_params(**overrides):
@@ -47,8 +47,8 @@ def default_params(**overrides):
         por_mineral=0.49, por_organic=0.9, rho_soc=0.0, rho_org=1300.0,
         K_sat=1.0e-5, theta_res=0.0, bc_psi_s=0.01, bc_lambda=0.2, vg_alpha=1.0, vg_n=2.0, impedance=7.0,
         vwc_forcing=0.0,
-        albedo=0.3, emissivity=0.97, kappa_s=2.0, C_h=1.2e-3, min_windspeed=0.01, tau_r=3600.0, beta_evap=1.0,
-        flow=0, swrc=0, unsat_k=0, seb=0, halo_policy=0, prescribed_albedo=0,
+        albedo=0.3, emissivity=0.97, kappa_s=2.0, C_h=1.2e-3, min_windspeed=0.01, tau_r=3600.0, beta_evap=1.0, field_capacity=0.25,
+        flow=0, swrc=0, unsat_k=0, seb=0, halo_policy=0, prescribed_albedo=0, evap_resistance=0, reserved=0,
     )
     for k, v in overrides.items():
         if k not in d:

@@ -134,8 +134,8 @@ struct ParamsD {  // plain doubles + ints across the C API
     // soil_hydraulic_properties.jl / FreezeCurves
     double K_sat, theta_res, bc_psi_s, bc_lambda, vg_alpha, vg_n, impedance, vwc_forcing;
     // surface energy balance
-    double albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap;
-    int32_t flow, swrc, unsat_k, seb, halo_policy, prescribed_albedo;
+    double albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap, field_capacity;
+    int32_t flow, swrc, unsat_k, seb, halo_policy, prescribed_albedo, evap_resistance, reserved;
 };
 
 template <class NF> struct Params {
@@ -144,8 +144,8 @@ template <class NF> struct Params {
     NF c_water, c_ice, c_air, c_mineral, c_organic;
     NF por_mineral, por_organic, rho_soc, rho_org;
     NF K_sat, theta_res, bc_psi_s, bc_lambda, vg_alpha, vg_n, impedance, vwc_forcing;
-    NF albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap;
-    int flow, swrc, unsat_k, seb, halo_policy, prescribed_albedo;
+    NF albedo, emissivity, kappa_s, C_h, min_windspeed, tau_r, beta_evap, field_capacity;
+    int flow, swrc, unsat_k, seb, halo_policy, prescribed_albedo, evap_resistance;
     explicit Params(const ParamsD& d)
         : rho_w(NF(d.rho_w)), rho_i(NF(d.rho_i)), rho_a(NF(d.rho_a)), c_a(NF(d.c_a)), Lsl(NF(d.Lsl)), Llg(NF(d.Llg)),
           Lsg(NF(d.Lsg)), g(NF(d.g)), Tref(NF(d.Tref)), sigma(NF(d.sigma)), kappa_vk(NF(d.kappa_vk)),
@@ -156,8 +156,8 @@ template <class NF> struct Params {
           theta_res(NF(d.theta_res)), bc_psi_s(NF(d.bc_psi_s)), bc_lambda(NF(d.bc_lambda)), vg_alpha(NF(d.vg_alpha)),
           vg_n(NF(d.vg_n)), impedance(NF(d.impedance)), vwc_forcing(NF(d.vwc_forcing)), albedo(NF(d.albedo)),
           emissivity(NF(d.emissivity)), kappa_s(NF(d.kappa_s)), C_h(NF(d.C_h)), min_windspeed(NF(d.min_windspeed)),
-          tau_r(NF(d.tau_r)), beta_evap(NF(d.beta_evap)), flow(d.flow), swrc(d.swrc), unsat_k(d.unsat_k), seb(d.seb),
-          halo_policy(d.halo_policy), prescribed_albedo(d.prescribed_albedo) {}
+          tau_r(NF(d.tau_r)), beta_evap(NF(d.beta_evap)), field_capacity(NF(d.field_capacity)), flow(d.flow), swrc(d.swrc), unsat_k(d.unsat_k), seb(d.seb),
+          halo_policy(d.halo_policy), prescribed_albedo(d.prescribed_albedo), evap_resistance(d.evap_resistance) {}
 };
 
 // ---------------------------------------------------------------------------
@@ -723,7 +723,20 @@ template <class NF> class Oracle {
         for (long i = col_lo(); i < col_hi(); ++i) {
             NF ra = aerodynamic_resistance(i);
             NF dq = humidity_vpd(i, Ts[i]);
-            evap[i] = p.beta_evap * dq / ra;
+            // ground_evaporation_resistance_factor (ground_resistance_factor.jl:12,36-56)
+            NF beta = p.beta_evap;
+            if (p.evap_resistance == 1) {
+                NF por = porosity(p);
+                Fractions<NF> fr = volumetric_fractions(por, sat[C(Nz, i)], liq[C(Nz, i)], organic_fraction(p));
+                NF fc = p.field_capacity;
+                if (fr.water < fc) {
+                    NF t = NF(1) - std::cos(NF(3.141592653589793) * fr.water / fc);
+                    beta = (t * t) / NF(4);
+                } else {
+                    beta = NF(1);
+                }
+            }
+            evap[i] = beta * dq / ra;
         }
     }
     void compute_runoff() {  // direct_surface_runoff.jl:87-117

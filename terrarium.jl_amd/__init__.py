@@ -19,7 +19,8 @@ from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapac
                      SoilHydraulicsSURFEX, SoilTexture, NoFlow, RichardsEq, SoilHydrology, SoilEnergyWaterCarbon, ConstantAlbedo,
                      PrescribedAlbedo,
                      ImplicitSkinTemperature, SurfaceEnergyBalance, ConstantAerodynamics, PrescribedAtmosphere,
-                     DirectSurfaceRunoff, BareGroundEvaporation, SurfaceHydrology, DefaultInitializer,
+                     DirectSurfaceRunoff, BareGroundEvaporation, ConstantEvaporationResistanceFactor, SoilMoistureResistanceFactor,
+                     SurfaceHydrology, DefaultInitializer,
                      ConstantSoilTemperature, QuasiThermalSteadyState, ConstantSaturation, SaturationWaterTable,
                      SoilInitializer, SoilModel, LandModel, flatten)
 from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, PrescribedBottomTemperature,

@@ -57,8 +57,8 @@ class TrmParams(C.Structure):
         "k_water k_ice k_air k_mineral k_organic c_water c_ice c_air c_mineral c_organic "
         "por_mineral por_organic rho_soc rho_org "
         "K_sat theta_res bc_psi_s bc_lambda vg_alpha vg_n impedance vwc_forcing "
-        "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap").split()] + [
-        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy prescribed_albedo".split()]
+        "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap field_capacity").split()] + [
+        (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy prescribed_albedo evap_resistance reserved".split()]
 
 
 class TerrariumHipError(RuntimeError):

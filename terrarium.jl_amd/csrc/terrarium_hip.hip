@@ -223,6 +223,8 @@ template <class NF> DevParams<NF> make_dev_params(const trm_params& q) {
     p.tau_r = (NF)q.tau_r;
     p.rtau_r = NF(1) / p.tau_r;
     p.beta_evap = (NF)q.beta_evap;
+    p.field_capacity = (NF)q.field_capacity;
+    p.evap_resistance = q.evap_resistance;
     p.Tref = (NF)q.Tref;
     p.eps_mw = (NF)q.eps_mw;
     p.one_minus_eps_mw = NF(1) - p.eps_mw;
@@ -1165,6 +1167,7 @@ int trm_default_params(trm_params* p) {
     p->impedance = 7.0; p->vwc_forcing = 0.0;
     p->albedo = 0.3; p->emissivity = 0.97; p->kappa_s = 2.0; p->C_h = 1.2e-3; p->min_windspeed = 0.01; p->tau_r = 3600.0;
     p->beta_evap = 1.0;
+    p->field_capacity = 0.25;
     p->flow = TRM_FLOW_NOFLOW; p->swrc = TRM_SWRC_BROOKS_COREY; p->unsat_k = TRM_UNSATK_LINEAR; p->seb = 0;
     p->halo_policy = TRM_HALO_REFERENCE_ZERO;
     return TRM_OK;

@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
                 uint32_t viol_s = 0;
                 const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, c.liq, fractions(p, c.sat, c.liq, viol_s));
                 const NF Ts_in = sf.out.Ts;
-                surface_processes(p, sf.in, Ts_in, c.T, c.sat, Kf_top, S, RICHARDS, v.g.dzc_top, sf.out);
+                surface_processes(p, sf.in, Ts_in, c.T, c.sat, c.liq, Kf_top, S, RICHARDS, v.g.dzc_top, sf.out);
                 if (ln.is_top) {
                     bc.flux_U = -flux_term_top(sf.out.ghf, v.g);
                     if (RICHARDS) bc.flux_S = -flux_term_top(-sf.out.infil, v.g);

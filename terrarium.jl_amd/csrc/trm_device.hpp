@@ -291,8 +291,8 @@ template <class NF> struct DevParams {
     NF org, solid_frac, frac_organic, frac_mineral;
     // surface energy balance
     NF albedo, emissivity, one_minus_emissivity, eps_sigma, kappa_s2, rkappa_s2, C_h, min_windspeed, tau_r, rtau_r, beta_evap;
-    NF sigma;
-    int prescribed_albedo;
+    NF sigma, field_capacity;
+    int prescribed_albedo, evap_resistance;
     NF Tref, eps_mw, one_minus_eps_mw, ca_rhoa, Llg_rhoa;
 };
 
@@ -490,13 +490,26 @@ template <class NF> TRM_DEV void seb_fluxes(const DevParams<NF>& p, const SebIn<
 // bare-ground evaporation, direct runoff / infiltration, then the fused SEB kernel twice.
 // 0-D per column; it runs in its own small launch (k_surface) so that its registers (exp, divides)
 // do not inflate the per-cell kernels.
+TRM_DEV double cos_(double x) { return cos(x); }
+TRM_DEV float cos_(float x) { return cosf(x); }
+// ground_evaporation_resistance_factor (ground_resistance_factor.jl:12,36-56): the constant factor, or Lee & Pielke's
+// soil-moisture limitation from the liquid water content of the top cell against the field capacity
+template <class NF> TRM_DEV NF evaporation_resistance_factor(const DevParams<NF>& p, NF sat_top, NF liq_top) {
+    if (p.evap_resistance == 0) return p.beta_evap;
+    const NF water = (sat_top * p.por) * liq_top;          // volumetric_fractions(soil).water
+    if (water < p.field_capacity) {
+        const NF t = NF(1) - cos_(NF(3.141592653589793) * water / p.field_capacity);
+        return (t * t) / NF(4);
+    }
+    return NF(1);
+}
 template <class NF>
-TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF Ts_in, NF T_ground, NF sat_top,
+TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF Ts_in, NF T_ground, NF sat_top, NF liq_top,
                                                NF Kf_top, NF S, bool richards, NF dz_top, SebOut<NF>& o) {
     o.Ts = Ts_in;
     NF ra = aerodynamic_resistance(p, in.wind);
     // bare_ground_evaporation.jl:49-62
-    o.evap = p.beta_evap * humidity_vpd(p, in.pres, in.qair, o.Ts) / ra;
+    o.evap = evaporation_resistance_factor(p, sat_top, liq_top) * humidity_vpd(p, in.pres, in.qair, o.Ts) / ra;
     // direct_surface_runoff.jl:87-117
     NF excess = richards ? S : NF(0);
     bool unsat = sat_top < NF(1);

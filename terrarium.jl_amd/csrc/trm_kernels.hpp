@@ -120,13 +120,13 @@ template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __
     uint32_t viol = 0;
     const NF T_top = TOP_ARRAYS ? v.top_T[i] : v.T[top], sat_top = TOP_ARRAYS ? v.top_sat[i] : v.sat[top];
     NF Kf_top;
+    const NF liq_top = (FROM_STATE && TOP_ARRAYS) ? v.top_liq[i] : v.liq[top];
     if (FROM_STATE) {
-        const NF liq_top = TOP_ARRAYS ? v.top_liq[i] : v.liq[top];
         Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));   // (in front of the fused step)
     } else {
         Kf_top = v.Kf[top];
     }
-    surface_processes(p, in, v.Ts[i], T_top, sat_top, Kf_top, v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
+    surface_processes(p, in, v.Ts[i], T_top, sat_top, liq_top, Kf_top, v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
     v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
     v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
 }

@@ -246,9 +246,25 @@ class DirectSurfaceRunoff:
 
 
 @dataclass
-class BareGroundEvaporation:
-    """bare_ground_evaporation.jl:12-24 with ConstantEvaporationResistanceFactor"""
+class ConstantEvaporationResistanceFactor:
+    """ground_resistance_factor.jl:6-12"""
     factor: float = 1.0
+
+
+@dataclass
+class SoilMoistureResistanceFactor:
+    """ground_resistance_factor.jl:14-56 (Lee & Pielke 1992): beta = (1 - cos(pi theta_1 / theta_fc))^2 / 4 below the field
+    capacity of the soil's hydraulic properties, 1 above."""
+
+
+@dataclass
+class BareGroundEvaporation:
+    """bare_ground_evaporation.jl:12-24: E = beta dq / r_a with the ground resistance factor beta."""
+    ground_resistance: Union[ConstantEvaporationResistanceFactor, SoilMoistureResistanceFactor] = field(default_factory=ConstantEvaporationResistanceFactor)
+
+    @property
+    def factor(self):
+        return getattr(self.ground_resistance, "factor", 1.0)
 
 
 @dataclass
@@ -362,7 +378,7 @@ def flatten(model) -> "_capi.TrmParams":
     p.vwc_forcing = float(hyd.vwc_forcing) if isinstance(hyd.vwc_forcing, (int, float)) else 0.0  # arrays: uploaded by initialize
     # surface defaults (used only when seb = 1)
     p.albedo, p.emissivity, p.kappa_s, p.C_h = 0.3, 0.97, 2.0, 1.2e-3
-    p.min_windspeed, p.tau_r, p.beta_evap = 0.01, 3600.0, 1.0
+    p.min_windspeed, p.tau_r, p.beta_evap, p.field_capacity = 0.01, 3600.0, 1.0, 0.25
     p.seb = 0
     if getattr(model, "coupled_surface", False):
         p.seb = 1
@@ -375,6 +391,10 @@ def flatten(model) -> "_capi.TrmParams":
         p.C_h = model.atmosphere.aerodynamics.C_h
         p.min_windspeed = model.atmosphere.min_windspeed
         p.tau_r = model.surface_hydrology.surface_runoff.tau_r
-        p.beta_evap = model.surface_hydrology.evapotranspiration.factor
+        evap = model.surface_hydrology.evapotranspiration
+        p.beta_evap = evap.factor
+        if isinstance(evap.ground_resistance, SoilMoistureResistanceFactor):
+            p.evap_resistance = 1
+        p.field_capacity = hp.field_capacity(soil.strat.texture)
     p.halo_policy = _capi.HALO[model.halo_policy]
     return p

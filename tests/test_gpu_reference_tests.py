@@ -386,3 +386,39 @@ def _state_at(make, nsteps):
     i = make()
     trm.run(i, steps=nsteps, dt=600.0)
     return i.state.temperature
+
+
+# ground_resistance_factor.jl:36-56: soil-moisture limited bare-ground evaporation, device vs oracle through a LandModel run
+def test_soil_moisture_evaporation_resistance():
+    import oracle
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=16), 90)
+    rng = np.random.default_rng(6)
+    zc = grid.z_centers()
+    sat = np.clip(np.minimum(1.0, 0.8 - 0.05 * zc)[:, None] * (1.0 + 0.08 * rng.uniform(-1, 1, 90))[None, :], 0.05, 1.0)   # land_model_tests.jl:19
+    fc = 0.42                                                   # top-cell water content 0.36..0.42: beta from ~0.8 to 1
+    hyd = trm.SoilHydrology(vertical_flow=trm.RichardsEq(), hydraulic_properties=trm.ConstantSoilHydraulics(field_capacity_value=fc))
+    land = trm.LandModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=hyd),
+                         surface_hydrology=trm.SurfaceHydrology(evapotranspiration=trm.BareGroundEvaporation(ground_resistance=trm.SoilMoistureResistanceFactor())))
+    p = trm.flatten(land)
+    assert p.evap_resistance == 1 and p.field_capacity == fc
+    integ = trm.initialize(land, trm.ForwardEuler(dt=60.0), initializers=dict(temperature=4.0, saturation_water_ice=sat))
+    st = integ.state
+    o = oracle.Oracle(90, grid.thickness, oracle.default_params(flow=1, seb=1, evap_resistance=1, field_capacity=fc))
+    o.set("temperature", 4.0); o.set("saturation_water_ice", sat); o.initialize()
+    ref = oracle.Oracle(90, grid.thickness, oracle.default_params(flow=1, seb=1))
+    ref.set("temperature", 4.0); ref.set("saturation_water_ice", sat); ref.initialize()
+    st.compute_auxiliary(); o.compute_auxiliary(); ref.compute_evaporation()
+    water = sat[-1] * 0.49
+    beta = np.where(water < fc, (1 - np.cos(np.pi * water / fc)) ** 2 / 4, 1.0)
+    assert beta.min() < 0.97 and beta.max() == 1.0
+    E = st.evaporation_ground
+    assert np.allclose(E, o.get("evaporation_ground"), rtol=1e-10, atol=0)
+    assert np.allclose(E / ref.get("evaporation_ground"), beta, rtol=1e-9)       # the factor itself, against the constant-beta evaporation
+    st.set_option("steps_per_launch", 4)
+    trm.run(integ, steps=12)
+    o.run(60.0, 12)
+    assert st.status() == 0 and o.status() == 0
+    for name in ("temperature", "saturation_water_ice", "skin_temperature", "latent_heat_flux"):
+        a, b = st.get(name), o.get(name)
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-10, name
+    assert np.allclose(st.evaporation_ground, o.get("evaporation_ground"), rtol=1e-9, atol=0)

@@ -572,3 +572,24 @@ def test_k20_prescribed_albedo():
     assert np.array_equal(o.get("surface_shortwave_up"), np.array([0.4, 0.2]) * 250.0)
     for i, e in enumerate((0.8, 0.95)):
         assert o.get("surface_longwave_up")[i] == pytest.approx(e * p.sigma * (3.0 + 273.15) ** 4 + (1 - e) * 80.0, rel=1e-14)
+
+
+# ground_resistance_factor.jl:36-56 (SoilMoistureResistanceFactor; no reference test holds a value for it: the formula's
+# own limits are the known answers -- beta(0) = 0, beta(fc / 2) = 1/4, beta(>= fc) = 1)
+def test_soil_moisture_evaporation_resistance_limits():
+    p = default_params(seb=1, flow=1, evap_resistance=1, field_capacity=0.25)
+    o = Oracle(4, trm.ExponentialSpacing(N=10).get_spacing(), p)
+    por = 0.49
+    sat = np.full((10, 4), 0.9)
+    sat[-1] = np.array([0.0, 0.125 / por, 0.25 / por, 0.9])         # water content 0, fc/2, fc, > fc in the top cell
+    o.set("saturation_water_ice", sat)
+    o.set("temperature", 5.0)
+    o.initialize()
+    o.set("skin_temperature", 5.0)
+    o.compute_evaporation()
+    beta = o.get("evaporation_ground")
+    ref = Oracle(4, trm.ExponentialSpacing(N=10).get_spacing(), default_params(seb=1, flow=1))
+    ref.set("saturation_water_ice", sat); ref.set("temperature", 5.0); ref.initialize(); ref.set("skin_temperature", 5.0)
+    ref.compute_evaporation()
+    beta = beta / ref.get("evaporation_ground")
+    assert beta[0] == 0.0 and beta[1] == pytest.approx(0.25, rel=1e-12) and beta[2] == pytest.approx(1.0, abs=1e-12) and beta[3] == 1.0
