@@ -83,8 +83,19 @@ def spawn_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank that dies (no such device, ...) must not leave the others waiting in a rendezvous
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    out = procs[0].stdout.read()
+    codes = [p.wait() for p in procs]
     sys.stdout.write(out)
     sys.stdout.flush()
     return max(abs(c) for c in codes)
@@ -217,6 +228,8 @@ def main():
     backend = os.environ.get("TRM_BENCH_BACKEND", "nccl")
     if os.environ.get("TRM_BENCH_SHARE_DEVICE"):
         local_rank = local_rank % torch.cuda.device_count()
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants device {local_rank} but this node has {torch.cuda.device_count()} GPU(s)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -299,10 +312,20 @@ def main():
                    "status_flags": int(nan_flag)},
         "roofline": roofline_object(config, Nz, Nh, wordsize, kernel_s, kernel_name, pmc_name),
     }
+    hung = False
     if world > 1:
-        # global diagnostics through the library's own RCCL path (trm_comm_init / trm_reduce_global), beside torch's
-        out["config"]["abi_global_status"] = abi_global_status(dev, dist, rank, world, local_rank, backend, status)
-    dev.close()
+        # global diagnostics through the library's own RCCL path (trm_comm_init / trm_status_global), beside torch's.  It runs
+        # in a watchdog thread: should a collective of this never-before-exercised path block, the line is still printed
+        # (with "timeout") and the process leaves through os._exit.
+        import threading
+        box = {}
+        th = threading.Thread(target=lambda: box.setdefault("r", abi_global_status(dev, dist, rank, world, local_rank, backend, status)), daemon=True)
+        th.start()
+        th.join(60.0)
+        hung = th.is_alive()
+        out["config"]["abi_global_status"] = "timeout" if hung else box.get("r", "failed")
+    if not hung:
+        dev.close()
 
     single = rank == 0 and n_gpus == 1
     if single and args.multistep > 1 and args.kernel == "fused" and not heun and not args.series:
@@ -312,7 +335,9 @@ def main():
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(W, w, args.cpu_seconds)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+    if hung:
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 
