@@ -277,3 +277,102 @@ class Oracle:
 
     def status(self):
         return self.lib.trm_oracle_status(self.h)
+
+
+# ---- vegetation (oracle/vegetation_oracle.hpp) -------------------------------------------------------------------------------
+VEG_PARAM_NAMES = ("tau25 Kc25 Ko25 q10_tau q10_Kc q10_Ko alpha_leaf alpha_a alpha_C3 cq k_ext T_CO2_high T_CO2_low T_photos_high "
+                   "T_photos_low theta_r g1 g_min cn_sapwood cn_root aws SLA awl LAI_min LAI_max gamma_L gamma_R gamma_S nu_seed "
+                   "gamma_v_min root_a root_b wilting_point field_capacity C_mass").split()
+
+
+class VegParamsD(C.Structure):
+    _fields_ = [(n, C.c_double) for n in VEG_PARAM_NAMES]
+
+
+def default_vegetation_params(**overrides):
+    """Reference defaults (needleleaf-tree PFT): photosynthesis.jl:17-68, stomatal_conductance.jl:16-24,
+    autotrophic_respiration.jl:14-23, carbon_dynamics.jl:18-43, vegetation_dynamics.jl:15-22, root_distribution.jl:23-29,
+    soil_hydraulic_properties.jl:74-80, physical_constants.jl:50."""
+    d = dict(tau25=2600.0, Kc25=30.0, Ko25=3.0e4, q10_tau=0.57, q10_Kc=2.1, q10_Ko=1.2, alpha_leaf=0.17, alpha_a=0.5, alpha_C3=0.08,
+             cq=4.6e-6, k_ext=0.5, T_CO2_high=42.0, T_CO2_low=-4.0, T_photos_high=30.0, T_photos_low=15.0, theta_r=0.7,
+             g1=2.3, g_min=0.5, cn_sapwood=330.0, cn_root=29.0, aws=10.0,
+             SLA=10.0, awl=2.0, LAI_min=1.0, LAI_max=6.0, gamma_L=0.3, gamma_R=0.3, gamma_S=0.05,
+             nu_seed=0.001, gamma_v_min=0.002, root_a=7.0, root_b=2.0, wilting_point=0.05, field_capacity=0.25, C_mass=12.0)
+    for k, v in overrides.items():
+        if k not in d:
+            raise KeyError(k)
+        d[k] = v
+    return VegParamsD(**d)
+
+
+VEG_FIELDS = dict(carbon_vegetation=0, vegetation_area_fraction=1, tend_carbon_vegetation=2, tend_vegetation_area_fraction=3,
+                  balanced_leaf_area_index=4, phenology_factor=5, leaf_area_index=6, canopy_water_conductance=7,
+                  leaf_to_air_co2_ratio=8, net_assimilation=9, leaf_respiration=10, gross_primary_production=11,
+                  autotrophic_respiration=12, net_primary_production=13, air_temperature=14, air_pressure=15,
+                  specific_humidity=16, surface_shortwave_down=17, CO2=18, soil_moisture_limiting_factor=19,
+                  daily_leaf_respiration=20, ground_temperature=21)
+VEG_SCALARS = dict(lambda_NPP=0, LAI_b=1, Lambda_loc=2, C_veg_tend=3, f_deciduous=4, phenology_factor=5, LAI=6, gamma_v=7, nu_star=8,
+                   nu_tendency=9, gw_can=10, lambda_c=11, tau=12, Kc=13, Ko=14, Gamma_star=15, PAR=16, APAR=17, pres_i=18,
+                   temperature_stress=19, c_1=20, c_2=21, Vc_max=22, JE=23, JC=24, Rd=25, Ag=26, resp_Rd=27, resp_An=28,
+                   f_temp_air=29, f_temp_soil=30, resp10=31, Rm=32, Rg=33, Ra=34, NPP=35, root_density=36, plant_available_water=37)
+
+
+def _veg_lib():
+    lib = _lib()
+    if not getattr(lib, "_veg_ready", False):
+        lib.trm_oracle_veg_create.restype = C.c_void_p
+        lib.trm_oracle_veg_create.argtypes = [C.c_int, C.c_long, C.POINTER(VegParamsD), C.POINTER(ParamsD)]
+        lib.trm_oracle_veg_destroy.argtypes = [C.c_void_p]
+        lib.trm_oracle_veg_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.trm_oracle_veg_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.trm_oracle_veg_compute_auxiliary.argtypes = [C.c_void_p]
+        lib.trm_oracle_veg_compute_tendencies.argtypes = [C.c_void_p]
+        lib.trm_oracle_veg_timestep.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+        lib.trm_oracle_veg_time.restype = C.c_double
+        lib.trm_oracle_veg_time.argtypes = [C.c_void_p]
+        lib.trm_oracle_veg_scalar.restype = C.c_double
+        lib.trm_oracle_veg_scalar.argtypes = [C.POINTER(VegParamsD), C.c_int, C.POINTER(C.c_double)]
+        lib._veg_ready = True
+    return lib
+
+
+def veg_scalar(name, *args, params=None):
+    """One of the scalar vegetation formulas (unit known-answer tests of test/vegetation/*.jl)."""
+    p = params if params is not None else default_vegetation_params()
+    x = (C.c_double * 8)(*[float(a) for a in args])
+    return _veg_lib().trm_oracle_veg_scalar(C.byref(p), VEG_SCALARS[name], x)
+
+
+class VegetationOracle:
+    """The standalone VegetationModel (src/models/vegetation/vegetation_model.jl) on `num_columns` points."""
+
+    def __init__(self, num_columns, veg_params=None, params=None, dtype=np.float64):
+        self.lib = _veg_lib()
+        self.dtype = np.dtype(dtype)
+        self.Nh = int(num_columns)
+        self.veg_params = veg_params if veg_params is not None else default_vegetation_params()
+        self.params = params if params is not None else default_params()
+        self.h = self.lib.trm_oracle_veg_create(0 if self.dtype == np.float64 else 1, self.Nh, C.byref(self.veg_params), C.byref(self.params))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.trm_oracle_veg_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set(self, name, value):
+        a = np.empty(self.Nh, dtype=self.dtype)
+        a[...] = value
+        assert self.lib.trm_oracle_veg_set(self.h, VEG_FIELDS[name], a.ctypes.data) == 0, name
+
+    def get(self, name):
+        a = np.empty(self.Nh, dtype=self.dtype)
+        assert self.lib.trm_oracle_veg_get(self.h, VEG_FIELDS[name], a.ctypes.data) == 0, name
+        return a
+
+    def compute_auxiliary(self): self.lib.trm_oracle_veg_compute_auxiliary(self.h)
+    def compute_tendencies(self): self.lib.trm_oracle_veg_compute_tendencies(self.h)
+    def timestep(self, dt, finalize=True, heun=False): self.lib.trm_oracle_veg_timestep(self.h, float(dt), int(finalize), int(heun))
+    def time(self): return self.lib.trm_oracle_veg_time(self.h)

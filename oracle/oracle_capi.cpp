@@ -3,6 +3,7 @@
 // ctypes harness in oracle/oracle.py.  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may load the resulting library.
 #include "terrarium_oracle.hpp"
+#include "vegetation_oracle.hpp"
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -188,5 +189,81 @@ void trm_oracle_compute_surface_energy_fluxes(OracleHandle* h) { DISPATCH(h, o->
 // compute_surface_energy_fluxes!(out, i, j, ...) once per column, skin temperature as it is (surface_energy_balance.jl:119-144)
 void trm_oracle_seb_fluxes_only(OracleHandle* h) { DISPATCH(h, { for (long i = 0; i < o->Nh; ++i) o->seb_fluxes(i); }); }
 void trm_oracle_update_skin_temperature(OracleHandle* h) { DISPATCH(h, o->update_skin_temperature()); }
+
+// ---- vegetation (oracle/vegetation_oracle.hpp) ---------------------------------------------------------------------
+struct VegHandle {
+    int precision;
+    VegetationOracle<double>* d;
+    VegetationOracle<float>* f;
+};
+VegHandle* trm_oracle_veg_create(int precision, long nh, const VegParamsD* vp, const ParamsD* cp) {
+    VegHandle* h = new VegHandle{precision, nullptr, nullptr};
+    if (precision == 0) h->d = new VegetationOracle<double>(nh, *vp, *cp);
+    else h->f = new VegetationOracle<float>(nh, *vp, *cp);
+    return h;
+}
+void trm_oracle_veg_destroy(VegHandle* h) { if (h) { delete h->d; delete h->f; delete h; } }
+int trm_oracle_veg_set(VegHandle* h, int id, const void* src) {
+    if (h->precision == 0) { auto* v = h->d->field(id); if (!v) return 1; std::memcpy(v->data(), src, sizeof(double) * h->d->Nh); }
+    else { auto* v = h->f->field(id); if (!v) return 1; std::memcpy(v->data(), src, sizeof(float) * h->f->Nh); }
+    return 0;
+}
+int trm_oracle_veg_get(VegHandle* h, int id, void* dst) {
+    if (h->precision == 0) { auto* v = h->d->field(id); if (!v) return 1; std::memcpy(dst, v->data(), sizeof(double) * h->d->Nh); }
+    else { auto* v = h->f->field(id); if (!v) return 1; std::memcpy(dst, v->data(), sizeof(float) * h->f->Nh); }
+    return 0;
+}
+void trm_oracle_veg_compute_auxiliary(VegHandle* h) { DISPATCH(h, o->compute_auxiliary()); }
+void trm_oracle_veg_compute_tendencies(VegHandle* h) { DISPATCH(h, o->compute_tendencies()); }
+void trm_oracle_veg_timestep(VegHandle* h, double dt, int finalize, int heun) {
+    DISPATCH(h, { if (heun) o->timestep_heun(dt, finalize != 0); else o->timestep_euler(dt, finalize != 0); });
+}
+double trm_oracle_veg_time(VegHandle* h) { double t = 0; DISPATCH(h, t = o->time); return t; }
+// scalar formulas for the unit known-answer tests (test/vegetation/*.jl); `what` selects the function, x[] its arguments
+double trm_oracle_veg_scalar(const VegParamsD* vp, int what, const double* x) {
+    VegParams<double> p(*vp);
+    double a = 0, b = 0, c3 = 0;
+    switch (what) {
+        case 0: return veg_lambda_NPP(p, x[0]);
+        case 1: return veg_LAI_b(p, x[0]);
+        case 2: return veg_Lambda_loc(p, x[0]);
+        case 3: return veg_C_veg_tend(p, x[0], x[1]);
+        case 4: return veg_f_deciduous<double>();
+        case 5: return veg_phenology_factor<double>();
+        case 6: return veg_LAI(x[0]);
+        case 7: return veg_gamma_v(p);
+        case 8: return veg_nu_star(p, x[0]);
+        case 9: return veg_nu_tendency(p, x[0], x[1], x[2], x[3]);
+        case 10: return veg_gw_can(p, x[0], x[1], x[2], x[3], x[4]);
+        case 11: return veg_lambda_c(p, x[0]);
+        case 12: veg_kinetic(p, x[0], a, b, c3); return a;
+        case 13: veg_kinetic(p, x[0], a, b, c3); return b;
+        case 14: veg_kinetic(p, x[0], a, b, c3); return c3;
+        case 15: return veg_Gamma_star(x[0], x[1]);
+        case 16: return veg_PAR(p, x[0]);
+        case 17: return veg_APAR(p, x[0], x[1]);
+        case 18: return veg_pres_i(x[0], x[1]);
+        case 19: return veg_temperature_stress(p, x[0]);
+        case 20: veg_assimilation_factors(p, x[0], x[1], x[2], x[3], x[4], x[5], a, b); return a;
+        case 21: veg_assimilation_factors(p, x[0], x[1], x[2], x[3], x[4], x[5], a, b); return b;
+        case 22: return veg_Vc_max(x[0], x[1], x[2], x[3], x[4], x[5], x[6]);
+        case 23: veg_JE_JC(x[0], x[1], x[2], x[3], a, b); return a;
+        case 24: veg_JE_JC(x[0], x[1], x[2], x[3], a, b); return b;
+        case 25: return veg_Rd(p, x[0], x[1]);
+        case 26: return veg_Ag(p, x[0], x[1], x[2], x[3], x[4]);
+        case 27: veg_respiration_assimilation(p, x[0], x[1], x[2], x[3], x[4], x[5], x[6], a, b); return a;   // Rd
+        case 28: veg_respiration_assimilation(p, x[0], x[1], x[2], x[3], x[4], x[5], x[6], a, b); return b;   // An
+        case 29: veg_f_temp(x[0], x[1], a, b); return a;
+        case 30: veg_f_temp(x[0], x[1], a, b); return b;
+        case 31: return veg_resp10<double>();
+        case 32: return veg_Rm(p, x[0], x[1], x[2], x[3], x[4]);
+        case 33: return veg_Rg(x[0], x[1]);
+        case 34: return veg_Ra(p, x[0], x[1], x[2], x[3], x[4], x[5]);
+        case 35: return veg_NPP(x[0], x[1]);
+        case 36: return veg_root_density(p, x[0]);
+        case 37: return veg_plant_available_water(p, x[0]);
+        default: return std::nan("");
+    }
+}
 
 }  // extern "C"
