@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 6
+#define TRM_ABI_VERSION 7
 
 typedef struct trm_ctx trm_ctx;
 
@@ -109,7 +109,31 @@ enum {
      * per column instead of trm_params.albedo / .emissivity when trm_params.prescribed_albedo = 1 */
     TRM_FIELD_ALBEDO = 29,
     TRM_FIELD_EMISSIVITY = 30,
-    TRM_FIELD_COUNT = 31
+    /* ---- vegetation (VegetationCarbon, src/processes/vegetation/; enabled by trm_set_vegetation) -- all 2-D ---- */
+    TRM_FIELD_CARBON_VEGETATION = 31,        /* prognostic, kgC/m^2   carbon_dynamics.jl:55                          */
+    TRM_FIELD_VEGETATION_AREA_FRACTION = 32, /* prognostic           vegetation_dynamics.jl:27                      */
+    TRM_FIELD_TEND_CARBON_VEGETATION = 33,
+    TRM_FIELD_TEND_VEGETATION_AREA_FRACTION = 34,
+    TRM_FIELD_BALANCED_LEAF_AREA_INDEX = 35, /* carbon_dynamics.jl:56                                                */
+    TRM_FIELD_PHENOLOGY_FACTOR = 36,         /* phenology.jl:24-25                                                   */
+    TRM_FIELD_LEAF_AREA_INDEX = 37,
+    TRM_FIELD_CANOPY_WATER_CONDUCTANCE = 38, /* m/s                  stomatal_conductance.jl:29-30                  */
+    TRM_FIELD_LEAF_TO_AIR_CO2_RATIO = 39,
+    TRM_FIELD_NET_ASSIMILATION = 40,         /* gC/m^2/s             photosynthesis.jl:73-75                        */
+    TRM_FIELD_LEAF_RESPIRATION = 41,
+    TRM_FIELD_GROSS_PRIMARY_PRODUCTION = 42, /* kgC/m^2/s                                                            */
+    TRM_FIELD_AUTOTROPHIC_RESPIRATION = 43,  /* autotrophic_respiration.jl:33-34                                     */
+    TRM_FIELD_NET_PRIMARY_PRODUCTION = 44,
+    TRM_FIELD_CO2 = 45,                      /* input, ppm (default 380)   prescribed_atmosphere.jl:10-14           */
+    TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR = 46, /* input (default 1) without soil; the root-weighted integral of     */
+                                             /* plant_available_water with it   plant_available_water.jl:21-36       */
+    TRM_FIELD_DAILY_LEAF_RESPIRATION = 47,   /* input, gC/m^2/s      autotrophic_respiration.jl:36                  */
+    TRM_FIELD_VEGETATION_GROUND_TEMPERATURE = 48, /* `ground_temperature` input of the standalone VegetationModel      */
+                                             /* (default 10 degC, autotrophic_respiration.jl:38); with soil the top cell is read */
+    /* 3-D, Nz rows (allocated by trm_set_vegetation) */
+    TRM_FIELD_PLANT_AVAILABLE_WATER = 49,    /* plant_available_water.jl:22                                          */
+    TRM_FIELD_ROOT_FRACTION = 50,            /* static, normalised   root_distribution.jl:45-63                     */
+    TRM_FIELD_COUNT = 51
 };
 
 /* ---- diagnostics ---------------------------------------------------------- */
@@ -187,6 +211,38 @@ typedef struct trm_params {
 
 /* Fill `p` with the reference defaults. */
 int trm_default_params(trm_params* p);
+
+/* ---- vegetation: the parameter structs of VegetationCarbon's processes (needleleaf-tree PFT defaults) --------------- */
+typedef struct trm_vegetation_params {
+    /* LUEPhotosynthesis  photosynthesis.jl:17-68 */
+    double tau25, Kc25, Ko25, q10_tau, q10_Kc, q10_Ko, alpha_leaf, alpha_a, alpha_C3, cq, k_ext, T_CO2_high, T_CO2_low,
+        T_photos_high, T_photos_low, theta_r;
+    /* MedlynStomatalConductance  stomatal_conductance.jl:16-24 */
+    double g1, g_min;
+    /* PALADYNAutotrophicRespiration  autotrophic_respiration.jl:14-23 */
+    double cn_sapwood, cn_root, aws;
+    /* PALADYNCarbonDynamics  carbon_dynamics.jl:18-43 */
+    double SLA, awl, LAI_min, LAI_max, gamma_L, gamma_R, gamma_S;
+    /* PALADYNVegetationDynamics  vegetation_dynamics.jl:15-22 */
+    double nu_seed, gamma_v_min;
+    /* StaticExponentialRootDistribution  root_distribution.jl:23-29 */
+    double root_a, root_b;
+    /* wilting point / field capacity of the soil's hydraulic properties (FieldCapacityLimitedPAW) */
+    double wilting_point, field_capacity;
+    /* PhysicalConstants.C_mass  physical_constants.jl:50 */
+    double C_mass;
+} trm_vegetation_params;
+int trm_default_vegetation_params(trm_vegetation_params* p);
+/* Enables the vegetation processes of the context (allocating their 3-D fields, setting the input defaults and the static
+ * root fractions).  TRM_VEGETATION_STANDALONE: the context IS a VegetationModel (src/models/vegetation/vegetation_model.jl):
+ * trm_step / trm_step_heun / trm_update_state / trm_compute_auxiliary / trm_compute_tendencies / trm_explicit_step act on
+ * the vegetation state alone; soil moisture limitation and ground temperature are inputs.  One launch covers
+ * update_state! + explicit_step! for all `nsteps` (the 0-D column stays in registers). */
+enum { TRM_VEGETATION_OFF = 0, TRM_VEGETATION_STANDALONE = 1 };
+int trm_set_vegetation(trm_ctx* ctx, const trm_vegetation_params* p, int mode);
+/* FieldCapacityLimitedPAW (plant_available_water.jl:36-94): plant_available_water per cell from the soil state of the
+ * context and soil_moisture_limiting_factor = sum_k PAW_k * root_fraction_k. */
+int trm_compute_plant_available_water(trm_ctx* ctx);
 
 /* initialize(model, timestepper) allocation part (src/state_variables.jl:303-314, 418-430):
  * creates all state buffers on `g->device`, zero-filled, inputs at their defaults. */

@@ -22,7 +22,9 @@ from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapac
                      DirectSurfaceRunoff, BareGroundEvaporation, ConstantEvaporationResistanceFactor, SoilMoistureResistanceFactor,
                      SurfaceHydrology, DefaultInitializer,
                      ConstantSoilTemperature, QuasiThermalSteadyState, ConstantSaturation, SaturationWaterTable,
-                     SoilInitializer, SoilModel, LandModel, flatten)
+                     SoilInitializer, SoilModel, LandModel, flatten, LUEPhotosynthesis, MedlynStomatalConductance,
+                     PALADYNAutotrophicRespiration, PALADYNPhenology, PALADYNCarbonDynamics, PALADYNVegetationDynamics,
+                     StaticExponentialRootDistribution, FieldCapacityLimitedPAW, VegetationCarbon, VegetationModel, flatten_vegetation)
 from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, PrescribedBottomTemperature,
                          GroundHeatFlux, GeothermalHeatFlux, InfiltrationFlux, ImpermeableBoundary, FreeDrainage,
                          merge_boundary_conditions, DeviceState, ModelIntegrator, FieldTimeSeries, InputSource, InputSources, initialize, initialize_integrator,

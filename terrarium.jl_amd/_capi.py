@@ -24,9 +24,19 @@ FIELD = dict(
     evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
     specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27, vwc_forcing=28,
     albedo=29, emissivity=30,
+    carbon_vegetation=31, vegetation_area_fraction=32, tend_carbon_vegetation=33, tend_vegetation_area_fraction=34,
+    balanced_leaf_area_index=35, phenology_factor=36, leaf_area_index=37, canopy_water_conductance=38, leaf_to_air_co2_ratio=39,
+    net_assimilation=40, leaf_respiration=41, gross_primary_production=42, autotrophic_respiration=43, net_primary_production=44,
+    CO2=45, soil_moisture_limiting_factor=46, daily_leaf_respiration=47, vegetation_ground_temperature=48,
+    plant_available_water=49, root_fraction=50,
 )
 INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidity", "rainfall",
-                "surface_shortwave_down", "surface_longwave_down", "albedo", "emissivity")
+                "surface_shortwave_down", "surface_longwave_down", "albedo", "emissivity", "CO2",
+                "soil_moisture_limiting_factor", "daily_leaf_respiration", "vegetation_ground_temperature")
+VEGETATION = dict(off=0, standalone=1)
+VEG_PARAM_NAMES = ("tau25 Kc25 Ko25 q10_tau q10_Kc q10_Ko alpha_leaf alpha_a alpha_C3 cq k_ext T_CO2_high T_CO2_low T_photos_high "
+                   "T_photos_low theta_r g1 g_min cn_sapwood cn_root aws SLA awl LAI_min LAI_max gamma_L gamma_R gamma_S nu_seed "
+                   "gamma_v_min root_a root_b wilting_point field_capacity C_mass").split()
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4,
               derive_closure_fields=5, steps_per_launch=6)
@@ -41,7 +51,8 @@ EXPORTS = (
     "trm_step trm_step_heun trm_step_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_option "
     "trm_get_option trm_set_stream trm_synchronize "
     "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs trm_save_state trm_restore_state "
-    "trm_comm_unique_id trm_comm_init trm_comm_destroy trm_comm_info trm_reduce_global trm_status_global").split()
+    "trm_comm_unique_id trm_comm_init trm_comm_destroy trm_comm_info trm_reduce_global trm_status_global "
+    "trm_default_vegetation_params trm_set_vegetation trm_compute_plant_available_water").split()
 TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2, raster=3)
 
 
@@ -59,6 +70,10 @@ class TrmParams(C.Structure):
         "K_sat theta_res bc_psi_s bc_lambda vg_alpha vg_n impedance vwc_forcing "
         "albedo emissivity kappa_s C_h min_windspeed tau_r beta_evap field_capacity").split()] + [
         (n, C.c_int32) for n in "flow swrc unsat_k seb halo_policy prescribed_albedo evap_resistance reserved".split()]
+
+
+class TrmVegetationParams(C.Structure):
+    _fields_ = [(n, C.c_double) for n in VEG_PARAM_NAMES]
 
 
 class TerrariumHipError(RuntimeError):
@@ -113,6 +128,9 @@ def lib():
     L.trm_set_option.argtypes = [vp, i32, i32]
     L.trm_get_option.argtypes = [vp, i32, C.POINTER(i32)]
     L.trm_set_stream.argtypes = [vp, vp]
+    L.trm_default_vegetation_params.argtypes = [C.POINTER(TrmVegetationParams)]
+    L.trm_set_vegetation.argtypes = [vp, C.POINTER(TrmVegetationParams), i32]
+    L.trm_compute_plant_available_water.argtypes = [vp]
     L.trm_comm_unique_id.argtypes = [vp]
     L.trm_comm_init.argtypes = [vp, i32, i32, vp]
     L.trm_comm_destroy.argtypes = [vp]
@@ -132,6 +150,12 @@ def check(ctx, rc, what):
         err = TerrariumHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
         err.code = rc
         raise err
+
+
+def default_vegetation_params() -> TrmVegetationParams:
+    p = TrmVegetationParams()
+    check(None, lib().trm_default_vegetation_params(C.byref(p)), "trm_default_vegetation_params")
+    return p
 
 
 def default_params() -> TrmParams:

@@ -4,6 +4,7 @@
 #include "trm_kernels.hpp"
 #include "trm_packed_f32.hpp"
 #include "trm_column.hpp"
+#include "trm_vegetation.hpp"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types only: the library is opened lazily by trm_comm_init (no link-time dependency)
@@ -83,6 +84,9 @@ struct trm_ctx {
     int comm_rank = 0, comm_world = 1;
     hipStream_t comm_stream = nullptr;
     double* d_comm = nullptr;   // [2 * (Nz + 1) + 8] doubles: send | recv
+    // vegetation (trm_set_vegetation)
+    int veg_mode = TRM_VEGETATION_OFF;
+    trm_vegetation_params veg_params{};
     // multi-step program with time series: device copies of the slot table and the per-step rows
     void* d_series_table = nullptr;
     void* d_series_rows = nullptr;
@@ -113,13 +117,20 @@ int fail(trm_ctx* ctx, int code, const std::string& msg) {
 long field_rows(const trm_ctx* c, int field) {
     if (field == TRM_FIELD_HYDRAULIC_CONDUCTIVITY) return c->Nz + 1;
     if (field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING) return c->Nz;
+    if (field == TRM_FIELD_PLANT_AVAILABLE_WATER || field == TRM_FIELD_ROOT_FRACTION) return c->Nz;
     return 1;
 }
 bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
 bool is_input_field(int f) {
-    return (f >= TRM_FIELD_AIR_TEMPERATURE && f <= TRM_FIELD_SURFACE_LONGWAVE_DOWN) || f == TRM_FIELD_ALBEDO || f == TRM_FIELD_EMISSIVITY;
+    return (f >= TRM_FIELD_AIR_TEMPERATURE && f <= TRM_FIELD_SURFACE_LONGWAVE_DOWN) || f == TRM_FIELD_ALBEDO || f == TRM_FIELD_EMISSIVITY ||
+           (f >= TRM_FIELD_CO2 && f <= TRM_FIELD_VEGETATION_GROUND_TEMPERATURE);
 }
-bool is_3d(int field) { return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING; }
+bool is_3d(int field) {
+    return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING || field == TRM_FIELD_PLANT_AVAILABLE_WATER ||
+           field == TRM_FIELD_ROOT_FRACTION;
+}
+// the 3-D vegetation fields exist only once trm_set_vegetation has run
+bool is_lazy_field(int field) { return field == TRM_FIELD_PLANT_AVAILABLE_WATER || field == TRM_FIELD_ROOT_FRACTION; }
 // elements of the device buffer of a field: [Nh][Nzp] for 3-D fields, [Nh] for 2-D fields
 size_t field_elems(const trm_ctx* c, int field) { return is_3d(field) ? (size_t)c->Nh * c->Nzp : (size_t)c->Nh; }
 
@@ -416,6 +427,8 @@ template <class NF> StageView<NF> make_stage_view(const trm_ctx* c) {
     return w;
 }
 
+template <class NF> int upload_impl(trm_ctx* c, int field, const NF* host);
+
 template <class NF> struct Ops {
     static bool richards(const trm_ctx* c) { return c->params.flow == TRM_FLOW_RICHARDS; }
 
@@ -507,7 +520,8 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     static int reset_tendencies(trm_ctx* c, const FieldSet& s) {
-        for (int f : {TRM_FIELD_TEND_INTERNAL_ENERGY, TRM_FIELD_TEND_SATURATION_WATER_ICE, TRM_FIELD_TEND_SURFACE_EXCESS_WATER})
+        for (int f : {TRM_FIELD_TEND_INTERNAL_ENERGY, TRM_FIELD_TEND_SATURATION_WATER_ICE, TRM_FIELD_TEND_SURFACE_EXCESS_WATER,
+                      TRM_FIELD_TEND_CARBON_VEGETATION, TRM_FIELD_TEND_VEGETATION_AREA_FRACTION})
             TRM_HIP(c, hipMemsetAsync(s.f[f], 0, field_elems(c, f) * sizeof(NF), c->stream));
         return TRM_OK;
     }
@@ -598,6 +612,78 @@ template <class NF> struct Ops {
         return generic;
     }
     // ---- fused step, column per (half-)wavefront ------------------------------------------------------
+    // ---- vegetation (trm_vegetation.hpp) ---------------------------------------------------------------
+    static VegDev<NF> veg_dev(const trm_ctx* c) {
+        VegDev<NF> p;
+        const double* s = &c->veg_params.tau25;
+        NF* t = &p.tau25;
+        for (int n = 0; n < 35; ++n) t[n] = (NF)s[n];
+        p.eps_mw = (NF)c->params.eps_mw;
+        p.one_minus_eps_mw = NF(1) - p.eps_mw;
+        return p;
+    }
+    static VegView<NF> veg_view(const trm_ctx* c) {
+        VegView<NF> v;
+        auto F = [&](int id) { return (NF*)c->state.f[id]; };
+        v.Nh = c->Nh;
+        v.C_veg = F(TRM_FIELD_CARBON_VEGETATION); v.nu = F(TRM_FIELD_VEGETATION_AREA_FRACTION);
+        v.G_C_veg = F(TRM_FIELD_TEND_CARBON_VEGETATION); v.G_nu = F(TRM_FIELD_TEND_VEGETATION_AREA_FRACTION);
+        v.LAI_b = F(TRM_FIELD_BALANCED_LEAF_AREA_INDEX); v.phen = F(TRM_FIELD_PHENOLOGY_FACTOR); v.LAI = F(TRM_FIELD_LEAF_AREA_INDEX);
+        v.gw_can = F(TRM_FIELD_CANOPY_WATER_CONDUCTANCE); v.lambda_c = F(TRM_FIELD_LEAF_TO_AIR_CO2_RATIO);
+        v.An = F(TRM_FIELD_NET_ASSIMILATION); v.Rd = F(TRM_FIELD_LEAF_RESPIRATION); v.GPP = F(TRM_FIELD_GROSS_PRIMARY_PRODUCTION);
+        v.Ra = F(TRM_FIELD_AUTOTROPHIC_RESPIRATION); v.NPP = F(TRM_FIELD_NET_PRIMARY_PRODUCTION);
+        v.Tair = F(TRM_FIELD_AIR_TEMPERATURE); v.pres = F(TRM_FIELD_AIR_PRESSURE); v.qair = F(TRM_FIELD_SPECIFIC_HUMIDITY);
+        v.swd = F(TRM_FIELD_SURFACE_SHORTWAVE_DOWN); v.CO2 = F(TRM_FIELD_CO2); v.smlf = F(TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR);
+        v.daily_Rd = F(TRM_FIELD_DAILY_LEAF_RESPIRATION);
+        v.Tground = F(TRM_FIELD_VEGETATION_GROUND_TEMPERATURE);
+        v.Tground_stride = 1;
+        return v;
+    }
+    template <int MODE> static int veg_launch(trm_ctx* c, double dt, int nsteps, int finalize) {
+        hipLaunchKernelGGL((k_vegetation<NF, MODE>), col_grid(c), dim3(256), 0, c->stream, veg_view(c), veg_dev(c), (NF)dt, nsteps, finalize);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    // nsteps steps of the standalone VegetationModel; time series inputs are evaluated by the host between launches
+    static int veg_step(trm_ctx* c, double dt, int nsteps, int finalize, bool heun) {
+        int n = 0;
+        while (n < nsteps) {
+            const int m = c->series.empty() ? nsteps - n : 1;
+            const int fin = (finalize && n + m == nsteps) ? 1 : 0;
+            int rc = update_inputs(c, c->state, c->time);
+            if (!rc) rc = heun ? veg_launch<VEG_HEUN>(c, dt, m, fin) : veg_launch<VEG_EULER>(c, dt, m, fin);
+            if (rc) return rc;
+            for (int j = 0; j < m; ++j) c->time += dt;
+            c->iteration += m;
+            n += m;
+        }
+        return TRM_OK;
+    }
+    static int plant_available_water(trm_ctx* c) {
+        const DevParams<NF>& p = launch_args<NF>(c).p;
+        hipLaunchKernelGGL((k_plant_available_water<NF>), col_grid(c), dim3(256), 0, c->stream,
+                           (const NF*)c->state.f[TRM_FIELD_SATURATION_WATER_ICE], (const NF*)c->state.f[TRM_FIELD_LIQUID_WATER_FRACTION],
+                           (const NF*)c->state.f[TRM_FIELD_ROOT_FRACTION], (NF*)c->state.f[TRM_FIELD_PLANT_AVAILABLE_WATER],
+                           (NF*)c->state.f[TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR], c->Nh, c->Nz, c->Nzp, p.por, veg_dev(c), (const NF*)c->d_dzc);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    // static root fractions: density at the cell centres x thickness, normalised over the column (root_distribution.jl:45-63)
+    static int upload_root_fraction(trm_ctx* c) {
+        const VegDev<NF> p = veg_dev(c);
+        std::vector<NF> R((size_t)c->Nz);
+        NF total = NF(0);
+        for (int k = 0; k < c->Nz; ++k) {
+            const NF z = (NF)c->h_zC[k], dz = (NF)c->h_dzc[k];
+            R[k] = (NF(0.5) * (p.root_a * std::exp(p.root_a * z) + p.root_b * std::exp(p.root_b * z))) * dz;
+        }
+        for (int k = 0; k < c->Nz; ++k) total = total + R[k];
+        std::vector<NF> host((size_t)c->Nz * c->Nh);
+        for (int k = 0; k < c->Nz; ++k)
+            for (long i = 0; i < c->Nh; ++i) host[(size_t)k * c->Nh + i] = R[k] / total;
+        return upload_impl<NF>(c, TRM_FIELD_ROOT_FRACTION, host.data());
+    }
+
     // ---- fused step, column per (half-)wavefront ------------------------------------------------------
     static dim3 column_grid(const trm_ctx* c, int lpc) {
         dim3 grid = wave_grid(c, lpc);
@@ -780,6 +866,7 @@ template <class NF> struct Ops {
         return rc;
     }
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
+        if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level to one lane: columns deeper than 64 levels take the reference-order kernels
         const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
         // Resident-column multi-step program (TRM_OPT_STEPS_PER_LAUNCH > 1): legal when nothing the host evaluates changes
@@ -823,7 +910,7 @@ template <class NF> struct Ops {
     // ---- Heun (heun.jl:37-71), reference-order kernels on a second copy of the state -----------------
     static int copy_state_to_stage(trm_ctx* c) {
         for (int f = 0; f < TRM_FIELD_COUNT; ++f)
-            TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], field_elems(c, f) * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+            if (c->state.f[f] && c->stage.f[f]) TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], field_elems(c, f) * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
         TRM_HIP(c, hipMemcpyAsync(c->stage.kf_top, c->state.kf_top, (size_t)c->Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
         return TRM_OK;
     }
@@ -881,12 +968,16 @@ int finish(trm_ctx* c, int rc) {
 
 int alloc_fields(trm_ctx* c, FieldSet& s) {
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
+        if (is_lazy_field(f) && c->veg_mode == TRM_VEGETATION_OFF) continue;
+        if (s.f[f]) continue;
         size_t bytes = field_elems(c, f) * c->esize;
         TRM_HIP(c, hipMalloc(&s.f[f], bytes));
         TRM_HIP(c, hipMemset(s.f[f], 0, bytes));
     }
-    TRM_HIP(c, hipMalloc(&s.kf_top, (size_t)c->Nh * c->esize));
-    TRM_HIP(c, hipMemset(s.kf_top, 0, (size_t)c->Nh * c->esize));
+    if (!s.kf_top) {
+        TRM_HIP(c, hipMalloc(&s.kf_top, (size_t)c->Nh * c->esize));
+        TRM_HIP(c, hipMemset(s.kf_top, 0, (size_t)c->Nh * c->esize));
+    }
     return TRM_OK;
 }
 
@@ -1287,6 +1378,7 @@ int trm_get_grid(const trm_ctx* c, double* z_faces, double* z_centers, double* d
 
 int trm_upload(trm_ctx* c, int field, const void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_upload: bad argument");
+    if (!c->state.f[field]) return fail(c, TRM_EINVAL, "trm_upload: the field exists only after trm_set_vegetation");
     TRM_HIP(c, hipSetDevice(c->device));
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
     if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_consistent = false;
@@ -1310,6 +1402,7 @@ static const char* kStaleTendencies =
 int trm_download(trm_ctx* c, int field, void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_download: bad argument");
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
+    if (!c->state.f[field]) return fail(c, TRM_EINVAL, "trm_download: the field exists only after trm_set_vegetation");
     TRM_HIP(c, hipSetDevice(c->device));
     return c->precision == TRM_F64 ? download_impl<double>(c, field, (double*)host) : download_impl<float>(c, field, (float*)host);
 }
@@ -1448,16 +1541,23 @@ int trm_update_inputs(trm_ctx* c) {
 int trm_update_state(trm_ctx* c, int compute_tendencies) {
     TRM_ENTER(c);
     c->tend_valid = true;
+    if (c->veg_mode == TRM_VEGETATION_STANDALONE) {
+        int rc = DISPATCH(c, update_inputs(c, c->state, c->time));
+        if (!rc) rc = compute_tendencies ? DISPATCH(c, template veg_launch<VEG_UPDATE>(c, 0.0, 1, 0)) : DISPATCH(c, template veg_launch<VEG_AUX>(c, 0.0, 1, 0));
+        return finish(c, rc);
+    }
     int rc = DISPATCH(c, update_inputs(c, c->state, c->time));
     if (rc) return rc;
     return finish(c, DISPATCH(c, update_state(c, c->state, compute_tendencies != 0)));
 }
 int trm_compute_auxiliary(trm_ctx* c) {
     TRM_ENTER(c);
+    if (c->veg_mode == TRM_VEGETATION_STANDALONE) return finish(c, DISPATCH(c, template veg_launch<VEG_AUX>(c, 0.0, 1, 0)));
     return finish(c, DISPATCH(c, compute_auxiliary(c, c->state)));
 }
 int trm_compute_tendencies(trm_ctx* c) {
     TRM_ENTER(c);
+    if (c->veg_mode == TRM_VEGETATION_STANDALONE) return finish(c, DISPATCH(c, template veg_launch<VEG_TEND>(c, 0.0, 1, 0)));
     return finish(c, DISPATCH(c, compute_tendencies(c, c->state)));
 }
 int trm_reset_tendencies(trm_ctx* c) {
@@ -1467,6 +1567,7 @@ int trm_reset_tendencies(trm_ctx* c) {
 }
 int trm_explicit_step(trm_ctx* c, double dt) {
     TRM_ENTER(c);
+    if (c->veg_mode == TRM_VEGETATION_STANDALONE) return finish(c, DISPATCH(c, template veg_launch<VEG_EXPLICIT>(c, dt, 1, 0)));
     c->top_valid = false;
     c->closure_consistent = false;
     return finish(c, DISPATCH(c, explicit_step(c, c->state, dt)));
@@ -1505,6 +1606,7 @@ int trm_step_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
 int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
     TRM_ENTER(c);
     if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step_heun: nsteps < 0");
+    if (c->veg_mode == TRM_VEGETATION_STANDALONE) return finish(c, DISPATCH(c, veg_step(c, dt, nsteps, finalize, true)));
     const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 &&
                             !(c->precision == TRM_F64 ? Ops<double>::generic_bcs(c) : Ops<float>::generic_bcs(c));
     if (!fused_heun && !c->has_stage) {   // the reference-order kernels work on a second copy of the state
@@ -1525,13 +1627,13 @@ int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
 
 int trm_save_state(trm_ctx* c) {
     TRM_ENTER(c);
-    if (!c->has_saved) {
+    {   // (allocates what is missing: everything the first time, the vegetation fields once they exist)
         int rc = alloc_fields(c, c->saved);
         if (rc) return rc;
         c->has_saved = true;
     }
     for (int f = 0; f < TRM_FIELD_COUNT; ++f)
-        TRM_HIP(c, hipMemcpyAsync(c->saved.f[f], c->state.f[f], field_elems(c, f) * c->esize, hipMemcpyDeviceToDevice, c->stream));
+        if (c->state.f[f] && c->saved.f[f]) TRM_HIP(c, hipMemcpyAsync(c->saved.f[f], c->state.f[f], field_elems(c, f) * c->esize, hipMemcpyDeviceToDevice, c->stream));
     TRM_HIP(c, hipMemcpyAsync(c->saved.kf_top, c->state.kf_top, (size_t)c->Nh * c->esize, hipMemcpyDeviceToDevice, c->stream));
     TRM_HIP(c, hipMemcpyAsync(&c->saved_status, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
@@ -1545,7 +1647,7 @@ int trm_restore_state(trm_ctx* c) {
     TRM_ENTER(c);
     if (!c->has_saved) return fail(c, TRM_EINVAL, "trm_restore_state: nothing was saved");
     for (int f = 0; f < TRM_FIELD_COUNT; ++f)
-        TRM_HIP(c, hipMemcpyAsync(c->state.f[f], c->saved.f[f], field_elems(c, f) * c->esize, hipMemcpyDeviceToDevice, c->stream));
+        if (c->state.f[f] && c->saved.f[f]) TRM_HIP(c, hipMemcpyAsync(c->state.f[f], c->saved.f[f], field_elems(c, f) * c->esize, hipMemcpyDeviceToDevice, c->stream));
     TRM_HIP(c, hipMemcpyAsync(c->state.kf_top, c->saved.kf_top, (size_t)c->Nh * c->esize, hipMemcpyDeviceToDevice, c->stream));
     TRM_HIP(c, hipMemcpyAsync(c->d_status, &c->saved_status, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     c->time = c->saved_time;
@@ -1574,6 +1676,53 @@ int trm_reduce(trm_ctx* c, int field, int op, double* out) {
     if (!out || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_reduce: bad argument");
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     return c->precision == TRM_F64 ? reduce_impl<double>(c, field, op, out) : reduce_impl<float>(c, field, op, out);
+}
+
+// ---- vegetation ---------------------------------------------------------------------------
+int trm_default_vegetation_params(trm_vegetation_params* p) {
+    if (!p) return TRM_EINVAL;
+    // photosynthesis.jl:17-68
+    p->tau25 = 2600.0; p->Kc25 = 30.0; p->Ko25 = 3.0e4; p->q10_tau = 0.57; p->q10_Kc = 2.1; p->q10_Ko = 1.2; p->alpha_leaf = 0.17;
+    p->alpha_a = 0.5; p->alpha_C3 = 0.08; p->cq = 4.6e-6; p->k_ext = 0.5; p->T_CO2_high = 42.0; p->T_CO2_low = -4.0;
+    p->T_photos_high = 30.0; p->T_photos_low = 15.0; p->theta_r = 0.7;
+    p->g1 = 2.3; p->g_min = 0.5;                                              // stomatal_conductance.jl:16-24
+    p->cn_sapwood = 330.0; p->cn_root = 29.0; p->aws = 10.0;                  // autotrophic_respiration.jl:14-23
+    p->SLA = 10.0; p->awl = 2.0; p->LAI_min = 1.0; p->LAI_max = 6.0; p->gamma_L = 0.3; p->gamma_R = 0.3; p->gamma_S = 0.05;   // carbon_dynamics.jl:18-43
+    p->nu_seed = 0.001; p->gamma_v_min = 0.002;                               // vegetation_dynamics.jl:15-22
+    p->root_a = 7.0; p->root_b = 2.0;                                         // root_distribution.jl:23-29
+    p->wilting_point = 0.05; p->field_capacity = 0.25;                        // soil_hydraulic_properties.jl:74-80
+    p->C_mass = 12.0;                                                         // physical_constants.jl:50
+    return TRM_OK;
+}
+
+int trm_set_vegetation(trm_ctx* c, const trm_vegetation_params* p, int mode) {
+    TRM_ENTER(c);
+    if (!p || (mode != TRM_VEGETATION_OFF && mode != TRM_VEGETATION_STANDALONE)) return fail(c, TRM_EINVAL, "trm_set_vegetation: bad argument");
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    c->veg_params = *p;
+    const bool first = c->veg_mode == TRM_VEGETATION_OFF && mode != TRM_VEGETATION_OFF && !c->state.f[TRM_FIELD_ROOT_FRACTION];
+    c->veg_mode = mode;
+    c->args_valid = false;
+    if (mode == TRM_VEGETATION_OFF) return TRM_OK;
+    int rc = alloc_fields(c, c->state);          // the 3-D vegetation fields
+    if (rc) return rc;
+    if (first) {
+        // input defaults: CO2 380 ppm (prescribed_atmosphere.jl:14), soil moisture limiting factor 1 (photosynthesis.jl:76),
+        // ground temperature 10 degC (autotrophic_respiration.jl:38)
+        const struct { int f; double v; } defaults[] = {{TRM_FIELD_CO2, 380.0}, {TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR, 1.0},
+                                                       {TRM_FIELD_VEGETATION_GROUND_TEMPERATURE, 10.0}};
+        for (auto& d : defaults) {
+            rc = c->precision == TRM_F64 ? fill_row<double>(c, d.f, d.v) : fill_row<float>(c, d.f, d.v);
+            if (rc) return rc;
+        }
+    }
+    return c->precision == TRM_F64 ? Ops<double>::upload_root_fraction(c) : Ops<float>::upload_root_fraction(c);
+}
+
+int trm_compute_plant_available_water(trm_ctx* c) {
+    TRM_ENTER(c);
+    if (c->veg_mode == TRM_VEGETATION_OFF) return fail(c, TRM_EINVAL, "trm_compute_plant_available_water: call trm_set_vegetation first");
+    return finish(c, DISPATCH(c, plant_available_water(c)));
 }
 
 // ---- multi-device diagnostics --------------------------------------------------------

@@ -1,0 +1,224 @@
+// trm_vegetation.hpp -- the 0-D vegetation processes of VegetationCarbon on the device.
+//
+// One thread per column: plant functional type parameters are launch constants, every process is a handful of scalar
+// formulas (src/processes/vegetation/*.jl), so a whole `update_state!` + `explicit_step!` of the vegetation state is one
+// pass over ~11 per-column inputs and ~14 outputs -- a streaming kernel with ~150 flops per column, far below any
+// roofline at N145 (56 951 threads: latency-bound, ~3 us).  Order of the processes and the deliberate use of the PREVIOUS
+// evaluation's net assimilation by the stomatal conductance follow compute_auxiliary!(state, grid, veg::VegetationCarbon,
+// ...) (vegetation_carbon.jl:66-104).
+#pragma once
+#include "trm_device.hpp"
+
+namespace trm {
+
+// trm_vegetation_params converted to NF (field order = include/terrarium_hip.h)
+template <class NF> struct VegDev {
+    NF tau25, Kc25, Ko25, q10_tau, q10_Kc, q10_Ko, alpha_leaf, alpha_a, alpha_C3, cq, k_ext, T_CO2_high, T_CO2_low, T_photos_high,
+        T_photos_low, theta_r, g1, g_min, cn_sapwood, cn_root, aws, SLA, awl, LAI_min, LAI_max, gamma_L, gamma_R, gamma_S, nu_seed,
+        gamma_v_min, root_a, root_b, wilting_point, field_capacity, C_mass;
+    // physical constants / atmosphere parameters the processes read
+    NF eps_mw, one_minus_eps_mw;
+};
+template <class NF> struct VegView {
+    long Nh;
+    NF *C_veg, *nu, *G_C_veg, *G_nu, *LAI_b, *phen, *LAI, *gw_can, *lambda_c, *An, *Rd, *GPP, *Ra, *NPP;
+    const NF *Tair, *pres, *qair, *swd, *CO2, *smlf, *daily_Rd, *Tground;
+    long Tground_stride;   // 1 for the input field; the soil's top temperature is read with the level pitch
+};
+
+TRM_DEV double log_(double x) { return log(x); }
+TRM_DEV float log_(float x) { return logf(x); }
+
+// carbon_dynamics.jl:62-73, 84-87, 98-105, 116-126
+template <class NF> TRM_DEV NF veg_lambda_NPP(const VegDev<NF>& p, NF LAI_b) {
+    if (LAI_b < p.LAI_min) return NF(0);
+    if (LAI_b <= p.LAI_max) return (LAI_b - p.LAI_min) / (p.LAI_max - p.LAI_min);
+    return NF(1);
+}
+template <class NF> TRM_DEV NF veg_LAI_b(const VegDev<NF>& p, NF C_veg) { return C_veg / ((NF(2) / p.SLA) + p.awl); }
+template <class NF> TRM_DEV NF veg_C_veg_tendency(const VegDev<NF>& p, NF LAI_b, NF NPP) {
+    const NF lambda = veg_lambda_NPP(p, LAI_b);
+    const NF litter = (p.gamma_L / p.SLA + p.gamma_R / p.SLA + p.gamma_S * p.awl) * LAI_b;
+    return (NF(1) - lambda) * NPP - litter;
+}
+// vegetation_dynamics.jl:41-88 (disturbance rate = its minimum, seeding through nu_star)
+template <class NF> TRM_DEV NF veg_nu_tendency(const VegDev<NF>& p, NF LAI_b, NF C_veg, NF NPP, NF nu) {
+    const NF lambda = veg_lambda_NPP(p, LAI_b);
+    const NF nu_star = jl_max(nu, p.nu_seed);
+    return (lambda * NPP / C_veg) * nu_star * (NF(1) - nu) - p.gamma_v_min * nu_star;
+}
+// phenology.jl:32-63: evergreen placeholder, f_deciduous = 0 and phen = 1
+template <class NF> TRM_DEV NF veg_LAI(NF LAI_b, NF& phen) {
+    const NF f_deciduous = NF(0);
+    phen = NF(1);
+    return (f_deciduous * phen + (NF(1) - f_deciduous)) * LAI_b;
+}
+// stomatal_conductance.jl:45-81
+template <class NF> TRM_DEV NF veg_gw_can(const VegDev<NF>& p, NF vpd, NF An, NF co2, NF LAI, NF beta) {
+    const NF g_min = p.g_min / NF(1000);
+    const NF g0 = g_min * (NF(1) - exp_(-p.k_ext * LAI)) * beta;
+    return g0 + NF(1.6) * (NF(1) + p.g1 / sqrt_(vpd)) * An / co2 * NF(1.0e6);
+}
+template <class NF> TRM_DEV NF veg_lambda_c(const VegDev<NF>& p, NF vpd) {
+    return NF(1) - NF(1) / (NF(1) + p.g1 / sqrt_(vpd * NF(1.0e-3)));
+}
+// photosynthesis.jl:165-188
+template <class NF> TRM_DEV NF veg_temperature_stress(const VegDev<NF>& p, NF T_air) {
+    const NF k1 = NF(2) * log_(NF(1) / NF(0.99) - NF(1)) / (p.T_CO2_low - p.T_photos_low);
+    const NF k2 = NF(0.5) * (p.T_CO2_low + p.T_photos_low);
+    const NF k3 = log_(NF(0.99) / NF(0.01)) / (p.T_CO2_high - p.T_photos_high);
+    if (p.T_CO2_low < T_air && T_air < p.T_CO2_high) {
+        const NF low = NF(1) / (NF(1) + exp_(k1 * (k2 - T_air)));
+        const NF high = NF(1) - NF(0.01) * exp_(k3 * (T_air - p.T_photos_high));
+        return low * high;
+    }
+    return NF(0);
+}
+// x^y of Base for the Q10 responses (photosynthesis.jl:93-98): integer-valued exponents take the compensated power
+template <class NF> TRM_DEV NF veg_pow(NF x, NF y) {
+    if (x == NF(1)) return NF(1);
+    const NF yt = (NF)(int)y;
+    if (yt == y && y > NF(-4096) && y < NF(4096)) return pow_int(x, (int)y);
+    return pow_generic(x, y);
+}
+// photosynthesis.jl:290-337 compute_respiration_assimilation -> (Rd, An) [gC/m^2/s]
+template <class NF> TRM_DEV void veg_respiration_assimilation(const VegDev<NF>& p, NF T_air, NF swdown, NF pres, NF co2, NF LAI, NF lambda_c, NF beta, NF& Rd, NF& An) {
+    const NF pres_O2 = NF(0.209) * pres;            // physics_utils.jl:16-20
+    const NF pres_a = co2 * NF(1.0e-6) * pres;      // physics_utils.jl:27-30
+    Rd = NF(0);
+    An = NF(0);
+    if (swdown > NF(0) && T_air > NF(-3) && LAI > NF(0)) {
+        const NF e = (T_air - NF(25)) * NF(0.1);    // Q10 kinetics, :93-98
+        const NF tau = p.tau25 * veg_pow(p.q10_tau, e), Kc = p.Kc25 * veg_pow(p.q10_Kc, e), Ko = p.Ko25 * veg_pow(p.q10_Ko, e);
+        const NF Gamma = pres_O2 / (NF(2) * tau);                                                        // :111-114
+        const NF PAR = NF(0.5) * swdown * (NF(1) - p.alpha_leaf) * p.cq;                                 // :122-126
+        const NF APAR = p.alpha_a * PAR * (NF(1) - exp_(-p.k_ext * LAI));                                // :138-143
+        const NF pres_i = lambda_c * pres_a;                                                             // :155-158
+        const NF T_stress = veg_temperature_stress(p, T_air);
+        const NF c1 = p.alpha_C3 * T_stress * p.C_mass * (pres_i - Gamma) / (pres_i + NF(2) * Gamma);    // :206-217
+        const NF c2 = (pres_i - Gamma) / (pres_i + Kc * (NF(1) + pres_O2 / Ko));
+        const NF Vc_max = c1 * APAR * (pres_i + Kc * (NF(1) + pres_O2 / Ko)) / (pres_i - Gamma);         // :230-234
+        Rd = p.alpha_C3 * Vc_max * beta;                                                                 // :263-267
+        const NF JE = c1 * APAR, JC = c2 * Vc_max, s = JE + JC;                                          // :245-250, 278-283
+        const NF Ag = (s - sqrt_(s * s - NF(4) * p.theta_r * JE * JC)) / (NF(2) * p.theta_r) * beta;
+        An = Ag - Rd;
+    }
+}
+// autotrophic_respiration.jl:46-126 -> Ra [kgC/m^2/s]
+template <class NF> TRM_DEV NF veg_autotrophic_respiration(const VegDev<NF>& p, NF T_air, NF T_soil, NF Rd_daily, NF phen, NF C_veg, NF GPP) {
+    const NF f_air = exp_(NF(308.56) * (NF(1) / NF(56.02) - NF(1) / (NF(46.02) + T_air)));
+    const NF f_soil = boolmul(T_soil > NF(7), exp_(NF(308.56) * (NF(1) / NF(56.02) - NF(1) / (NF(46.02) + T_soil))));
+    const NF resp10 = NF(0.066);
+    const NF R_leaf = Rd_daily / NF(1000);
+    const NF R_stem = resp10 * f_air * (p.awl * ((NF(2) / p.SLA) + p.awl)) / (C_veg * p.aws * p.cn_sapwood);
+    const NF R_root = resp10 * f_soil * phen * (NF(2) / p.SLA) / (p.SLA * C_veg * p.cn_root);
+    const NF Rm = R_leaf + R_stem + R_root;
+    const NF Rg = NF(0.25) * (GPP - Rm);
+    return Rm + Rg;
+}
+// plant_available_water.jl:77-94
+template <class NF> TRM_DEV NF veg_plant_available_water(const VegDev<NF>& p, NF theta_w) {
+    return jl_max(jl_min(NF(1), (theta_w - p.wilting_point) / (p.field_capacity - p.wilting_point)), NF(0));
+}
+
+// what one vegetation column carries through a step
+template <class NF> struct VegColumn {
+    NF C_veg, nu, An;                     // prognostic state + the carried net assimilation
+    NF LAI_b, phen, LAI, gw_can, lambda_c, Rd, GPP, Ra, NPP, G_C_veg, G_nu;
+};
+template <class NF> struct VegInputs { NF Tair, pres, qair, swd, CO2, smlf, daily_Rd, Tground; };
+
+// compute_auxiliary!(state, grid, veg, constants, atmos, soil) for one column (vegetation_carbon.jl:66-104)
+template <class NF> TRM_DEV void veg_auxiliary(const VegDev<NF>& p, const VegInputs<NF>& in, VegColumn<NF>& c) {
+    c.LAI_b = veg_LAI_b(p, c.C_veg);
+    c.LAI = veg_LAI(c.LAI_b, c.phen);
+    // compute_vpd at the air temperature (prescribed_atmosphere.jl:176-182, physical_constants.jl:83-97)
+    const NF e_sat = saturation_vapor_pressure(in.Tair);
+    const NF e_air = in.qair * in.pres / (p.eps_mw + p.one_minus_eps_mw * in.qair);
+    const NF vpd = jl_max(e_sat - e_air, NF(0.1));
+    c.gw_can = veg_gw_can(p, vpd, c.An, in.CO2, c.LAI, in.smlf);     // An of the previous evaluation
+    c.lambda_c = veg_lambda_c(p, vpd);
+    veg_respiration_assimilation(p, in.Tair, in.swd, in.pres, in.CO2, c.LAI, c.lambda_c, in.smlf, c.Rd, c.An);
+    c.GPP = c.An * NF(1.0e-3);
+    c.Ra = veg_autotrophic_respiration(p, in.Tair, in.Tground, in.daily_Rd, c.phen, c.C_veg, c.GPP);
+    c.NPP = c.GPP - c.Ra;
+}
+template <class NF> TRM_DEV void veg_tendencies(const VegDev<NF>& p, VegColumn<NF>& c) {
+    c.G_C_veg = veg_C_veg_tendency(p, c.LAI_b, c.NPP);
+    c.G_nu = veg_nu_tendency(p, c.LAI_b, c.C_veg, c.NPP, c.nu);
+}
+
+// MODE: 0 compute_auxiliary!, 1 + compute_tendencies! (update_state!), 2 one ForwardEuler step, 3 one Heun step;
+// nsteps > 1 (modes 2, 3) keeps the column in registers.  `finalize`: compute_auxiliary! once more at the end.
+// 4 compute_tendencies! alone (from the stored auxiliaries), 5 explicit_step! alone.
+enum { VEG_AUX = 0, VEG_UPDATE = 1, VEG_EULER = 2, VEG_HEUN = 3, VEG_TEND = 4, VEG_EXPLICIT = 5 };
+template <class NF, int MODE>
+__global__ void __launch_bounds__(256) k_vegetation(VegView<NF> v, VegDev<NF> p, NF dt, int nsteps, int finalize) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.Nh) return;
+    if (MODE == VEG_TEND) {
+        VegColumn<NF> t;
+        t.C_veg = v.C_veg[i]; t.nu = v.nu[i]; t.LAI_b = v.LAI_b[i]; t.NPP = v.NPP[i];
+        veg_tendencies(p, t);
+        v.G_C_veg[i] += t.G_C_veg;      // (accumulates, like every compute_tendencies!)
+        v.G_nu[i] += t.G_nu;
+        return;
+    }
+    if (MODE == VEG_EXPLICIT) {
+        v.C_veg[i] = v.C_veg[i] + v.G_C_veg[i] * dt;
+        v.nu[i] = v.nu[i] + v.G_nu[i] * dt;
+        return;
+    }
+    VegInputs<NF> in = {v.Tair[i], v.pres[i], v.qair[i], v.swd[i], v.CO2[i], v.smlf[i], v.daily_Rd[i], v.Tground[i * v.Tground_stride]};
+    VegColumn<NF> c;
+    c.C_veg = v.C_veg[i];
+    c.nu = v.nu[i];
+    c.An = v.An[i];
+    c.G_C_veg = c.G_nu = NF(0);
+    if (MODE == VEG_AUX || MODE == VEG_UPDATE) {
+        veg_auxiliary(p, in, c);
+        if (MODE == VEG_UPDATE) veg_tendencies(p, c);
+    } else {
+        for (int s = 0; s < nsteps; ++s) {
+            veg_auxiliary(p, in, c);
+            veg_tendencies(p, c);
+            if (MODE == VEG_HEUN) {   // heun.jl:37-71: predictor, tendencies at the stage, average
+                VegColumn<NF> st = c;
+                st.C_veg = c.C_veg + c.G_C_veg * dt;
+                st.nu = c.nu + c.G_nu * dt;
+                veg_auxiliary(p, in, st);
+                veg_tendencies(p, st);
+                c.G_C_veg = (c.G_C_veg + st.G_C_veg) / NF(2);
+                c.G_nu = (c.G_nu + st.G_nu) / NF(2);
+            }
+            c.C_veg = c.C_veg + c.G_C_veg * dt;
+            c.nu = c.nu + c.G_nu * dt;
+        }
+        if (finalize) veg_auxiliary(p, in, c);
+        v.C_veg[i] = c.C_veg;
+        v.nu[i] = c.nu;
+    }
+    if (MODE != VEG_AUX) { v.G_C_veg[i] = c.G_C_veg; v.G_nu[i] = c.G_nu; }
+    v.LAI_b[i] = c.LAI_b; v.phen[i] = c.phen; v.LAI[i] = c.LAI; v.gw_can[i] = c.gw_can; v.lambda_c[i] = c.lambda_c;
+    v.An[i] = c.An; v.Rd[i] = c.Rd; v.GPP[i] = c.GPP; v.Ra[i] = c.Ra; v.NPP[i] = c.NPP;
+}
+
+// FieldCapacityLimitedPAW + StaticExponentialRootDistribution (plant_available_water.jl:36-94, root_distribution.jl:38-63):
+// plant_available_water per cell from the liquid water content, and its root-weighted column integral
+// Integral(PAW * root_fraction / dz) dz = sum_k PAW_k * root_fraction_k, the soil moisture limiting factor.
+template <class NF> __global__ void __launch_bounds__(256) k_plant_available_water(const NF* sat, const NF* liq, const NF* root_fraction, NF* paw, NF* smlf,
+                                                                                   long Nh, int Nz, int Nzp, NF por, VegDev<NF> p, const NF* dzc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nh) return;
+    NF acc = NF(0);
+    for (int k = 0; k < Nz; ++k) {      // Oceananigans' Integral sums from the bottom cell up
+        const long c = i * Nzp + k;
+        const NF water = (sat[c] * por) * liq[c];
+        const NF w = veg_plant_available_water(p, water);
+        paw[c] = w;
+        acc = acc + (w * root_fraction[c] / dzc[k]) * dzc[k];
+    }
+    smlf[i] = acc;
+}
+
+}  // namespace trm

@@ -152,8 +152,11 @@ class DeviceState:
         return int(r.value)
 
     def get(self, name) -> np.ndarray:
-        if name == "ground_temperature":  # view of the top soil layer (soil_energy.jl:52-57)
-            return self.get("temperature")[-1]
+        if name == "ground_temperature":
+            if getattr(self, "vegetation_mode", "off") == "standalone":   # an input of the VegetationModel (no soil)
+                name = "vegetation_ground_temperature"
+            else:                                                          # view of the top soil layer (soil_energy.jl:52-57)
+                return self.get("temperature")[-1]
         if name == "rainfall_ground":  # alias of rainfall (canopy_interception.jl:11-15)
             name = "rainfall"
         rows = self.rows(name)
@@ -192,7 +195,17 @@ class DeviceState:
         self._check(self._lib.trm_set_bc(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], _capi.BC_KIND[kind], ptr,
                                          scalar), "trm_set_bc")
 
+    def set_vegetation(self, veg_params, mode="standalone"):
+        """Enables the vegetation processes (trm_set_vegetation)."""
+        self._check(self._lib.trm_set_vegetation(self._ctx, C.byref(veg_params), _capi.VEGETATION[mode]), "trm_set_vegetation")
+        self.vegetation_mode = mode
+
+    def compute_plant_available_water(self):
+        self._check(self._lib.trm_compute_plant_available_water(self._ctx), "trm_compute_plant_available_water")
+
     def set_forcing(self, name, value):
+        if name == "ground_temperature":
+            name = "vegetation_ground_temperature"
         a = np.empty(self.grid.Nh, dtype=self.dtype)
         a[...] = value
         self._check(self._lib.trm_set_forcing(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_set_forcing")
@@ -405,6 +418,8 @@ def initialize(model, timestepper=None, boundary_conditions=None, initializers=N
     inits = dict(initializers or {})
     inputs = dict(inputs or {})
     state = DeviceState(model.grid, M.flatten(model))
+    if isinstance(model, M.VegetationModel):
+        state.set_vegetation(M.flatten_vegetation(model.vegetation, model.constants), "standalone")
     integ = ModelIntegrator(model, timestepper, state, bcs, inits, inputs)
     initialize_integrator(integ)
     return integ
@@ -436,6 +451,8 @@ def initialize_integrator(integ: ModelIntegrator):
         st.set("vwc_forcing", forcing)   # per-cell user forcing (soil_hydrology.jl:37-38)
     for name, value in integ.initializers.items():
         st.set(name, value)
+    if isinstance(integ.model, M.VegetationModel):
+        return integ                 # (no process initialisers: initialize!(state, model::VegetationModel) is the default no-op)
     _apply_model_initializer(st, integ.model)
     st.initialize()
     return integ

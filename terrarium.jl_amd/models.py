@@ -25,6 +25,7 @@ class PhysicalConstants:
     kappa: float = 0.4
     epsilon: float = 0.622
     R_a: float = 287.058
+    C_mass: float = 12.0
 
 
 # ---- src/processes/soil/energy/soil_thermal_properties.jl:14-46 -------------
@@ -339,6 +340,120 @@ class LandModel:
     vegetation: None = None
 
     coupled_surface = True
+
+
+# ---- vegetation (src/processes/vegetation/, needleleaf-tree PFT defaults) ----------------------------------------------
+@dataclass
+class LUEPhotosynthesis:
+    """photosynthesis.jl:17-68"""
+    tau25: float = 2600.0
+    Kc25: float = 30.0
+    Ko25: float = 3.0e4
+    q10_tau: float = 0.57
+    q10_Kc: float = 2.1
+    q10_Ko: float = 1.2
+    alpha_leaf: float = 0.17
+    alpha_a: float = 0.5
+    alpha_C3: float = 0.08
+    cq: float = 4.6e-6
+    k_ext: float = 0.5
+    T_CO2_high: float = 42.0
+    T_CO2_low: float = -4.0
+    T_photos_high: float = 30.0
+    T_photos_low: float = 15.0
+    theta_r: float = 0.7
+
+
+@dataclass
+class MedlynStomatalConductance:
+    """stomatal_conductance.jl:16-24"""
+    g1: float = 2.3
+    g_min: float = 0.5
+
+
+@dataclass
+class PALADYNAutotrophicRespiration:
+    """autotrophic_respiration.jl:14-23"""
+    cn_sapwood: float = 330.0
+    cn_root: float = 29.0
+    aws: float = 10.0
+
+
+@dataclass
+class PALADYNPhenology:
+    """phenology.jl:14-18 (evergreen placeholder: f_deciduous = 0, phenology factor 1)"""
+
+
+@dataclass
+class PALADYNCarbonDynamics:
+    """carbon_dynamics.jl:18-43"""
+    SLA: float = 10.0
+    awl: float = 2.0
+    LAI_min: float = 1.0
+    LAI_max: float = 6.0
+    gamma_L: float = 0.3
+    gamma_R: float = 0.3
+    gamma_S: float = 0.05
+
+
+@dataclass
+class PALADYNVegetationDynamics:
+    """vegetation_dynamics.jl:15-22"""
+    nu_seed: float = 0.001
+    gamma_v_min: float = 0.002
+
+
+@dataclass
+class StaticExponentialRootDistribution:
+    """root_distribution.jl:23-29"""
+    a: float = 7.0
+    b: float = 2.0
+
+
+@dataclass
+class FieldCapacityLimitedPAW:
+    """plant_available_water.jl:17-19"""
+
+
+@dataclass
+class VegetationCarbon:
+    """vegetation_carbon.jl:6-64"""
+    photosynthesis: LUEPhotosynthesis = field(default_factory=LUEPhotosynthesis)
+    stomatal_conductance: MedlynStomatalConductance = field(default_factory=MedlynStomatalConductance)
+    autotrophic_respiration: PALADYNAutotrophicRespiration = field(default_factory=PALADYNAutotrophicRespiration)
+    phenology: PALADYNPhenology = field(default_factory=PALADYNPhenology)
+    carbon_dynamics: PALADYNCarbonDynamics = field(default_factory=PALADYNCarbonDynamics)
+    vegetation_dynamics: PALADYNVegetationDynamics = field(default_factory=PALADYNVegetationDynamics)
+    root_distribution: StaticExponentialRootDistribution = field(default_factory=StaticExponentialRootDistribution)
+    plant_available_water: FieldCapacityLimitedPAW = field(default_factory=FieldCapacityLimitedPAW)
+
+
+@dataclass
+class VegetationModel:
+    """src/models/vegetation/vegetation_model.jl:13-32: natural vegetation of a single plant functional type, driven by
+    the prescribed atmosphere alone (soil moisture limitation and ground temperature are inputs)."""
+    grid: ColumnGrid
+    atmosphere: PrescribedAtmosphere = field(default_factory=PrescribedAtmosphere)
+    vegetation: VegetationCarbon = field(default_factory=VegetationCarbon)
+    constants: PhysicalConstants = field(default_factory=PhysicalConstants)
+    initializer: object = field(default_factory=DefaultInitializer)
+    halo_policy: str = "reference_zero"
+    soil: SoilEnergyWaterCarbon = field(default_factory=SoilEnergyWaterCarbon)   # (the context's unused soil columns)
+
+
+def flatten_vegetation(veg: VegetationCarbon, constants: PhysicalConstants = None, hydraulics=None, texture=None) -> "_capi.TrmVegetationParams":
+    """VegetationCarbon -> trm_vegetation_params (include/terrarium_hip.h)."""
+    p = _capi.default_vegetation_params()
+    for part in (veg.photosynthesis, veg.stomatal_conductance, veg.autotrophic_respiration, veg.carbon_dynamics, veg.vegetation_dynamics):
+        for k, v in vars(part).items():
+            setattr(p, k, v)
+    p.root_a, p.root_b = veg.root_distribution.a, veg.root_distribution.b
+    if hydraulics is not None:
+        tex = texture or SoilTexture()
+        p.wilting_point, p.field_capacity = hydraulics.wilting_point(tex), hydraulics.field_capacity(tex)
+    if constants is not None:
+        p.C_mass = getattr(constants, "C_mass", 12.0)
+    return p
 
 
 def flatten(model) -> "_capi.TrmParams":
