@@ -21,6 +21,14 @@ FIELDS = dict(
     evaporation_ground=18, infiltration=19, surface_runoff=20, air_temperature=21, air_pressure=22, windspeed=23,
     specific_humidity=24, rainfall=25, surface_shortwave_down=26, surface_longwave_down=27, vwc_forcing=28,
     albedo=29, emissivity=30,
+    # LandModel with vegetation (ids of include/terrarium_hip.h)
+    carbon_vegetation=31, vegetation_area_fraction=32, tend_carbon_vegetation=33, tend_vegetation_area_fraction=34,
+    balanced_leaf_area_index=35, phenology_factor=36, leaf_area_index=37, canopy_water_conductance=38,
+    leaf_to_air_co2_ratio=39, net_assimilation=40, leaf_respiration=41, gross_primary_production=42,
+    autotrophic_respiration=43, net_primary_production=44, CO2=45, soil_moisture_limiting_factor=46,
+    daily_leaf_respiration=47, plant_available_water=49, root_fraction=50, canopy_water=51, tend_canopy_water=52,
+    canopy_water_interception=53, canopy_water_removal=54, saturation_canopy_water=55, rainfall_ground=56,
+    evaporation_canopy=57, transpiration=58, SAI=59,
 )
 BC_VARS = dict(internal_energy=0, saturation_water_ice=1, temperature=2, liquid_water_fraction=3, pressure_head=4)
 BC_KINDS = dict(noflux=0, value=1, flux=2, gradient=3)
@@ -232,6 +240,12 @@ class Oracle:
     def clear_series(self): self.lib.trm_oracle_clear_series(self.h)
     def update_inputs(self): self.lib.trm_oracle_update_inputs(self.h)
 
+    def enable_vegetation(self, veg_params=None):
+        """LandModel(grid; soil, vegetation = VegetationCarbon): couple the vegetation and canopy processes."""
+        self.veg_params = veg_params if veg_params is not None else default_vegetation_params()
+        self.lib.trm_oracle_enable_vegetation.argtypes = [C.c_void_p, C.POINTER(VegParamsD)]
+        self.lib.trm_oracle_enable_vegetation(self.h, C.byref(self.veg_params))
+
     def set_land_model(self, on=True):
         self.lib.trm_oracle_set_land_model(self.h, int(on))
 
@@ -282,7 +296,7 @@ class Oracle:
 # ---- vegetation (oracle/vegetation_oracle.hpp) -------------------------------------------------------------------------------
 VEG_PARAM_NAMES = ("tau25 Kc25 Ko25 q10_tau q10_Kc q10_Ko alpha_leaf alpha_a alpha_C3 cq k_ext T_CO2_high T_CO2_low T_photos_high "
                    "T_photos_low theta_r g1 g_min cn_sapwood cn_root aws SLA awl LAI_min LAI_max gamma_L gamma_R gamma_S nu_seed "
-                   "gamma_v_min root_a root_b wilting_point field_capacity C_mass").split()
+                   "gamma_v_min root_a root_b wilting_point field_capacity C_mass alpha_int canopy_k_ext w_can_max tau_w C_can").split()
 
 
 class VegParamsD(C.Structure):
@@ -297,7 +311,8 @@ def default_vegetation_params(**overrides):
              cq=4.6e-6, k_ext=0.5, T_CO2_high=42.0, T_CO2_low=-4.0, T_photos_high=30.0, T_photos_low=15.0, theta_r=0.7,
              g1=2.3, g_min=0.5, cn_sapwood=330.0, cn_root=29.0, aws=10.0,
              SLA=10.0, awl=2.0, LAI_min=1.0, LAI_max=6.0, gamma_L=0.3, gamma_R=0.3, gamma_S=0.05,
-             nu_seed=0.001, gamma_v_min=0.002, root_a=7.0, root_b=2.0, wilting_point=0.05, field_capacity=0.25, C_mass=12.0)
+             nu_seed=0.001, gamma_v_min=0.002, root_a=7.0, root_b=2.0, wilting_point=0.05, field_capacity=0.25, C_mass=12.0,
+             alpha_int=0.2, canopy_k_ext=0.5, w_can_max=2.0e-4, tau_w=86400.0, C_can=0.006)
     for k, v in overrides.items():
         if k not in d:
             raise KeyError(k)
@@ -314,7 +329,9 @@ VEG_FIELDS = dict(carbon_vegetation=0, vegetation_area_fraction=1, tend_carbon_v
 VEG_SCALARS = dict(lambda_NPP=0, LAI_b=1, Lambda_loc=2, C_veg_tend=3, f_deciduous=4, phenology_factor=5, LAI=6, gamma_v=7, nu_star=8,
                    nu_tendency=9, gw_can=10, lambda_c=11, tau=12, Kc=13, Ko=14, Gamma_star=15, PAR=16, APAR=17, pres_i=18,
                    temperature_stress=19, c_1=20, c_2=21, Vc_max=22, JE=23, JC=24, Rd=25, Ag=26, resp_Rd=27, resp_An=28,
-                   f_temp_air=29, f_temp_soil=30, resp10=31, Rm=32, Rg=33, Ra=34, NPP=35, root_density=36, plant_available_water=37)
+                   f_temp_air=29, f_temp_soil=30, resp10=31, Rm=32, Rg=33, Ra=34, NPP=35, root_density=36, plant_available_water=37,
+                   canopy_interception=38, canopy_saturation_fraction=39, canopy_water_removal=40, w_can_tendency=41,
+                   precip_ground=42, transpiration=43, evaporation_ground=44, evaporation_canopy=45, canopy_ground_resistance=46)
 
 
 def _veg_lib():

@@ -3,7 +3,6 @@
 // ctypes harness in oracle/oracle.py.  Only tests/, __graft_entry__.smoke() and
 // bench.py's cpu_baseline leg may load the resulting library.
 #include "terrarium_oracle.hpp"
-#include "vegetation_oracle.hpp"
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -52,6 +51,8 @@ void trm_oracle_destroy(OracleHandle* h) {
     delete h->f;
     delete h;
 }
+// LandModel(grid; soil, vegetation = VegetationCarbon): couple the vegetation and canopy processes (land_model.jl:24-34)
+void trm_oracle_enable_vegetation(OracleHandle* h, const VegParamsD* vp) { DISPATCH(h, o->enable_vegetation(*vp)); }
 long trm_oracle_field_rows(OracleHandle* h, int id) {
     long r = 0;
     DISPATCH(h, r = o->field_rows(id));
@@ -262,6 +263,15 @@ double trm_oracle_veg_scalar(const VegParamsD* vp, int what, const double* x) {
         case 35: return veg_NPP(x[0], x[1]);
         case 36: return veg_root_density(p, x[0]);
         case 37: return veg_plant_available_water(p, x[0]);
+        case 38: return canopy_interception(p, x[0], x[1], x[2]);
+        case 39: return canopy_saturation_fraction(p, x[0], x[1], x[2]);
+        case 40: return canopy_water_removal(p, x[0]);
+        case 41: return canopy_w_can_tendency(x[0], x[1], x[2]);
+        case 42: return canopy_precip_ground(x[0], x[1], x[2]);
+        case 43: return canopy_transpiration(x[0], x[1], x[2]);
+        case 44: return canopy_evaporation_ground(x[0], x[1], x[2], x[3]);
+        case 45: return canopy_evaporation_canopy(x[0], x[1], x[2]);
+        case 46: return canopy_ground_resistance(p, x[0], x[1], x[2]);
         default: return std::nan("");
     }
 }

@@ -390,6 +390,10 @@ enum FieldId {
     // inputs (PrescribedAtmosphere)
     F_AIR_TEMPERATURE = 21, F_AIR_PRESSURE = 22, F_WINDSPEED = 23, F_SPECIFIC_HUMIDITY = 24, F_RAINFALL = 25,
     F_SW_DOWN = 26, F_LW_DOWN = 27,
+    F_CARBON_VEGETATION = 31, F_TEND_VEGETATION_AREA_FRACTION = 34, F_NET_PRIMARY_PRODUCTION = 44, F_CO2 = 45,
+    F_SOIL_MOISTURE_LIMITING_FACTOR = 46, F_DAILY_LEAF_RESPIRATION = 47, F_PLANT_AVAILABLE_WATER = 49, F_ROOT_FRACTION = 50,
+    F_CANOPY_WATER = 51, F_TEND_CANOPY_WATER = 52, F_CANOPY_WATER_INTERCEPTION = 53, F_CANOPY_WATER_REMOVAL = 54,
+    F_SATURATION_CANOPY_WATER = 55, F_RAINFALL_GROUND = 56, F_EVAPORATION_CANOPY = 57, F_TRANSPIRATION = 58, F_STEM_AREA_INDEX = 59,
     F_VWC_FORCING = 28, F_ALBEDO = 29, F_EMISSIVITY = 30,  // user vwc_forcing evaluated per cell (soil_hydrology.jl:37-38, forcings.jl:13-15)
     F_COUNT = 29
 };
@@ -399,9 +403,14 @@ template <class NF> struct Bc {
     std::vector<NF> value;  // per column
 };
 
+}  // namespace trm_oracle
+#include "vegetation_oracle.hpp"   // the 0-D vegetation / canopy processes the coupled LandModel below steps
+namespace trm_oracle {
+
 template <class NF> class Oracle {
   public:
     Grid<NF> g;
+    ParamsD pd;
     Params<NF> p;
     long Nh;
     int Nz;
@@ -428,7 +437,13 @@ template <class NF> class Oracle {
     Bc<NF> bc[BCV_COUNT][2];  // [var][0 = bottom, 1 = top]
     bool land_model = false;  // LandModel wiring of ground_heat_flux / infiltration flux BCs
 
-    Oracle(long nh, int nz, const double* thickness, double dx, const ParamsD& pd) : p(pd), Nh(nh), Nz(nz) {
+    // LandModel(vegetation = VegetationCarbon) (land_model.jl:24-25,79-97): the vegetation state, the canopy water store and
+    // the canopy evapotranspiration fluxes; plant available water per cell (halo layout) and the static root fractions per level
+    bool veg_on = false;
+    VegetationOracle<NF> veg;
+    std::vector<NF> w_can, G_w_can, I_can, R_can, f_can, rain_ground, E_can, transp, SAI, paw, root_frac;
+
+    Oracle(long nh, int nz, const double* thickness, double dx, const ParamsD& pd_in) : pd(pd_in), p(pd_in), Nh(nh), Nz(nz) {
         g.build(nh, nz, thickness, dx);
         size_t n3 = (size_t)(nz + 2) * nh, nf = (size_t)(nz + 3) * nh, n2 = (size_t)nh;
         for (auto* v : {&U, &sat, &T, &liq, &psi, &G_U, &G_sat, &Fvwc}) v->assign(n3, NF(0));
@@ -462,6 +477,7 @@ template <class NF> class Oracle {
             case F_TEND_INTERNAL_ENERGY: return &G_U;
             case F_TEND_SATURATION: return &G_sat;
             case F_VWC_FORCING: return &Fvwc;
+            case F_PLANT_AVAILABLE_WATER: return veg_on ? &paw : nullptr;
             default: return nullptr;
         }
     }
@@ -489,12 +505,42 @@ template <class NF> class Oracle {
             case F_LW_DOWN: return &lwd;
             case F_ALBEDO: return &albedo_in;
             case F_EMISSIVITY: return &emissivity_in;
+            default: break;
+        }
+        if (!veg_on) return nullptr;
+        if (id >= F_CARBON_VEGETATION && id <= F_NET_PRIMARY_PRODUCTION) return veg.field(id - F_CARBON_VEGETATION);
+        switch (id) {
+            case F_CO2: return &veg.CO2;
+            case F_SOIL_MOISTURE_LIMITING_FACTOR: return &veg.smlf;
+            case F_DAILY_LEAF_RESPIRATION: return &veg.daily_Rd;
+            case F_CANOPY_WATER: return &w_can;
+            case F_TEND_CANOPY_WATER: return &G_w_can;
+            case F_CANOPY_WATER_INTERCEPTION: return &I_can;
+            case F_CANOPY_WATER_REMOVAL: return &R_can;
+            case F_SATURATION_CANOPY_WATER: return &f_can;
+            case F_RAINFALL_GROUND: return &rain_ground;
+            case F_EVAPORATION_CANOPY: return &E_can;
+            case F_TRANSPIRATION: return &transp;
+            case F_STEM_AREA_INDEX: return &SAI;
             default: return nullptr;
         }
     }
+    // LandModel(grid; soil, vegetation): switch the vegetation and canopy processes on
+    void enable_vegetation(const VegParamsD& vp) {
+        veg = VegetationOracle<NF>(Nh, vp, pd);
+        veg_on = true;
+        for (auto* v : {&w_can, &G_w_can, &I_can, &R_can, &f_can, &rain_ground, &E_can, &transp, &SAI}) v->assign((size_t)Nh, NF(0));
+        paw.assign((size_t)(Nz + 2) * Nh, NF(0));
+        // root_fraction (root_distribution.jl:51-63): density at the cell centres times the thickness, normalised over the column
+        root_frac.assign((size_t)Nz + 2, NF(0));
+        NF total = NF(0);
+        for (int k = 1; k <= Nz; ++k) { root_frac[k] = veg_root_density(veg.p, g.zC[k]) * g.dzc[k]; }
+        for (int k = 1; k <= Nz; ++k) total = total + root_frac[k];
+        for (int k = 1; k <= Nz; ++k) root_frac[k] = root_frac[k] / total;
+    }
     long field_rows(int id) const {
         if (id == F_HYDRAULIC_CONDUCTIVITY) return Nz + 1;
-        if (id <= F_TEND_SATURATION || id == F_VWC_FORCING) return Nz;
+        if (id <= F_TEND_SATURATION || id == F_VWC_FORCING || id == F_PLANT_AVAILABLE_WATER || id == F_ROOT_FRACTION) return Nz;
         return 1;
     }
     int set_field(int id, const NF* src) {  // set!(field, array): interior only
@@ -511,6 +557,10 @@ template <class NF> class Oracle {
         return 1;
     }
     int get_field(int id, NF* dst) {
+        if (id == F_ROOT_FRACTION && veg_on) {
+            for (int k = 1; k <= Nz; ++k) std::fill(dst + (size_t)(k - 1) * Nh, dst + (size_t)k * Nh, root_frac[k]);
+            return 0;
+        }
         if (id == F_HYDRAULIC_CONDUCTIVITY) {
             for (int k = 1; k <= Nz + 1; ++k) std::memcpy(dst + (size_t)(k - 1) * Nh, &Kf[C(k, 0)], sizeof(NF) * Nh);
             return 0;
@@ -718,31 +768,79 @@ template <class NF> class Oracle {
         NF de = compute_vpd(p, pres[i], qair[i], Tsurf);
         return p.eps_mw * de / pres[i];
     }
+    // ground_evaporation_resistance_factor (ground_resistance_factor.jl:12,36-56)
+    inline NF ground_resistance_factor(long i) const {
+        NF beta = p.beta_evap;
+        if (p.evap_resistance == 1) {
+            NF por = porosity(p);
+            Fractions<NF> fr = volumetric_fractions(por, sat[C(Nz, i)], liq[C(Nz, i)], organic_fraction(p));
+            NF fc = p.field_capacity;
+            if (fr.water < fc) {
+                NF t = NF(1) - std::cos(NF(3.141592653589793) * fr.water / fc);
+                beta = (t * t) / NF(4);
+            } else {
+                beta = NF(1);
+            }
+        }
+        return beta;
+    }
     void compute_evaporation() {  // bare_ground_evaporation.jl:49-62
         TRM_OMP_FOR
         for (long i = col_lo(); i < col_hi(); ++i) {
             NF ra = aerodynamic_resistance(i);
             NF dq = humidity_vpd(i, Ts[i]);
-            // ground_evaporation_resistance_factor (ground_resistance_factor.jl:12,36-56)
-            NF beta = p.beta_evap;
-            if (p.evap_resistance == 1) {
-                NF por = porosity(p);
-                Fractions<NF> fr = volumetric_fractions(por, sat[C(Nz, i)], liq[C(Nz, i)], organic_fraction(p));
-                NF fc = p.field_capacity;
-                if (fr.water < fc) {
-                    NF t = NF(1) - std::cos(NF(3.141592653589793) * fr.water / fc);
-                    beta = (t * t) / NF(4);
-                } else {
-                    beta = NF(1);
-                }
-            }
+            NF beta = ground_resistance_factor(i);
             evap[i] = beta * dq / ra;
+        }
+    }
+    // compute_auxiliary!(state, grid, veg::VegetationCarbon, constants, atmos, soil) (vegetation_carbon.jl:66-104) with the
+    // soil present: plant available water from the soil's liquid water content (plant_available_water.jl:48-94), its
+    // root-weighted integral as the soil moisture limiting factor (:33-38, Integral sums (W r / dz) dz from the bottom
+    // cell up) and ground_temperature = the top soil cell (soil_energy.jl:48-57), then the 0-D processes.
+    void compute_vegetation() {
+        NF por = porosity(p), org = organic_fraction(p);
+        for (long i = col_lo(); i < col_hi(); ++i) {
+            NF acc = NF(0);
+            for (int k = 1; k <= Nz; ++k) {
+                Fractions<NF> fr = volumetric_fractions(por, sat[C(k, i)], liq[C(k, i)], org);
+                NF w = veg_plant_available_water(veg.p, fr.water);
+                paw[C(k, i)] = w;
+                acc = acc + (w * root_frac[k] / g.dzc[k]) * g.dzc[k];
+            }
+            veg.smlf[i] = acc;
+            veg.Tground[i] = T[C(Nz, i)];
+            veg.Tair[i] = Tair[i]; veg.pres[i] = pres[i]; veg.qair[i] = qair[i]; veg.swd[i] = swd[i];
+        }
+        veg.compute_auxiliary(col_lo(), col_hi());
+    }
+    // compute_auxiliary!(state, grid, ::PALADYNCanopyInterception, atmos) (canopy_interception.jl:170-199)
+    void compute_canopy_interception() {
+        for (long i = col_lo(); i < col_hi(); ++i) {
+            NF LAI = veg.LAI[i], sai = SAI[i], w = w_can[i];
+            f_can[i] = canopy_saturation_fraction(veg.p, w, LAI, sai);
+            I_can[i] = canopy_interception(veg.p, rain[i], LAI, sai);
+            R_can[i] = canopy_water_removal(veg.p, w);
+            rain_ground[i] = canopy_precip_ground(rain[i], I_can[i], R_can[i]);
+        }
+    }
+    // compute_evapotranspiration! of PALADYNCanopyEvapotranspiration (canopy_evapotranspiration.jl:127-158)
+    void compute_canopy_evapotranspiration() {
+        for (long i = col_lo(); i < col_hi(); ++i) {
+            NF Tg = T[C(Nz, i)];
+            NF dqs = humidity_vpd(i, Ts[i]);
+            NF dqg = humidity_vpd(i, Tg);
+            NF ra = aerodynamic_resistance(i);
+            NF re = canopy_ground_resistance(veg.p, veg.LAI[i], SAI[i], jl_max(wind[i], p.min_windspeed));
+            NF beta = ground_resistance_factor(i);
+            transp[i] = canopy_transpiration(dqs, ra, veg.gw_can[i]);
+            evap[i] = canopy_evaporation_ground(dqg, beta, ra, re);
+            E_can[i] = canopy_evaporation_canopy(dqs, f_can[i], ra);
         }
     }
     void compute_runoff() {  // direct_surface_runoff.jl:87-117
         TRM_OMP_FOR
         for (long i = col_lo(); i < col_hi(); ++i) {
-            NF rainfall = rain[i];
+            NF rainfall = veg_on ? rain_ground[i] : rain[i];   // rainfall_ground(i, j, grid, fields, canopy_interception)
             NF excess = richards() ? S[i] : NF(0);
             NF k_unsat = Kf[C(Nz, i)];
             NF sat_top = sat[C(Nz, i)];
@@ -775,7 +873,9 @@ template <class NF> class Oracle {
         NF ra = aerodynamic_resistance(i);
         NF Q_T = (Tsurf - Tair[i]) / ra;
         Hs[i] = sensible_heat_flux(p, Q_T);
-        NF Q_h = et_coupled ? evap[i] : humidity_vpd(i, Tsurf) / ra;
+        // surface_humidity_flux of the ET scheme: ground evaporation, plus canopy evaporation and transpiration under a
+        // canopy (bare_ground_evaporation.jl:29, canopy_evapotranspiration.jl:97-102)
+        NF Q_h = !et_coupled ? humidity_vpd(i, Tsurf) / ra : (veg_on ? evap[i] + E_can[i] + transp[i] : evap[i]);
         Hl[i] = latent_heat_flux(p, Q_h);
         ghf[i] = rnet[i] - Hs[i] - Hl[i];
     }
@@ -798,7 +898,13 @@ template <class NF> class Oracle {
     void compute_auxiliary() {
         compute_hydraulics();  // soil_coupled.jl:62-72 (energy/bgc are no-ops)
         if (p.seb) {           // land_model.jl:79-88
-            compute_evaporation();
+            if (veg_on) {      // vegetation, then surface hydrology = canopy interception, evapotranspiration, runoff
+                compute_vegetation();
+                compute_canopy_interception();
+                compute_canopy_evapotranspiration();
+            } else {
+                compute_evaporation();
+            }
             compute_runoff();
             compute_surface_energy_fluxes();
             compute_surface_energy_fluxes();
@@ -808,6 +914,8 @@ template <class NF> class Oracle {
     // ---- compute_tendencies!(state, model) ----------------------------------
     void compute_tendencies() {
         NF por = porosity(p), org = organic_fraction(p);
+        if (veg_on)   // compute_tendencies!(surface_hydrology): canopy water (canopy_interception.jl:201-215)
+            for (long i = col_lo(); i < col_hi(); ++i) G_w_can[i] = canopy_w_can_tendency(I_can[i], E_can[i], R_can[i]);
         // hydrology first (soil_coupled.jl:80-90)
         if (richards()) {
             TRM_OMP_FOR
@@ -842,6 +950,7 @@ template <class NF> class Oracle {
                 G_U[C(k, i)] += dUdt;
             }
         }
+        if (veg_on) veg.compute_tendencies(col_lo(), col_hi());   // land_model.jl:94
     }
 
     // ---- update_state! (state_variables.jl:72-80) ---------------------------
@@ -851,6 +960,11 @@ template <class NF> class Oracle {
         for (int k = 1; k <= Nz; ++k)
             for (long i = i0_; i < i1_; ++i) { G_U[C(k, i)] = NF(0); G_sat[C(k, i)] = NF(0); }
         std::fill(G_S.begin() + i0_, G_S.begin() + i1_, NF(0));
+        if (veg_on) {
+            std::fill(G_w_can.begin() + i0_, G_w_can.begin() + i1_, NF(0));
+            std::fill(veg.G_C_veg.begin() + i0_, veg.G_C_veg.begin() + i1_, NF(0));
+            std::fill(veg.G_nu.begin() + i0_, veg.G_nu.begin() + i1_, NF(0));
+        }
     }
     void update_state(bool tendencies = true, bool inputs = true) {
         reset_tendencies();
@@ -895,6 +1009,10 @@ template <class NF> class Oracle {
         }
         if (p.seb)
             for (long i = col_lo(); i < col_hi(); ++i) Ts[i] = Ts[i] + NF(0) * dt;  // skin_temperature: prognostic, zero tendency
+        if (veg_on) {
+            for (long i = col_lo(); i < col_hi(); ++i) w_can[i] = w_can[i] + G_w_can[i] * dt;
+            veg.explicit_step(dt, col_lo(), col_hi());
+        }
     }
 
     // ---- hydrology closure (soil_hydraulic_closures.jl:23-44) ---------------
@@ -1066,6 +1184,12 @@ template <class NF> class Oracle {
             for (size_t n = 0; n < G_sat.size(); ++n) G_sat[n] = (G_sat[n] + stage.G_sat[n]) / NF(2);
             for (size_t n = 0; n < G_S.size(); ++n) G_S[n] = (G_S[n] + stage.G_S[n]) / NF(2);
         }
+        if (veg_on)
+            for (long i = 0; i < Nh; ++i) {
+                G_w_can[i] = (G_w_can[i] + stage.G_w_can[i]) / NF(2);
+                veg.G_C_veg[i] = (veg.G_C_veg[i] + stage.veg.G_C_veg[i]) / NF(2);
+                veg.G_nu[i] = (veg.G_nu[i] + stage.veg.G_nu[i]) / NF(2);
+            }
         status |= stage.status;
         explicit_step(NF(dt));
         closure();

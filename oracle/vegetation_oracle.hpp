@@ -8,9 +8,11 @@
 // StaticExponentialRootDistribution and FieldCapacityLimitedPAW, driven as the standalone `VegetationModel`
 // (src/models/vegetation/vegetation_model.jl:34-49) by the explicit time steppers.  Written from the Julia sources as
 // text; pinned by the reference's unit tests under test/vegetation/ (tests/test_oracle_vegetation.py).
+// (included by terrarium_oracle.hpp just in front of its Oracle class: the Julia Base helpers, Params and compute_vpd come from there)
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <vector>
 
 namespace trm_oracle {
@@ -33,17 +35,19 @@ struct VegParamsD {   // plain doubles across the C API; field order = include/t
     double wilting_point, field_capacity;
     // PhysicalConstants.C_mass (physical_constants.jl:50)
     double C_mass;
+    // PALADYNCanopyInterception (canopy_interception.jl:37-49) and PALADYNCanopyEvapotranspiration.C_can (canopy_evapotranspiration.jl:33-40)
+    double alpha_int, canopy_k_ext, w_can_max, tau_w, C_can;
 };
 
 template <class NF> struct VegParams {
     NF tau25, Kc25, Ko25, q10_tau, q10_Kc, q10_Ko, alpha_leaf, alpha_a, alpha_C3, cq, k_ext, T_CO2_high, T_CO2_low, T_photos_high,
         T_photos_low, theta_r, g1, g_min, cn_sapwood, cn_root, aws, SLA, awl, LAI_min, LAI_max, gamma_L, gamma_R, gamma_S, nu_seed,
-        gamma_v_min, root_a, root_b, wilting_point, field_capacity, C_mass;
+        gamma_v_min, root_a, root_b, wilting_point, field_capacity, C_mass, alpha_int, canopy_k_ext, w_can_max, tau_w, C_can;
     VegParams() {}
     explicit VegParams(const VegParamsD& d) {
         const double* s = &d.tau25;
         NF* t = &tau25;
-        for (int n = 0; n < 35; ++n) t[n] = NF(s[n]);
+        for (int n = 0; n < 40; ++n) t[n] = NF(s[n]);
     }
 };
 
@@ -196,6 +200,28 @@ template <class NF> inline NF veg_plant_available_water(const VegParams<NF>& p, 
     return jl_max(jl_min(NF(1), (theta_w - p.wilting_point) / (p.field_capacity - p.wilting_point)), NF(0));
 }
 
+// ---- canopy hydrology (surface_hydrology/canopy_interception/canopy_interception.jl:64-118) --------------------------------
+template <class NF> inline NF canopy_interception(const VegParams<NF>& p, NF precip, NF LAI, NF SAI) {            // :64-67
+    return p.alpha_int * precip * (NF(1) - std::exp(-p.canopy_k_ext * (LAI + SAI)));
+}
+template <class NF> inline NF canopy_saturation_fraction(const VegParams<NF>& p, NF w_can, NF LAI, NF SAI) {      // :74-78
+    NF w_max = p.w_can_max * (LAI + SAI);
+    return w_max > 0 ? w_can / w_max : NF(0);
+}
+template <class NF> inline NF canopy_water_removal(const VegParams<NF>& p, NF w_can) { return jl_max(w_can, NF(0)) / p.tau_w; }   // :85-91
+template <class NF> inline NF canopy_w_can_tendency(NF I_can, NF E_can, NF R_can) { return I_can - E_can - R_can; }              // :100-106
+template <class NF> inline NF canopy_precip_ground(NF precip, NF I_can, NF R_can) { return precip - I_can + R_can; }             // :118-124
+// canopy evapotranspiration (evapotranspiration/canopy_evapotranspiration.jl:52-82, 163-176)
+template <class NF> inline NF canopy_transpiration(NF dq, NF ra, NF gw_can) {
+    NF rs = 1 / jl_max(gw_can, std::sqrt(std::numeric_limits<NF>::epsilon()));
+    return dq / (ra + rs);
+}
+template <class NF> inline NF canopy_evaporation_ground(NF dq, NF beta, NF ra, NF re) { return beta * dq / (ra + re); }
+template <class NF> inline NF canopy_evaporation_canopy(NF dq, NF f_can, NF ra) { return f_can * dq / ra; }
+template <class NF> inline NF canopy_ground_resistance(const VegParams<NF>& p, NF LAI, NF SAI, NF wind) {
+    return (1 - std::exp(-LAI - SAI)) / (p.C_can * wind);
+}
+
 // ---- the standalone VegetationModel on Nh columns ------------------------------------------------------------------------
 template <class NF> class VegetationOracle {
   public:
@@ -208,6 +234,7 @@ template <class NF> class VegetationOracle {
     double time = 0.0;
     long long iteration = 0;
 
+    VegetationOracle() : Nh(0), c(ParamsD{}) {}
     VegetationOracle(long nh, const VegParamsD& vp, const ParamsD& cp) : Nh(nh), p(vp), c(cp) {
         for (auto* v : {&C_veg, &nu, &G_C_veg, &G_nu, &LAI_b, &phen, &LAI, &gw_can, &lambda_c, &An, &Rd, &GPP, &Ra, &NPP, &daily_Rd}) v->assign(nh, NF(0));
         // input defaults (prescribed_atmosphere.jl:90-92,148,221-223,14; photosynthesis.jl:76; autotrophic_respiration.jl:38)
@@ -225,8 +252,9 @@ template <class NF> class VegetationOracle {
         return (id >= 0 && id < 22) ? all[id] : nullptr;
     }
     // compute_auxiliary!(state, grid, veg::VegetationCarbon, constants, atmos, soil = nothing) (vegetation_carbon.jl:66-104)
-    void compute_auxiliary() {
-        for (long i = 0; i < Nh; ++i) {
+    void compute_auxiliary(long lo = 0, long hi = -1) {
+        if (hi < 0) hi = Nh;
+        for (long i = lo; i < hi; ++i) {
             // (plant available water: no-op without soil, the limiting factor is an input)
             LAI_b[i] = veg_LAI_b(p, C_veg[i]);                                         // carbon dynamics
             phen[i] = veg_phenology_factor<NF>();                                      // phenology
@@ -244,14 +272,16 @@ template <class NF> class VegetationOracle {
         }
     }
     // compute_tendencies!(state, grid, veg::VegetationCarbon) (vegetation_carbon.jl:111-118); tendencies accumulate on reset fields
-    void compute_tendencies() {
-        for (long i = 0; i < Nh; ++i) {
+    void compute_tendencies(long lo = 0, long hi = -1) {
+        if (hi < 0) hi = Nh;
+        for (long i = lo; i < hi; ++i) {
             G_C_veg[i] = veg_C_veg_tend(p, LAI_b[i], NPP[i]);
             G_nu[i] = veg_nu_tendency(p, LAI_b[i], C_veg[i], NPP[i], nu[i]);
         }
     }
-    void explicit_step(NF dt) {
-        for (long i = 0; i < Nh; ++i) {
+    void explicit_step(NF dt, long lo = 0, long hi = -1) {
+        if (hi < 0) hi = Nh;
+        for (long i = lo; i < hi; ++i) {
             C_veg[i] = C_veg[i] + G_C_veg[i] * dt;
             nu[i] = nu[i] + G_nu[i] * dt;
         }
