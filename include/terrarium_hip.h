@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 7
+#define TRM_ABI_VERSION 8
 
 typedef struct trm_ctx trm_ctx;
 
@@ -133,7 +133,17 @@ enum {
     /* 3-D, Nz rows (allocated by trm_set_vegetation) */
     TRM_FIELD_PLANT_AVAILABLE_WATER = 49,    /* plant_available_water.jl:22                                          */
     TRM_FIELD_ROOT_FRACTION = 50,            /* static, normalised   root_distribution.jl:45-63                     */
-    TRM_FIELD_COUNT = 51
+    /* LandModel with vegetation: PALADYNCanopyInterception / PALADYNCanopyEvapotranspiration, one value per column */
+    TRM_FIELD_CANOPY_WATER = 51,             /* prognostic, m        canopy_interception.jl:55                      */
+    TRM_FIELD_TEND_CANOPY_WATER = 52,
+    TRM_FIELD_CANOPY_WATER_INTERCEPTION = 53, /* m/s                 canopy_interception.jl:56-59                   */
+    TRM_FIELD_CANOPY_WATER_REMOVAL = 54,
+    TRM_FIELD_SATURATION_CANOPY_WATER = 55,
+    TRM_FIELD_RAINFALL_GROUND = 56,          /* rain reaching the ground, m/s: what the runoff scheme routes        */
+    TRM_FIELD_EVAPORATION_CANOPY = 57,       /* m/s                  canopy_evapotranspiration.jl:90-92             */
+    TRM_FIELD_TRANSPIRATION = 58,
+    TRM_FIELD_STEM_AREA_INDEX = 59,          /* input `SAI` (default 0)   canopy_interception.jl:64                 */
+    TRM_FIELD_COUNT = 60
 };
 
 /* ---- diagnostics ---------------------------------------------------------- */
@@ -231,14 +241,26 @@ typedef struct trm_vegetation_params {
     double wilting_point, field_capacity;
     /* PhysicalConstants.C_mass  physical_constants.jl:50 */
     double C_mass;
+    /* PALADYNCanopyInterception (canopy_interception.jl:37-49): interception factor, canopy extinction coefficient,
+     * interception capacity [m], removal timescale [s]; PALADYNCanopyEvapotranspiration.C_can: ground-canopy drag
+     * coefficient (canopy_evapotranspiration.jl:33-40).  Used by TRM_VEGETATION_COUPLED only. */
+    double alpha_int, canopy_k_ext, w_can_max, tau_w, C_can;
 } trm_vegetation_params;
 int trm_default_vegetation_params(trm_vegetation_params* p);
 /* Enables the vegetation processes of the context (allocating their 3-D fields, setting the input defaults and the static
  * root fractions).  TRM_VEGETATION_STANDALONE: the context IS a VegetationModel (src/models/vegetation/vegetation_model.jl):
  * trm_step / trm_step_heun / trm_update_state / trm_compute_auxiliary / trm_compute_tendencies / trm_explicit_step act on
  * the vegetation state alone; soil moisture limitation and ground temperature are inputs.  One launch covers
- * update_state! + explicit_step! for all `nsteps` (the 0-D column stays in registers). */
-enum { TRM_VEGETATION_OFF = 0, TRM_VEGETATION_STANDALONE = 1 };
+ * update_state! + explicit_step! for all `nsteps` (the 0-D column stays in registers).
+ * TRM_VEGETATION_COUPLED (contexts with surface_energy_balance = 1): LandModel(grid; soil, vegetation) of
+ * src/models/coupled/land_model.jl:79-97.  compute_auxiliary! becomes soil hydraulics -> plant available water from the
+ * soil state, ground temperature = top soil cell, the vegetation processes -> canopy interception -> canopy
+ * evapotranspiration (transpiration through the stomatal conductance, ground evaporation below the canopy, evaporation of
+ * intercepted water) -> runoff of the rain reaching the ground -> the surface energy balance with the latent heat of all
+ * three humidity fluxes; canopy_water, carbon_vegetation and vegetation_area_fraction are stepped with the soil.  The
+ * 0-D part of one step is ONE launch in front of the soil column kernel; the resident multi-step program and the
+ * single-launch Heun do not apply (steps run one launch pair each, Heun on the reference-order kernels). */
+enum { TRM_VEGETATION_OFF = 0, TRM_VEGETATION_STANDALONE = 1, TRM_VEGETATION_COUPLED = 2 };
 int trm_set_vegetation(trm_ctx* ctx, const trm_vegetation_params* p, int mode);
 /* FieldCapacityLimitedPAW (plant_available_water.jl:36-94): plant_available_water per cell from the soil state of the
  * context and soil_moisture_limiting_factor = sum_k PAW_k * root_fraction_k. */

@@ -20,7 +20,7 @@ from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapac
                      PrescribedAlbedo,
                      ImplicitSkinTemperature, SurfaceEnergyBalance, ConstantAerodynamics, PrescribedAtmosphere,
                      DirectSurfaceRunoff, BareGroundEvaporation, ConstantEvaporationResistanceFactor, SoilMoistureResistanceFactor,
-                     SurfaceHydrology, DefaultInitializer,
+                     SurfaceHydrology, NoCanopyInterception, PALADYNCanopyInterception, PALADYNCanopyEvapotranspiration, DefaultInitializer,
                      ConstantSoilTemperature, QuasiThermalSteadyState, ConstantSaturation, SaturationWaterTable,
                      SoilInitializer, SoilModel, LandModel, flatten, LUEPhotosynthesis, MedlynStomatalConductance,
                      PALADYNAutotrophicRespiration, PALADYNPhenology, PALADYNCarbonDynamics, PALADYNVegetationDynamics,

@@ -29,14 +29,16 @@ FIELD = dict(
     net_assimilation=40, leaf_respiration=41, gross_primary_production=42, autotrophic_respiration=43, net_primary_production=44,
     CO2=45, soil_moisture_limiting_factor=46, daily_leaf_respiration=47, vegetation_ground_temperature=48,
     plant_available_water=49, root_fraction=50,
+    canopy_water=51, tend_canopy_water=52, canopy_water_interception=53, canopy_water_removal=54, saturation_canopy_water=55,
+    rainfall_ground=56, evaporation_canopy=57, transpiration=58, SAI=59,
 )
 INPUT_FIELDS = ("air_temperature", "air_pressure", "windspeed", "specific_humidity", "rainfall",
                 "surface_shortwave_down", "surface_longwave_down", "albedo", "emissivity", "CO2",
-                "soil_moisture_limiting_factor", "daily_leaf_respiration", "vegetation_ground_temperature")
-VEGETATION = dict(off=0, standalone=1)
+                "soil_moisture_limiting_factor", "daily_leaf_respiration", "vegetation_ground_temperature", "SAI")
+VEGETATION = dict(off=0, standalone=1, coupled=2)
 VEG_PARAM_NAMES = ("tau25 Kc25 Ko25 q10_tau q10_Kc q10_Ko alpha_leaf alpha_a alpha_C3 cq k_ext T_CO2_high T_CO2_low T_photos_high "
                    "T_photos_low theta_r g1 g_min cn_sapwood cn_root aws SLA awl LAI_min LAI_max gamma_L gamma_R gamma_S nu_seed "
-                   "gamma_v_min root_a root_b wilting_point field_capacity C_mass").split()
+                   "gamma_v_min root_a root_b wilting_point field_capacity C_mass alpha_int canopy_k_ext w_can_max tau_w C_can").split()
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4,
               derive_closure_fields=5, steps_per_launch=6)

@@ -10,6 +10,7 @@
 #include <rccl/rccl.h>   // types only: the library is opened lazily by trm_comm_init (no link-time dependency)
 
 #include <cmath>
+#include <limits>
 #include <type_traits>
 #include <cstdio>
 #include <cstdlib>
@@ -123,7 +124,7 @@ long field_rows(const trm_ctx* c, int field) {
 bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
 bool is_input_field(int f) {
     return (f >= TRM_FIELD_AIR_TEMPERATURE && f <= TRM_FIELD_SURFACE_LONGWAVE_DOWN) || f == TRM_FIELD_ALBEDO || f == TRM_FIELD_EMISSIVITY ||
-           (f >= TRM_FIELD_CO2 && f <= TRM_FIELD_VEGETATION_GROUND_TEMPERATURE);
+           (f >= TRM_FIELD_CO2 && f <= TRM_FIELD_VEGETATION_GROUND_TEMPERATURE) || f == TRM_FIELD_STEM_AREA_INDEX;
 }
 bool is_3d(int field) {
     return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING || field == TRM_FIELD_PLANT_AVAILABLE_WATER ||
@@ -505,10 +506,12 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
+    static bool coupled(const trm_ctx* c) { return c->veg_mode == TRM_VEGETATION_COUPLED; }
     static int compute_auxiliary(trm_ctx* c, const FieldSet& s) {
         int rc = hydraulics(c, s);
         if (rc) return rc;
-        if (c->params.seb) rc = surface(c, s);
+        if (coupled(c)) rc = surface_veg<false, false>(c, s, 0.0);
+        else if (c->params.seb) rc = surface(c, s);
         return rc;
     }
     static int compute_tendencies(trm_ctx* c, const FieldSet& s) {
@@ -517,11 +520,15 @@ template <class NF> struct Ops {
         if (richards(c)) hipLaunchKernelGGL((k_tendencies<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
         else hipLaunchKernelGGL((k_tendencies<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
         TRM_HIP(c, hipGetLastError());
+        if (coupled(c)) {   // surface hydrology (canopy water) and vegetation tendencies (land_model.jl:90-97)
+            hipLaunchKernelGGL((k_vegetation<NF, VEG_TEND>), col_grid(c), dim3(256), 0, c->stream, veg_view(c, s), veg_dev(c), NF(0), 1, 0);
+            TRM_HIP(c, hipGetLastError());
+        }
         return TRM_OK;
     }
     static int reset_tendencies(trm_ctx* c, const FieldSet& s) {
         for (int f : {TRM_FIELD_TEND_INTERNAL_ENERGY, TRM_FIELD_TEND_SATURATION_WATER_ICE, TRM_FIELD_TEND_SURFACE_EXCESS_WATER,
-                      TRM_FIELD_TEND_CARBON_VEGETATION, TRM_FIELD_TEND_VEGETATION_AREA_FRACTION})
+                      TRM_FIELD_TEND_CARBON_VEGETATION, TRM_FIELD_TEND_VEGETATION_AREA_FRACTION, TRM_FIELD_TEND_CANOPY_WATER})
             TRM_HIP(c, hipMemsetAsync(s.f[f], 0, field_elems(c, f) * sizeof(NF), c->stream));
         return TRM_OK;
     }
@@ -537,6 +544,10 @@ template <class NF> struct Ops {
         if (richards(c)) hipLaunchKernelGGL((k_explicit_step<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
         else hipLaunchKernelGGL((k_explicit_step<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
         TRM_HIP(c, hipGetLastError());
+        if (coupled(c)) {
+            hipLaunchKernelGGL((k_vegetation<NF, VEG_EXPLICIT>), col_grid(c), dim3(256), 0, c->stream, veg_view(c, s), veg_dev(c), (NF)dt, 1, 0);
+            TRM_HIP(c, hipGetLastError());
+        }
         return TRM_OK;
     }
     // hydrology closure: adjust_saturation_profile! + compute_water_table! (+ saturation_to_pressure!)
@@ -617,14 +628,16 @@ template <class NF> struct Ops {
         VegDev<NF> p;
         const double* s = &c->veg_params.tau25;
         NF* t = &p.tau25;
-        for (int n = 0; n < 35; ++n) t[n] = (NF)s[n];
+        for (int n = 0; n < 40; ++n) t[n] = (NF)s[n];
         p.eps_mw = (NF)c->params.eps_mw;
         p.one_minus_eps_mw = NF(1) - p.eps_mw;
+        p.sqrt_eps = std::sqrt(std::numeric_limits<NF>::epsilon());
         return p;
     }
-    static VegView<NF> veg_view(const trm_ctx* c) {
+    static VegView<NF> veg_view(const trm_ctx* c) { return veg_view(c, c->state); }
+    static VegView<NF> veg_view(const trm_ctx* c, const FieldSet& s) {
         VegView<NF> v;
-        auto F = [&](int id) { return (NF*)c->state.f[id]; };
+        auto F = [&](int id) { return (NF*)s.f[id]; };
         v.Nh = c->Nh;
         v.C_veg = F(TRM_FIELD_CARBON_VEGETATION); v.nu = F(TRM_FIELD_VEGETATION_AREA_FRACTION);
         v.G_C_veg = F(TRM_FIELD_TEND_CARBON_VEGETATION); v.G_nu = F(TRM_FIELD_TEND_VEGETATION_AREA_FRACTION);
@@ -637,7 +650,30 @@ template <class NF> struct Ops {
         v.daily_Rd = F(TRM_FIELD_DAILY_LEAF_RESPIRATION);
         v.Tground = F(TRM_FIELD_VEGETATION_GROUND_TEMPERATURE);
         v.Tground_stride = 1;
+        const bool canopy = coupled(c);
+        auto G = [&](int id) { return canopy ? F(id) : (NF*)nullptr; };
+        v.w_can = G(TRM_FIELD_CANOPY_WATER); v.G_w_can = G(TRM_FIELD_TEND_CANOPY_WATER); v.I_can = G(TRM_FIELD_CANOPY_WATER_INTERCEPTION);
+        v.R_can = G(TRM_FIELD_CANOPY_WATER_REMOVAL); v.f_can = G(TRM_FIELD_SATURATION_CANOPY_WATER); v.rain_ground = G(TRM_FIELD_RAINFALL_GROUND);
+        v.E_can = G(TRM_FIELD_EVAPORATION_CANOPY); v.transp = G(TRM_FIELD_TRANSPIRATION); v.SAI = G(TRM_FIELD_STEM_AREA_INDEX);
+        v.paw = F(TRM_FIELD_PLANT_AVAILABLE_WATER);
+        v.root_fraction = (const NF*)c->state.f[TRM_FIELD_ROOT_FRACTION];   // static: one copy serves the stage as well
         return v;
+    }
+    // the 0-D part of the coupled LandModel's compute_auxiliary! (+ tendencies and explicit step of the 0-D prognostics)
+    template <bool FROM_STATE, bool ADVANCE> static int surface_veg(trm_ctx* c, const FieldSet& s, double dt) {
+        const View<NF>& v = cached_view<NF>(c, s);
+        const DevParams<NF>& p = launch_args<NF>(c).p;
+        const VegView<NF> vv = veg_view(c, s);
+        const VegDev<NF> vp = veg_dev(c);
+        if constexpr (FROM_STATE) {
+            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, true, H, true, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt)); }
+            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, false, H, true, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt)); }
+        } else {   // (the conductivity of the top face comes from the field: the hydraulics variant is not needed)
+            if (richards(c)) hipLaunchKernelGGL((k_surface_veg<NF, true, HYD_GENERIC, false, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt);
+            else hipLaunchKernelGGL((k_surface_veg<NF, false, HYD_GENERIC, false, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt);
+        }
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
     }
     template <int MODE> static int veg_launch(trm_ctx* c, double dt, int nsteps, int finalize) {
         hipLaunchKernelGGL((k_vegetation<NF, MODE>), col_grid(c), dim3(256), 0, c->stream, veg_view(c), veg_dev(c), (NF)dt, nsteps, finalize);
@@ -707,7 +743,8 @@ template <class NF> struct Ops {
     template <bool RICH> static bool derive_now(const trm_ctx* c) {
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
         const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && std::is_same<NF, double>::value && state_bytes > ((size_t)256 << 20));
-        return want && c->closure_consistent && !c->closure_escaped;
+        // (the coupled vegetation reads T and liq of the whole column from memory every step)
+        return want && c->closure_consistent && !c->closure_escaped && !coupled(c);
     }
     // fp32, reference-default hydraulics: two columns per lane with packed math (trm_packed_f32.hpp)
     static bool packed_path(trm_ctx* c) {
@@ -872,7 +909,7 @@ template <class NF> struct Ops {
         // Resident-column multi-step program (TRM_OPT_STEPS_PER_LAUNCH > 1): legal when nothing the host evaluates changes
         // between the steps of a launch -- constants, or device-resident time series the program interpolates itself --
         // and the branch-free boundary kinds apply.
-        const int spl = (fused && !generic_bcs(c) && series_fit_program(c)) ? c->opt_steps_per_launch : 1;
+        const int spl = (fused && !generic_bcs(c) && series_fit_program(c) && !coupled(c)) ? c->opt_steps_per_launch : 1;
         int n = 0;
         while (n < nsteps) {
             const int m = std::min(spl, nsteps - n);
@@ -893,11 +930,13 @@ template <class NF> struct Ops {
             } else {
                 // LandModel: the 0-D surface processes run as their own small launch in front of the fused
                 // column kernel (and once more after it when finalizing)
-                if (c->params.seb) rc = surface(c, c->state, true);
+                if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt);   // + the 0-D prognostics' step
+                else if (c->params.seb) rc = surface(c, c->state, true);
                 if (!rc) rc = wave_step(c, dt, fin);
                 c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
                 c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
-                if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
+                if (!rc && fin && coupled(c)) rc = surface_veg<true, false>(c, c->state, 0.0);
+                else if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             }
             if (rc) return rc;
             for (int j = 0; j < m; ++j) c->time += dt;   // tick! per step: the same sequence of sums as per-step calls
@@ -936,7 +975,7 @@ template <class NF> struct Ops {
         return rc;
     }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
-        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c)) return heun_step_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
         c->top_valid = false;
         c->tend_valid = true;
         c->closure_consistent = true;   // (ends with closure!)
@@ -951,6 +990,9 @@ template <class NF> struct Ops {
         if (!rc) rc = average(c, TRM_FIELD_TEND_INTERNAL_ENERGY);
         if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SATURATION_WATER_ICE);
         if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SURFACE_EXCESS_WATER);
+        if (coupled(c))
+            for (int f : {TRM_FIELD_TEND_CANOPY_WATER, TRM_FIELD_TEND_CARBON_VEGETATION, TRM_FIELD_TEND_VEGETATION_AREA_FRACTION})
+                if (!rc) rc = average(c, f);
         if (!rc) rc = explicit_step(c, c->state, dt);
         if (!rc) rc = closure(c, c->state);
         if (!rc && finalize) rc = compute_auxiliary(c, c->state);
@@ -1607,13 +1649,13 @@ int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
     TRM_ENTER(c);
     if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step_heun: nsteps < 0");
     if (c->veg_mode == TRM_VEGETATION_STANDALONE) return finish(c, DISPATCH(c, veg_step(c, dt, nsteps, finalize, true)));
-    const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 &&
+    const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && c->veg_mode != TRM_VEGETATION_COUPLED &&
                             !(c->precision == TRM_F64 ? Ops<double>::generic_bcs(c) : Ops<float>::generic_bcs(c));
-    if (!fused_heun && !c->has_stage) {   // the reference-order kernels work on a second copy of the state
+    if (!fused_heun) {   // the reference-order kernels work on a second copy of the state (fields enabled since the last call included)
         int rc = alloc_fields(c, c->stage);
         if (rc) return rc;
+        if (!c->has_stage) c->args_valid = false;
         c->has_stage = true;
-        c->args_valid = false;
     }
     for (int n = 0; n < nsteps; ++n) {
         int fin = (finalize && n == nsteps - 1) ? 1 : 0;
@@ -1692,12 +1734,16 @@ int trm_default_vegetation_params(trm_vegetation_params* p) {
     p->root_a = 7.0; p->root_b = 2.0;                                         // root_distribution.jl:23-29
     p->wilting_point = 0.05; p->field_capacity = 0.25;                        // soil_hydraulic_properties.jl:74-80
     p->C_mass = 12.0;                                                         // physical_constants.jl:50
+    p->alpha_int = 0.2; p->canopy_k_ext = 0.5; p->w_can_max = 2.0e-4; p->tau_w = 86400.0;   // canopy_interception.jl:37-49
+    p->C_can = 0.006;                                                         // canopy_evapotranspiration.jl:33-40
     return TRM_OK;
 }
 
 int trm_set_vegetation(trm_ctx* c, const trm_vegetation_params* p, int mode) {
     TRM_ENTER(c);
-    if (!p || (mode != TRM_VEGETATION_OFF && mode != TRM_VEGETATION_STANDALONE)) return fail(c, TRM_EINVAL, "trm_set_vegetation: bad argument");
+    if (!p || mode < TRM_VEGETATION_OFF || mode > TRM_VEGETATION_COUPLED) return fail(c, TRM_EINVAL, "trm_set_vegetation: bad argument");
+    if (mode == TRM_VEGETATION_COUPLED && !c->params.seb)
+        return fail(c, TRM_EINVAL, "trm_set_vegetation: TRM_VEGETATION_COUPLED needs a LandModel context (surface_energy_balance = 1)");
     TRM_HIP(c, hipStreamSynchronize(c->stream));
     c->veg_params = *p;
     const bool first = c->veg_mode == TRM_VEGETATION_OFF && mode != TRM_VEGETATION_OFF && !c->state.f[TRM_FIELD_ROOT_FRACTION];

@@ -475,16 +475,20 @@ template <class NF> TRM_DEV void seb_radiation_inputs(const DevParams<NF>& p, co
         in.one_minus_emissivity = p.one_minus_emissivity;
     }
 }
-template <class NF> TRM_DEV void seb_fluxes(const DevParams<NF>& p, const SebIn<NF>& in, NF ra, SebOut<NF>& o) {
-    // surface_energy_balance.jl:119-144 with the ET-coupled latent heat flux (turbulent_fluxes.jl:130-143)
+// surface_energy_balance.jl:119-144 with the ET-coupled latent heat flux (turbulent_fluxes.jl:130-143); Q_h is the
+// surface_humidity_flux of the evapotranspiration scheme
+template <class NF> TRM_DEV void seb_fluxes_humidity(const DevParams<NF>& p, const SebIn<NF>& in, NF ra, NF Q_h, SebOut<NF>& o) {
     o.swu = in.albedo * in.swd;
     NF Tk = o.Ts + p.Tref;
     o.lwu = in.eps_sigma * pow_int(Tk, 4) + in.one_minus_emissivity * in.lwd;
     o.rnet = o.swu - in.swd + o.lwu - in.lwd;
     NF Q_T = (o.Ts - in.Tair) / ra;
     o.Hs = p.ca_rhoa * Q_T;
-    o.Hl = p.Llg_rhoa * o.evap;
+    o.Hl = p.Llg_rhoa * Q_h;
     o.ghf = o.rnet - o.Hs - o.Hl;
+}
+template <class NF> TRM_DEV void seb_fluxes(const DevParams<NF>& p, const SebIn<NF>& in, NF ra, SebOut<NF>& o) {
+    seb_fluxes_humidity(p, in, ra, o.evap, o);   // bare ground: the ground evaporation alone (bare_ground_evaporation.jl:29)
 }
 // compute_auxiliary! of the surface processes for one column (land_model.jl:79-88):
 // bare-ground evaporation, direct runoff / infiltration, then the fused SEB kernel twice.
@@ -502,6 +506,20 @@ template <class NF> TRM_DEV NF evaporation_resistance_factor(const DevParams<NF>
         return (t * t) / NF(4);
     }
     return NF(1);
+}
+// direct_surface_runoff.jl:87-117: infiltration and runoff of the rain that reaches the ground
+template <class NF> TRM_DEV void surface_runoff(const DevParams<NF>& p, NF rain, NF sat_top, NF Kf_top, NF S, bool richards, SebOut<NF>& o) {
+    NF excess = richards ? S : NF(0);
+    bool unsat = sat_top < NF(1);
+    NF drainage;
+    if (excess > NF(0)) {
+        drainage = div_const(jl_max(excess, NF(0)), p.tau_r, p.rtau_r);
+        o.infil = boolmul(unsat, jl_min(drainage, Kf_top));
+    } else {
+        drainage = NF(0);
+        o.infil = boolmul(unsat, jl_min(rain, Kf_top));
+    }
+    o.runoff = rain + drainage - o.infil;
 }
 template <class NF>
 TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF Ts_in, NF T_ground, NF sat_top, NF liq_top,

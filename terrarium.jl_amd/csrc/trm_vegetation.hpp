@@ -6,8 +6,14 @@
 // roofline at N145 (56 951 threads: latency-bound, ~3 us).  Order of the processes and the deliberate use of the PREVIOUS
 // evaluation's net assimilation by the stomatal conductance follow compute_auxiliary!(state, grid, veg::VegetationCarbon,
 // ...) (vegetation_carbon.jl:66-104).
+//
+// TRM_VEGETATION_COUPLED (LandModel with vegetation, land_model.jl:79-97): k_surface_veg is the 0-D part of one step --
+// plant available water from the soil column, the vegetation processes, canopy interception, canopy evapotranspiration,
+// runoff, the surface energy balance x2 and (ADVANCE) the tendencies and explicit step of canopy_water,
+// carbon_vegetation and vegetation_area_fraction -- in one launch in front of the soil column kernel, which reads only
+// the ground heat flux and the infiltration it leaves behind.
 #pragma once
-#include "trm_device.hpp"
+#include "trm_kernels.hpp"
 
 namespace trm {
 
@@ -15,15 +21,22 @@ namespace trm {
 template <class NF> struct VegDev {
     NF tau25, Kc25, Ko25, q10_tau, q10_Kc, q10_Ko, alpha_leaf, alpha_a, alpha_C3, cq, k_ext, T_CO2_high, T_CO2_low, T_photos_high,
         T_photos_low, theta_r, g1, g_min, cn_sapwood, cn_root, aws, SLA, awl, LAI_min, LAI_max, gamma_L, gamma_R, gamma_S, nu_seed,
-        gamma_v_min, root_a, root_b, wilting_point, field_capacity, C_mass;
+        gamma_v_min, root_a, root_b, wilting_point, field_capacity, C_mass, alpha_int, canopy_k_ext, w_can_max, tau_w, C_can;
     // physical constants / atmosphere parameters the processes read
     NF eps_mw, one_minus_eps_mw;
+    NF sqrt_eps;   // sqrt(eps(NF)): floor of the stomatal conductance (canopy_evapotranspiration.jl:53)
 };
 template <class NF> struct VegView {
     long Nh;
     NF *C_veg, *nu, *G_C_veg, *G_nu, *LAI_b, *phen, *LAI, *gw_can, *lambda_c, *An, *Rd, *GPP, *Ra, *NPP;
     const NF *Tair, *pres, *qair, *swd, *CO2, *smlf, *daily_Rd, *Tground;
+    TRM_DEV NF* smlf_out() const { return const_cast<NF*>(smlf); }   // the coupled model computes the limiting factor itself
     long Tground_stride;   // 1 for the input field; the soil's top temperature is read with the level pitch
+    // canopy hydrology of the coupled LandModel (null in the standalone VegetationModel)
+    NF *w_can, *G_w_can, *I_can, *R_can, *f_can, *rain_ground, *E_can, *transp;
+    const NF* SAI;
+    NF* paw;                   // plant_available_water [Nh][Nzp]
+    const NF* root_fraction;   // [Nh][Nzp]
 };
 
 TRM_DEV double log_(double x) { return log(x); }
@@ -160,13 +173,15 @@ __global__ void __launch_bounds__(256) k_vegetation(VegView<NF> v, VegDev<NF> p,
         VegColumn<NF> t;
         t.C_veg = v.C_veg[i]; t.nu = v.nu[i]; t.LAI_b = v.LAI_b[i]; t.NPP = v.NPP[i];
         veg_tendencies(p, t);
-        v.G_C_veg[i] += t.G_C_veg;      // (accumulates, like every compute_tendencies!)
-        v.G_nu[i] += t.G_nu;
+        v.G_C_veg[i] = t.G_C_veg;       // (assigned, not accumulated: carbon_dynamics.jl:184, vegetation_dynamics.jl:150)
+        v.G_nu[i] = t.G_nu;
+        if (v.w_can) v.G_w_can[i] = v.I_can[i] - v.E_can[i] - v.R_can[i];   // canopy_interception.jl:100-106, 201-215
         return;
     }
     if (MODE == VEG_EXPLICIT) {
         v.C_veg[i] = v.C_veg[i] + v.G_C_veg[i] * dt;
         v.nu[i] = v.nu[i] + v.G_nu[i] * dt;
+        if (v.w_can) v.w_can[i] = v.w_can[i] + v.G_w_can[i] * dt;
         return;
     }
     VegInputs<NF> in = {v.Tair[i], v.pres[i], v.qair[i], v.swd[i], v.CO2[i], v.smlf[i], v.daily_Rd[i], v.Tground[i * v.Tground_stride]};
@@ -219,6 +234,96 @@ template <class NF> __global__ void __launch_bounds__(256) k_plant_available_wat
         acc = acc + (w * root_fraction[c] / dzc[k]) * dzc[k];
     }
     smlf[i] = acc;
+}
+
+// ---- canopy hydrology (canopy_interception.jl:64-124, canopy_evapotranspiration.jl:52-82,163-176) -----------------------
+template <class NF> struct CanopyOut { NF f_can, I_can, R_can, rain_ground, E_can, transp; };
+template <class NF> TRM_DEV void canopy_interception(const VegDev<NF>& p, NF rain, NF LAI, NF SAI, NF w_can, CanopyOut<NF>& o) {
+    const NF w_max = p.w_can_max * (LAI + SAI);
+    o.f_can = w_max > NF(0) ? w_can / w_max : NF(0);
+    o.I_can = p.alpha_int * rain * (NF(1) - exp_(-p.canopy_k_ext * (LAI + SAI)));
+    o.R_can = jl_max(w_can, NF(0)) / p.tau_w;
+    o.rain_ground = rain - o.I_can + o.R_can;
+}
+
+// The 0-D part of compute_auxiliary!(state, model::LandModel) with vegetation, one thread per column.
+// FROM_STATE: the top-face hydraulic conductivity is formed from the top cell (in front of the fused column kernel, which
+// does not materialise K); otherwise it is read from the hydraulic_conductivity field compute_hydraulics! filled.
+// ADVANCE: compute_tendencies! + explicit_step! of the 0-D prognostics follow in the same launch.
+template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool ADVANCE>
+__global__ void __launch_bounds__(256) k_surface_veg(View<NF> v, DevParams<NF> p, VegView<NF> vv, VegDev<NF> vp, NF dt) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= v.Nh) return;
+    uint32_t viol = 0;
+    // FieldCapacityLimitedPAW: plant available water per cell and its root-weighted integral (plant_available_water.jl:33-94)
+    NF smlf = NF(0), sat_top = NF(0), liq_top = NF(0);
+    for (int k = 0; k < v.Nz; ++k) {
+        const long c = i * v.Nzp + k;
+        sat_top = v.sat[c];
+        liq_top = v.liq[c];
+        const NF w = veg_plant_available_water(vp, (sat_top * p.por) * liq_top);
+        vv.paw[c] = w;
+        smlf = smlf + (w * vv.root_fraction[c] / v.dzc[k]) * v.dzc[k];
+    }
+    const long top = i * v.Nzp + (v.Nz - 1);
+    const NF T_ground = v.T[top];       // ground_temperature = the top soil cell (soil_energy.jl:48-57)
+    // vegetation processes (vegetation_carbon.jl:66-104)
+    VegInputs<NF> vin = {v.Tair[i], v.pres[i], v.qair[i], v.swd[i], vv.CO2[i], smlf, vv.daily_Rd[i], T_ground};
+    VegColumn<NF> vc;
+    vc.C_veg = vv.C_veg[i];
+    vc.nu = vv.nu[i];
+    vc.An = vv.An[i];
+    vc.G_C_veg = vc.G_nu = NF(0);
+    veg_auxiliary(vp, vin, vc);
+    // canopy interception, then canopy evapotranspiration (surface_hydrology.jl:36-49)
+    SebIn<NF> in = {vin.Tair, vin.pres, v.wind[i], vin.qair, v.rain[i], vin.swd, v.lwd[i], NF(0), NF(0), NF(0)};
+    seb_radiation_inputs(p, v.albedo, v.emissivity, (unsigned)i * (unsigned)sizeof(NF), in);
+    const NF SAI = vv.SAI[i];
+    NF w_can = vv.w_can[i];
+    CanopyOut<NF> co;
+    canopy_interception(vp, in.rain, vc.LAI, SAI, w_can, co);
+    SebOut<NF> o;
+    o.Ts = v.Ts[i];
+    const NF ra = aerodynamic_resistance(p, in.wind);
+    {
+        const NF dqs = humidity_vpd(p, in.pres, in.qair, o.Ts);       // canopy -> atmosphere
+        const NF dqg = humidity_vpd(p, in.pres, in.qair, T_ground);   // ground -> canopy
+        const NF re = (NF(1) - exp_(-vc.LAI - SAI)) / (vp.C_can * jl_max(in.wind, p.min_windspeed));
+        const NF beta = evaporation_resistance_factor(p, sat_top, liq_top);
+        const NF rs = NF(1) / jl_max(vc.gw_can, vp.sqrt_eps);
+        co.transp = dqs / (ra + rs);
+        o.evap = beta * dqg / (ra + re);
+        co.E_can = co.f_can * dqs / ra;
+    }
+    // runoff of the rain that reaches the ground (direct_surface_runoff.jl:87-117)
+    NF Kf_top;
+    if (FROM_STATE) Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));
+    else Kf_top = v.Kf[top];
+    surface_runoff(p, co.rain_ground, sat_top, Kf_top, v.S[i], RICHARDS, o);
+    // surface energy balance x2 with the humidity flux of all three pathways (canopy_evapotranspiration.jl:97-102)
+    const NF Q_h = o.evap + co.E_can + co.transp;
+    const NF dz_top = v.dzc[v.Nz - 1];
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        seb_fluxes_humidity(p, in, ra, Q_h, o);
+        o.Ts = T_ground - div_const(o.ghf * dz_top, p.kappa_s2, p.rkappa_s2);
+        seb_fluxes_humidity(p, in, ra, Q_h, o);
+    }
+    v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
+    v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
+    vv.smlf_out()[i] = smlf;
+    vv.LAI_b[i] = vc.LAI_b; vv.phen[i] = vc.phen; vv.LAI[i] = vc.LAI; vv.gw_can[i] = vc.gw_can; vv.lambda_c[i] = vc.lambda_c;
+    vv.An[i] = vc.An; vv.Rd[i] = vc.Rd; vv.GPP[i] = vc.GPP; vv.Ra[i] = vc.Ra; vv.NPP[i] = vc.NPP;
+    vv.f_can[i] = co.f_can; vv.I_can[i] = co.I_can; vv.R_can[i] = co.R_can; vv.rain_ground[i] = co.rain_ground;
+    vv.E_can[i] = co.E_can; vv.transp[i] = co.transp;
+    if (ADVANCE) {   // compute_tendencies! + explicit_step! of the 0-D prognostics (land_model.jl:90-97)
+        const NF G_w = co.I_can - co.E_can - co.R_can;
+        veg_tendencies(vp, vc);
+        vv.G_w_can[i] = G_w; vv.G_C_veg[i] = vc.G_C_veg; vv.G_nu[i] = vc.G_nu;
+        vv.w_can[i] = w_can + G_w * dt;
+        vv.C_veg[i] = vc.C_veg + vc.G_C_veg * dt;
+        vv.nu[i] = vc.nu + vc.G_nu * dt;
+    }
+    if (viol) atomicOr(v.status, viol);
 }
 
 }  // namespace trm

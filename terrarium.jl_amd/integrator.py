@@ -157,8 +157,8 @@ class DeviceState:
                 name = "vegetation_ground_temperature"
             else:                                                          # view of the top soil layer (soil_energy.jl:52-57)
                 return self.get("temperature")[-1]
-        if name == "rainfall_ground":  # alias of rainfall (canopy_interception.jl:11-15)
-            name = "rainfall"
+        if name == "rainfall_ground" and getattr(self, "vegetation_mode", "off") != "coupled":
+            name = "rainfall"          # NoCanopyInterception: alias of rainfall (canopy_interception.jl:11-15)
         rows = self.rows(name)
         a = np.empty((rows, self.grid.Nh), dtype=self.dtype)
         self._check(self._lib.trm_download(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_download")
@@ -420,6 +420,9 @@ def initialize(model, timestepper=None, boundary_conditions=None, initializers=N
     state = DeviceState(model.grid, M.flatten(model))
     if isinstance(model, M.VegetationModel):
         state.set_vegetation(M.flatten_vegetation(model.vegetation, model.constants), "standalone")
+    elif getattr(model, "vegetation", None) is not None:    # LandModel(grid; soil, vegetation) (land_model.jl:24-34)
+        state.set_vegetation(M.flatten_vegetation(model.vegetation, model.constants, model.soil.hydrology.hydraulic_properties,
+                                                  model.soil.strat.texture, model.surface_hydrology), "coupled")
     integ = ModelIntegrator(model, timestepper, state, bcs, inits, inputs)
     initialize_integrator(integ)
     return integ

@@ -269,11 +269,45 @@ class BareGroundEvaporation:
 
 
 @dataclass
+class NoCanopyInterception:
+    """canopy_interception.jl:1-23: all the rain reaches the ground."""
+
+
+@dataclass
+class PALADYNCanopyInterception:
+    """canopy_interception.jl:37-49: interception I = alpha_int P (1 - exp(-k_ext (LAI + SAI))), a canopy water store of
+    capacity w_can_max (LAI + SAI) emptied over tau_w."""
+    alpha_int: float = 0.2
+    k_ext: float = 0.5
+    w_can_max: float = 2.0e-4
+    tau_w: float = 86400.0
+
+
+@dataclass
+class PALADYNCanopyEvapotranspiration:
+    """canopy_evapotranspiration.jl:25-40: transpiration, ground evaporation below the canopy, evaporation of intercepted water."""
+    C_can: float = 0.006
+    ground_resistance: Union[ConstantEvaporationResistanceFactor, SoilMoistureResistanceFactor] = field(default_factory=ConstantEvaporationResistanceFactor)
+
+    @property
+    def factor(self):
+        return getattr(self.ground_resistance, "factor", 1.0)
+
+
+@dataclass
 class SurfaceHydrology:
-    """surface_hydrology.jl:10-34 in the `vegetation = nothing` configuration
-    (land_model.jl:119-125): BareGroundEvaporation + NoCanopyInterception."""
-    evapotranspiration: BareGroundEvaporation = field(default_factory=BareGroundEvaporation)
+    """surface_hydrology.jl:10-34.  Defaults: the `vegetation = nothing` configuration (land_model.jl:119-125),
+    BareGroundEvaporation + NoCanopyInterception; `SurfaceHydrology.canopy()` gives the reference's own default
+    (PALADYNCanopyInterception + PALADYNCanopyEvapotranspiration, surface_hydrology.jl:26-33) that a LandModel with
+    vegetation takes."""
+    evapotranspiration: Union[BareGroundEvaporation, PALADYNCanopyEvapotranspiration] = field(default_factory=BareGroundEvaporation)
     surface_runoff: DirectSurfaceRunoff = field(default_factory=DirectSurfaceRunoff)
+    canopy_interception: Union[NoCanopyInterception, PALADYNCanopyInterception] = field(default_factory=NoCanopyInterception)
+
+    @classmethod
+    def canopy(cls, **kw):
+        return cls(evapotranspiration=kw.pop("evapotranspiration", PALADYNCanopyEvapotranspiration()),
+                   canopy_interception=kw.pop("canopy_interception", PALADYNCanopyInterception()), **kw)
 
 
 # ---- initialisers (src/models/soil/soil_model_init.jl) ------------------------
@@ -326,20 +360,31 @@ class SoilModel:
 
 @dataclass
 class LandModel:
-    """src/models/coupled/land_model.jl:10-44 with `vegetation = nothing`: soil +
-    surface energy balance + bare-ground surface hydrology + PrescribedAtmosphere,
-    ground_heat_flux / -infiltration wired as the soil's top flux BCs (:46-66)."""
+    """src/models/coupled/land_model.jl:10-44: soil + surface energy balance + surface hydrology + PrescribedAtmosphere,
+    ground_heat_flux / -infiltration wired as the soil's top flux BCs (:46-66).  `vegetation = None` (the default HERE; the
+    reference's is VegetationCarbon) is the bare-ground configuration of the hot path; with `vegetation = VegetationCarbon()`
+    the defaults follow land_model.jl:108-125: Richards soil, canopy interception and canopy evapotranspiration."""
     grid: ColumnGrid
-    soil: SoilEnergyWaterCarbon = field(default_factory=SoilEnergyWaterCarbon)
+    soil: SoilEnergyWaterCarbon = None
     surface_energy_balance: SurfaceEnergyBalance = field(default_factory=SurfaceEnergyBalance)
-    surface_hydrology: SurfaceHydrology = field(default_factory=SurfaceHydrology)
+    surface_hydrology: SurfaceHydrology = None
     atmosphere: PrescribedAtmosphere = field(default_factory=PrescribedAtmosphere)
     constants: PhysicalConstants = field(default_factory=PhysicalConstants)
     initializer: object = field(default_factory=DefaultInitializer)
     halo_policy: str = "reference_zero"
-    vegetation: None = None
+    vegetation: object = None
 
     coupled_surface = True
+
+    def __post_init__(self):
+        if self.soil is None:      # default_soil (land_model.jl:108-109)
+            self.soil = SoilEnergyWaterCarbon() if self.vegetation is None else SoilEnergyWaterCarbon(hydrology=SoilHydrology(vertical_flow=RichardsEq()))
+        if self.surface_hydrology is None:   # default_surface_hydrology (land_model.jl:115-125)
+            self.surface_hydrology = SurfaceHydrology() if self.vegetation is None else SurfaceHydrology.canopy()
+        canopy = isinstance(self.surface_hydrology.evapotranspiration, PALADYNCanopyEvapotranspiration)
+        if canopy != (self.vegetation is not None) or canopy != isinstance(self.surface_hydrology.canopy_interception, PALADYNCanopyInterception):
+            raise ValueError("LandModel: canopy interception / canopy evapotranspiration go with a vegetation scheme, "
+                             "bare-ground evaporation without one")
 
 
 # ---- vegetation (src/processes/vegetation/, needleleaf-tree PFT defaults) ----------------------------------------------
@@ -441,7 +486,8 @@ class VegetationModel:
     soil: SoilEnergyWaterCarbon = field(default_factory=SoilEnergyWaterCarbon)   # (the context's unused soil columns)
 
 
-def flatten_vegetation(veg: VegetationCarbon, constants: PhysicalConstants = None, hydraulics=None, texture=None) -> "_capi.TrmVegetationParams":
+def flatten_vegetation(veg: VegetationCarbon, constants: PhysicalConstants = None, hydraulics=None, texture=None,
+                       surface_hydrology=None) -> "_capi.TrmVegetationParams":
     """VegetationCarbon -> trm_vegetation_params (include/terrarium_hip.h)."""
     p = _capi.default_vegetation_params()
     for part in (veg.photosynthesis, veg.stomatal_conductance, veg.autotrophic_respiration, veg.carbon_dynamics, veg.vegetation_dynamics):
@@ -453,6 +499,10 @@ def flatten_vegetation(veg: VegetationCarbon, constants: PhysicalConstants = Non
         p.wilting_point, p.field_capacity = hydraulics.wilting_point(tex), hydraulics.field_capacity(tex)
     if constants is not None:
         p.C_mass = getattr(constants, "C_mass", 12.0)
+    if surface_hydrology is not None:
+        ci, et = surface_hydrology.canopy_interception, surface_hydrology.evapotranspiration
+        p.alpha_int, p.canopy_k_ext, p.w_can_max, p.tau_w = ci.alpha_int, ci.k_ext, ci.w_can_max, ci.tau_w
+        p.C_can = et.C_can
     return p
 
 

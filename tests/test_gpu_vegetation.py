@@ -80,11 +80,13 @@ def test_vegetation_process_interface():
     b.state.step(1800.0, 1, finalize=False)
     for n in PROG + AUX:
         assert np.array_equal(st.get(n), b.state.get(n)), n
-    # compute_tendencies! accumulates into the tendency fields, reset_tendencies! clears them
+    # compute_tendencies! ASSIGNS the vegetation tendencies (carbon_dynamics.jl:184, vegetation_dynamics.jl:150), reset_tendencies! clears them
     st.reset_tendencies(); st.compute_auxiliary(); st.compute_tendencies()
     g1 = st.get("tend_carbon_vegetation")
     st.compute_tendencies()
-    assert np.allclose(st.get("tend_carbon_vegetation"), 2 * g1, rtol=1e-15)
+    assert np.array_equal(st.get("tend_carbon_vegetation"), g1) and np.any(g1 != 0)
+    st.reset_tendencies()
+    assert np.all(st.get("tend_carbon_vegetation") == 0)
 
 
 def test_vegetation_switches_and_defaults():
