@@ -47,6 +47,7 @@ struct trm_ctx {
     void* bc_value[TRM_BCV_COUNT][2] = {};
     int bc_kind[TRM_BCV_COUNT][2] = {};
     void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr, *d_lvl = nullptr;
+    void* d_rootf = nullptr;   // static root fraction per level [Nz] (root_distribution.jl:45-63)
     std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
     double dzf_bot = 0, dzf_top = 0, dzc_bot = 0, dzc_top = 0, Az = 1;
     uint32_t* d_status = nullptr;
@@ -632,6 +633,12 @@ template <class NF> struct Ops {
         p.eps_mw = (NF)c->params.eps_mw;
         p.one_minus_eps_mw = NF(1) - p.eps_mw;
         p.sqrt_eps = std::sqrt(std::numeric_limits<NF>::epsilon());
+        p.paw_span = p.field_capacity - p.wilting_point;
+        p.rpaw_span = NF(1) / p.paw_span;
+        p.ln_q10_tau = std::log(p.q10_tau); p.ln_q10_Kc = std::log(p.q10_Kc); p.ln_q10_Ko = std::log(p.q10_Ko);
+        p.ts_k1 = NF(2) * std::log(NF(1) / NF(0.99) - NF(1)) / (p.T_CO2_low - p.T_photos_low);     // photosynthesis.jl:165-188
+        p.ts_k2 = NF(0.5) * (p.T_CO2_low + p.T_photos_low);
+        p.ts_k3 = std::log(NF(0.99) / NF(0.01)) / (p.T_CO2_high - p.T_photos_high);
         return p;
     }
     static VegView<NF> veg_view(const trm_ctx* c) { return veg_view(c, c->state); }
@@ -656,22 +663,26 @@ template <class NF> struct Ops {
         v.R_can = G(TRM_FIELD_CANOPY_WATER_REMOVAL); v.f_can = G(TRM_FIELD_SATURATION_CANOPY_WATER); v.rain_ground = G(TRM_FIELD_RAINFALL_GROUND);
         v.E_can = G(TRM_FIELD_EVAPORATION_CANOPY); v.transp = G(TRM_FIELD_TRANSPIRATION); v.SAI = G(TRM_FIELD_STEM_AREA_INDEX);
         v.paw = F(TRM_FIELD_PLANT_AVAILABLE_WATER);
-        v.root_fraction = (const NF*)c->state.f[TRM_FIELD_ROOT_FRACTION];   // static: one copy serves the stage as well
+        v.rootf = (const NF*)c->d_rootf;   // static: one copy serves the stage as well
         return v;
     }
     // the 0-D part of the coupled LandModel's compute_auxiliary! (+ tendencies and explicit step of the 0-D prognostics)
-    template <bool FROM_STATE, bool ADVANCE> static int surface_veg(trm_ctx* c, const FieldSet& s, double dt) {
+    template <bool FROM_STATE, bool ADVANCE> static int surface_veg(trm_ctx* c, const FieldSet& s, double dt, bool store_paw = true) {
         const View<NF>& v = cached_view<NF>(c, s);
         const DevParams<NF>& p = launch_args<NF>(c).p;
         const VegView<NF> vv = veg_view(c, s);
         const VegDev<NF> vp = veg_dev(c);
-        if constexpr (FROM_STATE) {
-            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, true, H, true, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt)); }
-            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, false, H, true, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt)); }
-        } else {   // (the conductivity of the top face comes from the field: the hydraulics variant is not needed)
-            if (richards(c)) hipLaunchKernelGGL((k_surface_veg<NF, true, HYD_GENERIC, false, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt);
-            else hipLaunchKernelGGL((k_surface_veg<NF, false, HYD_GENERIC, false, ADVANCE>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, (NF)dt);
-        }
+        SurfaceVegArgs<NF> a;
+        a.dt = (NF)dt;
+        a.richards = richards(c) ? 1 : 0;
+        a.from_state = FROM_STATE ? 1 : 0;
+        a.top_arrays = (FROM_STATE && c->top_valid && &s == &c->state) ? 1 : 0;
+        a.advance = ADVANCE ? 1 : 0;
+        a.store_paw = store_paw ? 1 : 0;
+        const dim3 blocks((unsigned)((c->Nh + 63) / 64));   // 64 columns per 256-thread workgroup
+        if (c->Nzp == 32) hipLaunchKernelGGL((k_surface_veg<NF, 32>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a);
+        else if (c->Nzp == 64) hipLaunchKernelGGL((k_surface_veg<NF, 64>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a);
+        else hipLaunchKernelGGL((k_surface_veg<NF, 0>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, a);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
@@ -695,12 +706,22 @@ template <class NF> struct Ops {
         }
         return TRM_OK;
     }
-    static int plant_available_water(trm_ctx* c) {
+    static int plant_available_water(trm_ctx* c) { return plant_available_water(c, c->state, true); }
+    static int plant_available_water(trm_ctx* c, const FieldSet& s, bool store_paw) {
         const DevParams<NF>& p = launch_args<NF>(c).p;
-        hipLaunchKernelGGL((k_plant_available_water<NF>), col_grid(c), dim3(256), 0, c->stream,
-                           (const NF*)c->state.f[TRM_FIELD_SATURATION_WATER_ICE], (const NF*)c->state.f[TRM_FIELD_LIQUID_WATER_FRACTION],
-                           (const NF*)c->state.f[TRM_FIELD_ROOT_FRACTION], (NF*)c->state.f[TRM_FIELD_PLANT_AVAILABLE_WATER],
-                           (NF*)c->state.f[TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR], c->Nh, c->Nz, c->Nzp, p.por, veg_dev(c), (const NF*)c->d_dzc);
+        const NF *sat = (const NF*)s.f[TRM_FIELD_SATURATION_WATER_ICE], *liq = (const NF*)s.f[TRM_FIELD_LIQUID_WATER_FRACTION];
+        NF *paw = (NF*)s.f[TRM_FIELD_PLANT_AVAILABLE_WATER], *smlf = (NF*)s.f[TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR];
+        const NF *rootf = (const NF*)c->d_rootf, *dzc = (const NF*)c->d_dzc, *rdzc = (const NF*)c->d_rdzc;
+        const dim3 blocks((unsigned)((c->Nh + 63) / 64));
+        if (c->Nzp == 32)
+            hipLaunchKernelGGL((k_plant_available_water_block<NF, 32>), blocks, dim3(256), 0, c->stream, sat, liq, rootf, dzc, rdzc, store_paw ? paw : nullptr, smlf,
+                               c->Nh, c->Nz, p.por, veg_dev(c));
+        else if (c->Nzp == 64)
+            hipLaunchKernelGGL((k_plant_available_water_block<NF, 64>), blocks, dim3(256), 0, c->stream, sat, liq, rootf, dzc, rdzc, store_paw ? paw : nullptr, smlf,
+                               c->Nh, c->Nz, p.por, veg_dev(c));
+        else
+            hipLaunchKernelGGL((k_plant_available_water<NF>), col_grid(c), dim3(256), 0, c->stream, sat, liq, (const NF*)c->state.f[TRM_FIELD_ROOT_FRACTION], paw, smlf,
+                               c->Nh, c->Nz, c->Nzp, p.por, veg_dev(c), dzc);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
@@ -714,6 +735,10 @@ template <class NF> struct Ops {
             R[k] = (NF(0.5) * (p.root_a * std::exp(p.root_a * z) + p.root_b * std::exp(p.root_b * z))) * dz;
         }
         for (int k = 0; k < c->Nz; ++k) total = total + R[k];
+        std::vector<NF> per_level((size_t)c->Nz);
+        for (int k = 0; k < c->Nz; ++k) per_level[k] = R[k] / total;
+        if (!c->d_rootf) TRM_HIP(c, hipMalloc(&c->d_rootf, (size_t)c->Nz * sizeof(NF)));
+        TRM_HIP(c, hipMemcpy(c->d_rootf, per_level.data(), (size_t)c->Nz * sizeof(NF), hipMemcpyHostToDevice));
         std::vector<NF> host((size_t)c->Nz * c->Nh);
         for (int k = 0; k < c->Nz; ++k)
             for (long i = 0; i < c->Nh; ++i) host[(size_t)k * c->Nh + i] = R[k] / total;
@@ -930,7 +955,9 @@ template <class NF> struct Ops {
             } else {
                 // LandModel: the 0-D surface processes run as their own small launch in front of the fused
                 // column kernel (and once more after it when finalizing)
-                if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt);   // + the 0-D prognostics' step
+                // (+ the 0-D prognostics' step; the per-cell plant_available_water field is materialised with the other
+                // per-cell auxiliaries: by the finalizing launch, or every step under TRM_OPT_WRITE_KF_EVERY_STEP)
+                if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt, c->opt_write_kf != 0);
                 else if (c->params.seb) rc = surface(c, c->state, true);
                 if (!rc) rc = wave_step(c, dt, fin);
                 c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
@@ -1393,7 +1420,7 @@ int trm_destroy(trm_ctx* c) {
         }
     for (auto& sr : c->series)
         if (sr.d_values) (void)hipFree(sr.d_values);
-    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_zero, c->d_top3, (void*)c->d_status, (void*)c->d_reduce, c->d_io, c->d_series_table, c->d_series_rows})
+    for (void* q : {c->d_zC, c->d_zF, c->d_dzc, c->d_rdzc, c->d_rdzf, c->d_psiz, c->d_lvl, c->d_rootf, c->d_zero, c->d_top3, (void*)c->d_status, (void*)c->d_reduce, c->d_io, c->d_series_table, c->d_series_rows})
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1421,6 +1448,9 @@ int trm_get_grid(const trm_ctx* c, double* z_faces, double* z_centers, double* d
 int trm_upload(trm_ctx* c, int field, const void* host) {
     if (!c || !host || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_upload: bad argument");
     if (!c->state.f[field]) return fail(c, TRM_EINVAL, "trm_upload: the field exists only after trm_set_vegetation");
+    if (field == TRM_FIELD_ROOT_FRACTION)
+        return fail(c, TRM_EINVAL, "trm_upload: root_fraction is a static function of the root distribution parameters "
+                                   "(root_distribution.jl:45-63): set them with trm_set_vegetation");
     TRM_HIP(c, hipSetDevice(c->device));
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
     if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_consistent = false;

@@ -25,18 +25,21 @@ template <class NF> struct VegDev {
     // physical constants / atmosphere parameters the processes read
     NF eps_mw, one_minus_eps_mw;
     NF sqrt_eps;   // sqrt(eps(NF)): floor of the stomatal conductance (canopy_evapotranspiration.jl:53)
+    NF paw_span, rpaw_span;   // field_capacity - wilting_point and its reciprocal, formed on the host in NF
+    // launch constants of the Q10 kinetics and the temperature stress (photosynthesis.jl:93-98, 165-188), formed on the host
+    NF ln_q10_tau, ln_q10_Kc, ln_q10_Ko, ts_k1, ts_k2, ts_k3;
 };
 template <class NF> struct VegView {
     long Nh;
     NF *C_veg, *nu, *G_C_veg, *G_nu, *LAI_b, *phen, *LAI, *gw_can, *lambda_c, *An, *Rd, *GPP, *Ra, *NPP;
     const NF *Tair, *pres, *qair, *swd, *CO2, *smlf, *daily_Rd, *Tground;
-    TRM_DEV NF* smlf_out() const { return const_cast<NF*>(smlf); }   // the coupled model computes the limiting factor itself
     long Tground_stride;   // 1 for the input field; the soil's top temperature is read with the level pitch
     // canopy hydrology of the coupled LandModel (null in the standalone VegetationModel)
     NF *w_can, *G_w_can, *I_can, *R_can, *f_can, *rain_ground, *E_can, *transp;
     const NF* SAI;
     NF* paw;                   // plant_available_water [Nh][Nzp]
-    const NF* root_fraction;   // [Nh][Nzp]
+    const NF* rootf;           // static root fraction per level [Nz] (root_distribution.jl:45-63)
+    TRM_DEV NF* smlf_out() const { return const_cast<NF*>(smlf); }   // the coupled model computes the limiting factor itself
 };
 
 TRM_DEV double log_(double x) { return log(x); }
@@ -77,9 +80,7 @@ template <class NF> TRM_DEV NF veg_lambda_c(const VegDev<NF>& p, NF vpd) {
 }
 // photosynthesis.jl:165-188
 template <class NF> TRM_DEV NF veg_temperature_stress(const VegDev<NF>& p, NF T_air) {
-    const NF k1 = NF(2) * log_(NF(1) / NF(0.99) - NF(1)) / (p.T_CO2_low - p.T_photos_low);
-    const NF k2 = NF(0.5) * (p.T_CO2_low + p.T_photos_low);
-    const NF k3 = log_(NF(0.99) / NF(0.01)) / (p.T_CO2_high - p.T_photos_high);
+    const NF k1 = p.ts_k1, k2 = p.ts_k2, k3 = p.ts_k3;
     if (p.T_CO2_low < T_air && T_air < p.T_CO2_high) {
         const NF low = NF(1) / (NF(1) + exp_(k1 * (k2 - T_air)));
         const NF high = NF(1) - NF(0.01) * exp_(k3 * (T_air - p.T_photos_high));
@@ -87,13 +88,10 @@ template <class NF> TRM_DEV NF veg_temperature_stress(const VegDev<NF>& p, NF T_
     }
     return NF(0);
 }
-// x^y of Base for the Q10 responses (photosynthesis.jl:93-98): integer-valued exponents take the compensated power
-template <class NF> TRM_DEV NF veg_pow(NF x, NF y) {
-    if (x == NF(1)) return NF(1);
-    const NF yt = (NF)(int)y;
-    if (yt == y && y > NF(-4096) && y < NF(4096)) return pow_int(x, (int)y);
-    return pow_generic(x, y);
-}
+// q10^e of the Q10 responses (photosynthesis.jl:93-98) as exp(e ln q10), ln q10 a launch constant: |e ln q10| < 4 over
+// the temperature range of the model, so the product's rounding moves the result by < 1e-15 relative (fp64) -- the
+// generic x^y of Base costs ~4x the instructions on the serial 0-D chain that bounds the kernel.  e = 0 gives exactly 1.
+template <class NF> TRM_DEV NF veg_q10(NF ln_q10, NF e) { return exp_(e * ln_q10); }
 // photosynthesis.jl:290-337 compute_respiration_assimilation -> (Rd, An) [gC/m^2/s]
 template <class NF> TRM_DEV void veg_respiration_assimilation(const VegDev<NF>& p, NF T_air, NF swdown, NF pres, NF co2, NF LAI, NF lambda_c, NF beta, NF& Rd, NF& An) {
     const NF pres_O2 = NF(0.209) * pres;            // physics_utils.jl:16-20
@@ -102,7 +100,7 @@ template <class NF> TRM_DEV void veg_respiration_assimilation(const VegDev<NF>& 
     An = NF(0);
     if (swdown > NF(0) && T_air > NF(-3) && LAI > NF(0)) {
         const NF e = (T_air - NF(25)) * NF(0.1);    // Q10 kinetics, :93-98
-        const NF tau = p.tau25 * veg_pow(p.q10_tau, e), Kc = p.Kc25 * veg_pow(p.q10_Kc, e), Ko = p.Ko25 * veg_pow(p.q10_Ko, e);
+        const NF tau = p.tau25 * veg_q10(p.ln_q10_tau, e), Kc = p.Kc25 * veg_q10(p.ln_q10_Kc, e), Ko = p.Ko25 * veg_q10(p.ln_q10_Ko, e);
         const NF Gamma = pres_O2 / (NF(2) * tau);                                                        // :111-114
         const NF PAR = NF(0.5) * swdown * (NF(1) - p.alpha_leaf) * p.cq;                                 // :122-126
         const NF APAR = p.alpha_a * PAR * (NF(1) - exp_(-p.k_ext * LAI));                                // :138-143
@@ -131,7 +129,7 @@ template <class NF> TRM_DEV NF veg_autotrophic_respiration(const VegDev<NF>& p, 
 }
 // plant_available_water.jl:77-94
 template <class NF> TRM_DEV NF veg_plant_available_water(const VegDev<NF>& p, NF theta_w) {
-    return jl_max(jl_min(NF(1), (theta_w - p.wilting_point) / (p.field_capacity - p.wilting_point)), NF(0));
+    return jl_max(jl_min(NF(1), div_const(theta_w - p.wilting_point, p.paw_span, p.rpaw_span)), NF(0));
 }
 
 // what one vegetation column carries through a step
@@ -142,7 +140,9 @@ template <class NF> struct VegColumn {
 template <class NF> struct VegInputs { NF Tair, pres, qair, swd, CO2, smlf, daily_Rd, Tground; };
 
 // compute_auxiliary!(state, grid, veg, constants, atmos, soil) for one column (vegetation_carbon.jl:66-104)
-template <class NF> TRM_DEV void veg_auxiliary(const VegDev<NF>& p, const VegInputs<NF>& in, VegColumn<NF>& c) {
+// ... in two halves: carbon pools -> leaf area -> stomatal conductance (what the canopy evapotranspiration needs), then
+// photosynthesis -> respiration -> net primary production (what the carbon tendencies need)
+template <class NF> TRM_DEV void veg_auxiliary_conductance(const VegDev<NF>& p, const VegInputs<NF>& in, VegColumn<NF>& c) {
     c.LAI_b = veg_LAI_b(p, c.C_veg);
     c.LAI = veg_LAI(c.LAI_b, c.phen);
     // compute_vpd at the air temperature (prescribed_atmosphere.jl:176-182, physical_constants.jl:83-97)
@@ -151,10 +151,16 @@ template <class NF> TRM_DEV void veg_auxiliary(const VegDev<NF>& p, const VegInp
     const NF vpd = jl_max(e_sat - e_air, NF(0.1));
     c.gw_can = veg_gw_can(p, vpd, c.An, in.CO2, c.LAI, in.smlf);     // An of the previous evaluation
     c.lambda_c = veg_lambda_c(p, vpd);
+}
+template <class NF> TRM_DEV void veg_auxiliary_carbon(const VegDev<NF>& p, const VegInputs<NF>& in, VegColumn<NF>& c) {
     veg_respiration_assimilation(p, in.Tair, in.swd, in.pres, in.CO2, c.LAI, c.lambda_c, in.smlf, c.Rd, c.An);
     c.GPP = c.An * NF(1.0e-3);
     c.Ra = veg_autotrophic_respiration(p, in.Tair, in.Tground, in.daily_Rd, c.phen, c.C_veg, c.GPP);
     c.NPP = c.GPP - c.Ra;
+}
+template <class NF> TRM_DEV void veg_auxiliary(const VegDev<NF>& p, const VegInputs<NF>& in, VegColumn<NF>& c) {
+    veg_auxiliary_conductance(p, in, c);
+    veg_auxiliary_carbon(p, in, c);
 }
 template <class NF> TRM_DEV void veg_tendencies(const VegDev<NF>& p, VegColumn<NF>& c) {
     c.G_C_veg = veg_C_veg_tendency(p, c.LAI_b, c.NPP);
@@ -246,84 +252,201 @@ template <class NF> TRM_DEV void canopy_interception(const VegDev<NF>& p, NF rai
     o.rain_ground = rain - o.I_can + o.R_can;
 }
 
-// The 0-D part of compute_auxiliary!(state, model::LandModel) with vegetation, one thread per column.
-// FROM_STATE: the top-face hydraulic conductivity is formed from the top cell (in front of the fused column kernel, which
-// does not materialise K); otherwise it is read from the hydraulic_conductivity field compute_hydraulics! filled.
-// ADVANCE: compute_tendencies! + explicit_step! of the 0-D prognostics follow in the same launch.
-template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool ADVANCE>
-__global__ void __launch_bounds__(256) k_surface_veg(View<NF> v, DevParams<NF> p, VegView<NF> vv, VegDev<NF> vp, NF dt) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= v.Nh) return;
+// The 0-D part of compute_auxiliary!(state, model::LandModel) with vegetation.
+//
+// NZP = 32 / 64 (the level pitch, Nz <= 64): a workgroup of 256 threads owns 64 consecutive columns.  Phase 1, all four
+// waves: the columns' cells are one contiguous run of the z-fastest layout, so sat / liq are read (and
+// plant_available_water written) fully coalesced; each cell's W r / dz * dz term goes to LDS (row pitch NZP + 1: the
+// phase-2 reads of 64 different rows then spread over the banks).  Phase 2, the first wave, one column per lane: the
+// bottom-up sum of the column's terms in the sequential order of Oceananigans' Integral (a DPP / tree reduction would
+// change the rounding; a per-level readlane or shuffle loop costs ~15 VALU per level and wave -- measured 23-27 us for
+// the N145 columns against 37 us for the whole soil step), then every 0-D process of the column.
+// NZP = 0 (Nz > 64, reference-order path only): one thread per column walks its cells.
+// Run-time switches (wave-uniform): from_state -- the top-face hydraulic conductivity is formed from the top cell (in
+// front of the fused column kernel, which does not materialise K) instead of read from the hydraulic_conductivity
+// field; top_arrays -- the top cell's (T, sat, liq) come from the compact per-column arrays the fused step wrote;
+// advance -- compute_tendencies! + explicit_step! of the 0-D prognostics follow in the same launch; store_paw -- the
+// per-cell plant_available_water field is materialised.
+template <class NF> struct SurfaceVegArgs { NF dt; int richards, from_state, top_arrays, advance, store_paw; };
+
+template <class NF> TRM_DEV NF paw_term(const VegDev<NF>& vp, NF por, NF sat, NF liq, NF rootf, NF dz, NF rdz, NF& w) {
+    w = jl_max(jl_min(NF(1), div_const((sat * por) * liq - vp.wilting_point, vp.paw_span, vp.rpaw_span)), NF(0));
+    return div_const(w * rootf, dz, rdz) * dz;
+}
+
+// Phases 1 and 2 of the workgroup-cooperative plant available water (see k_surface_veg): returns true in the threads
+// that own a column (waves 0 and 1, lane = column i) with the column's soil moisture limiting factor in `smlf`.
+template <class NF, int NZP>
+TRM_DEV bool block_soil_moisture_limit(const NF* __restrict__ sat, const NF* __restrict__ liq, const NF* __restrict__ rootf, const NF* __restrict__ dzc,
+                                       const NF* __restrict__ rdzc, NF* __restrict__ paw, long Nh, int Nz, NF por, const VegDev<NF>& vp, long& i, NF& smlf) {
+    __shared__ NF terms[64 * (NZP + 1)];
+    const long i0 = (long)blockIdx.x * 64;
+    const int ncol = (int)((Nh - i0) < 64 ? (Nh - i0) : 64);
+    const long base = i0 * NZP;
+    // a thread keeps its level k and walks the columns c0, c0 + 256 / NZP, ...: all of its loads are issued before the
+    // first use (one memory round trip instead of one per cell), the per-level constants are read once
+    constexpr int PASSES = NZP / 4, CPP = 256 / NZP;
+    const int k = threadIdx.x % NZP, c0 = threadIdx.x / NZP;
+    const bool level = k < Nz;
+    const NF rf = level ? rootf[k] : NF(0), dz = level ? dzc[k] : NF(1), rdz = level ? rdzc[k] : NF(1);
+    NF s_[PASSES], l_[PASSES];
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+        const int col = c0 + j * CPP;
+        const bool on = level && col < ncol;
+        s_[j] = on ? sat[base + col * NZP + k] : NF(0);
+        l_[j] = on ? liq[base + col * NZP + k] : NF(0);
+    }
+#pragma unroll
+    for (int j = 0; j < PASSES; ++j) {
+        const int col = c0 + j * CPP;
+        if (level && col < ncol) {
+            NF w;
+            const NF t = paw_term(vp, por, s_[j], l_[j], rf, dz, rdz, w);
+            if (paw) paw[base + col * NZP + k] = w;
+            terms[col * (NZP + 1) + k] = t;
+        }
+    }
+    __syncthreads();
+    // lane = column in the first TWO waves (k_surface_veg runs one half of the 0-D work in each; both need the factor)
+    const int row = threadIdx.x & 63;
+    if (threadIdx.x >= 128 || row >= ncol) return false;
+    i = i0 + row;
+    smlf = NF(0);
+    for (int kk = 0; kk < Nz; ++kk) smlf = smlf + terms[row * (NZP + 1) + kk];
+    return true;
+}
+// trm_compute_plant_available_water for Nz <= 64
+template <class NF, int NZP>
+__global__ void __launch_bounds__(256) k_plant_available_water_block(const NF* sat, const NF* liq, const NF* rootf, const NF* dzc, const NF* rdzc, NF* paw, NF* smlf,
+                                                                     long Nh, int Nz, NF por, VegDev<NF> p) {
+    long i;
+    NF acc;
+    if (block_soil_moisture_limit<NF, NZP>(sat, liq, rootf, dzc, rdzc, paw, Nh, Nz, por, p, i, acc) && threadIdx.x < 64) smlf[i] = acc;
+}
+
+template <class NF, int NZP>
+__global__ void __launch_bounds__(256) k_surface_veg(View<NF> v_arg, DevParams<NF> p_arg, VegView<NF> vv_arg, VegDev<NF> vp_arg, SurfaceVegArgs<NF> a) {
+    // ~330 scalar kernel arguments: every section below reads the ones it needs afresh from the kernarg segment
+    // (kernarg_reload, trm_kernels.hpp), so that their live ranges end with the section instead of spilling to VGPR lanes
+    // (measured: 501 v_readlane + 190 v_writelane in the first version of this kernel)
+    constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+    constexpr unsigned off_vv = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(VegView<NF>));
+    constexpr unsigned off_vp = round_up_to(off_vv + (unsigned)sizeof(VegView<NF>), (unsigned)alignof(VegDev<NF>));
+    constexpr bool BLOCK = NZP > 0;
+    const View<NF>& v = v_arg;
+    const DevParams<NF>& p = p_arg;
+    const VegView<NF>& vv = vv_arg;
+    // role 0 (wave 0): stomatal conductance, canopy hydrology, runoff, surface energy balance;  role 1 (wave 1):
+    // photosynthesis, respiration, carbon and area-fraction tendencies.  The two chains are independent (the conductance
+    // uses the PREVIOUS evaluation's net assimilation) and each is a serial latency chain, so they run side by side.
+    // role 2 (one thread per column, Nz > 64): both.
+    const int role = BLOCK ? (int)(threadIdx.x >> 6) : 2;
+    long i = BLOCK ? (long)blockIdx.x * 64 + (threadIdx.x & 63) : (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool owner = (role < 2 || !BLOCK) && i < v.Nh;
+    if (!BLOCK && !owner) return;
     uint32_t viol = 0;
-    // FieldCapacityLimitedPAW: plant available water per cell and its root-weighted integral (plant_available_water.jl:33-94)
-    NF smlf = NF(0), sat_top = NF(0), liq_top = NF(0);
-    for (int k = 0; k < v.Nz; ++k) {
-        const long c = i * v.Nzp + k;
-        sat_top = v.sat[c];
-        liq_top = v.liq[c];
-        const NF w = veg_plant_available_water(vp, (sat_top * p.por) * liq_top);
-        vv.paw[c] = w;
-        smlf = smlf + (w * vv.root_fraction[c] / v.dzc[k]) * v.dzc[k];
+    // per-column inputs first: their latency overlaps the cell phase, and the previous net assimilation is read before
+    // the barrier, i.e. before the other wave can store the new one
+    VegInputs<NF> vin = {};
+    VegColumn<NF> vc = {};
+    SebIn<NF> in = {};
+    NF SAI = NF(0), w_can = NF(0), Ts = NF(0), S = NF(0), sat_top = NF(0), liq_top = NF(0), T_ground = NF(0), Kf_field = NF(0);
+    if (owner) {
+        const long top = i * v.Nzp + (v.Nz - 1);
+        sat_top = a.top_arrays ? v.top_sat[i] : v.sat[top];
+        liq_top = a.top_arrays ? v.top_liq[i] : v.liq[top];
+        T_ground = a.top_arrays ? v.top_T[i] : v.T[top];       // ground_temperature = the top soil cell (soil_energy.jl:48-57)
+        vin = {v.Tair[i], v.pres[i], v.qair[i], v.swd[i], vv.CO2[i], NF(0), vv.daily_Rd[i], T_ground};
+        vc.C_veg = vv.C_veg[i];
+        vc.nu = vv.nu[i];
+        vc.An = vv.An[i];
+        if (role != 1) {
+            in = {vin.Tair, vin.pres, v.wind[i], vin.qair, v.rain[i], vin.swd, v.lwd[i], NF(0), NF(0), NF(0)};
+            seb_radiation_inputs(p, v.albedo, v.emissivity, (unsigned)i * (unsigned)sizeof(NF), in);
+            SAI = vv.SAI[i];
+            w_can = vv.w_can[i];
+            Ts = v.Ts[i];
+            S = v.S[i];
+            if (!a.from_state) Kf_field = v.Kf[top];
+        }
     }
-    const long top = i * v.Nzp + (v.Nz - 1);
-    const NF T_ground = v.T[top];       // ground_temperature = the top soil cell (soil_energy.jl:48-57)
-    // vegetation processes (vegetation_carbon.jl:66-104)
-    VegInputs<NF> vin = {v.Tair[i], v.pres[i], v.qair[i], v.swd[i], vv.CO2[i], smlf, vv.daily_Rd[i], T_ground};
-    VegColumn<NF> vc;
-    vc.C_veg = vv.C_veg[i];
-    vc.nu = vv.nu[i];
-    vc.An = vv.An[i];
-    vc.G_C_veg = vc.G_nu = NF(0);
-    veg_auxiliary(vp, vin, vc);
-    // canopy interception, then canopy evapotranspiration (surface_hydrology.jl:36-49)
-    SebIn<NF> in = {vin.Tair, vin.pres, v.wind[i], vin.qair, v.rain[i], vin.swd, v.lwd[i], NF(0), NF(0), NF(0)};
-    seb_radiation_inputs(p, v.albedo, v.emissivity, (unsigned)i * (unsigned)sizeof(NF), in);
-    const NF SAI = vv.SAI[i];
-    NF w_can = vv.w_can[i];
-    CanopyOut<NF> co;
-    canopy_interception(vp, in.rain, vc.LAI, SAI, w_can, co);
-    SebOut<NF> o;
-    o.Ts = v.Ts[i];
-    const NF ra = aerodynamic_resistance(p, in.wind);
-    {
-        const NF dqs = humidity_vpd(p, in.pres, in.qair, o.Ts);       // canopy -> atmosphere
-        const NF dqg = humidity_vpd(p, in.pres, in.qair, T_ground);   // ground -> canopy
-        const NF re = (NF(1) - exp_(-vc.LAI - SAI)) / (vp.C_can * jl_max(in.wind, p.min_windspeed));
-        const NF beta = evaporation_resistance_factor(p, sat_top, liq_top);
-        const NF rs = NF(1) / jl_max(vc.gw_can, vp.sqrt_eps);
-        co.transp = dqs / (ra + rs);
-        o.evap = beta * dqg / (ra + re);
-        co.E_can = co.f_can * dqs / ra;
+    NF smlf = NF(0);
+    if constexpr (BLOCK) {
+        long i_;
+        const View<NF>& v = kernarg_reload<View<NF>>(0);
+        const VegView<NF>& vv = kernarg_reload<VegView<NF>>(off_vv);
+        if (!block_soil_moisture_limit<NF, NZP>(v.sat, v.liq, vv.rootf, v.dzc, v.rdzc, a.store_paw ? vv.paw : nullptr, v.Nh, v.Nz,
+                                                kernarg_reload<DevParams<NF>>(off_p).por, kernarg_reload<VegDev<NF>>(off_vp), i_, smlf)) return;
+    } else {
+        const VegDev<NF>& vp = vp_arg;
+        for (int k = 0; k < v.Nz; ++k) {
+            const long c = i * v.Nzp + k;
+            NF w;
+            smlf = smlf + paw_term(vp, p.por, v.sat[c], v.liq[c], vv.rootf[k], v.dzc[k], v.rdzc[k], w);
+            if (a.store_paw) vv.paw[c] = w;
+        }
     }
-    // runoff of the rain that reaches the ground (direct_surface_runoff.jl:87-117)
-    NF Kf_top;
-    if (FROM_STATE) Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));
-    else Kf_top = v.Kf[top];
-    surface_runoff(p, co.rain_ground, sat_top, Kf_top, v.S[i], RICHARDS, o);
-    // surface energy balance x2 with the humidity flux of all three pathways (canopy_evapotranspiration.jl:97-102)
-    const NF Q_h = o.evap + co.E_can + co.transp;
-    const NF dz_top = v.dzc[v.Nz - 1];
-    for (int sweep = 0; sweep < 2; ++sweep) {
-        seb_fluxes_humidity(p, in, ra, Q_h, o);
-        o.Ts = T_ground - div_const(o.ghf * dz_top, p.kappa_s2, p.rkappa_s2);
-        seb_fluxes_humidity(p, in, ra, Q_h, o);
+    vin.smlf = smlf;
+    veg_auxiliary_conductance(kernarg_reload<VegDev<NF>>(off_vp), vin, vc);       // (cheap; both roles need the leaf area and the CO2 ratio)
+    if (role != 1) {
+        const DevParams<NF>& p = kernarg_reload<DevParams<NF>>(off_p);
+        const VegDev<NF>& vp = kernarg_reload<VegDev<NF>>(off_vp);
+        const NF dz_top = kernarg_reload<View<NF>>(0).g.dzc_top;
+        // canopy interception, then canopy evapotranspiration (surface_hydrology.jl:36-49)
+        CanopyOut<NF> co;
+        canopy_interception(vp, in.rain, vc.LAI, SAI, w_can, co);
+        SebOut<NF> o;
+        o.Ts = Ts;
+        const NF ra = aerodynamic_resistance(p, in.wind);
+        {
+            const NF dqs = humidity_vpd(p, in.pres, in.qair, o.Ts);       // canopy -> atmosphere
+            const NF dqg = humidity_vpd(p, in.pres, in.qair, T_ground);   // ground -> canopy
+            const NF re = (NF(1) - exp_(-vc.LAI - SAI)) / (vp.C_can * jl_max(in.wind, p.min_windspeed));
+            const NF beta = evaporation_resistance_factor(p, sat_top, liq_top);
+            const NF rs = NF(1) / jl_max(vc.gw_can, vp.sqrt_eps);
+            co.transp = dqs / (ra + rs);
+            o.evap = beta * dqg / (ra + re);
+            co.E_can = co.f_can * dqs / ra;
+        }
+        // runoff of the rain that reaches the ground (direct_surface_runoff.jl:87-117)
+        const NF Kf_top = a.from_state ? conductivity_hydraulic<NF, HYD_GENERIC, false>(p, liq_top, fractions(p, sat_top, liq_top, viol)) : Kf_field;
+        surface_runoff(p, co.rain_ground, sat_top, Kf_top, S, a.richards != 0, o);
+        // surface energy balance x2 with the humidity flux of all three pathways (canopy_evapotranspiration.jl:97-102)
+        const NF Q_h = o.evap + co.E_can + co.transp;
+        // (one copy of the flux code, executed four times: the kernel is bound by cold instruction fetch, not by issue)
+#pragma clang loop unroll(disable)
+        for (int n = 0; n < 4; ++n) {
+            seb_fluxes_humidity(p, in, ra, Q_h, o);
+            if ((n & 1) == 0) o.Ts = T_ground - div_const(o.ghf * dz_top, p.kappa_s2, p.rkappa_s2);
+        }
+        const View<NF>& v = kernarg_reload<View<NF>>(0);
+        const VegView<NF>& vv = kernarg_reload<VegView<NF>>(off_vv);
+        vv.smlf_out()[i] = smlf;
+        vv.LAI_b[i] = vc.LAI_b; vv.phen[i] = vc.phen; vv.LAI[i] = vc.LAI; vv.gw_can[i] = vc.gw_can; vv.lambda_c[i] = vc.lambda_c;
+        v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
+        v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
+        vv.f_can[i] = co.f_can; vv.I_can[i] = co.I_can; vv.R_can[i] = co.R_can; vv.rain_ground[i] = co.rain_ground;
+        vv.E_can[i] = co.E_can; vv.transp[i] = co.transp;
+        if (a.advance) {   // compute_tendencies! + explicit_step! of the canopy water (land_model.jl:90-97)
+            const NF G_w = co.I_can - co.E_can - co.R_can;
+            vv.G_w_can[i] = G_w;
+            vv.w_can[i] = w_can + G_w * a.dt;
+        }
     }
-    v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
-    v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
-    vv.smlf_out()[i] = smlf;
-    vv.LAI_b[i] = vc.LAI_b; vv.phen[i] = vc.phen; vv.LAI[i] = vc.LAI; vv.gw_can[i] = vc.gw_can; vv.lambda_c[i] = vc.lambda_c;
-    vv.An[i] = vc.An; vv.Rd[i] = vc.Rd; vv.GPP[i] = vc.GPP; vv.Ra[i] = vc.Ra; vv.NPP[i] = vc.NPP;
-    vv.f_can[i] = co.f_can; vv.I_can[i] = co.I_can; vv.R_can[i] = co.R_can; vv.rain_ground[i] = co.rain_ground;
-    vv.E_can[i] = co.E_can; vv.transp[i] = co.transp;
-    if (ADVANCE) {   // compute_tendencies! + explicit_step! of the 0-D prognostics (land_model.jl:90-97)
-        const NF G_w = co.I_can - co.E_can - co.R_can;
-        veg_tendencies(vp, vc);
-        vv.G_w_can[i] = G_w; vv.G_C_veg[i] = vc.G_C_veg; vv.G_nu[i] = vc.G_nu;
-        vv.w_can[i] = w_can + G_w * dt;
-        vv.C_veg[i] = vc.C_veg + vc.G_C_veg * dt;
-        vv.nu[i] = vc.nu + vc.G_nu * dt;
+    if (role != 0) {
+        const VegDev<NF>& vp = kernarg_reload<VegDev<NF>>(off_vp);
+        veg_auxiliary_carbon(vp, vin, vc);
+        const VegView<NF>& vv = kernarg_reload<VegView<NF>>(off_vv);
+        vv.An[i] = vc.An; vv.Rd[i] = vc.Rd; vv.GPP[i] = vc.GPP; vv.Ra[i] = vc.Ra; vv.NPP[i] = vc.NPP;
+        if (a.advance) {   // ... and of the vegetation carbon and area fraction
+            veg_tendencies(vp, vc);
+            vv.G_C_veg[i] = vc.G_C_veg; vv.G_nu[i] = vc.G_nu;
+            vv.C_veg[i] = vc.C_veg + vc.G_C_veg * a.dt;
+            vv.nu[i] = vc.nu + vc.G_nu * a.dt;
+        }
     }
-    if (viol) atomicOr(v.status, viol);
+    if (viol) atomicOr(kernarg_reload<View<NF>>(0).status, viol);
 }
 
 }  // namespace trm
