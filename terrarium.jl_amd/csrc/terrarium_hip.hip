@@ -474,13 +474,17 @@ template <class NF> struct Ops {
     // hydraulics specialisation of this context (trm_device.hpp: HYD_*)
     static int hyd(const trm_ctx* c) {
         if (c->params.swrc == TRM_SWRC_BROOKS_COREY && c->params.unsat_k == TRM_UNSATK_LINEAR) return HYD_BC_LINEAR;
-        if (c->params.swrc == TRM_SWRC_VAN_GENUCHTEN && c->params.unsat_k == TRM_UNSATK_VAN_GENUCHTEN) return HYD_VG_VG;
+        if (c->params.swrc == TRM_SWRC_VAN_GENUCHTEN && c->params.unsat_k == TRM_UNSATK_VAN_GENUCHTEN) {
+            // the compile-time instance is van Genuchten's n = 2 (every reference test and example); other n: generic
+            // (n = 2 exactly: -1/m = -2 {INT}, 1/n = (n-1)/n = 1/2 {HALVES, 1}, n/(n+1) = RN(2/3) {THIRDS, 2} in make_pow_spec)
+            if (c->params.vg_n == 2.0) return HYD_VG_N2;
+        }
         return HYD_GENERIC;
     }
 #define TRM_BY_HYD(c, CALL)                                   \
     switch (hyd(c)) {                                         \
         case HYD_BC_LINEAR: { constexpr int H = HYD_BC_LINEAR; CALL; } break; \
-        case HYD_VG_VG: { constexpr int H = HYD_VG_VG; CALL; } break;         \
+        case HYD_VG_N2: { constexpr int H = HYD_VG_N2; CALL; } break;         \
         default: { constexpr int H = HYD_GENERIC; CALL; } break;             \
     }
 
@@ -771,9 +775,12 @@ template <class NF> struct Ops {
         // (the coupled vegetation reads T and liq of the whole column from memory every step)
         return want && c->closure_consistent && !c->closure_escaped && !coupled(c);
     }
-    // fp32, reference-default hydraulics: two columns per lane with packed math (trm_packed_f32.hpp)
+    // fp32: two columns per lane with packed math (trm_packed_f32.hpp) -- the reference-default hydraulics, and van
+    // Genuchten retention with Mualem conductivity
     static bool packed_path(trm_ctx* c) {
-        if (!std::is_same<NF, float>::value || !c->opt_packed || generic_bcs(c) || hyd(c) != HYD_BC_LINEAR) return false;
+        if (!std::is_same<NF, float>::value || !c->opt_packed || generic_bcs(c)) return false;
+        if (hyd(c) == HYD_VG_N2) return true;
+        if (hyd(c) != HYD_BC_LINEAR) return false;
         const auto& spec = launch_args<NF>(c).p.bc_neg_inv_lambda;
         return spec.kind == POW_INT && spec.n == -5;
     }
@@ -784,7 +791,8 @@ template <class NF> struct Ops {
             const long pairs = (c->Nh + 1) / 2;
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            hipLaunchKernelGGL((k_step_pk<RICH, LPC>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, (float)dt, finalize, wkf);
+            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, (float)dt, finalize, wkf);
+            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, (float)dt, finalize, wkf);
             TRM_HIP(c, hipGetLastError());
         }
         return TRM_OK;

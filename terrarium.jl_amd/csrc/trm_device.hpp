@@ -220,6 +220,22 @@ TRM_DEV float sqrt_(float x) { return sqrtf(x); }
 TRM_DEV double fabs_(double x) { return fabs(x); }
 TRM_DEV float fabs_(float x) { return fabsf(x); }
 
+// 10^y for the ice impedance of partially frozen cells (soil_hydraulic_properties.jl:201-221), y in [-Omega, 0] and not
+// integer-valued: exp(y ln 10) with ln 10 in two pieces and the product's rounding error carried along (fma residual), so
+// the result is the library exp's (< 1 ulp) times (1 + O(eps^2 |y|)) -- within 2 ulp of Base's 10.0^y, against ~230
+// instructions for the generic pow.  A wave pays for this path whenever ANY of its 64 cells sits on a freezing front:
+// about half the waves of the N145 van Genuchten workloads (measured: 608 -> see DESIGN 4.1 VALU per wave).
+TRM_DEV double exp10_frac(double y) {
+    const double hi = 2.302585092994046, lo = -2.1707562233822494e-16;
+    const double p = y * hi, e = fma_(y, hi, -p) + y * lo, r = exp_(p);
+    return fma_(r, e, r);
+}
+TRM_DEV float exp10_frac(float y) {
+    const float hi = 2.3025851f, lo = -3.1975437e-08f;
+    const float p = y * hi, e = fma_(y, hi, -p) + y * lo, r = exp_(p);
+    return fma_(r, e, r);
+}
+
 // pow_body(x, -5) with the loop unrolled: the same operations in the same order as pow_int(x, -5) for
 // finite x (x * 0 and 1 * x folded; they are exact), i.e. bit-identical -- the BrooksCorey default
 // lambda = 0.2 evaluates r^(-1/lambda) = r^(-5.0) for every cell and step.
@@ -264,7 +280,9 @@ template <class NF> TRM_DEV NF jl_pow(NF x, const PowSpec<NF>& s) {
 // ---------------------------------------------------------------------------
 // Hydraulics specialisation of the kernels (dead-code elimination + register pressure):
 enum { HYD_BC_LINEAR = 0,   // BrooksCorey SWRC + UnsatKLinear: the reference default (soil_hydraulic_properties.jl:132-140)
-       HYD_VG_VG = 1,       // VanGenuchten SWRC + UnsatKVanGenuchten: the tested/examples variant
+       HYD_VG_N2 = 1,       // VanGenuchten SWRC + UnsatKVanGenuchten with n = 2: the variant of every reference test and
+                            // example (exponents -1/m = -2, 1/n = (n-1)/n = 1/2, n/(n+1) = 2/3 fixed at compile time: no
+                            // run-time PowSpec dispatch, a straight-line cell); any other n takes HYD_GENERIC
        HYD_GENERIC = 2 };   // any combination, decided at run time
 
 template <class NF> struct DevParams {
@@ -357,7 +375,9 @@ template <class NF> TRM_DEV NF conductivity_linear(const DevParams<NF>& p, const
 // CPU path stops at its SoilVolume @assert (soil_volume.jl:26-28) before K is ever evaluated, here it is reported through
 // TRM_STATUS_COMPOSITION_OUT_OF_RANGE -- and K is NaN instead of the complex magnitude.  Keeping the out-of-line
 // complex path callable from the step kernel costs 29 VGPRs (96 vs 67, 5 vs 7 waves per SIMD) and 8 % of its time.
-template <class NF, bool COMPLEX_FALLBACK = true> TRM_DEV NF conductivity_vg(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
+// N2: the exponents of n = 2 as compile-time forms -- x^(2/3) = cbrt(x)^2 and y^(1/2) = sqrt(y), exactly what jl_pow
+// evaluates for the PowSpecs {THIRDS, 2} and {HALVES, 1} (its x == 1 shortcut returns what the roots return there).
+template <class NF, bool COMPLEX_FALLBACK = true, bool N2 = false> TRM_DEV NF conductivity_vg(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
     NF x = f.water / p.por;
     // I_ice = 10^(-Omega (1 - f)): Base.:^ takes the integer path when the exponent is integer-valued
     NF y = -p.impedance * (NF(1) - liq);
@@ -369,11 +389,18 @@ template <class NF, bool COMPLEX_FALLBACK = true> TRM_DEV NF conductivity_vg(con
     } else {
         NF yt = (NF)(int)y;
         if (yt == y && y > NF(-4096) && y < NF(4096)) I_ice = pow_int(NF(10), (int)y);
-        else I_ice = pow_generic(NF(10), y);
+        else I_ice = exp10_frac(y);
     }
     if (x >= NF(0) && x <= NF(1)) {
-        NF inner = NF(1) - jl_pow(x, p.vgk_e1);
-        NF t = NF(1) - jl_pow(inner, p.vgk_e2);
+        NF inner, t;
+        if (N2) {
+            const NF c = cbrt_(x);
+            inner = NF(1) - c * c;
+            t = NF(1) - sqrt_(inner);
+        } else {
+            inner = NF(1) - jl_pow(x, p.vgk_e1);
+            t = NF(1) - jl_pow(inner, p.vgk_e2);
+        }
         return fabs_(p.K_sat * I_ice * sqrt_(x) * (t * t));
     }
     if (!COMPLEX_FALLBACK) return Limits<NF>::nan();
@@ -381,7 +408,7 @@ template <class NF, bool COMPLEX_FALLBACK = true> TRM_DEV NF conductivity_vg(con
 }
 template <class NF, int HYD, bool COMPLEX_FALLBACK = true> TRM_DEV NF conductivity_hydraulic(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
     if (HYD == HYD_BC_LINEAR) return conductivity_linear(p, f);
-    if (HYD == HYD_VG_VG) return conductivity_vg<NF, COMPLEX_FALLBACK>(p, liq, f);
+    if (HYD == HYD_VG_N2) return conductivity_vg<NF, COMPLEX_FALLBACK, true>(p, liq, f);
     return p.unsat_k == 0 ? conductivity_linear(p, f) : conductivity_vg<NF, COMPLEX_FALLBACK>(p, liq, f);
 }
 
@@ -408,16 +435,20 @@ template <class NF> TRM_DEV NF swrc_psi_bc(const DevParams<NF>& p, NF theta) {
     NF v = -p.bc_psi_s * jl_pow(r, p.bc_neg_inv_lambda);
     return (theta < p.por) ? v : -p.bc_psi_s;
 }
-template <class NF> TRM_DEV NF swrc_psi_vg(const DevParams<NF>& p, NF theta) {
+template <class NF, bool N2 = false> TRM_DEV NF swrc_psi_vg(const DevParams<NF>& p, NF theta) {
     if (theta < p.por) {
         NF r = div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
+        if (N2) {   // r^(-2) = (1 / r)^2 (pow_int, n = -2), then the square root
+            const NF rr = NF(1) / r;
+            return p.neg_inv_alpha * sqrt_(rr * rr - NF(1));
+        }
         return p.neg_inv_alpha * jl_pow(jl_pow(r, p.vg_neg_inv_m) - NF(1), p.vg_inv_n);
     }
     return NF(0);
 }
 template <class NF, int HYD> TRM_DEV NF swrc_psi(const DevParams<NF>& p, NF theta) {
     if (HYD == HYD_BC_LINEAR) return swrc_psi_bc(p, theta);
-    if (HYD == HYD_VG_VG) return swrc_psi_vg(p, theta);
+    if (HYD == HYD_VG_N2) return swrc_psi_vg<NF, true>(p, theta);
     return p.swrc == 1 ? swrc_psi_vg(p, theta) : swrc_psi_bc(p, theta);
 }
 template <class NF> TRM_DEV NF swrc_theta(const DevParams<NF>& p, NF psi, NF theta_sat) {

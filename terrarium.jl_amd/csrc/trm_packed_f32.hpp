@@ -126,6 +126,18 @@ TRM_DEV v2f pressure_head2(const DevParams<float>& p, v2f sat, float z, float ps
     const v2f psih = max2(splat(0.0f), z0 - z);
     return psih + psim + psiz;
 }
+// van Genuchten retention / Mualem conductivity (HYD_VG_N2): the square and cube roots, the reciprocal powers and the ice
+// impedance are per-component instruction sequences whatever the layout, so the scalar functions are called on each
+// component (identical bits by construction); everything around them -- composition, stencil, closures -- stays packed.
+template <int HYD> TRM_DEV v2f conductivity_hydraulic2(const DevParams<float>& p, v2f liq, const Frac2& f) {
+    if (HYD == HYD_BC_LINEAR) return conductivity_linear2(p, f);
+    return v2f{conductivity_vg<float, false>(p, liq.x, Frac<float>{f.water.x, f.ice.x, f.air.x}),
+               conductivity_vg<float, false>(p, liq.y, Frac<float>{f.water.y, f.ice.y, f.air.y})};
+}
+template <int HYD> TRM_DEV v2f pressure_head_hyd2(const DevParams<float>& p, v2f sat, float z, float psiz, v2f z0) {
+    if (HYD == HYD_BC_LINEAR) return pressure_head2(p, sat, z, psiz, z0);
+    return v2f{pressure_head<float, HYD_VG_N2>(p, sat.x, z, psiz, z0.x), pressure_head<float, HYD_VG_N2>(p, sat.y, z, psiz, z0.y)};
+}
 // upwind_conductivity on both components
 TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(lt(g, splat(0.0f)), Kdn, Kup)); }
 
@@ -134,14 +146,13 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // grid: one wave per 2 * (64 / LPC) columns
 // (Deriving T and liq from (U, sat) instead of reading them, as k_column can, was measured here as well: C5 562 vs 533 us
 // per step -- the packed kernel is not short of bytes -- and is not offered.)
-template <bool RICHARDS, int LPC>
+template <bool RICHARDS, int LPC, int HYD>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
     const DevParams<float>& p = p_arg;
     using namespace pk;
     typedef float NF;
-    constexpr int HYD = HYD_BC_LINEAR;
     constexpr int CPW = 64 / LPC;   // column PAIRS per wave
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
@@ -166,7 +177,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, D
     uint32_t viol_old = 0;   // (bounds of the incoming state were flagged by the launch that produced it)
     const Frac2 f = fractions2(p, sat, liq, viol_old);
     const v2f kap = conductivity2(p, f);
-    const v2f Kc = need_kc ? conductivity_linear2(p, f) : splat(0.0f);
+    const v2f Kc = need_kc ? conductivity_hydraulic2<HYD>(p, liq, f) : splat(0.0f);
 
     const v2f T_sh = up2(T), kap_sh = up2(kap);
     v2f flux_U = splat(0.0f), flux_S = splat(0.0f);
@@ -273,10 +284,10 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, D
     v2f ln, Tn;
     const DevParams<float>& p2 = kernarg_reload<DevParams<float>>(off_p);   // (second half of the step: see kernarg_reload)
     energy_closure2(p2, Unew, snew, ln, Tn, viol);
-    const v2f psin = RICHARDS ? pressure_head2(p2, snew, L.zC, L.psiz, z0) : splat(0.0f);
+    const v2f psin = RICHARDS ? pressure_head_hyd2<HYD>(p2, snew, L.zC, L.psiz, z0) : splat(0.0f);
     v2f Kf_out = Kf_lo, Kf_out_top = Kc;
     if (finalize && write_kf) {
-        const v2f Kc_new = conductivity_linear2(p, fractions2(p, snew, ln, viol));
+        const v2f Kc_new = conductivity_hydraulic2<HYD>(p, ln, fractions2(p, snew, ln, viol));
         const v2f Kmin_new = min2(Kc_new, up2(Kc_new));
         Kf_out = sel(is_bot || is_top, Kc_new, Kmin_new);
         Kf_out_top = Kc_new;

@@ -234,6 +234,26 @@ def test_partly_filled_lane_groups(config, dtype, Nz):
     assert_fields_match(dev, orc, W.compared_fields(w), exact, tol, f"Nz={Nz} heun ")
 
 
+@pytest.mark.parametrize("params", [dict(swrc=1, unsat_k=1, vg_alpha=1.3, vg_n=1.7), dict(swrc=1, unsat_k=1, vg_alpha=2.0, vg_n=3.0),
+                                    dict(swrc=1, unsat_k=0, vg_alpha=2.0, vg_n=2.0), dict(swrc=0, unsat_k=1, vg_alpha=2.0, vg_n=2.0)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_generic_hydraulics_parity(params, dtype):
+    """The compile-time van Genuchten instance is n = 2 (every reference test and example); any other exponent and the
+    mixed retention / conductivity combinations take the run-time instance (HYD_GENERIC): generic x^y, device pow vs the
+    oracle's, 1e-10 / 1e-4.  Fused == reference-order kernels bit for bit there too."""
+    lat, lon = small_columns(60)
+    w = W.make_workload("land", lat, lon, 20, dtype=dtype)
+    w["params"].update(params)
+    orc, dev, ref = W.setup_oracle(w), W.setup_device(w), W.setup_device(w)
+    ref.set_option("step_kernel", "unfused")
+    orc.run(w["dt"], 15)
+    dev.step(w["dt"], 15, True)
+    ref.step(w["dt"], 15, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), False, TOL64 if dtype == np.float64 else TOL32, f"{params} ")
+    for n in W.compared_fields(w):
+        assert np.array_equal(dev.get(n), ref.get(n), equal_nan=True), n
+
+
 def test_bc_kinds_parity():
     """Value / Flux / Gradient boundary conditions on every variable that carries them."""
     lat, lon = small_columns(80)
@@ -495,15 +515,18 @@ def test_save_and_restore_state_on_device():
         assert np.array_equal(dev.get(n), v, equal_nan=True), n
 
 
+@pytest.mark.parametrize("hydraulics", ["default", "vg"])
 @pytest.mark.parametrize("config,Nz,Nh", [("heat", 20, 101), ("richards", 32, 130), ("richards", 64, 77), ("land", 64, 64), ("land", 20, 33),
                                           ("richards", 5, 1), ("land", 32, 2)])
-def test_packed_fp32_equals_scalar_bitwise(config, Nz, Nh):
-    """fp32 with the reference-default hydraulics steps two columns per lane with packed instructions
+def test_packed_fp32_equals_scalar_bitwise(config, Nz, Nh, hydraulics):
+    """fp32 (reference-default or van Genuchten hydraulics) steps two columns per lane with packed instructions
     (trm_packed_f32.hpp): every operation is the scalar kernel's, so the results are the scalar kernel's bit for bit --
     odd column counts, partly filled waves, flux boundary conditions, the saturation repair and LandModel included."""
     lat, lon = small_columns(max(Nh, 2))
     lat, lon = lat[:Nh], lon[:Nh]
-    w = W.make_workload(config, lat, lon, Nz, dtype=np.float32)
+    if config == "heat" and hydraulics == "vg":
+        pytest.skip("hydraulics do not enter the heat-only configuration")
+    w = W.make_workload(config, lat, lon, Nz, dtype=np.float32, hydraulics=hydraulics)
     if config == "richards":
         w["bcs"][("saturation_water_ice", "top")] = ("flux", np.where(np.arange(Nh) % 3 == 0, -3.0e-4, 0.0))
         w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(Nh, 0.05))
