@@ -289,7 +289,7 @@ def main():
         nan_flag = status
     kernel_s = ms * 1e-3 / max(args.steps, 1)            # average duration of one step launch on this GPU
     value = total_columns * args.steps / elapsed
-    packed = dt_name == "f32" and WORKLOADS[args.workload][2] == "default" and args.kernel == "fused" and not heun
+    packed = dt_name == "f32" and args.kernel == "fused" and not heun      # (fp32: two columns per lane, default and van Genuchten hydraulics)
     kernel_name = ("k_step_pk" if packed else "k_column") if args.kernel == "fused" else "unfused sequence"
     pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series) else None
 

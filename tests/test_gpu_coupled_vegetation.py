@@ -168,3 +168,20 @@ def test_coupled_needs_land_model_and_dry_canopy_is_inert():
     for n in ("canopy_water", "canopy_water_interception", "canopy_water_removal", "evaporation_canopy", "rainfall_ground", "saturation_canopy_water"):
         assert np.all(st.get(n) == 0.0), n
     assert np.all(st.transpiration > 0) and np.all(np.isfinite(st.latent_heat_flux))
+
+
+@pytest.mark.parametrize("N", [40, 70])
+def test_coupled_deep_and_64_lane_columns(N):
+    """Nz = 40 takes the 64-lane column kernel and the 64-level pitch of the cooperative 0-D kernel; Nz = 70 is deeper than
+    the fused kernels go: reference-order kernels and the one-thread-per-column 0-D kernel."""
+    integ, o = make_pair(130, np.float64, seed=11, N=N)
+    for _ in range(10):
+        trm.timestep(integ)
+        o.timestep(0.5)
+    assert integ.state.status() == 0 and o.status() == 0
+    assert_close(integ.state, o, PROG + SURFACE + VEG_AUX + CANOPY_AUX, np.float64)
+    st = integ.state
+    st.compute_plant_available_water()
+    assert np.allclose(st.soil_moisture_limiting_factor, o.get("soil_moisture_limiting_factor"), rtol=1e-12)
+    with pytest.raises(trm.TerrariumHipError):
+        st.set("root_fraction", 0.0)          # static: derived from the root distribution parameters
