@@ -51,6 +51,8 @@ WORKLOADS = {
     "c3vg": ("C3-VG: N145 mask x 32 levels, heat + Richards (VanGenuchten SWRC + Mualem K with ice impedance), fp64", "richards", "vg", "N145", 32, "f64", 1),
     "c4": ("C4: N145 mask x 32 levels, full bare-ground LandModel (heat + Richards + surface energy balance, PrescribedAtmosphere), default hydraulics (BrooksCorey SWRC, linear K), fp64", "land", "default", "N145", 32, "f64", 1),
     "c4vg": ("C4-VG: as C4 with the land-model test's hydraulics (VanGenuchten(alpha=2, n=2) SWRC + Mualem K with ice impedance), fp64", "land", "vg", "N145", 32, "f64", 1),
+    "c4vgveg": ("C4-VG coupled to vegetation: LandModel(vegetation = VegetationCarbon) -- canopy interception, canopy evapotranspiration, plant available water, "
+                "photosynthesis / respiration / carbon dynamics -- on the N145 columns x 32 levels, van Genuchten hydraulics, fp64, dt = 0.05 s", "landveg", "vg", "N145", 32, "f64", 1),
     "c5": ("C5: synthetic 0.1-degree grid, 812500 columns per GPU x 64 levels, heat + Richards + SEB, default hydraulics, fp32", "land", "default", 812500, 64, "f32", 1),
     "c5vg": ("C5-VG: as C5 with VanGenuchten SWRC + Mualem K, fp32", "land", "vg", 812500, 64, "f32", 1),
 }
@@ -61,8 +63,10 @@ def algorithmic_bytes_per_column_step(config, Nz, wordsize):
     if config == "heat":
         return wordsize * (5 * Nz + 1)          # U,sat read; U,T,liq written; T_ub
     b = wordsize * (8 * Nz + 4)                 # U,sat read; U,sat,T,liq,psi,K written; S r+w, water_table, K top face
-    if config == "land":
+    if config in ("land", "landveg"):
         b += wordsize * 18                      # 7 forcing reads, T_s r+w, 9 flux/diagnostic writes
+    if config == "landveg":
+        b += wordsize * (2 * Nz + 45)           # sat, liq of the column for the plant available water; ~20 per-column reads, ~25 writes
     return b
 
 
@@ -254,7 +258,7 @@ def main():
         DAY = 86400.0
         nodes = np.arange(0.0, (args.steps + args.warmup + 2) * w["dt"] + 600.0, 600.0)
         ph = 2 * np.pi * nodes[:, None] / DAY - w["lon"][None, :]
-        if config == "land":
+        if config in ("land", "landveg"):
             dev.set_forcing_series("air_temperature", nodes, w["T0"][None, :] + 5.0 * np.sin(ph))
             dev.set_forcing_series("surface_shortwave_down", nodes, np.maximum(0.0, 600.0 * np.sin(ph)))
         else:

@@ -7,6 +7,7 @@ import pytest
 
 import oracle
 import terrarium_jl_amd as trm
+import workloads as W
 
 pytestmark = pytest.mark.gpu
 
@@ -185,3 +186,14 @@ def test_coupled_deep_and_64_lane_columns(N):
     assert np.allclose(st.soil_moisture_limiting_factor, o.get("soil_moisture_limiting_factor"), rtol=1e-12)
     with pytest.raises(trm.TerrariumHipError):
         st.set("root_fraction", 0.0)          # static: derived from the root distribution parameters
+
+
+def test_bench_workload_with_vegetation_matches_oracle():
+    """The `c4vgveg` workload of bench.py (tests/workloads.py "landveg") on a sample of the N72 columns, device vs oracle."""
+    lat, lon = W.columns_from_mask("N72")
+    w = W.make_workload("landveg", lat[::40], lon[::40], 32, hydraulics="vg")
+    orc, dev = W.setup_oracle(w), W.setup_device(w)
+    orc.run(w["dt"], 30)
+    dev.step(w["dt"], 30, True)
+    assert dev.status() == 0 and orc.status() == 0
+    assert_close(dev, orc, PROG + SURFACE + VEG_AUX + CANOPY_AUX, np.float64)

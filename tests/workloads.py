@@ -20,7 +20,9 @@ def synthetic_columns(num_columns):
 
 
 def make_workload(config, lat, lon, Nz, dtype=np.float64, hydraulics="default", halo_policy="reference_zero", t=0.0):
-    """config in {"heat", "richards", "land"}; lat/lon in radians, one per column.
+    """config in {"heat", "richards", "land", "landveg"}; lat/lon in radians, one per column.  "landveg" is "land" coupled to
+    VegetationCarbon (canopy interception + canopy evapotranspiration), stepped at 0.05 s: the reference applies its
+    per-year carbon turnover rates per second (carbon_dynamics.jl:98-105), so the vegetation carbon only survives short steps.
     Returns a dict: thickness, params overrides, initial fields, BCs, forcing inputs, dt."""
     Nh = lat.size
     rng = np.random.Generator(np.random.PCG64(SEED))
@@ -30,6 +32,9 @@ def make_workload(config, lat, lon, Nz, dtype=np.float64, hydraulics="default", 
     zc = grid.z_centers().astype(np.float64)
     T0 = 20.0 - np.abs(40.0 * np.sin(lat))                       # soil_heat_global.jl:51
     T_init = T0[None, :] - 0.05 * zc[:, None]                     # soil_heat_global.jl:59-64
+    vegetation = config == "landveg"
+    if vegetation:
+        config = "land"
     w = dict(config=config, Nh=Nh, Nz=Nz, dtype=np.dtype(dtype), thickness=thickness, lat=lat, lon=lon, T0=T0, u=u)
     params = dict(halo_policy={"reference_zero": 0, "mirror": 1}[halo_policy])
     fields = dict(temperature=T_init)
@@ -57,6 +62,11 @@ def make_workload(config, lat, lon, Nz, dtype=np.float64, hydraulics="default", 
                 surface_shortwave_down=np.maximum(0.0, 600.0 * np.sin(phase)),
                 surface_longwave_down=np.full(Nh, 300.0), rainfall=1.0e-8 * (u > 0.5))
             fields["skin_temperature"] = T_init[-1].copy()
+    if vegetation:
+        w["vegetation"] = True
+        fields.update(carbon_vegetation=1.5 + 0.5 * u, vegetation_area_fraction=0.5 + 0.3 * u, canopy_water=2.5e-5 * (1.0 + u))
+        inputs.update(SAI=0.5 + 0.25 * u, CO2=np.full(Nh, 400.0))
+        dt = 0.05
     w.update(params=params, fields=fields, bcs=bcs, inputs=inputs, dt=dt)
     return w
 
@@ -85,6 +95,8 @@ def setup_oracle(w, omp=False):
     import oracle
     p = oracle.default_params(**w["params"])
     o = oracle.Oracle(w["Nh"], w["thickness"], p, dtype=w["dtype"], omp=omp)
+    if w.get("vegetation"):
+        o.enable_vegetation()
     for name, v in w["fields"].items():
         o.set(name, v)
     for (var, side), (kind, value) in w["bcs"].items():
@@ -101,6 +113,8 @@ def setup_device(w, device=0):
         setattr(p, k, v)
     grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(w["thickness"])), w["Nh"], dtype=w["dtype"], device=device)
     d = trm.DeviceState(grid, p)
+    if w.get("vegetation"):     # LandModel(grid; soil, vegetation = VegetationCarbon()) with the default canopy schemes
+        d.set_vegetation(trm.flatten_vegetation(trm.VegetationCarbon(), surface_hydrology=trm.SurfaceHydrology.canopy()), "coupled")
     for name, v in w["fields"].items():
         d.set(name, v)
     for (var, side), (kind, value) in w["bcs"].items():
