@@ -131,8 +131,8 @@ TRM_DEV v2f pressure_head2(const DevParams<float>& p, v2f sat, float z, float ps
 // component (identical bits by construction); everything around them -- composition, stencil, closures -- stays packed.
 template <int HYD> TRM_DEV v2f conductivity_hydraulic2(const DevParams<float>& p, v2f liq, const Frac2& f) {
     if (HYD == HYD_BC_LINEAR) return conductivity_linear2(p, f);
-    return v2f{conductivity_vg<float, false>(p, liq.x, Frac<float>{f.water.x, f.ice.x, f.air.x}),
-               conductivity_vg<float, false>(p, liq.y, Frac<float>{f.water.y, f.ice.y, f.air.y})};
+    return v2f{conductivity_vg<float, false, true>(p, liq.x, Frac<float>{f.water.x, f.ice.x, f.air.x}),
+               conductivity_vg<float, false, true>(p, liq.y, Frac<float>{f.water.y, f.ice.y, f.air.y})};
 }
 template <int HYD> TRM_DEV v2f pressure_head_hyd2(const DevParams<float>& p, v2f sat, float z, float psiz, v2f z0) {
     if (HYD == HYD_BC_LINEAR) return pressure_head2(p, sat, z, psiz, z0);
