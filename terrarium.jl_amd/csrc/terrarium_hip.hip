@@ -684,9 +684,10 @@ template <class NF> struct Ops {
         a.advance = ADVANCE ? 1 : 0;
         a.store_paw = store_paw ? 1 : 0;
         const dim3 blocks((unsigned)((c->Nh + 63) / 64));   // 64 columns per 256-thread workgroup
-        if (c->Nzp == 32) hipLaunchKernelGGL((k_surface_veg<NF, 32>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a);
-        else if (c->Nzp == 64) hipLaunchKernelGGL((k_surface_veg<NF, 64>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a);
-        else hipLaunchKernelGGL((k_surface_veg<NF, 0>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, a);
+        // (the kernel is bound by cold instruction fetch: the hydraulics of the top-face conductivity are compiled in)
+        if (c->Nzp == 32) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, 32, H>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a)); }
+        else if (c->Nzp == 64) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, 64, H>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a)); }
+        else hipLaunchKernelGGL((k_surface_veg<NF, 0, HYD_GENERIC>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, a);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }

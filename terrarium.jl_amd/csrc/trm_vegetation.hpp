@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256) k_plant_available_water_block(const NF* s
     if (block_soil_moisture_limit<NF, NZP>(sat, liq, rootf, dzc, rdzc, paw, Nh, Nz, por, p, i, acc) && threadIdx.x < 64) smlf[i] = acc;
 }
 
-template <class NF, int NZP>
+template <class NF, int NZP, int HYD>
 __global__ void __launch_bounds__(256) k_surface_veg(View<NF> v_arg, DevParams<NF> p_arg, VegView<NF> vv_arg, VegDev<NF> vp_arg, SurfaceVegArgs<NF> a) {
     // ~330 scalar kernel arguments: every section below reads the ones it needs afresh from the kernarg segment
     // (kernarg_reload, trm_kernels.hpp), so that their live ranges end with the section instead of spilling to VGPR lanes
@@ -410,7 +410,7 @@ __global__ void __launch_bounds__(256) k_surface_veg(View<NF> v_arg, DevParams<N
             co.E_can = co.f_can * dqs / ra;
         }
         // runoff of the rain that reaches the ground (direct_surface_runoff.jl:87-117)
-        const NF Kf_top = a.from_state ? conductivity_hydraulic<NF, HYD_GENERIC, false>(p, liq_top, fractions(p, sat_top, liq_top, viol)) : Kf_field;
+        const NF Kf_top = a.from_state ? conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol)) : Kf_field;
         surface_runoff(p, co.rain_ground, sat_top, Kf_top, S, a.richards != 0, o);
         // surface energy balance x2 with the humidity flux of all three pathways (canopy_evapotranspiration.jl:97-102)
         const NF Q_h = o.evap + co.E_can + co.transp;
