@@ -12,7 +12,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 python bench.py --steps 100 --warmup 10 > $OUT/bench_c3.json 2> $OUT/bench_c3.err
-for wl in c2 c3vg c4 c4vg c5vg; do python bench.py --workload $wl --no-cpu-baseline --no-hbm-resident --multistep 0 --steps 50 --warmup 5 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; done
+for wl in c2 c3vg c4 c4vg c5vg c4vgveg; do python bench.py --workload $wl --no-cpu-baseline --no-hbm-resident --multistep 0 --steps 50 --warmup 5 > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; done
 python bench.py --integrator heun --no-cpu-baseline --no-hbm-resident --multistep 0 > $OUT/bench_c3_heun.json 2>/dev/null
 python bench.py --kernel unfused --no-cpu-baseline --no-hbm-resident --multistep 0 > $OUT/bench_c3_unfused.json 2>/dev/null
 echo benches done
@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python ben
 find $OUT/trace -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_default_bench.csv \;
 echo trace done
 # counters: one workload per command so that dispatch counts stay small; FETCH and WRITE in separate passes
-for wl in c3 c3x8 c5; do
+for wl in c3 c3x8 c5 c4vg c5vg; do
   B="python bench.py --workload $wl --no-cpu-baseline --no-hbm-resident --multistep 0 --steps 20 --warmup 2 --spinup-ms 0"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_${wl}/fetch -- $B > /dev/null 2> $OUT/pmc_${wl}_fetch.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_${wl}/write -- $B > /dev/null 2> $OUT/pmc_${wl}_write.err

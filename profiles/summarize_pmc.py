@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (workload table and the algorithmic-bytes formula)
 
-SIZES = {"c3": 56951, "c3x8": 455608, "c5": 812500, "c4": 56951, "c2": 14017}
+SIZES = {"c3": 56951, "c3x8": 455608, "c5": 812500, "c5vg": 812500, "c4": 56951, "c4vg": 56951, "c3vg": 56951, "c4vgveg": 56951, "c2": 14017}
 
 
 def collect(directory, kernel):
@@ -38,7 +38,7 @@ def collect(directory, kernel):
 
 def main(out, wl, commit):
     desc, config, hydraulics, columns, Nz, dt_name, replicas = bench.WORKLOADS[wl]
-    kernel = "k_step_pk" if (dt_name == "f32" and hydraulics == "default") else "k_column"
+    kernel = "k_step_pk" if dt_name == "f32" else "k_column"
     Nh = SIZES[wl]
     word = 8 if dt_name == "f64" else 4
     counters, ndisp, names = {}, {}, []
