@@ -26,6 +26,7 @@ CASES = {
     "c3_n145_richards_vg": ("richards", "vg", 32, 12, 50, np.float64),
     "c4_n145_land": ("land", "vg", 32, 12, 30, np.float64),
     "c5_f32_land": ("land", "vg", 64, 12, 20, np.float32),
+    "c4_n145_land_vegetation": ("landveg", "vg", 32, 12, 30, np.float64),
 }
 
 

@@ -79,6 +79,11 @@ FIELDS_SEB = ("skin_temperature", "ground_heat_flux", "surface_shortwave_up", "s
               "surface_runoff")
 
 
+FIELDS_VEGETATION = ("carbon_vegetation", "vegetation_area_fraction", "canopy_water", "leaf_area_index", "canopy_water_conductance",
+                     "net_assimilation", "net_primary_production", "soil_moisture_limiting_factor", "plant_available_water",
+                     "canopy_water_interception", "rainfall_ground", "evaporation_canopy", "transpiration")
+
+
 def compared_fields(w):
     names = list(FIELDS_3D)
     if w["config"] != "heat":
@@ -87,6 +92,8 @@ def compared_fields(w):
         names += ["hydraulic_conductivity"]
     if w["config"] == "land":
         names += list(FIELDS_SEB)
+    if w.get("vegetation"):
+        names += list(FIELDS_VEGETATION)
     return names
 
 
