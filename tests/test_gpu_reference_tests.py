@@ -422,3 +422,60 @@ def test_soil_moisture_evaporation_resistance():
         a, b = st.get(name), o.get(name)
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-10, name
     assert np.allclose(st.evaporation_ground, o.get("evaporation_ground"), rtol=1e-9, atol=0)
+
+
+def _load_example(name):
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", name + ".py")
+    spec = importlib.util.spec_from_file_location(name, path)
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    return ex
+
+
+def test_example_soil_heat_column_matches_oracle():
+    """examples/soil_heat_column.py (mirror of examples/simulations/soil_heat_column.jl): Float32 column, quasi-steady initial
+    temperature, saturated, surface held at 1 degC, one step + three days -- against the oracle."""
+    import oracle
+    ex = _load_example("soil_heat_column")
+    integ = ex.build()
+    trm.timestep(integ)
+    trm.run(integ, period=3 * 86400.0)
+    grid = integ.state.grid
+    o = oracle.Oracle(1, grid.thickness, oracle.default_params(), dtype=np.float32)
+    zc = grid.z_centers()
+    o.set("temperature", (-1.0 - 0.02 / 1.0 * zc).astype(np.float32))      # QuasiThermalSteadyState(T0 = -1): T0 - Qgeo / k_eff z
+    o.set("saturation_water_ice", 1.0)
+    o.set_bc("temperature", "top", "value", 1.0)
+    o.initialize()
+    o.timestep(300.0)
+    o.run(300.0, int(3 * 86400.0 // 300.0))
+    assert trm.current_time(integ) == o.clock()[0] == 300.0 * (1 + 864)
+    for name in ("temperature", "liquid_water_fraction", "internal_energy"):       # fp32: 1e-4 (the last bit moves after 865 steps)
+        a, b = integ.state.get(name).astype(np.float64), o.get(name).astype(np.float64)
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= 1e-4, name
+    T = integ.state.temperature[:, 0]
+    assert T[-1] > 0.0 and T.min() < 0.0 and integ.state.liquid_water_fraction[-1, 0] == 1.0      # the thaw front has entered the column
+
+
+def test_example_land_column_matches_oracle():
+    """examples/land_column.py (mirror of examples/simulations/land_column.jl): the vegetation-coupled LandModel, one 60 s step."""
+    import oracle
+    ex = _load_example("land_column")
+    integ = ex.build()
+    trm.timestep(integ, 60.0)
+    st = integ.state
+    grid = st.grid
+    o = oracle.Oracle(1, grid.thickness, oracle.default_params(flow=1, seb=1, swrc=1, unsat_k=1, vg_alpha=2.0, vg_n=2.0))
+    o.enable_vegetation()
+    o.set("saturation_water_ice", np.minimum(1.0, 0.5 - 0.1 * grid.z_centers()))
+    o.set("carbon_vegetation", 0.1)
+    o.initialize()
+    o.timestep(60.0)
+    assert st.status() == 0 and o.status() == 0
+    for name in ("temperature", "saturation_water_ice", "internal_energy", "skin_temperature", "ground_heat_flux", "latent_heat_flux",
+                 "transpiration", "evaporation_ground", "carbon_vegetation", "leaf_area_index", "soil_moisture_limiting_factor", "infiltration"):
+        a, b = st.get(name), o.get(name)
+        assert np.all(np.isfinite(a)), name
+        assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300 + 1e-6 * np.abs(b).max())) < 1e-10, name
