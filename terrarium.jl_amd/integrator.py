@@ -435,7 +435,9 @@ def initialize_integrator(integ: ModelIntegrator):
     st.set_clock(0.0, 0)
     st.clear_series()
     for (var, side), (kind, value) in integ.boundary_conditions.items():
-        if isinstance(value, FieldTimeSeries):
+        if isinstance(value, RasterInputSource):
+            value.attach_boundary(st, var, side, kind)     # a named input variable as boundary value (soil_heat_global_era5.jl:31-44)
+        elif isinstance(value, FieldTimeSeries):
             st.set_bc_series(var, side, kind, value.times, value.values, value.time_indexing)
         else:
             st.set_bc(var, side, kind, value(0.0) if callable(value) else value)

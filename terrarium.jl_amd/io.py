@@ -456,3 +456,12 @@ class RasterInputSource:
             state.set_forcing(self.name, cols)
         else:
             state.set_forcing_series(self.name, self.times, cols, "raster")
+
+    def attach_boundary(self, state, var, side, kind):
+        """The source feeds a boundary condition -- `PrescribedSurfaceTemperature(:Tair)` with `InputSource(grid, raster; name
+        = :Tair)` (examples/simulations/soil_heat_global_era5.jl:31-44): same update rule, evaluated into the boundary values."""
+        cols = self.columns()
+        if self.static:
+            state.set_bc(var, side, kind, cols)
+        else:
+            state.set_bc_series(var, side, kind, self.times, cols, "raster")

@@ -479,3 +479,39 @@ def test_example_land_column_matches_oracle():
         a, b = st.get(name), o.get(name)
         assert np.all(np.isfinite(a)), name
         assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300 + 1e-6 * np.abs(b).max())) < 1e-10, name
+
+
+def test_example_soil_heat_global_era5_matches_oracle(tmp_path):
+    """examples/soil_heat_global_era5.py (mirror of examples/simulations/soil_heat_global_era5.jl) on a synthetic 2 m temperature
+    file the test writes byte by byte: the raster source feeds the surface boundary value with the Raster extension's time rule;
+    per-step launches, the resident multi-step program and the oracle agree."""
+    import oracle
+    from hdf5_writer import Writer
+    ex = _load_example("soil_heat_global_era5")
+    mask = trm.masks.load_land_mask("N72")
+    ny, nx = mask.shape
+    rng = np.random.default_rng(9)
+    nt = 6
+    lat = np.linspace(-1.5, 1.5, ny)[:, None]
+    t2m = (288.0 - 30.0 * np.abs(np.sin(lat)) + rng.normal(0.0, 2.0, (nt, ny, nx))).astype(np.float32)       # K
+    w = Writer()
+    w.dataset("time", np.arange(nt, dtype=np.int32), attrs={"units": "hours since 2023-01-01 00:00:00", "calendar": "standard"})
+    w.dataset("t2m", t2m, layout="chunked", chunks=(1, ny, nx), deflate=True, shuffle=True, attrs={"units": "K"})
+    path = tmp_path / "era5_land_2m_temperature.nc"
+    path.write_bytes(w.tobytes())
+    results = []
+    for spl in (1, 25):
+        grid, integ, Tair = ex.build(str(path), dtype=np.float64)
+        assert grid.num_columns == 14017 and not Tair.static and np.array_equal(Tair.times, 3600.0 * np.arange(nt))
+        integ.state.set_option("steps_per_launch", spl)
+        trm.run(integ, steps=100, dt=120.0)               # 3 h 20 min: across three forcing intervals
+        results.append(integ.state.get("temperature"))
+    assert np.array_equal(results[0], results[1])
+    cols = Tair.columns()
+    o = oracle.Oracle(grid.num_columns, grid.thickness, oracle.default_params())
+    o.set("temperature", cols[0][None, :] - 0.02 * grid.z_centers()[:, None])
+    o.set("saturation_water_ice", 1.0)
+    o.set_bc_series("temperature", "top", "value", Tair.times, cols, "raster")
+    o.initialize()
+    o.run(120.0, 100)
+    assert np.array_equal(results[0], o.get("temperature"))
