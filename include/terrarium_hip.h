@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 8
+#define TRM_ABI_VERSION 9
 
 typedef struct trm_ctx trm_ctx;
 
@@ -289,6 +289,12 @@ int trm_field_device_ptr(trm_ctx* ctx, int field, void** dev, int64_t* pitch_ele
 
 /* Field boundary conditions (src/models/soil/soil_model_bcs.jl, src/boundary_conditions.jl:25-28):
  * `values` is a per-column array [Nh] or NULL to broadcast `scalar`. */
+/* Device array [num_columns] of the boundary values of (var, side), as set by trm_set_bc / trm_set_bc_series: a coupled
+ * model that lives on the same device writes the next coupling interval's values there itself (the SpeedyWeather
+ * coupling of examples/simulations/speedy_dry_land.jl:45-66 does `set!(state.inputs.air_temperature, Tair)` per coupling
+ * step).  Valid until the context is destroyed; writes must be ordered before the next trm_step on the context's stream
+ * (trm_set_stream) or by a device synchronisation.  Fails if the condition carries no values (NoFlux) or a time series. */
+int trm_bc_device_ptr(trm_ctx* ctx, int var, int side, void** dev);
 int trm_set_bc(trm_ctx* ctx, int bc_var, int side, int kind, const void* values, double scalar);
 /* update_inputs! (src/state_variables.jl:154-162): same as trm_upload on an input field. */
 int trm_set_forcing(trm_ctx* ctx, int input_field, const void* per_column);

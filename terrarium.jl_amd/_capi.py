@@ -48,7 +48,7 @@ TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE, TRM_ECOM
 
 EXPORTS = (
     "trm_abi_version trm_default_params trm_create trm_destroy trm_last_error trm_field_rows trm_get_grid "
-    "trm_upload trm_download trm_field_device_ptr trm_set_bc trm_set_forcing trm_initialize trm_update_state "
+    "trm_upload trm_download trm_field_device_ptr trm_bc_device_ptr trm_set_bc trm_set_forcing trm_initialize trm_update_state "
     "trm_compute_auxiliary trm_compute_tendencies trm_reset_tendencies trm_explicit_step trm_closure trm_invclosure "
     "trm_step trm_step_heun trm_step_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_option "
     "trm_get_option trm_set_stream trm_synchronize "
@@ -107,6 +107,7 @@ def lib():
     L.trm_upload.argtypes = [vp, i32, vp]
     L.trm_download.argtypes = [vp, i32, vp]
     L.trm_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64)]
+    L.trm_bc_device_ptr.argtypes = [vp, i32, i32, C.POINTER(vp)]
     L.trm_set_bc.argtypes = [vp, i32, i32, i32, vp, dbl]
     L.trm_set_forcing.argtypes = [vp, i32, vp]
     L.trm_set_forcing_series.argtypes = [vp, i32, i32, vp, vp, i32]

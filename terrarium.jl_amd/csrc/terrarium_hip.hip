@@ -1501,6 +1501,15 @@ int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems
     return TRM_OK;
 }
 
+int trm_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
+    if (!c || !dev || var < 0 || var >= TRM_BCV_COUNT || (side != TRM_TOP && side != TRM_BOTTOM)) return fail(c, TRM_EINVAL, "trm_bc_device_ptr: bad argument");
+    if (c->bc_kind[var][side] == TRM_BC_NOFLUX || !c->bc_value[var][side]) return fail(c, TRM_EINVAL, "trm_bc_device_ptr: the condition carries no values (set it with trm_set_bc first)");
+    for (const auto& sr : c->series)
+        if (sr.is_bc && sr.var == var && sr.side == side) return fail(c, TRM_EINVAL, "trm_bc_device_ptr: the boundary values are evaluated from a time series every step");
+    *dev = c->bc_value[var][side];
+    return TRM_OK;
+}
+
 int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, double scalar) {
     if (!c || var < 0 || var >= TRM_BCV_COUNT || (side != TRM_TOP && side != TRM_BOTTOM) || kind < 0 || kind > TRM_BC_GRADIENT)
         return fail(c, TRM_EINVAL, "trm_set_bc: bad argument");

@@ -111,6 +111,14 @@ def InputSources(*sources):
     return dict(sources)
 
 
+class DeviceArray:
+    """A view of library-owned device memory (CUDA array interface v2; HIP pointers on ROCm builds of the consumers)."""
+
+    def __init__(self, ptr, shape, dtype, owner):
+        self._owner = owner      # keeps the context alive
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=np.dtype(dtype).str, data=(int(ptr), False), version=2, strides=None)
+
+
 class DeviceState:
     """Owns one `trm_ctx` (one device's shard of columns) and exposes the state
     variables by the reference's names; reading an attribute downloads the field
@@ -194,6 +202,22 @@ class DeviceState:
             ptr, scalar = arr.ctypes.data, 0.0
         self._check(self._lib.trm_set_bc(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], _capi.BC_KIND[kind], ptr,
                                          scalar), "trm_set_bc")
+
+    # -- zero-copy device views (coupling with a model on the same device; speedy_dry_land.jl:45-66) -----------------------
+    def device_array(self, name) -> "DeviceArray":
+        """The device buffer of a field as a `__cuda_array_interface__` object (`torch.as_tensor(a, device="cuda")`, CuPy, ...):
+        `[num_columns]` for 2-D fields, `[num_columns][pitch]` for 3-D fields -- the z-FASTEST device layout, level k of
+        column i at [i, k], k = 0 the bottom cell, entries k >= rows are padding."""
+        ptr, pitch = C.c_void_p(), C.c_int64()
+        self._check(self._lib.trm_field_device_ptr(self._ctx, _capi.FIELD[name], C.byref(ptr), C.byref(pitch)), "trm_field_device_ptr")
+        shape = (self.grid.Nh,) if self.rows(name) == 1 else (self.grid.Nh, int(pitch.value))
+        return DeviceArray(ptr.value, shape, self.dtype, self)
+
+    def bc_device_array(self, var, side) -> "DeviceArray":
+        """The device array `[num_columns]` of a boundary condition's values (trm_bc_device_ptr)."""
+        ptr = C.c_void_p()
+        self._check(self._lib.trm_bc_device_ptr(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], C.byref(ptr)), "trm_bc_device_ptr")
+        return DeviceArray(ptr.value, (self.grid.Nh,), self.dtype, self)
 
     def set_vegetation(self, veg_params, mode="standalone"):
         """Enables the vegetation processes (trm_set_vegetation)."""

@@ -515,3 +515,39 @@ def test_example_soil_heat_global_era5_matches_oracle(tmp_path):
     o.initialize()
     o.run(120.0, 100)
     assert np.array_equal(results[0], o.get("temperature"))
+
+
+def test_example_coupled_dry_land_zero_copy_exchange():
+    """examples/coupled_dry_land.py (the coupling structure of examples/simulations/speedy_dry_land.jl): the atmosphere writes the
+    boundary values and reads the surface temperature through device views of the library's buffers; the result equals the
+    same sequence driven through host arrays (set_bc / download), bit for bit."""
+    import torch
+    ex = _load_example("coupled_dry_land")
+    grid, integ, lat, lon = ex.build(nlat_half=8)
+    _, ref, _, _ = ex.build(nlat_half=8)
+    land = ex.TerrariumDryLand(integ)
+    lat_d, lon_d = (torch.as_tensor(x, device="cuda", dtype=torch.float32) for x in (lat, lon))
+    T_soil = land.initialize()
+    assert T_soil.shape == (grid.num_columns,) and np.array_equal(T_soil.cpu().numpy(), (integ.state.temperature[-1] + np.float32(273.15)))
+    T_air = T_soil.clone()
+    T_soil_ref = T_soil.clone()
+    T_air_ref = T_air.clone()
+    for n in range(6):
+        T_air = ex.toy_atmosphere(torch, lat_d, lon_d, n * 900.0, T_soil, T_air, 900.0)
+        T_soil = land.timestep(T_air, 900.0)
+        # the same exchange through the host
+        T_air_ref = ex.toy_atmosphere(torch, lat_d, lon_d, n * 900.0, T_soil_ref, T_air_ref, 900.0)
+        ref.state.set_bc("temperature", "top", "value", (T_air_ref - 273.15).cpu().numpy())
+        trm.run(ref, period=900.0, dt=300.0)
+        T_soil_ref = torch.as_tensor(ref.state.temperature[-1], device="cuda") + 273.15
+    torch.cuda.synchronize()
+    assert trm.current_time(integ) == trm.current_time(ref) == 6 * 900.0
+    for name in ("temperature", "internal_energy", "liquid_water_fraction"):
+        assert np.array_equal(integ.state.get(name), ref.state.get(name)), name
+    # a 3-D device view is [column][level pitch], level fastest
+    dev = torch.as_tensor(integ.state.device_array("temperature"), device="cuda").cpu().numpy()
+    assert np.array_equal(dev[:, :grid.Nz].T, integ.state.get("temperature"))
+    # boundary values that come from a time series cannot be handed out
+    integ.state.set_bc_series("temperature", "top", "value", [0.0, 1.0e6], np.zeros((2, grid.num_columns)))
+    with pytest.raises(trm.TerrariumHipError):
+        integ.state.bc_device_array("temperature", "top")
