@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v_arg, De
     const bool colok = i < Nh;              // uniform within the column's lanes
     const bool act = colok && k < Nz;
     const int ii = colok ? i : Nh - 1;      // safe index for the tail wave
-    const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF), ib = ib0;
+    const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(k < Nz ? k : Nz - 1)) * (unsigned)sizeof(NF), cb = cb0;
     uint32_t viol = 0;
 
