@@ -244,7 +244,6 @@ def main():
     n_gpus = world
 
     import workloads as W
-    import terrarium_jl_amd as trm
     from terrarium_jl_amd import parallel
 
     w, desc, config, Nz, dt_name = build_workload(W, parallel, args.workload, world, rank, args.scaling)

@@ -9,7 +9,7 @@ and sharding.  All field arithmetic runs on the GPU.
 """
 import ctypes as C
 from dataclasses import dataclass
-from typing import Callable, Dict, Optional
+from typing import Optional
 
 import numpy as np
 

@@ -15,7 +15,6 @@ device: linear between the bracketing nodes, flat beyond the ends (TerrariumRast
 """
 import datetime
 import re
-import struct
 import zlib
 
 import numpy as np
