@@ -144,13 +144,7 @@ def run_timed(dev, w, config, steps, warmup, spinup_ms, heun, sync, barrier=None
     # --spinup-ms, then restored once more.  The timed K steps start from exactly the state the W steps produced.
     spun = 0.0
     while spun < spinup_ms:
-        if heun:
-            t1 = time.perf_counter()
-            dev.step_heun(dt, STABLE_STEPS, finalize=False)
-            sync()
-            spun += (time.perf_counter() - t1) * 1e3
-        else:
-            spun += dev.step_timed(dt, STABLE_STEPS, finalize=False)
+        spun += (dev.step_heun_timed if heun else dev.step_timed)(dt, STABLE_STEPS, finalize=False)
         dev.restore_state()
     (barrier or sync)()
     t0 = time.perf_counter()
@@ -159,13 +153,7 @@ def run_timed(dev, w, config, steps, warmup, spinup_ms, heun, sync, barrier=None
         n = min(steps - done, STABLE_STEPS) if chunked else steps
         if chunked and done > 0:
             dev.restore_state()
-        if heun:    # no event-timed entry point for Heun: the wall clock of the synchronous call stands in
-            t1 = time.perf_counter()
-            dev.step_heun(dt, n, finalize=False)
-            sync()
-            ms += (time.perf_counter() - t1) * 1e3
-        else:
-            ms += dev.step_timed(dt, n, finalize=False)  # n steps = n launches, HIP events on the library's stream
+        ms += (dev.step_heun_timed if heun else dev.step_timed)(dt, n, finalize=False)  # n steps = n launches, HIP events on the library's stream
         done += n
     sync()
     (barrier or sync)()

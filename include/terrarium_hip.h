@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 9
+#define TRM_ABI_VERSION 10
 
 typedef struct trm_ctx trm_ctx;
 
@@ -360,6 +360,8 @@ int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
 int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
 int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);
+/* The same for trm_step_heun. */
+int trm_step_heun_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);
 
 /* Device-side checkpoint of the whole state (every field, the clock, the status word): trm_save_state copies it into
  * a second set of buffers owned by the context, trm_restore_state copies it back.  One slot; no host traffic. */

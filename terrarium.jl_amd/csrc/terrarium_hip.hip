@@ -1715,6 +1715,21 @@ int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
     return finish(c, TRM_OK);
 }
 
+int trm_step_heun_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
+    TRM_ENTER(c);
+    if (nsteps < 0 || !ms) return fail(c, TRM_EINVAL, "trm_step_heun_timed: bad argument");
+    const int async = c->opt_async;
+    c->opt_async = 1;                       // (no synchronisation between the two event records)
+    TRM_HIP(c, hipEventRecord(c->ev0, c->stream));
+    const int rc = trm_step_heun(c, dt, nsteps, finalize);
+    c->opt_async = async;
+    if (rc) return rc;
+    TRM_HIP(c, hipEventRecord(c->ev1, c->stream));
+    TRM_HIP(c, hipEventSynchronize(c->ev1));
+    TRM_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return TRM_OK;
+}
+
 int trm_save_state(trm_ctx* c) {
     TRM_ENTER(c);
     {   // (allocates what is missing: everything the first time, the vegetation fields once they exist)

@@ -299,6 +299,11 @@ class DeviceState:
                     "trm_step_timed")
         return float(ms.value)
 
+    def step_heun_timed(self, dt, nsteps=1, finalize=False) -> float:
+        ms = C.c_float()
+        self._check(self._lib.trm_step_heun_timed(self._ctx, float(dt), int(nsteps), int(finalize), C.byref(ms)), "trm_step_heun_timed")
+        return float(ms.value)
+
     def clock(self):
         t, it = C.c_double(), C.c_int64()
         self._check(self._lib.trm_clock(self._ctx, C.byref(t), C.byref(it)), "trm_clock")
