@@ -378,7 +378,7 @@ template <class NF> TRM_DEV NF conductivity_linear(const DevParams<NF>& p, const
 // N2: the exponents of n = 2 as compile-time forms -- x^(2/3) = cbrt(x)^2 and y^(1/2) = sqrt(y), exactly what jl_pow
 // evaluates for the PowSpecs {THIRDS, 2} and {HALVES, 1} (its x == 1 shortcut returns what the roots return there).
 template <class NF, bool COMPLEX_FALLBACK = true, bool N2 = false> TRM_DEV NF conductivity_vg(const DevParams<NF>& p, NF liq, const Frac<NF>& f) {
-    NF x = f.water / p.por;
+    NF x = div_const(f.water, p.por, p.rpor);
     // I_ice = 10^(-Omega (1 - f)): Base.:^ takes the integer path when the exponent is integer-valued
     NF y = -p.impedance * (NF(1) - liq);
     NF I_ice;
@@ -439,7 +439,7 @@ template <class NF, bool N2 = false> TRM_DEV NF swrc_psi_vg(const DevParams<NF>&
     if (theta < p.por) {
         NF r = div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
         if (N2) {   // r^(-2) = (1 / r)^2 (pow_int, n = -2), then the square root
-            const NF rr = NF(1) / r;
+            const NF rr = div_nr(NF(1), r);
             return p.neg_inv_alpha * sqrt_(rr * rr - NF(1));
         }
         return p.neg_inv_alpha * jl_pow(jl_pow(r, p.vg_neg_inv_m) - NF(1), p.vg_inv_n);
@@ -470,21 +470,25 @@ template <class NF, int HYD> TRM_DEV NF pressure_head(const DevParams<NF>& p, NF
 
 // ---- surface energy balance ---------------------------
 template <class NF> TRM_DEV NF saturation_vapor_pressure(NF T) {  // physics_utils.jl:54,67-73
-    if (T <= NF(0)) return NF(611.0) * exp_(NF(22.46) * T / (T + NF(272.62)));
-    return NF(611.0) * exp_(NF(17.62) * T / (T + NF(243.12)));
+    // (div_nr: every divisor of the surface processes is normal and far from the range limits -- temperatures in degC
+    // offset by ~250, pressures ~1e5, resistances in [1, 1e6] -- so the sequence IS the IEEE division, see div_nr)
+    // (the branch of the reference selects the Magnus coefficients; one exp and one divide whatever the signs in the wave)
+    const bool ice = T <= NF(0);
+    const NF a = ice ? NF(22.46) : NF(17.62), b = ice ? NF(272.62) : NF(243.12);
+    return NF(611.0) * exp_(div_nr(a * T, T + b));
 }
 template <class NF> TRM_DEV NF humidity_vpd(const DevParams<NF>& p, NF pres, NF q_air, NF Ts) {
     // physical_constants.jl:83-97 compute_vpd; physics_utils.jl:38
     NF e_sat = saturation_vapor_pressure(Ts);
-    NF e_air = q_air * pres / (p.eps_mw + p.one_minus_eps_mw * q_air);
+    NF e_air = div_nr(q_air * pres, p.eps_mw + p.one_minus_eps_mw * q_air);
     NF vpd = jl_max(e_sat - e_air, NF(0.1));
-    return p.eps_mw * vpd / pres;
+    return div_nr(p.eps_mw * vpd, pres);
 }
 template <class NF> TRM_DEV NF aerodynamic_resistance(const DevParams<NF>& p, NF windspeed) {
     // prescribed_atmosphere.jl:110-116,137
     NF V = jl_max(windspeed, p.min_windspeed);
     NF Va = jl_max(V, NF(1.0e-6));
-    return NF(1) / (p.C_h * Va);
+    return div_nr(NF(1), p.C_h * Va);
 }
 
 // (albedo, eps_sigma = emissivity * sigma, one_minus_emissivity: ConstantAlbedo's launch constants or PrescribedAlbedo's
@@ -513,7 +517,7 @@ template <class NF> TRM_DEV void seb_fluxes_humidity(const DevParams<NF>& p, con
     NF Tk = o.Ts + p.Tref;
     o.lwu = in.eps_sigma * pow_int(Tk, 4) + in.one_minus_emissivity * in.lwd;
     o.rnet = o.swu - in.swd + o.lwu - in.lwd;
-    NF Q_T = (o.Ts - in.Tair) / ra;
+    NF Q_T = div_nr(o.Ts - in.Tair, ra);
     o.Hs = p.ca_rhoa * Q_T;
     o.Hl = p.Llg_rhoa * Q_h;
     o.ghf = o.rnet - o.Hs - o.Hl;
@@ -558,7 +562,7 @@ TRM_DEV void surface_processes(const DevParams<NF>& p, const SebIn<NF>& in, NF T
     o.Ts = Ts_in;
     NF ra = aerodynamic_resistance(p, in.wind);
     // bare_ground_evaporation.jl:49-62
-    o.evap = evaporation_resistance_factor(p, sat_top, liq_top) * humidity_vpd(p, in.pres, in.qair, o.Ts) / ra;
+    o.evap = div_nr(evaporation_resistance_factor(p, sat_top, liq_top) * humidity_vpd(p, in.pres, in.qair, o.Ts), ra);
     // direct_surface_runoff.jl:87-117
     NF excess = richards ? S : NF(0);
     bool unsat = sat_top < NF(1);
