@@ -165,7 +165,8 @@ enum {
                                     /* closure of the stored internal_energy / saturation (the library wrote them), a fused   */
                                     /* Euler step can re-derive them in registers instead of reading them: 2 of 5 field reads */
                                     /* less, bit-identical results.  0: never; 1: whenever legal; 2 (default): for fp64 states  */
-                                    /* beyond the 256 MiB Infinity Cache, where it was measured to win            */
+                                    /* beyond the 256 MiB Infinity Cache, and for the reference-default hydraulics / heat-only  */
+                                    /* on grids of >= 24 576 columns: where it was measured to win                */
     TRM_OPT_STEPS_PER_LAUNCH = 6    /* m >= 1 (default 1): trm_step keeps every column in registers for up to m steps per   */
                                     /* launch and writes the fields once per launch (temporal blocking of run!'s loop;     */
                                     /* bit-identical to m = 1).  Applies while no time series is attached and the boundary  */

@@ -767,12 +767,17 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     // Deriving T and liq in registers saves 2 of 11 field accesses and costs ~40 instructions per cell.  Measured on MI355X
-    // it does not pay while the step's state sits in the 256 MiB Infinity Cache (N145 fp64: 27.1 vs 26.9 us), wins once an
-    // fp64 state streams from HBM (8 x N145: 223 vs 240 us) and loses in fp32 (C5 van Genuchten: 754 vs 702 us).  AUTO
-    // therefore switches on the number format and the bytes one step touches.
+    // (profiles/tools/derive_crossover.py, ab_step.py; fp64): it wins once an fp64 state streams from HBM (8 x N145: 223 vs
+    // 240 us); with the state in the Infinity Cache it wins where the step is bound by the bytes it moves -- the
+    // reference-default hydraulics and heat-only from ~28 000 columns up (N145: 26.0-26.2 vs 27.7-28.4 us on two boxes, equal
+    // on a third; 36 864 columns -6.5 %) -- is neutral for van Genuchten and the LandModel (more arithmetic per byte) and
+    // loses on small grids (N72 heat-only: 7.1 vs 6.6 us, latency-bound) and in fp32 (C5 van Genuchten: 754 vs 702 us).
+    // AUTO switches on the number format, the bytes one step touches, the hydraulics and the column count.
     template <bool RICH> static bool derive_now(const trm_ctx* c) {
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
-        const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && std::is_same<NF, double>::value && state_bytes > ((size_t)256 << 20));
+        const bool beyond_cache = state_bytes > ((size_t)256 << 20);
+        const bool bound_by_bytes = c->Nh >= 24576 && !c->params.seb && (!RICH || hyd(c) == HYD_BC_LINEAR);
+        const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && std::is_same<NF, double>::value && (beyond_cache || bound_by_bytes));
         // (the coupled vegetation reads T and liq of the whole column from memory every step)
         return want && c->closure_consistent && !c->closure_escaped && !coupled(c);
     }
