@@ -150,3 +150,34 @@ def test_simulation_schedules():
     assert not t.actuates(1200.0, 2)
     assert t.actuates(1800.0, 3) and t.next_time() == 3600.0
     assert not t.actuates(3000.0, 5) and t.actuates(3700.0, 6) and t.next_time() == 5400.0
+
+
+def test_python_constants_match_the_header():
+    """Field ids, option ids, error codes and the vegetation parameter layout of terrarium.jl_amd/_capi.py and oracle/oracle.py
+    against include/terrarium_hip.h (the header is the contract; the Python tables are copies)."""
+    import re
+    import oracle
+    from terrarium_jl_amd import _capi
+    header = open(os.path.join(ROOT, "include", "terrarium_hip.h")).read()
+    enum = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(TRM_[A-Z0-9_]+)\s*=\s*(\d+)", header)}
+    alias = dict(SAI="STEM_AREA_INDEX", tend_internal_energy="TEND_INTERNAL_ENERGY")
+    for name, fid in _capi.FIELD.items():
+        key = "TRM_FIELD_" + alias.get(name, name).upper()
+        assert enum[key] == fid, (name, key)
+    assert enum["TRM_FIELD_COUNT"] == max(_capi.FIELD.values()) + 1 == len(_capi.FIELD)
+    for name, fid in oracle.FIELDS.items():          # the oracle's table is a subset with the same ids
+        assert _capi.FIELD[name] == fid, name
+    for name, oid in _capi.OPTION.items():
+        key = {"asynchronous": "TRM_OPT_ASYNC", "step_kernel": "TRM_OPT_STEP_KERNEL", "write_kf_every_step": "TRM_OPT_WRITE_KF_EVERY_STEP",
+               "vwc_forcing_field": "TRM_OPT_VWC_FORCING_FIELD", "packed_f32": "TRM_OPT_PACKED_F32",
+               "derive_closure_fields": "TRM_OPT_DERIVE_CLOSURE_FIELDS", "steps_per_launch": "TRM_OPT_STEPS_PER_LAUNCH"}[name]
+        assert enum[key] == oid, name
+    for code, key in enumerate(("TRM_OK", "TRM_EINVAL", "TRM_EHIP", "TRM_ENOMEM", "TRM_EUNSUPPORTED", "TRM_ESTALE", "TRM_ECOMM")):
+        assert enum[key] == code
+    assert _capi.VEGETATION == dict(off=enum["TRM_VEGETATION_OFF"], standalone=enum["TRM_VEGETATION_STANDALONE"], coupled=enum["TRM_VEGETATION_COUPLED"])
+    # vegetation parameter struct: the doubles of the header in order
+    body = header[header.index("typedef struct trm_vegetation_params {"):header.index("} trm_vegetation_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n.strip() for decl in re.findall(r"double([^;]+);", body) for n in decl.split(",")]
+    assert names == list(_capi.VEG_PARAM_NAMES) == [f[0] for f in oracle.VegParamsD._fields_]
+    assert int(re.search(r"#define TRM_ABI_VERSION (\d+)", header).group(1)) == _capi.lib().trm_abi_version()
