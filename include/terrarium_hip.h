@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 10
+#define TRM_ABI_VERSION 11
 
 typedef struct trm_ctx trm_ctx;
 
@@ -259,8 +259,10 @@ int trm_default_vegetation_params(trm_vegetation_params* p);
  * evapotranspiration (transpiration through the stomatal conductance, ground evaporation below the canopy, evaporation of
  * intercepted water) -> runoff of the rain reaching the ground -> the surface energy balance with the latent heat of all
  * three humidity fluxes; canopy_water, carbon_vegetation and vegetation_area_fraction are stepped with the soil.  The
- * 0-D part of one step is ONE launch in front of the soil column kernel; the resident multi-step program and the
- * single-launch Heun do not apply (steps run one launch pair each, Heun on the reference-order kernels). */
+ * 0-D part of one step is ONE launch in front of the soil column kernel; the resident multi-step program does not apply
+ * (Euler steps run one launch pair each).  trm_step_heun takes four launches per step: the 0-D processes at the state, the
+ * soil column with both stages in registers (storing only what the 0-D processes need of the stage), the 0-D processes at
+ * the stage, the averaged 0-D update. */
 enum { TRM_VEGETATION_OFF = 0, TRM_VEGETATION_STANDALONE = 1, TRM_VEGETATION_COUPLED = 2 };
 int trm_set_vegetation(trm_ctx* ctx, const trm_vegetation_params* p, int mode);
 /* FieldCapacityLimitedPAW (plant_available_water.jl:36-94): plant_available_water per cell from the soil state of the

@@ -672,17 +672,18 @@ template <class NF> struct Ops {
     }
     // the 0-D part of the coupled LandModel's compute_auxiliary! (+ tendencies and explicit step of the 0-D prognostics)
     template <bool FROM_STATE, bool ADVANCE> static int surface_veg(trm_ctx* c, const FieldSet& s, double dt, bool store_paw = true) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        const VegView<NF> vv = veg_view(c, s);
-        const VegDev<NF> vp = veg_dev(c);
-        SurfaceVegArgs<NF> a;
+        SurfaceVegArgs<NF> a{};
         a.dt = (NF)dt;
         a.richards = richards(c) ? 1 : 0;
         a.from_state = FROM_STATE ? 1 : 0;
         a.top_arrays = (FROM_STATE && c->top_valid && &s == &c->state) ? 1 : 0;
         a.advance = ADVANCE ? 1 : 0;
         a.store_paw = store_paw ? 1 : 0;
+        return surface_veg_launch(c, cached_view<NF>(c, s), veg_view(c, s), a);
+    }
+    static int surface_veg_launch(trm_ctx* c, const View<NF>& v, const VegView<NF>& vv, const SurfaceVegArgs<NF>& a) {
+        const DevParams<NF>& p = launch_args<NF>(c).p;
+        const VegDev<NF> vp = veg_dev(c);
         const dim3 blocks((unsigned)((c->Nh + 63) / 64));   // 64 columns per 256-thread workgroup
         // (the kernel is bound by cold instruction fetch: the hydraulics of the top-face conductivity are compiled in)
         if (c->Nzp == 32) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, 32, H>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a)); }
@@ -891,6 +892,13 @@ template <class NF> struct Ops {
         a.series = (const SeriesTable<NF>*)c->d_series_table;
         a.series_rows = (const SeriesRow*)c->d_series_rows;
         a.nseries = (int)c->series.size();
+        a.stage_sat = a.stage_liq = a.stage_T = a.stage_S = nullptr;
+        if (PROG == PROG_HEUN && coupled(c)) {   // the stage's soil state is needed by the 0-D processes evaluated at the stage
+            a.stage_sat = (NF*)c->stage.f[TRM_FIELD_SATURATION_WATER_ICE];
+            a.stage_liq = (NF*)c->stage.f[TRM_FIELD_LIQUID_WATER_FRACTION];
+            a.stage_T = (NF*)c->stage.f[TRM_FIELD_TEMPERATURE];
+            a.stage_S = (NF*)c->stage.f[TRM_FIELD_SURFACE_EXCESS_WATER];
+        }
         const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
         const bool derive = derive_now<RICH>(c);
         if constexpr (PROG == PROG_MULTI) {
@@ -1015,7 +1023,70 @@ template <class NF> struct Ops {
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
     }
+    // Heun of the vegetation-coupled LandModel in four launches (heun.jl:37-71 with land_model.jl:79-97).  The soil column's
+    // two stages stay in registers (k_column<PROG_HEUN>); what the 0-D processes need AT the stage -- the stage's saturation,
+    // liquid fraction, temperature, surface excess water -- is the only part of it that is stored.  The final soil state does not
+    // depend on the stage's 0-D evaluation (its boundary fluxes are the state's, heun.jl:64-69), so the order is:
+    //   1. k_surface_veg(state): auxiliaries, first-stage 0-D tendencies, PREDICTED 0-D prognostics -> stage arrays
+    //   2. k_column<PROG_HEUN>: the soil step; stage soil fields -> stage arrays
+    //   3. k_surface_veg(stage): auxiliaries and 0-D tendencies at the stage (inputs evaluated at t + dt)
+    //   4. k_heun_average_0d: averaged tendencies, explicit step of canopy water, vegetation carbon, area fraction
+    static int heun_step_coupled_fused(trm_ctx* c, double dt, int finalize) {
+        int rc = update_inputs(c, c->state, c->time);
+        if (!rc) rc = update_inputs(c, c->stage, c->time + dt);
+        if (rc) return rc;
+        const VegView<NF> vs = veg_view(c, c->state);
+        VegView<NF> vg = veg_view(c, c->stage);
+        View<NF> sv = cached_view<NF>(c, c->stage);
+        // inputs of the stage: its own arrays where a time series feeds them (evaluated at t + dt above), else the state's
+        auto fed = [&](int field) {
+            for (const auto& sr : c->series) if (!sr.is_bc && sr.field == field) return true;
+            return false;
+        };
+        const View<NF>& v0 = cached_view<NF>(c, c->state);
+        if (!fed(TRM_FIELD_AIR_TEMPERATURE)) sv.Tair = v0.Tair;
+        if (!fed(TRM_FIELD_AIR_PRESSURE)) sv.pres = v0.pres;
+        if (!fed(TRM_FIELD_WINDSPEED)) sv.wind = v0.wind;
+        if (!fed(TRM_FIELD_SPECIFIC_HUMIDITY)) sv.qair = v0.qair;
+        if (!fed(TRM_FIELD_RAINFALL)) sv.rain = v0.rain;
+        if (!fed(TRM_FIELD_SURFACE_SHORTWAVE_DOWN)) sv.swd = v0.swd;
+        if (!fed(TRM_FIELD_SURFACE_LONGWAVE_DOWN)) sv.lwd = v0.lwd;
+        if (!fed(TRM_FIELD_ALBEDO)) sv.albedo = v0.albedo;
+        if (!fed(TRM_FIELD_EMISSIVITY)) sv.emissivity = v0.emissivity;
+        vg.Tair = sv.Tair; vg.pres = sv.pres; vg.qair = sv.qair; vg.swd = sv.swd;
+        if (!fed(TRM_FIELD_CO2)) vg.CO2 = vs.CO2;
+        if (!fed(TRM_FIELD_DAILY_LEAF_RESPIRATION)) vg.daily_Rd = vs.daily_Rd;
+        if (!fed(TRM_FIELD_STEM_AREA_INDEX)) vg.SAI = vs.SAI;
+        SurfaceVegArgs<NF> a{};
+        a.dt = (NF)dt;
+        a.richards = richards(c) ? 1 : 0;
+        a.from_state = 1;
+        a.top_arrays = (c->top_valid && !c->top_escaped) ? 1 : 0;
+        a.advance = 3;
+        a.store_paw = c->opt_write_kf != 0;
+        a.st_w_can = vg.w_can; a.st_C_veg = vg.C_veg; a.st_nu = vg.nu; a.st_An = vg.An; a.st_Ts = sv.Ts;
+        rc = surface_veg_launch(c, v0, vs, a);
+        if (!rc) rc = column_program<PROG_HEUN>(c, dt, finalize, 1);
+        if (rc) return rc;
+        c->closure_consistent = true;
+        c->tend_valid = finalize != 0;
+        c->top_valid = !c->top_escaped;
+        SurfaceVegArgs<NF> b{};
+        b.dt = (NF)dt;
+        b.richards = a.richards;
+        b.from_state = 1;
+        b.top_arrays = 0;
+        b.advance = 2;
+        b.store_paw = 0;
+        rc = surface_veg_launch(c, sv, vg, b);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_heun_average_0d<NF>), col_grid(c), dim3(256), 0, c->stream, vs, vg, (NF)dt, c->Nh);
+        TRM_HIP(c, hipGetLastError());
+        if (finalize) rc = surface_veg<true, false>(c, c->state, 0.0);
+        return rc;
+    }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
         c->top_valid = false;
         c->tend_valid = true;

@@ -186,6 +186,9 @@ template <class NF> struct ColumnArgs {
     const SeriesTable<NF>* series;
     const SeriesRow* series_rows;
     int nseries;
+    // Heun of the vegetation-coupled LandModel: the stage's saturation, liquid fraction, temperature ([Nh][Nzp]) and surface
+    // excess water ([Nh]) are stored for the 0-D processes that are evaluated AT the stage (null otherwise)
+    NF *stage_sat, *stage_liq, *stage_T, *stage_S;
 };
 
 #ifndef TRM_COLUMN_WAVES_EULER
@@ -284,6 +287,12 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
         Cell<NF> s;
         over_stage = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, s, z0s, bad);
         column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0s, s, viol);
+        if (a.stage_T && ln.act) {   // (wave-uniform: the stage leaves the registers only for the coupled vegetation)
+            const unsigned cb = block_local(cb0);
+            stg(a.stage_sat, cb, s.sat);
+            stg(a.stage_liq, cb, s.liq);
+            stg(a.stage_T, cb, s.T);
+        }
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
         const NF bTb2 = vTb ? ldg(a.bcT_bot_stage, ib0) : NF(0), bTt2 = vTt ? ldg(a.bcT_top_stage, ib0) : NF(0);
         uint32_t viol_stage = 0;
@@ -405,6 +414,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
                     GS_out = NF(0) + jl_min(NF(0), S);
                     if (PROG == PROG_HEUN) {
                         const NF S_stage = (S + GS_out * dt) + over_stage;
+                        if (a.stage_S) stg(a.stage_S, ib, S_stage);
                         GS_out = (GS_out + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
                     }
                     S = (S + GS_out * dt) + over;

@@ -267,7 +267,14 @@ template <class NF> TRM_DEV void canopy_interception(const VegDev<NF>& p, NF rai
 // field; top_arrays -- the top cell's (T, sat, liq) come from the compact per-column arrays the fused step wrote;
 // advance -- compute_tendencies! + explicit_step! of the 0-D prognostics follow in the same launch; store_paw -- the
 // per-cell plant_available_water field is materialised.
-template <class NF> struct SurfaceVegArgs { NF dt; int richards, from_state, top_arrays, advance, store_paw; };
+// advance: 0 compute_auxiliary! only; 1 + compute_tendencies! + explicit_step! of the 0-D prognostics; 2 + compute_tendencies!
+// alone (Heun's evaluation at the stage); 3 Heun's first stage on the state: tendencies stored, the PREDICTED 0-D prognostics,
+// the net assimilation and the skin temperature written to the stage's arrays (st_*), the state's left as they are.
+template <class NF> struct SurfaceVegArgs {
+    NF dt;
+    int richards, from_state, top_arrays, advance, store_paw;
+    NF *st_w_can, *st_C_veg, *st_nu, *st_An, *st_Ts;
+};
 
 template <class NF> TRM_DEV NF paw_term(const VegDev<NF>& vp, NF por, NF sat, NF liq, NF rootf, NF dz, NF rdz, NF& w) {
     w = jl_max(jl_min(NF(1), div_const((sat * por) * liq - vp.wilting_point, vp.paw_span, vp.rpaw_span)), NF(0));
@@ -428,10 +435,14 @@ __global__ void __launch_bounds__(256) k_surface_veg(View<NF> v_arg, DevParams<N
         v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
         vv.f_can[i] = co.f_can; vv.I_can[i] = co.I_can; vv.R_can[i] = co.R_can; vv.rain_ground[i] = co.rain_ground;
         vv.E_can[i] = co.E_can; vv.transp[i] = co.transp;
-        if (a.advance) {   // compute_tendencies! + explicit_step! of the canopy water (land_model.jl:90-97)
+        if (a.advance) {   // compute_tendencies! (+ explicit_step!) of the canopy water (land_model.jl:90-97)
             const NF G_w = co.I_can - co.E_can - co.R_can;
             vv.G_w_can[i] = G_w;
-            vv.w_can[i] = w_can + G_w * a.dt;
+            if (a.advance == 1) vv.w_can[i] = w_can + G_w * a.dt;
+            if (a.advance == 3) {
+                a.st_w_can[i] = w_can + G_w * a.dt;
+                a.st_Ts[i] = o.Ts + NF(0) * a.dt;          // the stage's zero-tendency skin temperature
+            }
         }
     }
     if (role != 0) {
@@ -442,11 +453,30 @@ __global__ void __launch_bounds__(256) k_surface_veg(View<NF> v_arg, DevParams<N
         if (a.advance) {   // ... and of the vegetation carbon and area fraction
             veg_tendencies(vp, vc);
             vv.G_C_veg[i] = vc.G_C_veg; vv.G_nu[i] = vc.G_nu;
-            vv.C_veg[i] = vc.C_veg + vc.G_C_veg * a.dt;
-            vv.nu[i] = vc.nu + vc.G_nu * a.dt;
+            if (a.advance == 1) {
+                vv.C_veg[i] = vc.C_veg + vc.G_C_veg * a.dt;
+                vv.nu[i] = vc.nu + vc.G_nu * a.dt;
+            }
+            if (a.advance == 3) {
+                a.st_C_veg[i] = vc.C_veg + vc.G_C_veg * a.dt;
+                a.st_nu[i] = vc.nu + vc.G_nu * a.dt;
+                a.st_An[i] = vc.An;                        // the stage starts from the state's evaluation (copyto!(stage, state))
+            }
         }
     }
     if (viol) atomicOr(kernarg_reload<View<NF>>(0).status, viol);
+}
+
+// Heun's average_tendencies! + explicit_step! for the three 0-D prognostics of the coupled LandModel (heun.jl:27-35, 64-69):
+// G <- (G_state + G_stage) / 2, u <- u + G dt.
+template <class NF> __global__ void __launch_bounds__(256) k_heun_average_0d(VegView<NF> st, VegView<NF> sg, NF dt, long Nh) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nh) return;
+    const NF Gw = (st.G_w_can[i] + sg.G_w_can[i]) / NF(2), Gc = (st.G_C_veg[i] + sg.G_C_veg[i]) / NF(2), Gn = (st.G_nu[i] + sg.G_nu[i]) / NF(2);
+    st.G_w_can[i] = Gw; st.G_C_veg[i] = Gc; st.G_nu[i] = Gn;
+    st.w_can[i] = st.w_can[i] + Gw * dt;
+    st.C_veg[i] = st.C_veg[i] + Gc * dt;
+    st.nu[i] = st.nu[i] + Gn * dt;
 }
 
 }  // namespace trm

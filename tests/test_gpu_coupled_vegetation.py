@@ -197,3 +197,25 @@ def test_bench_workload_with_vegetation_matches_oracle():
     dev.step(w["dt"], 30, True)
     assert dev.status() == 0 and orc.status() == 0
     assert_close(dev, orc, PROG + SURFACE + VEG_AUX + CANOPY_AUX, np.float64)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_coupled_heun_fused_equals_reference_order_kernels(dtype):
+    """Heun of the coupled model in four launches (the soil stages in registers, the 0-D processes evaluated at the state and at
+    the stage) against the reference-order kernels on a full copy of the state: bit for bit, with a forcing series so that the
+    stage sees its inputs at t + dt."""
+    a, _ = make_pair(190, dtype, seed=13, stepper=trm.Heun)
+    b, _ = make_pair(190, dtype, seed=13, stepper=trm.Heun)
+    b.state.set_option("step_kernel", "unfused")
+    rng = np.random.default_rng(5)
+    times = np.array([0.0, 2.0, 4.0, 8.0])
+    for integ in (a, b):
+        integ.state.set_forcing_series("air_temperature", times, rng.uniform(2.0, 20.0, (4, 190)))
+        integ.state.set_forcing_series("rainfall", times, rng.uniform(0.0, 2.0e-7, (4, 190)))
+        rng = np.random.default_rng(5)
+    for n in range(12):
+        a.state.step_heun(0.5, 1, finalize=(n % 4 == 3))
+        b.state.step_heun(0.5, 1, finalize=(n % 4 == 3))
+    assert a.state.status() == b.state.status() == 0
+    for n in PROG + SURFACE + VEG_AUX + CANOPY_AUX + TEND[:3]:
+        assert np.array_equal(a.state.get(n), b.state.get(n)), n
