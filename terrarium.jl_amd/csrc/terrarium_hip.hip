@@ -996,10 +996,18 @@ template <class NF> struct Ops {
     }
 
     // ---- Heun (heun.jl:37-71), reference-order kernels on a second copy of the state -----------------
+    // copyto!(stage, state) (heun.jl:45) for what the stage's predictor step reads before its own closure! and update_state!
+    // overwrite it: every per-column field, and of the per-cell fields the prognostics and their tendencies.  temperature,
+    // liquid fraction, pressure head, hydraulic conductivity and plant available water of the stage are outputs of
+    // closure!(stage) / compute_auxiliary!(stage) and are never read before that (k_explicit_step reads U, sat, S, Ts, the
+    // tendencies and the boundary fluxes only): 4 of 9 per-cell copies instead of all of them.
     static int copy_state_to_stage(trm_ctx* c) {
-        for (int f = 0; f < TRM_FIELD_COUNT; ++f)
-            if (c->state.f[f] && c->stage.f[f]) TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], field_elems(c, f) * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
-        TRM_HIP(c, hipMemcpyAsync(c->stage.kf_top, c->state.kf_top, (size_t)c->Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+        for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
+            if (!c->state.f[f] || !c->stage.f[f]) continue;
+            const bool needed = !is_3d(f) || f == TRM_FIELD_INTERNAL_ENERGY || f == TRM_FIELD_SATURATION_WATER_ICE ||
+                                f == TRM_FIELD_TEND_INTERNAL_ENERGY || f == TRM_FIELD_TEND_SATURATION_WATER_ICE;
+            if (needed) TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], field_elems(c, f) * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+        }
         return TRM_OK;
     }
     static int average(trm_ctx* c, int field) {
