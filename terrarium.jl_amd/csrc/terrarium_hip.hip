@@ -1093,7 +1093,35 @@ template <class NF> struct Ops {
         if (finalize) rc = surface_veg<true, false>(c, c->state, 0.0);
         return rc;
     }
+    // Heun with the generic boundary kinds (Gradient, Value on liquid fraction / saturation / pressure head, per-cell
+    // vwc_forcing): k_heun_generic, one launch per step like k_column<PROG_HEUN>
+    template <bool RICH, int H, int LPC> static int launch_heun_generic(trm_ctx* c, double dt, int finalize) {
+        const LaunchArgs<NF>& la = launch_args<NF>(c);
+        ColumnArgs<NF> a{};
+        a.dt = (NF)dt;
+        a.finalize = finalize;
+        a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
+        a.nsteps = 1;
+        hipLaunchKernelGGL((k_heun_generic<NF, RICH, H, LPC>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, la.stage, a);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int heun_step_generic_fused(trm_ctx* c, double dt, int finalize) {
+        int rc = update_inputs(c, c->state, c->time);
+        if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
+        if (!rc && c->params.seb) rc = surface(c, c->state, true);
+        if (rc) return rc;
+        const bool deep = c->Nz > 32;
+        if (richards(c)) { TRM_BY_HYD(c, rc = deep ? (launch_heun_generic<true, H, 64>(c, dt, finalize)) : (launch_heun_generic<true, H, 32>(c, dt, finalize))); }
+        else { TRM_BY_HYD(c, rc = deep ? (launch_heun_generic<false, H, 64>(c, dt, finalize)) : (launch_heun_generic<false, H, 32>(c, dt, finalize))); }
+        if (!rc) c->closure_consistent = true;
+        c->tend_valid = finalize != 0;
+        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+        if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
+        return rc;
+    }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
         c->top_valid = false;
@@ -1781,8 +1809,11 @@ int trm_step_heun(trm_ctx* c, double dt, int nsteps, int finalize) {
     TRM_ENTER(c);
     if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step_heun: nsteps < 0");
     if (c->veg_mode == TRM_VEGETATION_STANDALONE) return finish(c, DISPATCH(c, veg_step(c, dt, nsteps, finalize, true)));
-    const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && c->veg_mode != TRM_VEGETATION_COUPLED &&
-                            !(c->precision == TRM_F64 ? Ops<double>::generic_bcs(c) : Ops<float>::generic_bcs(c));
+    const bool generic = c->precision == TRM_F64 ? Ops<double>::generic_bcs(c) : Ops<float>::generic_bcs(c);
+    // (the one-launch programs keep the stage in registers; the coupled vegetation stores part of it, the reference-order
+    // kernels all of it -- with the generic boundary kinds AND the coupled vegetation they are what runs)
+    const bool fused_heun = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && c->veg_mode != TRM_VEGETATION_COUPLED;
+    (void)generic;
     if (!fused_heun) {   // the reference-order kernels work on a second copy of the state (fields enabled since the last call included)
         int rc = alloc_fields(c, c->stage);
         if (rc) return rc;

@@ -440,4 +440,191 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     if (viol && ln.act) atomicOr(v_arg.status, viol);
 }
 
+// ---- Heun with every boundary kind -------------------------------------------------------------------------------------
+// compute_auxiliary! + compute_tendencies! of the column in registers with the generic boundary handling of k_step_wave
+// (Value / Gradient on temperature, liquid fraction, saturation, pressure head; per-cell vwc_forcing), WITHOUT the
+// compute_z_bcs! terms.  `vb` supplies the boundary kinds and values: the state's view, or the stage's (values at t + dt).
+template <class NF, bool RICHARDS, int HYD, int LPC>
+TRM_DEV Tendency<NF> column_tendencies_generic(const View<NF>& vb, const DevParams<NF>& p, const LevelGeom<NF>& L, const LaneInfo& ln,
+                                               const Cell<NF>& c, int ii, unsigned cb, bool need_kc, uint32_t& viol) {
+    const bool is_bot = ln.is_bot, is_top = ln.is_top;
+    uint32_t viol_old = 0;
+    const Frac<NF> f = fractions(p, c.sat, c.liq, viol_old);
+    const NF kap = conductivity(p, f);
+    const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD, false>(p, c.liq, f) : NF(0);
+    const NF T_sh = shfl_up1<NF, LPC>(c.T), kap_sh = shfl_up1<NF, LPC>(kap);
+    NF T_m = T_sh, kap_m = kap_sh, T_h = NF(0), kap_h = NF(0), psi_hb = NF(0), psi_ht = NF(0);
+    const bool same_bot = vb.bc.kind[3][0] != 1 && vb.bc.kind[3][0] != 3 &&
+                          (RICHARDS ? (vb.bc.kind[1][0] != 1 && vb.bc.kind[1][0] != 3) : p.halo_policy == 1);
+    const bool same_top = vb.bc.kind[3][1] != 1 && vb.bc.kind[3][1] != 3 &&
+                          (RICHARDS ? (vb.bc.kind[1][1] != 1 && vb.bc.kind[1][1] != 3) : p.halo_policy == 1);
+    if (is_bot) {
+        T_m = halo_bottom(vb.bc.kind[2][0], bcval(vb, 2, 0), ii, c.T, vb.g);
+        kap_m = kap;
+        if (!same_bot) {
+            const NF lh = halo_bottom(vb.bc.kind[3][0], bcval(vb, 3, 0), ii, c.liq, vb.g);
+            const NF sh = sat_halo<NF, RICHARDS>(vb, p, 0, ii, c.sat);
+            kap_m = conductivity(p, fractions(p, sh, lh, viol));
+        }
+        if (RICHARDS) psi_hb = halo_bottom(vb.bc.kind[4][0], bcval(vb, 4, 0), ii, c.psi, vb.g);
+    }
+    if (is_top) {
+        T_h = halo_top(vb.bc.kind[2][1], bcval(vb, 2, 1), ii, c.T, vb.g);
+        kap_h = kap;
+        if (!same_top) {
+            const NF lh = halo_top(vb.bc.kind[3][1], bcval(vb, 3, 1), ii, c.liq, vb.g);
+            const NF sh = sat_halo<NF, RICHARDS>(vb, p, 1, ii, c.sat);
+            kap_h = conductivity(p, fractions(p, sh, lh, viol));
+        }
+        if (RICHARDS) psi_ht = halo_top(vb.bc.kind[4][1], bcval(vb, 4, 1), ii, c.psi, vb.g);
+    }
+    const NF qT_lo = -(NF(0.5) * (kap + kap_m)) * ((c.T - T_m) * L.rdzf_lo);
+    const NF qT_sh = shfl_dn1<NF, LPC>(qT_lo);
+    const NF qT_hi = is_top ? -(NF(0.5) * (kap_h + kap)) * ((T_h - c.T) * L.rdzf_hi) : qT_sh;
+    Tendency<NF> t;
+    t.gU = NF(0) + (-((qT_hi - qT_lo) * L.rdzc));
+    t.gS = NF(0);
+    t.Kf_lo = NF(0);
+    t.Kc = Kc;
+    if (need_kc) {
+        const NF Kc_m = shfl_up1<NF, LPC>(Kc);
+        const NF Kmin = jl_min(Kc, Kc_m);
+        t.Kf_lo = (is_bot || is_top) ? Kc : Kmin;
+    }
+    if (RICHARDS) {
+        const NF Kf_lo = t.Kf_lo;
+        const NF Kf_up = shfl_up1<NF, LPC>(Kf_lo), Kf_dn = shfl_dn1<NF, LPC>(Kf_lo), psi_sh = shfl_up1<NF, LPC>(c.psi);
+        const NF Kf_m = is_bot ? NF(0) : Kf_up;
+        const NF Kf_p = is_top ? Kc : Kf_dn;
+        const NF psi_m = is_bot ? psi_hb : psi_sh;
+        const NF g_lo = (c.psi - psi_m) * L.rdzf_lo;
+        const NF Ks_lo = upwind_conductivity(g_lo, Kf_m, Kf_lo, Kf_p);
+        const NF qW_lo = -Ks_lo * g_lo;
+        const NF qW_sh = shfl_dn1<NF, LPC>(qW_lo);
+        const NF g_t = (psi_ht - c.psi) * L.rdzf_hi;
+        const NF Ks_t = upwind_conductivity(g_t, Kf_lo, Kc, NF(0));
+        const NF qW_t = -Ks_t * g_t;
+        const NF qW_hi = is_top ? qW_t : qW_sh;
+        const NF F_user = vb.Fvwc ? ldg(vb.Fvwc, cb) : p.vwc_forcing;
+        const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + F_user;
+        t.gS = NF(0) + div_const(dtheta, p.por, p.rpor);
+    }
+    return t;
+}
+
+// One Heun step (heun.jl:37-71) with every boundary kind, both stages on the column in registers: the generic-boundary
+// counterpart of k_column<PROG_HEUN>.  `vs_arg`: the stage's view -- its boundary values are the series evaluated at t + dt
+// where a series feeds them, else the state's.
+template <class NF, bool RICHARDS, int HYD, int LPC>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
+    k_heun_generic(View<NF> v_arg, DevParams<NF> p_arg, View<NF> vs_arg, ColumnArgs<NF> a) {
+    constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+    constexpr unsigned off_vs = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(View<NF>));
+    const View<NF>& v = v_arg;
+    const DevParams<NF>& p = p_arg;
+    constexpr int CPW = 64 / LPC;
+    LaneInfo ln;
+    ln.lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    ln.k = ln.lane % LPC;
+    const int sub = ln.lane / LPC;
+    const int Nz = v.Nz, Nh = (int)v.Nh;
+    ln.is_bot = ln.k == 0;
+    ln.is_top = ln.k == Nz - 1;
+    const LevelGeom<NF> L = level_geom(v, ln.k);
+    const NF dt = a.dt;
+    const int finalize = a.finalize, write_kf = a.write_kf;
+    const bool need_kc = RICHARDS || write_kf;
+    const int i = wave * CPW + sub;
+    const bool colok = i < Nh;
+    ln.act = colok && ln.k < Nz;
+    const int ii = colok ? i : Nh - 1;
+    const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
+    const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);
+    uint32_t viol = 0;
+    bool bad = false;
+    const bool seb = p.seb != 0;
+
+    Cell<NF> c;
+    c.U = ldg(v.U, cb0);
+    c.sat = ldg(v.sat, cb0);
+    c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
+    c.T = ldg(v.T, cb0);
+    c.liq = ldg(v.liq, cb0);
+    // compute_z_bcs! terms of the STATE (both explicit steps use them: the stage's clock is still t for its predictor)
+    ColumnBC<NF> bc{};
+    {
+        NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
+        if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib0), v.g);
+        if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib0), v.g);
+        if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib0), v.g);
+        if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
+            const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
+            eS_t = -flux_term_top(seb ? -fS : fS, v.g);
+        }
+        bc.flux_U = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
+        bc.flux_S = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
+    }
+    // stage 1
+    const Tendency<NF> t = column_tendencies_generic<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, ii, cb0, need_kc, viol);
+    NF gU = t.gU, gS = t.gS, z0s, z0;
+    Cell<NF> s, n;
+    const NF over_stage = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, s, z0s, bad);
+    column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0s, s, viol);
+    // stage 2: tendencies at the stage with the stage's boundary values
+    uint32_t viol_stage = 0;
+    const Tendency<NF> t2 = column_tendencies_generic<NF, RICHARDS, HYD, LPC>(kernarg_reload<View<NF>>(off_vs), kernarg_reload<DevParams<NF>>(off_p), L, ln, s, ii, cb0, RICHARDS, viol_stage);
+    viol |= viol_stage;
+    gU = (t.gU + t2.gU) / NF(2);
+    gS = RICHARDS ? (t.gS + t2.gS) / NF(2) : NF(0);
+    const NF over = column_advance<NF, RICHARDS, LPC>(kernarg_reload<View<NF>>(0), L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
+    column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
+
+    NF Kf_out = t.Kf_lo, Kf_out_top = t.Kc;
+    if (finalize && write_kf) {
+        const DevParams<NF>& pf = kernarg_reload<DevParams<NF>>(off_p);
+        const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(pf, n.liq, fractions(pf, n.sat, n.liq, viol));
+        const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
+        const NF Kmin_new = jl_min(Kc_new, Kc_new_m);
+        Kf_out = (ln.is_bot || ln.is_top) ? Kc_new : Kmin_new;
+        Kf_out_top = Kc_new;
+    }
+    if (ln.act) {
+        const View<NF>& vo = kernarg_reload<View<NF>>(0);
+        const unsigned cb = block_local(cb0), ib = block_local(ib0);
+        stg(vo.U, cb, n.U);
+        stg(vo.T, cb, n.T);
+        stg(vo.liq, cb, n.liq);
+        if (RICHARDS) { stg(vo.sat, cb, n.sat); stg(vo.psi, cb, n.psi); }
+        if (finalize) {
+            stg(vo.G_U, cb, gU);
+            if (RICHARDS) stg(vo.G_sat, cb, gS);
+        }
+        if (write_kf) {
+            stg(vo.Kf, cb, Kf_out);
+            if (ln.is_top) stg(vo.Kf_top, ib, Kf_out_top);
+        }
+        if (ln.is_top) {
+            if (RICHARDS) {
+                NF S = ldg(vo.S, ib);
+                NF GS = NF(0) + jl_min(NF(0), S);
+                const NF S_stage = (S + GS * dt) + over_stage;
+                GS = (GS + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
+                S = (S + GS * dt) + over;
+                stg(vo.S, ib, S);
+                stg(vo.wt, ib, z0);
+                if (finalize) stg(vo.G_S, ib, GS);
+            }
+            if (seb) {
+                stg(vo.top_T, ib, n.T);
+                stg(vo.top_sat, ib, n.sat);
+                stg(vo.top_liq, ib, n.liq);
+                stg(vo.Ts, ib, ldg(vo.Ts, ib) + NF(0) * dt);
+            }
+        }
+        viol |= bad ? 1u : 0u;
+    }
+    if (viol && ln.act) atomicOr(v_arg.status, viol);
+}
+
 }  // namespace trm

@@ -234,6 +234,35 @@ def test_partly_filled_lane_groups(config, dtype, Nz):
     assert_fields_match(dev, orc, W.compared_fields(w), exact, tol, f"Nz={Nz} heun ")
 
 
+def test_bc_kinds_heun_parity():
+    """Heun with the generic boundary kinds runs in one launch per step as well (k_heun_generic): against the oracle and the
+    reference-order kernels bit for bit, with a gradient condition that is a time series (the stage takes it at t + dt)."""
+    lat, lon = small_columns(75)
+    w = W.make_workload("richards", lat, lon, 20)
+    rng = np.random.default_rng(11)
+    w["bcs"] = {
+        ("temperature", "top"): ("value", w["T0"] + 2.0),
+        ("temperature", "bottom"): ("gradient", np.full(75, 0.02)),
+        ("internal_energy", "bottom"): ("flux", np.full(75, 0.05)),
+        ("saturation_water_ice", "top"): ("flux", -1.0e-8 * rng.random(75)),
+        ("pressure_head", "bottom"): ("gradient", 0.0),                        # FreeDrainage()
+    }
+    times = np.array([0.0, 100.0, 250.0, 1000.0])
+    grad = rng.uniform(-0.05, 0.05, (4, 75))
+    orc, dev, ref = W.setup_oracle(w), W.setup_device(w), W.setup_device(w)
+    ref.set_option("step_kernel", "unfused")
+    for t in (orc, dev, ref):
+        t.set_bc_series("liquid_water_fraction", "top", "gradient", times, grad)
+    for n in range(9):
+        orc.timestep_heun(w["dt"], n == 8)
+    dev.step_heun(w["dt"], 9, True)
+    ref.step_heun(w["dt"], 9, True)
+    assert_fields_match(dev, orc, W.compared_fields(w), True, 0.0, "heun generic bcs ")
+    for n in W.compared_fields(w) + ["tend_internal_energy", "tend_saturation_water_ice"]:
+        assert np.array_equal(dev.get(n), ref.get(n), equal_nan=True), n
+    assert dev.clock() == ref.clock()
+
+
 @pytest.mark.parametrize("params", [dict(swrc=1, unsat_k=1, vg_alpha=1.3, vg_n=1.7), dict(swrc=1, unsat_k=1, vg_alpha=2.0, vg_n=3.0),
                                     dict(swrc=1, unsat_k=0, vg_alpha=2.0, vg_n=2.0), dict(swrc=0, unsat_k=1, vg_alpha=2.0, vg_n=2.0)])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
