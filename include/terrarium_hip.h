@@ -358,8 +358,9 @@ int trm_invclosure(trm_ctx* ctx);
  * TRM_FIELD_TEND_* field fail with TRM_ESTALE until trm_update_state(ctx, 1), trm_reset_tendencies or a finalizing
  * step has run.  TRM_KERNEL_UNFUSED materialises them at every step. */
 int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
-/* Same for Heun (heun.jl:37-71): with TRM_KERNEL_FUSED ONE launch per step (both stages on the column held in
- * registers; the stage never touches memory), otherwise the reference-order kernels on a second copy of the state. */
+/* Same for Heun (heun.jl:37-71): with TRM_KERNEL_FUSED and Nz <= 64 ONE launch per step (both stages on the column held in
+ * registers; the stage never touches memory; every boundary kind), four for TRM_VEGETATION_COUPLED; otherwise the
+ * reference-order kernels on a second copy of the state. */
 int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
 int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);
