@@ -21,7 +21,8 @@ from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapac
                      ImplicitSkinTemperature, SurfaceEnergyBalance, ConstantAerodynamics, PrescribedAtmosphere,
                      DirectSurfaceRunoff, BareGroundEvaporation, ConstantEvaporationResistanceFactor, SoilMoistureResistanceFactor,
                      SurfaceHydrology, NoCanopyInterception, PALADYNCanopyInterception, PALADYNCanopyEvapotranspiration, DefaultInitializer,
-                     ConstantSoilTemperature, QuasiThermalSteadyState, ConstantSaturation, SaturationWaterTable,
+                     ConstantSoilTemperature, QuasiThermalSteadyState, PiecewiseLinearInitialSoilTemperature, piecewise_linear,
+                     ConstantSaturation, SaturationWaterTable,
                      SoilInitializer, SoilModel, LandModel, flatten, LUEPhotosynthesis, MedlynStomatalConductance,
                      PALADYNAutotrophicRespiration, PALADYNPhenology, PALADYNCarbonDynamics, PALADYNVegetationDynamics,
                      StaticExponentialRootDistribution, FieldCapacityLimitedPAW, VegetationCarbon, VegetationModel, flatten_vegetation)

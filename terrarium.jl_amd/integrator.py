@@ -432,6 +432,8 @@ def _apply_model_initializer(state: DeviceState, model):
         state.set("temperature", en.T0)
     elif isinstance(en, M.QuasiThermalSteadyState):
         state.set("temperature", en.T0 - en.Qgeo / en.k_eff * zc)
+    elif isinstance(en, M.PiecewiseLinearInitialSoilTemperature):
+        state.set("temperature", M.piecewise_linear(*en.knots)(zc))
 
 
 def initialize(model, timestepper=None, boundary_conditions=None, initializers=None, inputs=None) -> ModelIntegrator:

@@ -2,6 +2,7 @@
 `@kwdef` parameter structs on the SoilModel hot path.  They
 hold no arrays; `flatten()` turns a model into the flat `trm_params` POD of
 include/terrarium_hip.h.  Names and defaults follow the reference."""
+import numpy as np
 from dataclasses import dataclass, field
 from typing import Optional, Union
 
@@ -326,6 +327,26 @@ class QuasiThermalSteadyState:
     T0: float = 0.0
     Qgeo: float = 0.02
     k_eff: float = 1.0
+
+
+def piecewise_linear(*knots):
+    """piecewise_linear(knots...) (src/utils/interpolation_utils.jl:6-14): f(z) linear between the (z, value) knots, given with
+    z in DESCENDING order, flat beyond the ends."""
+    zs = [float(k[0]) for k in knots]
+    ys = [float(k[1]) for k in knots]
+    if any(b > a for a, b in zip(zs, zs[1:])):
+        raise ValueError("depths must be sorted in descending order")
+    zr, yr = np.array(zs[::-1]), np.array(ys[::-1])
+    return lambda z: np.interp(z, zr, yr)
+
+
+@dataclass
+class PiecewiseLinearInitialSoilTemperature:
+    """soil_model_init.jl:86-114: temperature (degC) from (depth, value) knots, z in descending order."""
+    knots: tuple = ()
+
+    def __init__(self, *knots):
+        self.knots = tuple(knots[0]) if len(knots) == 1 and knots and isinstance(knots[0][0], (tuple, list)) else tuple(knots)
 
 
 @dataclass

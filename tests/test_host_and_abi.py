@@ -181,3 +181,14 @@ def test_python_constants_match_the_header():
     names = [n.strip() for decl in re.findall(r"double([^;]+);", body) for n in decl.split(",")]
     assert names == list(_capi.VEG_PARAM_NAMES) == [f[0] for f in oracle.VegParamsD._fields_]
     assert int(re.search(r"#define TRM_ABI_VERSION (\d+)", header).group(1)) == _capi.lib().trm_abi_version()
+
+
+# test/utils.jl:50-59 (piecewise_linear) and soil_model_init.jl:86-114
+def test_piecewise_linear_initializer():
+    f = trm.piecewise_linear((1.0, 1.0), (0.0, -1.0), (-2.0, -2.0))
+    assert f(2.0) == pytest.approx(1.0) and f(1.0) == pytest.approx(1.0) and f(0.5) == pytest.approx(0.0)
+    assert f(-1.0) == pytest.approx(-1.5) and f(-3.0) == pytest.approx(-2.0)
+    with pytest.raises(ValueError):
+        trm.piecewise_linear((0.0, 1.0), (1.0, 2.0))
+    init = trm.PiecewiseLinearInitialSoilTemperature((0.0, 5.0), (-0.5, 2.0), (-1.0, 1.0), (-10.0, 1.5))
+    assert init.knots[1] == (-0.5, 2.0)
