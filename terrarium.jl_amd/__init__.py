@@ -14,7 +14,7 @@ from . import masks
 from . import parallel
 from . import _capi
 from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapacities, SoilThermalProperties,
-                     SoilEnergyBalance, ConstantSoilPorosity, HomogeneousStratigraphy, ConstantSoilCarbonDensity,
+                     SoilEnergyBalance, ConstantSoilPorosity, SoilPorositySURFEX, HomogeneousStratigraphy, ConstantSoilCarbonDensity,
                      BrooksCorey, VanGenuchten, UnsatKLinear, UnsatKVanGenuchten, ConstantSoilHydraulics,
                      SoilHydraulicsSURFEX, SoilTexture, NoFlow, RichardsEq, SoilHydrology, SoilEnergyWaterCarbon, ConstantAlbedo,
                      PrescribedAlbedo,

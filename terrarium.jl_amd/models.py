@@ -72,6 +72,19 @@ class ConstantSoilPorosity:
 
 
 @dataclass
+class SoilPorositySURFEX:
+    """soil_porosity.jl:30-50 (Noilhan & Mahfouf 1996): mineral porosity = porosity_default + porosity_sand_coef * sand.
+    (The reference's `organic_porosity` method for this type reads an undefined variable, soil_porosity.jl:43, so the type
+    cannot be evaluated there; the evident intent -- `porosity_organic` -- is what `flatten` uses.)"""
+    porosity_default: float = 0.49
+    porosity_sand_coef: float = -0.11
+    porosity_organic: float = 0.9
+
+    def mineral(self, texture):
+        return self.porosity_default + self.porosity_sand_coef * texture.sand
+
+
+@dataclass
 class SoilTexture:
     """src/processes/soil/stratigraphy/soil_texture.jl:6-20: fractional mixture of sand, silt and clay."""
     sand: float = 1.0
@@ -91,7 +104,7 @@ class SoilTexture:
 @dataclass
 class HomogeneousStratigraphy:
     """homogeneous_strat.jl:9-15 (the texture only matters to SURFEX field capacity / wilting point, off the step path)."""
-    porosity: ConstantSoilPorosity = field(default_factory=ConstantSoilPorosity)
+    porosity: Union[ConstantSoilPorosity, "SoilPorositySURFEX"] = field(default_factory=ConstantSoilPorosity)
     texture: SoilTexture = field(default_factory=SoilTexture)
 
 
@@ -538,8 +551,12 @@ def flatten(model) -> "_capi.TrmParams":
     k, h = soil.energy.thermal_properties.conductivities, soil.energy.thermal_properties.heat_capacities
     p.k_water, p.k_ice, p.k_air, p.k_mineral, p.k_organic = k.water, k.ice, k.air, k.mineral, k.organic
     p.c_water, p.c_ice, p.c_air, p.c_mineral, p.c_organic = h.water, h.ice, h.air, h.mineral, h.organic
-    p.por_mineral = soil.strat.porosity.mineral_porosity
-    p.por_organic = soil.strat.porosity.organic_porosity
+    if isinstance(soil.strat.porosity, SoilPorositySURFEX):
+        p.por_mineral = soil.strat.porosity.mineral(soil.strat.texture)
+        p.por_organic = soil.strat.porosity.porosity_organic
+    else:
+        p.por_mineral = soil.strat.porosity.mineral_porosity
+        p.por_organic = soil.strat.porosity.organic_porosity
     p.rho_soc, p.rho_org = soil.biogeochem.rho_soc, soil.biogeochem.rho_org
     hyd = soil.hydrology
     hp = hyd.hydraulic_properties

@@ -192,3 +192,11 @@ def test_piecewise_linear_initializer():
         trm.piecewise_linear((0.0, 1.0), (1.0, 2.0))
     init = trm.PiecewiseLinearInitialSoilTemperature((0.0, 5.0), (-0.5, 2.0), (-1.0, 1.0), (-10.0, 1.5))
     assert init.knots[1] == (-0.5, 2.0)
+
+
+# soil_porosity.jl:30-50
+def test_soil_porosity_surfex():
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10))
+    strat = trm.HomogeneousStratigraphy(porosity=trm.SoilPorositySURFEX(), texture=trm.SoilTexture(sand=0.4, clay=0.2))
+    p = trm.flatten(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(strat=strat)))
+    assert p.por_mineral == 0.49 + (-0.11) * 0.4 and p.por_organic == 0.9
