@@ -532,3 +532,47 @@ def compute_tendencies(state: DeviceState, model=None): state.compute_tendencies
 def closure(state: DeviceState, model=None): state.closure()
 def invclosure(state: DeviceState, model=None): state.invclosure()
 def update_state(integ: ModelIntegrator, compute_tendencies=True): integ.state.update_state(compute_tendencies)
+
+
+# ---- the small interface functions the reference exports (src/timesteppers/*.jl, model_integrator.jl:39-66, grids) ----------
+def default_dt(timestepper) -> float:
+    """default_dt(timestepper) (forward_euler.jl:13, heun.jl:16)"""
+    return float(timestepper.dt)
+
+
+def is_adaptive(timestepper) -> bool:
+    """is_adaptive(timestepper) (forward_euler.jl:15, heun.jl:18): both explicit steppers use a fixed step."""
+    return False
+
+
+def iteration(integ: ModelIntegrator) -> int:
+    """Oceananigans.Solvers.iteration(integrator) (model_integrator.jl:55)"""
+    return int(integ.state.clock()[1])
+
+
+def time_step(integ: ModelIntegrator, dt: Optional[float] = None, **kwargs):
+    """Oceananigans.TimeSteppers.time_step!(integrator, dt) = timestep!(integrator, dt) (model_integrator.jl:62-64)"""
+    return timestep(integ, dt)
+
+
+def reset(integ: ModelIntegrator):
+    """initialize!(integrator) (model_integrator.jl:96-109): clock back to zero, inputs, initializers, process initialisers."""
+    return initialize_integrator(integ)
+
+
+def get_grid(model):
+    return model.grid
+
+
+def znodes(obj, location="center") -> np.ndarray:
+    """znodes(field) / znodes(grid, Center() | Face()): the vertical coordinates, bottom cell first (negative downwards)."""
+    grid = getattr(obj, "grid", obj)
+    grid = getattr(grid, "grid", grid) if not hasattr(grid, "z_centers") else grid
+    return grid.z_faces() if str(location).lower().startswith("f") else grid.z_centers()
+
+
+def zspacings(obj) -> np.ndarray:
+    """zspacings(grid, Center()): the layer thicknesses, bottom cell first."""
+    grid = getattr(obj, "grid", obj)
+    grid = getattr(grid, "grid", grid) if not hasattr(grid, "thickness") else grid
+    return np.asarray(grid.thickness, dtype=np.float64)[::-1].copy()

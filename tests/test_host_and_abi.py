@@ -200,3 +200,12 @@ def test_soil_porosity_surfex():
     strat = trm.HomogeneousStratigraphy(porosity=trm.SoilPorositySURFEX(), texture=trm.SoilTexture(sand=0.4, clay=0.2))
     p = trm.flatten(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(strat=strat)))
     assert p.por_mineral == 0.49 + (-0.11) * 0.4 and p.por_organic == 0.9
+
+
+def test_exported_interface_helpers():
+    """default_dt / is_adaptive (forward_euler.jl:13-15, heun.jl:16-18), znodes / zspacings of the column grid."""
+    g = trm.ColumnGrid(trm.ExponentialSpacing(N=5))
+    assert trm.default_dt(trm.ForwardEuler()) == 300.0 == trm.default_dt(trm.Heun()) and not trm.is_adaptive(trm.Heun())
+    zc, zf, dz = trm.znodes(g), trm.znodes(g, "face"), trm.zspacings(g)
+    assert zf[-1] == 0.0 and np.all(np.diff(zf) > 0) and np.allclose(np.diff(zf), dz) and np.allclose(zc, (zf[1:] + zf[:-1]) / 2)
+    assert trm.get_grid(trm.SoilModel(g)) is g
