@@ -551,3 +551,18 @@ def test_example_coupled_dry_land_zero_copy_exchange():
     integ.state.set_bc_series("temperature", "top", "value", [0.0, 1.0e6], np.zeros((2, grid.num_columns)))
     with pytest.raises(trm.TerrariumHipError):
         integ.state.bc_device_array("temperature", "top")
+
+
+def test_integrator_interface_helpers():
+    """iteration / time_step / reset (model_integrator.jl:55-64,96-109): reset returns the state to what initialize gave."""
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=12), 7)
+    integ = trm.initialize(trm.SoilModel(grid, initializer=trm.SoilInitializer()), trm.ForwardEuler(dt=120.0),
+                           boundary_conditions=trm.merge_boundary_conditions(trm.PrescribedSurfaceTemperature("T_ub", 3.0)))
+    T0, U0 = integ.state.temperature, integ.state.internal_energy
+    for _ in range(5):
+        trm.time_step(integ)
+    assert trm.iteration(integ) == 5 and trm.current_time(integ) == 600.0
+    assert not np.array_equal(integ.state.temperature, T0)
+    trm.reset(integ)
+    assert trm.iteration(integ) == 0 and trm.current_time(integ) == 0.0
+    assert np.array_equal(integ.state.temperature, T0) and np.array_equal(integ.state.internal_energy, U0)
