@@ -194,6 +194,16 @@ def test_piecewise_linear_initializer():
     assert init.knots[1] == (-0.5, 2.0)
 
 
+# test/soil/soil_stratigrapy_tests.jl:4-19
+def test_soil_porosity_surfex_reference_test():
+    porosity = trm.SoilPorositySURFEX()
+    por0 = porosity.mineral(trm.SoilTexture(sand=0.0, silt=0.7, clay=0.3))
+    assert por0 == pytest.approx(porosity.porosity_default)
+    for sand in np.arange(0.1, 1.01, 0.1):
+        por = porosity.mineral(trm.SoilTexture(sand=sand, silt=(1 - sand) * 0.7, clay=(1 - sand) * 0.3))
+        assert 0 < por < por0
+
+
 # soil_porosity.jl:30-50
 def test_soil_porosity_surfex():
     grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10))
