@@ -200,6 +200,9 @@ def main():
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the HBM-resident companion measurements (c3x8, c5)")
     ap.add_argument("--multistep", type=int, default=50, help="also time the resident-column multi-step kernel with this many steps per launch (temporal blocking; reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2], help="TRM_OPT_PIPELINE_PARTS (default: the library's auto rule)")
+    ap.add_argument("--steps-per-launch", type=int, default=1, help="TRM_OPT_STEPS_PER_LAUNCH of the measured context: 1 (default) = one launch per step, the state streams "
+                    "through memory every step -- the per-step HBM roofline; 0 = the library's own choice (what a plain run! gets)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -240,6 +243,9 @@ def main():
 
     dev = W.setup_device(w, device=local_rank)
     dev.set_option("step_kernel", args.kernel)
+    dev.set_option("steps_per_launch", args.steps_per_launch)
+    if args.pipeline is not None:
+        dev.set_option("pipeline_parts", args.pipeline)
     if args.series:
         # the SURVEY 8(d) diurnal cycle sampled every 10 minutes over the run, linear in between
         DAY = 86400.0
@@ -361,6 +367,9 @@ def hbm_resident_leg(W, parallel, args, sync, device):
         w, desc, config, Nz, dt_name = build_workload(W, parallel, name, 1, 0, "weak")
         wordsize = 8 if dt_name == "f64" else 4
         dev = W.setup_device(w, device=device)
+        dev.set_option("steps_per_launch", 1)
+        if args.pipeline is not None:
+            dev.set_option("pipeline_parts", args.pipeline)
         elapsed, ms, warm, _ = run_timed(dev, w, config, steps, 5, min(args.spinup_ms, 100.0), False, sync)
         status = dev.status()
         dev.close()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 11
+#define TRM_ABI_VERSION 12
 
 typedef struct trm_ctx trm_ctx;
 
@@ -167,10 +167,18 @@ enum {
                                     /* less, bit-identical results.  0: never; 1: whenever legal; 2 (default): for fp64 states  */
                                     /* beyond the 256 MiB Infinity Cache, and for the reference-default hydraulics / heat-only  */
                                     /* on grids of >= 24 576 columns: where it was measured to win                */
-    TRM_OPT_STEPS_PER_LAUNCH = 6    /* m >= 1 (default 1): trm_step keeps every column in registers for up to m steps per   */
-                                    /* launch and writes the fields once per launch (temporal blocking of run!'s loop;     */
-                                    /* bit-identical to m = 1).  Applies while no time series is attached and the boundary  */
-                                    /* kinds are the branch-free ones; otherwise one step per launch as usual               */
+    TRM_OPT_STEPS_PER_LAUNCH = 6,   /* trm_step keeps every column in registers for up to m steps per launch and writes the */
+                                    /* fields once per launch (temporal blocking of run!'s loop, model_integrator.jl:72-88;  */
+                                    /* bit-identical to m = 1).  0 (default): the library chooses -- 50 wherever the program  */
+                                    /* is legal (branch-free boundary kinds, constants or device-resident series the program  */
+                                    /* interpolates itself, no coupled vegetation), except fp32 contexts on the packed        */
+                                    /* two-columns-per-lane kernel; 1: one launch per step (state streams through memory      */
+                                    /* every step: what bench.py's headline measures); m > 1: explicit                        */
+    TRM_OPT_PIPELINE_PARTS = 7      /* LandModel contexts, one launch pair per step (surface processes, soil columns): the   */
+                                    /* columns are dealt to two internal streams so that the latency-bound surface launch of  */
+                                    /* one half runs under the column launch of the other (columns are independent; results   */
+                                    /* are bit-identical).  0: off; 1: whenever a call makes >= 2 such steps; 2 (default):    */
+                                    /* the same for contexts of >= 32 768 columns                                             */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

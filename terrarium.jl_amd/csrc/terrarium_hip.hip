@@ -77,7 +77,16 @@ struct trm_ctx {
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
-    int opt_derive = 2, opt_steps_per_launch = 1;
+    int opt_derive = 2;
+    int opt_steps_per_launch = 0;   // 0: chosen by the library (auto_steps_per_launch), 1: one launch per step, m > 1: up to m steps per launch
+    // Two-part pipeline of the per-step LandModel path (TRM_OPT_PIPELINE_PARTS): the columns are dealt to two internal streams,
+    // each running its own chain of (surface launch, column launch) per step; the latency-bound 0-D surface launch of one part
+    // runs under the column launch of the other.  Columns are independent, so the parts never synchronise inside a call.
+    int opt_pipeline = 2;           // 0: off, 1: whenever legal, 2: auto (column threshold)
+    int part = -1;                  // part the launch helpers currently address (-1: all columns)
+    long part_lo[2] = {0, 0}, part_n[2] = {0, 0};
+    hipStream_t pipe_stream[2] = {nullptr, nullptr};
+    hipEvent_t pipe_fork = nullptr, pipe_join[2] = {nullptr, nullptr}, pipe_stagger = nullptr;
     // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
     // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
     // `args_valid` and the next launch rebuilds them.
@@ -323,13 +332,38 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     return v;
 }
 
+// The view of columns [lo, lo + n) of `v`: every per-column / per-cell pointer advanced, the per-level tables shared.
+// (3-D fields are [Nh][Nzp], 2-D fields and boundary value arrays [Nh]; top_* are three [Nh] rows of one buffer.)
+template <class NF> View<NF> sub_view(const View<NF>& v, long lo, long n) {
+    View<NF> s = v;
+    s.Nh = n;
+    const long c3 = lo * v.Nzp;
+    auto p3 = [&](NF*& q) { if (q) q += c3; };
+    auto p2 = [&](NF*& q) { if (q) q += lo; };
+    auto c2 = [&](const NF*& q) { if (q) q += lo; };
+    p3(s.U); p3(s.sat); p3(s.T); p3(s.liq); p3(s.psi); p3(s.Kf); p3(s.G_U); p3(s.G_sat);
+    if (s.Fvwc) s.Fvwc += c3;
+    p2(s.S); p2(s.wt); p2(s.Kf_top); p2(s.G_S);
+    p2(s.Ts); p2(s.ghf); p2(s.infil); p2(s.swu); p2(s.lwu); p2(s.rnet); p2(s.Hs); p2(s.Hl); p2(s.evap); p2(s.runoff);
+    p2(s.top_T); p2(s.top_sat); p2(s.top_liq);
+    c2(s.Tair); c2(s.pres); c2(s.wind); c2(s.qair); c2(s.rain); c2(s.swd); c2(s.lwd); c2(s.albedo); c2(s.emissivity);
+    for (int a = 0; a < TRM_BCV_COUNT; ++a)
+        for (int b = 0; b < 2; ++b)
+            if (s.bc.value[a][b]) s.bc.value[a][b] = (const NF*)s.bc.value[a][b] + lo;
+    return s;
+}
+
 template <class NF> struct StageView { const NF *bcT_bot, *bcT_top; };
 template <class NF> StageView<NF> make_stage_view(const trm_ctx* c);
 template <class NF> struct LaunchArgs {
     DevParams<NF> p;
     View<NF> state, stage;
+    View<NF> part[2];   // the state's view restricted to the two pipeline parts
     StageView<NF> w;
 };
+// columns the launch helpers currently address: all of them, or one pipeline part
+long ncols(const trm_ctx* c) { return c->part >= 0 ? c->part_n[c->part] : c->Nh; }
+long first_col(const trm_ctx* c) { return c->part >= 0 ? c->part_lo[c->part] : 0; }
 template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
     if (!c->args) {
         c->args = new LaunchArgs<NF>();
@@ -340,6 +374,7 @@ template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
         a->p = make_dev_params<NF>(c->params);
         a->state = make_view<NF>(c, c->state);
         a->stage = make_view<NF>(c, c->stage);
+        for (int q = 0; q < 2; ++q) a->part[q] = sub_view<NF>(a->state, c->part_lo[q], c->part_n[q]);
         a->w = make_stage_view<NF>(c);
         c->args_valid = true;
     }
@@ -347,16 +382,28 @@ template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
 }
 template <class NF> const View<NF>& cached_view(trm_ctx* c, const FieldSet& s) {
     const LaunchArgs<NF>& a = launch_args<NF>(c);
-    return &s == &c->stage ? a.stage : a.state;
+    if (&s == &c->stage) return a.stage;
+    return c->part >= 0 ? a.part[c->part] : a.state;
 }
+// the state's view as the step launches see it (one pipeline part, or everything)
+template <class NF> const View<NF>& state_view(trm_ctx* c) { return cached_view<NF>(c, c->state); }
 
 dim3 cell_grid(const trm_ctx* c, long /*rows*/ = 0) { return dim3((unsigned)(((size_t)c->Nh * c->Nzp + 255) / 256), 1, 1); }
-dim3 col_grid(const trm_ctx* c) { return dim3((unsigned)((c->Nh + 255) / 256), 1, 1); }
+dim3 col_grid(const trm_ctx* c) { return dim3((unsigned)((ncols(c) + 255) / 256), 1, 1); }
 // lane = level kernels: one column per LPC lanes, 4 waves per workgroup
 dim3 wave_grid(const trm_ctx* c, int lpc) {
-    long waves = (c->Nh + (64 / lpc) - 1) / (64 / lpc);
+    long waves = (ncols(c) + (64 / lpc) - 1) / (64 / lpc);
     return dim3((unsigned)((waves + 3) / 4), 1, 1);
 }
+// addresses one pipeline part (its columns, its stream) for the lifetime of the scope
+struct PartScope {
+    trm_ctx* c;
+    hipStream_t stream;
+    PartScope(trm_ctx* ctx, int q) : c(ctx), stream(ctx->stream) {
+        if (q >= 0) { c->part = q; c->stream = c->pipe_stream[q]; }
+    }
+    ~PartScope() { c->part = -1; c->stream = stream; }
+};
 
 // Time interpolation indices of a series at time t -- Oceananigans' FieldTimeSeries indexing (Linear / Clamp /
 // Cyclical), restated; that package is not part of the reference tree (parity unpinned).
@@ -443,7 +490,7 @@ template <class NF> struct Ops {
         int nj = 0;
         auto flush = [&]() -> int {
             if (nj == 0) return TRM_OK;
-            hipLaunchKernelGGL(k_interp_series<NF>, dim3((unsigned)((c->Nh + 255) / 256), (unsigned)nj), dim3(256), 0, c->stream, jobs, c->Nh);
+            hipLaunchKernelGGL(k_interp_series<NF>, dim3((unsigned)((ncols(c) + 255) / 256), (unsigned)nj), dim3(256), 0, c->stream, jobs, ncols(c));
             TRM_HIP(c, hipGetLastError());
             nj = 0;
             return TRM_OK;
@@ -464,7 +511,8 @@ template <class NF> struct Ops {
             } else {
                 dst = (NF*)s.f[sr.field];
             }
-            const NF* base = (const NF*)sr.d_values;
+            const NF* base = (const NF*)sr.d_values + first_col(c);   // (a pipeline part evaluates its own columns)
+            dst += first_col(c);
             jobs.job[nj++] = SeriesJob<NF>{dst, base + (size_t)n1 * c->Nh, base + (size_t)n2 * c->Nh, f, g, sr.indexing == TRM_TIME_RASTER ? 1 : 0};
             if (nj == 16) { int rc = flush(); if (rc) return rc; }
         }
@@ -668,6 +716,16 @@ template <class NF> struct Ops {
         v.E_can = G(TRM_FIELD_EVAPORATION_CANOPY); v.transp = G(TRM_FIELD_TRANSPIRATION); v.SAI = G(TRM_FIELD_STEM_AREA_INDEX);
         v.paw = F(TRM_FIELD_PLANT_AVAILABLE_WATER);
         v.rootf = (const NF*)c->d_rootf;   // static: one copy serves the stage as well
+        if (c->part >= 0 && &s == &c->state) {   // one pipeline part: columns [lo, lo + n)
+            const long lo = first_col(c);
+            v.Nh = ncols(c);
+            for (NF** q : {&v.C_veg, &v.nu, &v.G_C_veg, &v.G_nu, &v.LAI_b, &v.phen, &v.LAI, &v.gw_can, &v.lambda_c, &v.An, &v.Rd, &v.GPP, &v.Ra, &v.NPP,
+                           &v.w_can, &v.G_w_can, &v.I_can, &v.R_can, &v.f_can, &v.rain_ground, &v.E_can, &v.transp})
+                if (*q) *q += lo;
+            for (const NF** q : {&v.Tair, &v.pres, &v.qair, &v.swd, &v.CO2, &v.smlf, &v.daily_Rd, &v.Tground, &v.SAI})
+                if (*q) *q += lo * (q == &v.Tground ? v.Tground_stride : 1);
+            if (v.paw) v.paw += lo * c->Nzp;
+        }
         return v;
     }
     // the 0-D part of the coupled LandModel's compute_auxiliary! (+ tendencies and explicit step of the 0-D prognostics)
@@ -684,7 +742,7 @@ template <class NF> struct Ops {
     static int surface_veg_launch(trm_ctx* c, const View<NF>& v, const VegView<NF>& vv, const SurfaceVegArgs<NF>& a) {
         const DevParams<NF>& p = launch_args<NF>(c).p;
         const VegDev<NF> vp = veg_dev(c);
-        const dim3 blocks((unsigned)((c->Nh + 63) / 64));   // 64 columns per 256-thread workgroup
+        const dim3 blocks((unsigned)((ncols(c) + 63) / 64));   // 64 columns per 256-thread workgroup
         // (the kernel is bound by cold instruction fetch: the hydraulics of the top-face conductivity are compiled in)
         if (c->Nzp == 32) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, 32, H>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a)); }
         else if (c->Nzp == 64) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, 64, H>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a)); }
@@ -760,7 +818,7 @@ template <class NF> struct Ops {
     // k_step_wave: the generic boundary kinds, Euler
     template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
-        const View<NF>& v = la.state;
+        const View<NF>& v = state_view<NF>(c);
         const DevParams<NF>& p = la.p;
         const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
         hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
@@ -795,11 +853,12 @@ template <class NF> struct Ops {
         if constexpr (std::is_same<NF, float>::value) {
             const LaunchArgs<NF>& la = launch_args<NF>(c);
             const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
-            const long pairs = (c->Nh + 1) / 2;
+            const long pairs = (ncols(c) + 1) / 2;
+            const View<NF>& sv = state_view<NF>(c);
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, (float)dt, finalize, wkf);
-            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, (float)dt, finalize, wkf);
+            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
             TRM_HIP(c, hipGetLastError());
         }
         return TRM_OK;
@@ -880,7 +939,7 @@ template <class NF> struct Ops {
     }
     template <bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
-        const View<NF>& v = la.state;
+        const View<NF>& v = state_view<NF>(c);
         const DevParams<NF>& p = la.p;
         ColumnArgs<NF> a;
         a.dt = (NF)dt;
@@ -949,50 +1008,107 @@ template <class NF> struct Ops {
         if (!rc && finalize) rc = compute_auxiliary(c, c->state);
         return rc;
     }
+    // TRM_OPT_STEPS_PER_LAUNCH = 0: run!'s loop (model_integrator.jl:72-88) is exactly trm_step(ctx, dt, nsteps, 0), so the
+    // resident-column program is what a plain call gets whenever it is legal.  Measured: 1.9-4.4 us per step
+    // against 6.4-12.5 on N72 / 7 119-column shards, 13.6 against 26 at N145.  fp32 contexts whose per-step path is the
+    // packed kernel (two columns per lane) keep it: the program runs the scalar fp32 instructions at the fp64 issue rate.
+    static int auto_steps_per_launch(trm_ctx* c) {
+        if (std::is_same<NF, float>::value && packed_path(c)) return 1;
+        return 50;
+    }
+    // ---- two-part pipeline of the per-step LandModel path -----------------------------------------------------------
+    static bool pipeline_now(const trm_ctx* c, int steps_left) {
+        if (c->opt_pipeline == 0 || steps_left < 2 || c->part_n[1] <= 0) return false;
+        return c->opt_pipeline == 1 || (c->params.seb && c->Nh >= 32768);
+    }
+    static int pipeline_fork(trm_ctx* c) {
+        for (int q = 0; q < 2; ++q)
+            if (!c->pipe_stream[q]) {
+                TRM_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[q], hipStreamNonBlocking));
+                TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_join[q], hipEventDisableTiming));
+            }
+        if (!c->pipe_fork) {
+            TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_fork, hipEventDisableTiming));
+            TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_stagger, hipEventDisableTiming));
+        }
+        TRM_HIP(c, hipEventRecord(c->pipe_fork, c->stream));
+        for (int q = 0; q < 2; ++q) TRM_HIP(c, hipStreamWaitEvent(c->pipe_stream[q], c->pipe_fork, 0));
+        return TRM_OK;
+    }
+    static int pipeline_join(trm_ctx* c) {
+        for (int q = 0; q < 2; ++q) {
+            TRM_HIP(c, hipEventRecord(c->pipe_join[q], c->pipe_stream[q]));
+            TRM_HIP(c, hipStreamWaitEvent(c->stream, c->pipe_join[q], 0));
+        }
+        return TRM_OK;
+    }
+    // One fused ForwardEuler step of the columns the launch helpers currently address: update_inputs!, the 0-D surface
+    // processes as their own small launch in front of the column kernel (LandModel), and once more after it when finalizing.
+    // (+ the 0-D prognostics' step of the coupled vegetation; the per-cell plant_available_water field is materialised with the
+    // other per-cell auxiliaries: by the finalizing launch, or every step under TRM_OPT_WRITE_KF_EVERY_STEP)
+    // stagger: +1 = record the stagger event after the surface launch, -1 = wait for it first (first pipelined step only)
+    static int fused_step(trm_ctx* c, double dt, int fin, int stagger = 0) {
+        if (stagger < 0) TRM_HIP(c, hipStreamWaitEvent(c->stream, c->pipe_stagger, 0));
+        int rc = update_inputs(c, c->state, c->time);
+        if (rc) return rc;
+        if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt, c->opt_write_kf != 0);
+        else if (c->params.seb) rc = surface(c, c->state, true);
+        if (stagger > 0) TRM_HIP(c, hipEventRecord(c->pipe_stagger, c->stream));
+        if (!rc) rc = wave_step(c, dt, fin);
+        c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
+        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+        if (!rc && fin && coupled(c)) rc = surface_veg<true, false>(c, c->state, 0.0);
+        else if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
+        return rc;
+    }
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level to one lane: columns deeper than 64 levels take the reference-order kernels
         const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
-        // Resident-column multi-step program (TRM_OPT_STEPS_PER_LAUNCH > 1): legal when nothing the host evaluates changes
-        // between the steps of a launch -- constants, or device-resident time series the program interpolates itself --
-        // and the branch-free boundary kinds apply.
-        const int spl = (fused && !generic_bcs(c) && series_fit_program(c) && !coupled(c)) ? c->opt_steps_per_launch : 1;
-        int n = 0;
-        while (n < nsteps) {
+        // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
+        // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
+        const bool program_ok = fused && !generic_bcs(c) && series_fit_program(c) && !coupled(c);
+        const int spl = !program_ok ? 1 : (c->opt_steps_per_launch > 0 ? c->opt_steps_per_launch : auto_steps_per_launch(c));
+        bool piped = false, first_piped = false;
+        int n = 0, rc = TRM_OK;
+        while (n < nsteps && !rc) {
             const int m = std::min(spl, nsteps - n);
             const int fin = (finalize && n + m == nsteps) ? 1 : 0;
-            int rc = (m > 1 && !c->series.empty()) ? upload_series_rows(c, dt, m) : update_inputs(c, c->state, c->time);
-            if (rc) return rc;
             if (!fused) {
+                rc = update_inputs(c, c->state, c->time);
                 c->top_valid = false;
                 c->tend_valid = true;
-                rc = unfused_step(c, dt, fin);
+                if (!rc) rc = unfused_step(c, dt, fin);
                 if (!rc) c->closure_consistent = true;   // closure! has just run
             } else if (m > 1) {
-                rc = column_program<PROG_MULTI>(c, dt, fin, m);
+                if (piped) { rc = pipeline_join(c); piped = false; if (rc) break; }
+                rc = c->series.empty() ? update_inputs(c, c->state, c->time) : upload_series_rows(c, dt, m);
+                if (!rc) rc = column_program<PROG_MULTI>(c, dt, fin, m);
                 if (!rc) c->closure_consistent = true;
                 c->tend_valid = fin != 0;
                 c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
+            } else if (piped || pipeline_now(c, nsteps - n)) {
+                if (!piped) { rc = pipeline_fork(c); if (rc) break; piped = first_piped = true; }
+                // every part sees the flags as they stood before this step
+                const bool top0 = c->top_valid, cc0 = c->closure_consistent;
+                for (int q = 0; q < 2 && !rc; ++q) {
+                    PartScope scope(c, q);
+                    c->top_valid = top0;
+                    c->closure_consistent = cc0;
+                    rc = fused_step(c, dt, fin, first_piped ? (q == 0 ? 1 : -1) : 0);
+                }
+                first_piped = false;
             } else {
-                // LandModel: the 0-D surface processes run as their own small launch in front of the fused
-                // column kernel (and once more after it when finalizing)
-                // (+ the 0-D prognostics' step; the per-cell plant_available_water field is materialised with the other
-                // per-cell auxiliaries: by the finalizing launch, or every step under TRM_OPT_WRITE_KF_EVERY_STEP)
-                if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt, c->opt_write_kf != 0);
-                else if (c->params.seb) rc = surface(c, c->state, true);
-                if (!rc) rc = wave_step(c, dt, fin);
-                c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
-                c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
-                if (!rc && fin && coupled(c)) rc = surface_veg<true, false>(c, c->state, 0.0);
-                else if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
+                rc = fused_step(c, dt, fin);
             }
-            if (rc) return rc;
+            if (rc) break;
             for (int j = 0; j < m; ++j) c->time += dt;   // tick! per step: the same sequence of sums as per-step calls
             c->iteration += m;
             n += m;
         }
-        return TRM_OK;
+        if (piped) { const int rj = pipeline_join(c); if (!rc) rc = rj; }
+        return rc;
     }
 
     // ---- Heun (heun.jl:37-71), reference-order kernels on a second copy of the state -----------------
@@ -1484,6 +1600,10 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     c->params = *p;
     c->Az = g->dx > 0 ? g->dx : 1.0 / (double)c->Nh;
     if (c->precision == TRM_F32) c->Az = (double)(float)c->Az;
+    // pipeline parts: two blocks of columns, the seam on a multiple of 64 (whole workgroups of every step kernel)
+    c->part_n[0] = std::min<long>(c->Nh, ((c->Nh / 2 + 63) / 64) * 64);
+    c->part_lo[1] = c->part_n[0];
+    c->part_n[1] = c->Nh - c->part_n[0];
     auto bail = [&](int rc) {
         g_create_error = c->err;
         trm_destroy(c);
@@ -1545,6 +1665,12 @@ int trm_destroy(trm_ctx* c) {
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (int q = 0; q < 2; ++q) {
+        if (c->pipe_stream[q]) { (void)hipStreamSynchronize(c->pipe_stream[q]); (void)hipStreamDestroy(c->pipe_stream[q]); }
+        if (c->pipe_join[q]) (void)hipEventDestroy(c->pipe_join[q]);
+    }
+    if (c->pipe_fork) (void)hipEventDestroy(c->pipe_fork);
+    if (c->pipe_stagger) (void)hipEventDestroy(c->pipe_stagger);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->args && c->args_free) c->args_free(c->args);
     delete c;
@@ -2067,8 +2193,12 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             c->opt_derive = value;
             return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH:
-            if (value < 1 || value > 100000) break;
+            if (value < 0 || value > 100000) break;
             c->opt_steps_per_launch = value;
+            return TRM_OK;
+        case TRM_OPT_PIPELINE_PARTS:
+            if (value < 0 || value > 2) break;
+            c->opt_pipeline = value;
             return TRM_OK;
         default: break;
     }
@@ -2084,6 +2214,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_PACKED_F32: *value = c->opt_packed; return TRM_OK;
         case TRM_OPT_DERIVE_CLOSURE_FIELDS: *value = c->opt_derive; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
+        case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

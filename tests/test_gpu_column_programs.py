@@ -99,12 +99,65 @@ def test_multistep_program_equals_per_step_launches_bitwise(config, hydraulics, 
     w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
     a, b = W.setup_device(w), W.setup_device(w)
     a.set_option("steps_per_launch", m)
+    b.set_option("steps_per_launch", 1)
     for d in (a, b):
         d.set_option("packed_f32", 0)
         d.step(w["dt"], 23, finalize=False)     # 23 = q * m + r: full launches and a shorter last one
         d.step(w["dt"], 10, finalize=True)
     assert a.clock() == b.clock()
     for n in all_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else []):
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status()
+
+
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz", CONFIGS)
+def test_default_steps_per_launch_is_the_resident_program_and_bit_identical(config, hydraulics, dtype, Nz):
+    """TRM_OPT_STEPS_PER_LAUNCH = 0 (the library default): a plain trm_step(ctx, dt, n, fin) -- run!'s loop,
+    model_integrator.jl:72-88 -- takes the resident-column program wherever it is legal (launches of up to 50 steps); same
+    bits, clock, status and tendencies as one launch per step."""
+    lat, lon = small_columns(97)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    a, b = W.setup_device(w, steps_per_launch=0), W.setup_device(w, steps_per_launch=1)
+    assert a.get_option("steps_per_launch") == 0 and trm.DeviceState(a.grid, a.params).get_option("steps_per_launch") == 0
+    for d in (a, b):
+        d.step(w["dt"], 57, finalize=False)     # 50 + 7
+        d.step(w["dt"], 1, finalize=False)
+        d.step(w["dt"], 12, finalize=True)
+    assert a.clock() == b.clock()
+    for n in all_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else []):
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status()
+
+
+PIPELINE_CONFIGS = [("land", "default", np.float64, 32, 131), ("land", "vg", np.float64, 50, 257), ("land", "default", np.float32, 64, 203),
+                    ("land", "vg", np.float32, 40, 129), ("landveg", "vg", np.float64, 32, 200), ("richards", "default", np.float64, 32, 131)]
+
+
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz,Nh", PIPELINE_CONFIGS)
+def test_two_part_pipeline_equals_single_stream_bitwise(config, hydraulics, dtype, Nz, Nh):
+    """TRM_OPT_PIPELINE_PARTS = 1: the per-step LandModel path on two internal streams, half the columns each (the seam on a
+    multiple of 64 columns, ragged second half), with a device-resident forcing series evaluated per part -- same bits as the
+    single-stream path, fields, diagnostics, tendencies, inputs and status."""
+    lat, lon = small_columns(Nh)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("pipeline_parts", 1)
+    b.set_option("pipeline_parts", 0)
+    tt = 600.0 * np.arange(4)
+    ph = 2 * np.pi * tt[:, None] / 86400.0 - w["lon"][None, :]
+    nsteps = 9 if config != "landveg" else 6
+    for d in (a, b):
+        if config != "richards":
+            d.set_forcing_series("air_temperature", tt * (w["dt"] / 60.0), w["T0"][None, :] + 5.0 * np.sin(ph), "linear")
+        else:
+            d.set_bc_series("temperature", "top", "value", tt, w["T0"][None, :] + 10.0 * np.sin(ph), "linear")
+        d.step(w["dt"], nsteps, finalize=False)
+        d.step(w["dt"], 1, finalize=False)       # (a single step never forks)
+        d.step(w["dt"], 3, finalize=True)
+    assert a.clock() == b.clock()
+    names = all_fields(w) + ["tend_internal_energy", "tend_saturation_water_ice", "tend_surface_excess_water"]
+    names += ["air_temperature"] if config != "richards" else []
+    for n in names:
         assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
     assert a.status() == b.status()
 
@@ -138,6 +191,7 @@ def test_multistep_with_time_series_interpolated_in_the_kernel(dtype, m):
     w = W.make_workload("heat", lat, lon, 20, dtype=dtype)
     a, b = W.setup_device(w), W.setup_device(w)
     a.set_option("steps_per_launch", m)
+    b.set_option("steps_per_launch", 1)
     times = np.array([0.0, 2000.0, 5000.0, 9000.0])
     vals = np.stack([w["T0"] + x for x in (0.0, 4.0, -3.0, 1.0)])
     flux = np.stack([np.full(lat.size, x) for x in (0.0, 0.08, 0.02, 0.05)])
@@ -152,6 +206,7 @@ def test_multistep_with_time_series_interpolated_in_the_kernel(dtype, m):
     w = W.make_workload("land", lat, lon, 32, dtype=dtype, hydraulics="default")
     a, b = W.setup_device(w), W.setup_device(w)
     a.set_option("steps_per_launch", m)
+    b.set_option("steps_per_launch", 1)
     tt = 600.0 * np.arange(6)
     ph = 2 * np.pi * tt[:, None] / 86400.0 - w["lon"][None, :]
     for d in (a, b):
@@ -170,6 +225,7 @@ def test_multistep_falls_back_for_generic_boundary_kinds():
     w = W.make_workload("heat", lat, lon, 20)
     a, b = W.setup_device(w), W.setup_device(w)
     a.set_option("steps_per_launch", 10)
+    b.set_option("steps_per_launch", 1)
     for d in (a, b):
         d.set_bc("temperature", "bottom", "gradient", 0.01)
         d.step(w["dt"], 25, finalize=True)

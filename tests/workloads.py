@@ -114,12 +114,16 @@ def setup_oracle(w, omp=False):
     return o
 
 
-def setup_device(w, device=0):
+def setup_device(w, device=0, steps_per_launch=1):
+    """steps_per_launch: TRM_OPT_STEPS_PER_LAUNCH of the context.  The parity tests default to 1 -- one launch per step, so that
+    `step(dt, n)` exercises the per-step kernels -- and cover the library's own default (0: the resident multi-step program
+    wherever it is legal) in tests/test_gpu_column_programs.py and through the host mirror (trm.initialize / trm.run)."""
     p = trm._capi.default_params()
     for k, v in w["params"].items():
         setattr(p, k, v)
     grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(w["thickness"])), w["Nh"], dtype=w["dtype"], device=device)
     d = trm.DeviceState(grid, p)
+    d.set_option("steps_per_launch", steps_per_launch)
     if w.get("vegetation"):     # LandModel(grid; soil, vegetation = VegetationCarbon()) with the default canopy schemes
         d.set_vegetation(trm.flatten_vegetation(trm.VegetationCarbon(), surface_hydrology=trm.SurfaceHydrology.canopy()), "coupled")
     for name, v in w["fields"].items():
