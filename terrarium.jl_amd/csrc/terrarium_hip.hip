@@ -77,7 +77,7 @@ struct trm_ctx {
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
-    int opt_derive = 2;
+    int opt_derive = 2, opt_prefetch = -1;
     int opt_steps_per_launch = 0;   // 0: chosen by the library (auto_steps_per_launch), 1: one launch per step, m > 1: up to m steps per launch
     // Two-part pipeline of the per-step LandModel path (TRM_OPT_PIPELINE_PARTS): the columns are dealt to two internal streams,
     // each running its own chain of (surface launch, column launch) per step; the latency-bound 0-D surface launch of one part
@@ -521,7 +521,11 @@ template <class NF> struct Ops {
 
     // hydraulics specialisation of this context (trm_device.hpp: HYD_*)
     static int hyd(const trm_ctx* c) {
-        if (c->params.swrc == TRM_SWRC_BROOKS_COREY && c->params.unsat_k == TRM_UNSATK_LINEAR) return HYD_BC_LINEAR;
+        if (c->params.swrc == TRM_SWRC_BROOKS_COREY && c->params.unsat_k == TRM_UNSATK_LINEAR) {
+            // the compile-time instance is lambda = 0.2 (-1/lambda = -5 exactly, Base's integer power); other lambda: generic
+            const PowSpec<NF> spec = make_pow_spec<NF>(NF(-1) / (NF)c->params.bc_lambda);
+            return (spec.kind == POW_INT && spec.n == -5) ? HYD_BC_LINEAR : HYD_GENERIC;
+        }
         if (c->params.swrc == TRM_SWRC_VAN_GENUCHTEN && c->params.unsat_k == TRM_UNSATK_VAN_GENUCHTEN) {
             // the compile-time instance is van Genuchten's n = 2 (every reference test and example); other n: generic
             // (n = 2 exactly: -1/m = -2 {INT}, 1/n = (n-1)/n = 1/2 {HALVES, 1}, n/(n+1) = RN(2/3) {THIRDS, 2} in make_pow_spec)
@@ -845,20 +849,19 @@ template <class NF> struct Ops {
     static bool packed_path(trm_ctx* c) {
         if (!std::is_same<NF, float>::value || !c->opt_packed || generic_bcs(c)) return false;
         if (hyd(c) == HYD_VG_N2) return true;
-        if (hyd(c) != HYD_BC_LINEAR) return false;
-        const auto& spec = launch_args<NF>(c).p.bc_neg_inv_lambda;
-        return spec.kind == POW_INT && spec.n == -5;
+        return hyd(c) == HYD_BC_LINEAR;
     }
     template <bool RICH, int LPC> static int launch_packed(trm_ctx* c, double dt, int finalize) {
         if constexpr (std::is_same<NF, float>::value) {
             const LaunchArgs<NF>& la = launch_args<NF>(c);
             const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+            const int pf = prefetch_columns(c);
             const long pairs = (ncols(c) + 1) / 2;
             const View<NF>& sv = state_view<NF>(c);
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
-            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, pf);
+            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, pf);
             TRM_HIP(c, hipGetLastError());
         }
         return TRM_OK;
@@ -937,6 +940,12 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipStreamSynchronize(c->stream));
         return TRM_OK;
     }
+    // Columns ahead that every wave of the Euler column program requests into the L2 (trm_column.hpp: prefetch_ahead).
+    // TRM_OPT_PREFETCH_COLUMNS: -1 = the library's rule, 0 = off, n > 0 = explicit (rounded to whole workgroups per XCD)
+    static int prefetch_columns(const trm_ctx* c) {
+        if (c->opt_prefetch >= 0) return (c->opt_prefetch / 64) * 64;
+        return 0;
+    }
     template <bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         const View<NF>& v = state_view<NF>(c);
@@ -952,6 +961,7 @@ template <class NF> struct Ops {
         a.series_rows = (const SeriesRow*)c->d_series_rows;
         a.nseries = (int)c->series.size();
         a.stage_sat = a.stage_liq = a.stage_T = a.stage_S = nullptr;
+        a.prefetch_columns = PROG == PROG_EULER ? prefetch_columns(c) : 0;
         if (PROG == PROG_HEUN && coupled(c)) {   // the stage's soil state is needed by the 0-D processes evaluated at the stage
             a.stage_sat = (NF*)c->stage.f[TRM_FIELD_SATURATION_WATER_ICE];
             a.stage_liq = (NF*)c->stage.f[TRM_FIELD_LIQUID_WATER_FRACTION];
@@ -2200,6 +2210,10 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             if (value < 0 || value > 2) break;
             c->opt_pipeline = value;
             return TRM_OK;
+        case TRM_OPT_PREFETCH_COLUMNS:
+            if (value < -1 || value > (1 << 24)) break;
+            c->opt_prefetch = value;
+            return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -2215,6 +2229,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_DERIVE_CLOSURE_FIELDS: *value = c->opt_derive; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
+        case TRM_OPT_PREFETCH_COLUMNS: *value = c->opt_prefetch; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

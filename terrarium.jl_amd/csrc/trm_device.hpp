@@ -279,7 +279,11 @@ template <class NF> TRM_DEV NF jl_pow(NF x, const PowSpec<NF>& s) {
 // reference's operation order (IEEE basic ops round identically everywhere).
 // ---------------------------------------------------------------------------
 // Hydraulics specialisation of the kernels (dead-code elimination + register pressure):
-enum { HYD_BC_LINEAR = 0,   // BrooksCorey SWRC + UnsatKLinear: the reference default (soil_hydraulic_properties.jl:132-140)
+enum { HYD_BC_LINEAR = 0,   // BrooksCorey SWRC + UnsatKLinear with the default lambda = 0.2: the reference default
+                            // (soil_hydraulic_properties.jl:132-140).  r^(-1/lambda) = r^(-5.0) takes Base's integer path: the
+                            // compensated power by squaring, unrolled (pow_int_m5) -- no run-time PowSpec dispatch and no
+                            // generic pow in the kernel (its ~40 literal constants were being kept in registers across the
+                            // loops of the multi-step / multi-group programs); any other lambda takes HYD_GENERIC
        HYD_VG_N2 = 1,       // VanGenuchten SWRC + UnsatKVanGenuchten with n = 2: the variant of every reference test and
                             // example (exponents -1/m = -2, 1/n = (n-1)/n = 1/2, n/(n+1) = 2/3 fixed at compile time: no
                             // run-time PowSpec dispatch, a straight-line cell); any other n takes HYD_GENERIC
@@ -430,9 +434,9 @@ template <class NF> TRM_DEV void energy_invclosure(const DevParams<NF>& p, NF T,
 }
 
 // FreezeCurves.jl 0.9 SWRCs (restated): psi_m(theta; theta_sat = por)
-template <class NF> TRM_DEV NF swrc_psi_bc(const DevParams<NF>& p, NF theta) {
+template <class NF, bool M5 = false> TRM_DEV NF swrc_psi_bc(const DevParams<NF>& p, NF theta) {
     NF r = div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
-    NF v = -p.bc_psi_s * jl_pow(r, p.bc_neg_inv_lambda);
+    NF v = -p.bc_psi_s * (M5 ? pow_int_m5(r) : jl_pow(r, p.bc_neg_inv_lambda));
     return (theta < p.por) ? v : -p.bc_psi_s;
 }
 template <class NF, bool N2 = false> TRM_DEV NF swrc_psi_vg(const DevParams<NF>& p, NF theta) {
@@ -447,7 +451,7 @@ template <class NF, bool N2 = false> TRM_DEV NF swrc_psi_vg(const DevParams<NF>&
     return NF(0);
 }
 template <class NF, int HYD> TRM_DEV NF swrc_psi(const DevParams<NF>& p, NF theta) {
-    if (HYD == HYD_BC_LINEAR) return swrc_psi_bc(p, theta);
+    if (HYD == HYD_BC_LINEAR) return swrc_psi_bc<NF, true>(p, theta);
     if (HYD == HYD_VG_N2) return swrc_psi_vg<NF, true>(p, theta);
     return p.swrc == 1 ? swrc_psi_vg(p, theta) : swrc_psi_bc(p, theta);
 }
