@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 12
+#define TRM_ABI_VERSION 13
 
 typedef struct trm_ctx trm_ctx;
 
@@ -179,9 +179,8 @@ enum {
                                     /* one half runs under the column launch of the other (columns are independent; results   */
                                     /* are bit-identical).  0: off; 1: whenever a call makes >= 2 such steps; 2 (default):    */
                                     /* the same for contexts of >= 32 768 columns                                             */
-    TRM_OPT_PREFETCH_COLUMNS = 8    /* fused Euler step: every wave requests the fields of the column group this many columns */
-                                    /* ahead of its own into the L2 while it computes.  -1 (default): the library's rule;     */
-                                    /* 0: off; n: explicit (rounded down to a multiple of 64)                                 */
+    TRM_OPT_COLUMN_GROUPS = 8       /* (experimental) fused Euler step: 2 = every wave steps two consecutive column groups,  */
+                                    /* the second one's fields requested before the first one's arithmetic; 1 (default): off  */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
@@ -295,6 +294,23 @@ int trm_get_grid(const trm_ctx* ctx, double* z_faces, double* z_centers, double*
 /* set!(field, array) / Array(interior(field)) */
 int trm_upload(trm_ctx* ctx, int field, const void* host);
 int trm_download(trm_ctx* ctx, int field, void* host);
+/* Rows [row0, row0 + nrows) of a field, host layout [nrows][num_columns]: `ground_temperature` (soil_energy.jl:52-57) is
+ * row Nz - 1 of temperature -- one row through PCIe, not the field. */
+int trm_download_rows(trm_ctx* ctx, int field, int row0, int nrows, void* host);
+/* ---- ColumnRingGrid (src/grids/column_ring_grid.jl:37-59,102-149) -------------------------------------------------------
+ * trm_set_ring_grid: the columns of the context are the points `mask_index[i]` (strictly increasing, one per column) of a
+ * full grid of `num_points` points in ring order -- `findall(mask)`; for a context that holds one shard of the columns, the
+ * shard's slice of that list.  Uploaded once; scatter / gather then run on the device:
+ *   trm_download_ring / trm_scatter_ring_device   RingGrids.Field(field, grid; fill_value) (lines 102-115): rows of a field
+ *       on the full grid, [nrows][num_points], `fill` outside the mask -- into host memory, or into a device buffer of a
+ *       coupled model on the same device (speedy_dry_land.jl:45-66 reads the land state as ring-grid fields)
+ *   trm_upload_ring / trm_gather_ring_device      Oceananigans.Field(ring_field, grid) (lines 117-149): the masked points of
+ *       a full-grid array [rows][num_points] become the field (all rows of it) */
+int trm_set_ring_grid(trm_ctx* ctx, int64_t num_points, const int64_t* mask_index);
+int trm_download_ring(trm_ctx* ctx, int field, int row0, int nrows, double fill, void* host);
+int trm_scatter_ring_device(trm_ctx* ctx, int field, int row0, int nrows, double fill, void* dev_out);
+int trm_upload_ring(trm_ctx* ctx, int field, const void* host_full);
+int trm_gather_ring_device(trm_ctx* ctx, int field, const void* dev_full);
 /* Device address of a field, for zero-copy consumers on the same device.  The device layout is z-fastest:
  * element (column i, level k) of a 3-D field is at dev[i * pitch_elems + k] (pitch 32 for Nz <= 32, 64 for
  * Nz <= 64); 2-D fields are dev[i] (pitch 1).  The top face of hydraulic_conductivity is not part of this
@@ -339,6 +355,29 @@ int trm_clear_series(trm_ctx* ctx);
 /* update_inputs!(state, clock): evaluates every series at the context clock (done implicitly by trm_step,
  * trm_step_heun and trm_update_state). */
 int trm_update_inputs(trm_ctx* ctx);
+
+/* ---- windowed time series -----------------------------------------------------------------------------
+ * A forcing record that does not fit in HBM -- one hourly year of the 7 atmospheric inputs is ~199 GB for a 0.1-degree shard --
+ * streams through a fixed window: create the series with its first levels (trm_set_forcing_series / trm_set_bc_series),
+ * then alternate
+ *     trm_series_trim_before(ctx, t)        -- releases the levels no evaluation at a time >= t can touch (the node at or
+ *                                              before t and everything after it stay)
+ *     trm_series_append(ctx, ...)           -- continues a series with `nt` further levels (`times` strictly increasing
+ *                                              and beyond the last level held).  The values are staged through pinned
+ *                                              memory and copied on a side stream UNDER whatever the context stream is
+ *                                              running; the next step that evaluates the series waits for them.  Freed
+ *                                              slots of the ring are reused; without free slots the ring grows.
+ * `is_bc` = 0: `id` is the input field, `side` ignored; `is_bc` = 1: `id` is the bc_var, `side` the boundary.  Results
+ * are bit-identical to the all-resident series as long as the window covers [t, t + dt] of every step taken (FieldTimeSeries
+ * `InMemory(chunk)` backends play this role on the reference side).  TRM_TIME_CYCLICAL series cannot be windowed. */
+int trm_series_append(trm_ctx* ctx, int is_bc, int id, int side, int nt, const double* times, const void* values);
+int trm_series_trim_before(trm_ctx* ctx, double t);
+int trm_series_info(const trm_ctx* ctx, int is_bc, int id, int side, int64_t* levels_held, int64_t* capacity, double* t_first, double* t_last);
+
+/* reset!(state) + reset!(clock) of initialize!(integrator) (state_variables.jl:102-120, model_integrator.jl:96-99): every
+ * prognostic, auxiliary and tendency field to zero, the status word cleared, the clock to (0, 0).  Inputs keep their values
+ * (initialize!(state, inputs) re-evaluates their sources next), as do boundary values, series and options. */
+int trm_reset(trm_ctx* ctx);
 
 /* initialize!(state, model) process initialisers (soil_coupled.jl:45-54): hydraulics, water table,
  * sat -> psi, T -> U.  Call after uploading the initial temperature / saturation. */

@@ -41,7 +41,7 @@ VEG_PARAM_NAMES = ("tau25 Kc25 Ko25 q10_tau q10_Kc q10_Ko alpha_leaf alpha_a alp
                    "gamma_v_min root_a root_b wilting_point field_capacity C_mass alpha_int canopy_k_ext w_can_max tau_w C_can").split()
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4,
-              derive_closure_fields=5, steps_per_launch=6, pipeline_parts=7, prefetch_columns=8)
+              derive_closure_fields=5, steps_per_launch=6, pipeline_parts=7, column_groups=8)
 KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
 TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE, TRM_ECOMM = range(7)
@@ -54,7 +54,9 @@ EXPORTS = (
     "trm_get_option trm_set_stream trm_synchronize "
     "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs trm_save_state trm_restore_state "
     "trm_comm_unique_id trm_comm_init trm_comm_destroy trm_comm_info trm_reduce_global trm_status_global "
-    "trm_default_vegetation_params trm_set_vegetation trm_compute_plant_available_water").split()
+    "trm_default_vegetation_params trm_set_vegetation trm_compute_plant_available_water "
+    "trm_series_append trm_series_trim_before trm_series_info trm_reset trm_download_rows trm_set_ring_grid trm_download_ring "
+    "trm_scatter_ring_device trm_upload_ring trm_gather_ring_device").split()
 TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2, raster=3)
 
 
@@ -141,6 +143,16 @@ def lib():
     L.trm_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.trm_reduce_global.argtypes = [vp, i32, i32, vp]
     L.trm_status_global.argtypes = [vp, C.POINTER(C.c_uint32)]
+    L.trm_series_append.argtypes = [vp, i32, i32, i32, i32, vp, vp]
+    L.trm_series_trim_before.argtypes = [vp, dbl]
+    L.trm_series_info.argtypes = [vp, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
+    L.trm_reset.argtypes = [vp]
+    L.trm_download_rows.argtypes = [vp, i32, i32, i32, vp]
+    L.trm_set_ring_grid.argtypes = [vp, i64, vp]
+    L.trm_download_ring.argtypes = [vp, i32, i32, i32, dbl, vp]
+    L.trm_scatter_ring_device.argtypes = [vp, i32, i32, i32, dbl, vp]
+    L.trm_upload_ring.argtypes = [vp, i32, vp]
+    L.trm_gather_ring_device.argtypes = [vp, i32, vp]
     for name in EXPORTS:
         if name not in ("trm_last_error",):
             getattr(L, name).restype = i32

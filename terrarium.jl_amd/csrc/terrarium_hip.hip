@@ -55,10 +55,26 @@ struct trm_ctx {
     struct Series {
         bool is_bc = false;
         int field = 0, var = 0, side = 0, indexing = 0;
-        std::vector<double> times;
-        void* d_values = nullptr;   // [nt][Nh]
+        std::vector<double> times;  // the time levels currently held, oldest first
+        void* d_values = nullptr;   // [cap][Nh]: a ring of time levels, level n of `times` in slot (head + n) % cap
+        long cap = 0, head = 0;
+        long pending_from = -1;     // first level (index into `times`) whose copy may still be in flight, or -1
+        size_t slot(int n) const { return (size_t)((head + n) % cap); }
     };
     std::vector<Series> series;
+    // trm_series_append: host values are staged through pinned memory and copied on a side stream under the running steps
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copy_done = nullptr;     // the last appended levels have reached the device
+    hipEvent_t copy_order = nullptr;    // the context stream's work at the time levels were last released (trim)
+    bool copy_pending = false, order_recorded = false;
+    void* h_stage = nullptr;            // pinned staging buffer
+    size_t h_stage_cap = 0;
+    // ring grid (ColumnRingGrid, column_ring_grid.jl:37-59): column i <-> point ring_index[i] of the full grid
+    long ring_points = 0;
+    int32_t* d_ring_inv = nullptr;      // [ring_points] column of a grid point, -1 outside the mask
+    int32_t* d_ring_idx = nullptr;      // [Nh] grid point of a column
+    void* d_ring = nullptr;             // staging [rows][ring_points]
+    size_t ring_cap = 0;
     void* bc_value_stage[TRM_BCV_COUNT][2] = {};  // Heun: the stage evaluates its boundary series at t + dt
     void* d_top3 = nullptr;  // LandModel: [3][Nh] (T, sat, liq) of the top cell as left by the last fused step
     bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)
@@ -77,7 +93,7 @@ struct trm_ctx {
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
-    int opt_derive = 2, opt_prefetch = -1;
+    int opt_derive = 2, opt_groups = 1;
     int opt_steps_per_launch = 0;   // 0: chosen by the library (auto_steps_per_launch), 1: one launch per step, m > 1: up to m steps per launch
     // Two-part pipeline of the per-step LandModel path (TRM_OPT_PIPELINE_PARTS): the columns are dealt to two internal streams,
     // each running its own chain of (surface launch, column launch) per step; the latency-bound 0-D surface launch of one part
@@ -483,6 +499,14 @@ template <class NF> struct Ops {
 
     // update_inputs!(state, clock) for the time series sources: evaluates every series at `time` into the input
     // field / boundary value array of field set `s` (the Heun stage has its own copies)
+    // Levels appended by trm_series_append travel on the side stream; a step that reads one of them first makes the context
+    // stream wait for the copy (steps that stay within the older levels run under it).
+    static int await_levels(trm_ctx* c, trm_ctx::Series& sr, int last_level) {
+        if (sr.pending_from < 0 || last_level < sr.pending_from) return TRM_OK;
+        TRM_HIP(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+        for (auto& o : c->series) o.pending_from = -1;     // (one event covers every copy issued so far)
+        return TRM_OK;
+    }
     static int update_inputs(trm_ctx* c, const FieldSet& s, double time) {
         if (c->series.empty()) return TRM_OK;
         const bool stage = &s == &c->stage;
@@ -499,6 +523,7 @@ template <class NF> struct Ops {
             int n1, n2;
             double f, g;
             series_time_indices(sr.times, sr.indexing, time, n1, n2, f, g);
+            if (int rw = await_levels(c, sr, std::max(n1, n2))) return rw;
             if (!sr.is_bc && stage && !c->has_stage) continue;   // (fused Heun: the stage's surface processes are never evaluated)
             NF* dst;
             if (sr.is_bc) {
@@ -513,7 +538,7 @@ template <class NF> struct Ops {
             }
             const NF* base = (const NF*)sr.d_values + first_col(c);   // (a pipeline part evaluates its own columns)
             dst += first_col(c);
-            jobs.job[nj++] = SeriesJob<NF>{dst, base + (size_t)n1 * c->Nh, base + (size_t)n2 * c->Nh, f, g, sr.indexing == TRM_TIME_RASTER ? 1 : 0};
+            jobs.job[nj++] = SeriesJob<NF>{dst, base + sr.slot(n1) * c->Nh, base + sr.slot(n2) * c->Nh, f, g, sr.indexing == TRM_TIME_RASTER ? 1 : 0};
             if (nj == 16) { int rc = flush(); if (rc) return rc; }
         }
         return flush();
@@ -855,13 +880,12 @@ template <class NF> struct Ops {
         if constexpr (std::is_same<NF, float>::value) {
             const LaunchArgs<NF>& la = launch_args<NF>(c);
             const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
-            const int pf = prefetch_columns(c);
             const long pairs = (ncols(c) + 1) / 2;
             const View<NF>& sv = state_view<NF>(c);
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, pf);
-            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, pf);
+            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
             TRM_HIP(c, hipGetLastError());
         }
         return TRM_OK;
@@ -922,7 +946,8 @@ template <class NF> struct Ops {
                 int n1, n2;
                 double f, g;
                 series_time_indices(sr.times, sr.indexing, t, n1, n2, f, g);
-                rows[(size_t)s * ns + j] = SeriesRow{(long long)n1 * c->Nh, (long long)n2 * c->Nh, f, g};
+                if (int rw = await_levels(c, sr, std::max(n1, n2))) return rw;
+                rows[(size_t)s * ns + j] = SeriesRow{(long long)(sr.slot(n1) * (size_t)c->Nh), (long long)(sr.slot(n2) * (size_t)c->Nh), f, g};
                 t += dt;
             }
         }
@@ -940,12 +965,6 @@ template <class NF> struct Ops {
         TRM_HIP(c, hipStreamSynchronize(c->stream));
         return TRM_OK;
     }
-    // Columns ahead that every wave of the Euler column program requests into the L2 (trm_column.hpp: prefetch_ahead).
-    // TRM_OPT_PREFETCH_COLUMNS: -1 = the library's rule, 0 = off, n > 0 = explicit (rounded to whole workgroups per XCD)
-    static int prefetch_columns(const trm_ctx* c) {
-        if (c->opt_prefetch >= 0) return (c->opt_prefetch / 64) * 64;
-        return 0;
-    }
     template <bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         const View<NF>& v = state_view<NF>(c);
@@ -961,7 +980,6 @@ template <class NF> struct Ops {
         a.series_rows = (const SeriesRow*)c->d_series_rows;
         a.nseries = (int)c->series.size();
         a.stage_sat = a.stage_liq = a.stage_T = a.stage_S = nullptr;
-        a.prefetch_columns = PROG == PROG_EULER ? prefetch_columns(c) : 0;
         if (PROG == PROG_HEUN && coupled(c)) {   // the stage's soil state is needed by the 0-D processes evaluated at the stage
             a.stage_sat = (NF*)c->stage.f[TRM_FIELD_SATURATION_WATER_ICE];
             a.stage_liq = (NF*)c->stage.f[TRM_FIELD_LIQUID_WATER_FRACTION];
@@ -977,6 +995,12 @@ template <class NF> struct Ops {
             else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
             else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
         } else if constexpr (PROG == PROG_EULER) {
+            if (c->opt_groups == 2 && H != HYD_GENERIC) {   // (experimental) two column groups per wave, the second one's fields requested early
+                dim3 g2 = grid;
+                g2.x = (grid.x + 1) / 2;
+                if (derive) hipLaunchKernelGGL((k_column_groups<NF, RICH, H, LPC, true, 2>), g2, block, 0, c->stream, v, p, a);
+                else hipLaunchKernelGGL((k_column_groups<NF, RICH, H, LPC, false, 2>), g2, block, 0, c->stream, v, p, a);
+            } else
             if (derive) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, true, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
             else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
         } else {
@@ -1040,6 +1064,10 @@ template <class NF> struct Ops {
         if (!c->pipe_fork) {
             TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_fork, hipEventDisableTiming));
             TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_stagger, hipEventDisableTiming));
+        }
+        if (c->copy_pending) {   // levels appended on the side stream: both parts are ordered behind the copy through the fork
+            TRM_HIP(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
+            for (auto& o : c->series) o.pending_from = -1;
         }
         TRM_HIP(c, hipEventRecord(c->pipe_fork, c->stream));
         for (int q = 0; q < 2; ++q) TRM_HIP(c, hipStreamWaitEvent(c->pipe_stream[q], c->pipe_fork, 0));
@@ -1460,6 +1488,43 @@ __global__ void __launch_bounds__(256) k_transpose(const NF* __restrict__ src, N
         }
     }
 }
+
+// Rows [row0, row0 + nrows) of a 3-D field in the host layout [nrows][Nh] (32 x 32 tiles through LDS, as k_transpose): the
+// output path of a snapshot writer that wants `ground_temperature` -- one row -- does not move the whole field.
+template <class NF>
+__global__ void __launch_bounds__(256) k_rows_to_host_layout(const NF* __restrict__ src, NF* __restrict__ dst, long Nh, int Nzp, int row0, int nrows) {
+    __shared__ NF tile[32][33];
+    const long i0 = (long)blockIdx.x * 32;
+    const int r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const long i = i0 + r;
+        const int k = row0 + r0 + tx;
+        tile[r][tx] = (i < Nh && r0 + tx < nrows && k < Nzp) ? src[(size_t)i * Nzp + k] : NF(0);
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int q = r0 + r;
+        const long i = i0 + tx;
+        if (q < nrows && i < Nh) dst[(size_t)q * Nh + i] = tile[tx][r];
+    }
+}
+// RingGrids.Field(field, grid; fill_value) (column_ring_grid.jl:102-115): rows [nrows][Nh] of the columns -> [nrows][P] on the
+// full ring grid, `fill` outside the mask.  One thread per grid point: coalesced writes, reads in column order.
+template <class NF> __global__ void k_scatter_ring(const NF* __restrict__ rows, NF* __restrict__ out, const int32_t* __restrict__ inv, long P, long Nh, NF fill) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int32_t col = inv[p];
+    const size_t r = blockIdx.y;
+    out[r * (size_t)P + p] = col >= 0 ? rows[r * (size_t)Nh + col] : fill;
+}
+// Oceananigans.Field(ring_field, grid) (column_ring_grid.jl:117-149): the masked points of [nrows][P] in ring order
+template <class NF> __global__ void k_gather_ring(const NF* __restrict__ full, NF* __restrict__ rows, const int32_t* __restrict__ idx, long P, long Nh) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nh) return;
+    const size_t r = blockIdx.y;
+    rows[r * (size_t)Nh + i] = full[r * (size_t)P + idx[i]];
+}
 int io_buffer(trm_ctx* c, size_t bytes) {
     if (bytes > c->io_cap) {
         if (c->d_io) TRM_HIP(c, hipFree(c->d_io));
@@ -1504,6 +1569,85 @@ template <class NF> int download_impl(trm_ctx* c, int field, NF* host) {
         TRM_HIP(c, hipMemcpyAsync((NF*)c->d_io + (size_t)c->Nz * Nh, c->state.kf_top, (size_t)Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
     TRM_HIP(c, hipMemcpyAsync(host, c->d_io, (size_t)rows * Nh * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+
+
+// rows [row0, row0 + nrows) of a field into the staging buffer d_io as [nrows][Nh] (on the context stream, not synchronised)
+template <class NF> int stage_rows(trm_ctx* c, int field, int row0, int nrows) {
+    const long Nh = c->Nh;
+    int rc = io_buffer(c, (size_t)nrows * Nh * sizeof(NF));
+    if (rc) return rc;
+    NF* io = (NF*)c->d_io;
+    if (!is_3d(field)) {
+        TRM_HIP(c, hipMemcpyAsync(io, c->state.f[field], (size_t)Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+        return TRM_OK;
+    }
+    const int cell_rows = std::min(nrows, c->Nz - row0);     // (the Face field's top face lives in its own [Nh] buffer)
+    if (cell_rows > 0) {
+        dim3 grid((unsigned)((Nh + 31) / 32), (unsigned)((cell_rows + 31) / 32));
+        hipLaunchKernelGGL((k_rows_to_host_layout<NF>), grid, dim3(256), 0, c->stream, (const NF*)c->state.f[field], io, Nh, c->Nzp, row0, cell_rows);
+        TRM_HIP(c, hipGetLastError());
+    }
+    if (row0 + nrows == c->Nz + 1)
+        TRM_HIP(c, hipMemcpyAsync(io + (size_t)(c->Nz - row0) * Nh, c->state.kf_top, (size_t)Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+    return TRM_OK;
+}
+int ring_buffer(trm_ctx* c, size_t bytes) {
+    if (bytes > c->ring_cap) {
+        if (c->d_ring) TRM_HIP(c, hipFree(c->d_ring));
+        c->d_ring = nullptr;
+        c->ring_cap = 0;
+        TRM_HIP(c, hipMalloc(&c->d_ring, bytes));
+        c->ring_cap = bytes;
+    }
+    return TRM_OK;
+}
+template <class NF> int scatter_ring_impl(trm_ctx* c, int field, int row0, int nrows, double fill, void* out, bool out_is_device) {
+    int rc = stage_rows<NF>(c, field, row0, nrows);
+    if (rc) return rc;
+    NF* dst = (NF*)out;
+    if (!out_is_device) {
+        if ((rc = ring_buffer(c, (size_t)nrows * c->ring_points * sizeof(NF)))) return rc;
+        dst = (NF*)c->d_ring;
+    }
+    dim3 grid((unsigned)((c->ring_points + 255) / 256), (unsigned)nrows);
+    hipLaunchKernelGGL((k_scatter_ring<NF>), grid, dim3(256), 0, c->stream, (const NF*)c->d_io, dst, c->d_ring_inv, c->ring_points, c->Nh, (NF)fill);
+    TRM_HIP(c, hipGetLastError());
+    if (!out_is_device) TRM_HIP(c, hipMemcpyAsync(out, dst, (size_t)nrows * c->ring_points * sizeof(NF), hipMemcpyDeviceToHost, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+// full-grid host (or device) array [rows][P] -> the field: gather on the device, then the usual layout change
+template <class NF> int gather_ring_impl(trm_ctx* c, int field, const void* full, bool full_is_device) {
+    const long Nh = c->Nh, rows = field_rows(c, field), P = c->ring_points;
+    const NF* src = (const NF*)full;
+    int rc;
+    if (!full_is_device) {
+        if ((rc = ring_buffer(c, (size_t)rows * P * sizeof(NF)))) return rc;
+        TRM_HIP(c, hipMemcpyAsync(c->d_ring, full, (size_t)rows * P * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+        src = (const NF*)c->d_ring;
+    }
+    if ((rc = io_buffer(c, (size_t)rows * Nh * sizeof(NF)))) return rc;
+    NF* io = (NF*)c->d_io;
+    dim3 grid((unsigned)((Nh + 255) / 256), (unsigned)rows);
+    hipLaunchKernelGGL((k_gather_ring<NF>), grid, dim3(256), 0, c->stream, src, is_3d(field) ? io : (NF*)c->state.f[field], c->d_ring_idx, P, Nh);
+    TRM_HIP(c, hipGetLastError());
+    if (is_3d(field)) {
+        dim3 tg((unsigned)((Nh + 31) / 32), (unsigned)((c->Nzp + 31) / 32));
+        hipLaunchKernelGGL((k_transpose<NF, true>), tg, dim3(256), 0, c->stream, (const NF*)io, (NF*)c->state.f[field], Nh, c->Nz, c->Nzp);
+        TRM_HIP(c, hipGetLastError());
+        if (rows == c->Nz + 1)
+            TRM_HIP(c, hipMemcpyAsync(c->state.kf_top, io + (size_t)c->Nz * Nh, (size_t)Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+    }
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+// every H2D copy of trm_series_append has finished (before a series buffer is freed or reallocated)
+int sync_copies(trm_ctx* c) {
+    if (c->copy_stream && c->copy_pending) TRM_HIP(c, hipStreamSynchronize(c->copy_stream));
+    c->copy_pending = false;
+    for (auto& o : c->series) o.pending_from = -1;
     return TRM_OK;
 }
 
@@ -1679,6 +1823,12 @@ int trm_destroy(trm_ctx* c) {
         if (c->pipe_stream[q]) { (void)hipStreamSynchronize(c->pipe_stream[q]); (void)hipStreamDestroy(c->pipe_stream[q]); }
         if (c->pipe_join[q]) (void)hipEventDestroy(c->pipe_join[q]);
     }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->copy_order) (void)hipEventDestroy(c->copy_order);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (void* q : {(void*)c->d_ring_inv, (void*)c->d_ring_idx, c->d_ring})
+        if (q) (void)hipFree(q);
     if (c->pipe_fork) (void)hipEventDestroy(c->pipe_fork);
     if (c->pipe_stagger) (void)hipEventDestroy(c->pipe_stagger);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1763,6 +1913,7 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
         return fail(c, TRM_EINVAL, "trm_set_bc: bad argument");
     TRM_HIP(c, hipSetDevice(c->device));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
+    if (int rs = sync_copies(c)) return rs;
     // a constant replaces an earlier time series of the same boundary value (which would otherwise overwrite it at the next step)
     for (size_t n = 0; n < c->series.size(); ++n) {
         auto& o = c->series[n];
@@ -1805,6 +1956,7 @@ int add_series(trm_ctx* c, trm_ctx::Series&& sr, int nt, const double* times, co
     if (sr.indexing < TRM_TIME_LINEAR || sr.indexing > TRM_TIME_RASTER) return fail(c, TRM_EINVAL, std::string(who) + ": bad time_indexing");
     TRM_HIP(c, hipSetDevice(c->device));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
+    if (int rs = sync_copies(c)) return rs;
     // replace an earlier series with the same target
     for (size_t n = 0; n < c->series.size(); ++n) {
         auto& o = c->series[n];
@@ -1815,6 +1967,8 @@ int add_series(trm_ctx* c, trm_ctx::Series&& sr, int nt, const double* times, co
         }
     }
     sr.times.assign(times, times + nt);
+    sr.cap = nt;
+    sr.head = 0;
     size_t bytes = (size_t)nt * (size_t)c->Nh * c->esize;
     TRM_HIP(c, hipMalloc(&sr.d_values, bytes));
     TRM_HIP(c, hipMemcpy(sr.d_values, values, bytes, hipMemcpyHostToDevice));
@@ -1856,6 +2010,7 @@ int trm_clear_series(trm_ctx* c) {
     if (!c) return TRM_EINVAL;
     TRM_HIP(c, hipSetDevice(c->device));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
+    if (int rs = sync_copies(c)) return rs;
     for (auto& sr : c->series)
         if (sr.d_values) (void)hipFree(sr.d_values);
     c->series.clear();
@@ -1865,6 +2020,196 @@ int trm_clear_series(trm_ctx* c) {
 #define TRM_ENTER(c)                                         \
     if (!(c)) return TRM_EINVAL;                             \
     TRM_HIP(c, hipSetDevice((c)->device));
+
+// ---- windowed time series ("device-side double-buffered forcing slabs") -------------------------------------
+namespace {
+trm_ctx::Series* find_series(trm_ctx* c, int is_bc, int id, int side) {
+    for (auto& sr : c->series)
+        if (sr.is_bc == (is_bc != 0) && (is_bc ? (sr.var == id && sr.side == side) : sr.field == id)) return &sr;
+    return nullptr;
+}
+}  // namespace
+
+int trm_series_append(trm_ctx* c, int is_bc, int id, int side, int nt, const double* times, const void* values) {
+    TRM_ENTER(c);
+    trm_ctx::Series* sr = find_series(c, is_bc, id, side);
+    if (!sr) return fail(c, TRM_EINVAL, "trm_series_append: no such series (create it with trm_set_forcing_series / trm_set_bc_series first)");
+    if (nt < 1 || !times || !values) return fail(c, TRM_EINVAL, "trm_series_append: nt >= 1, times and values are required");
+    if (sr->indexing == TRM_TIME_CYCLICAL) return fail(c, TRM_EINVAL, "trm_series_append: a cyclical series is periodic over its whole record and cannot be windowed");
+    if (!(times[0] > sr->times.back())) return fail(c, TRM_EINVAL, "trm_series_append: times must continue the series (strictly increasing)");
+    for (int n = 1; n < nt; ++n)
+        if (!(times[n] > times[n - 1])) return fail(c, TRM_EINVAL, "trm_series_append: times must be strictly increasing");
+    const size_t row = (size_t)c->Nh * c->esize;
+    const long held = (long)sr->times.size();
+    if (!c->copy_stream) {
+        TRM_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        TRM_HIP(c, hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming));
+    }
+    if (held + nt > sr->cap) {
+        // no free slots left (nothing was trimmed): the ring grows; the levels held are laid out from slot 0 again
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        if (int rs = sync_copies(c)) return rs;
+        const long cap = held + nt;
+        void* grown = nullptr;
+        TRM_HIP(c, hipMalloc(&grown, (size_t)cap * row));
+        for (long n = 0; n < held; ++n)
+            TRM_HIP(c, hipMemcpyAsync((char*)grown + (size_t)n * row, (char*)sr->d_values + sr->slot((int)n) * row, row, hipMemcpyDeviceToDevice, c->stream));
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        TRM_HIP(c, hipFree(sr->d_values));
+        sr->d_values = grown;
+        sr->cap = cap;
+        sr->head = 0;
+    }
+    // host -> pinned staging (the caller's array is borrowed for the duration of the call only) -> device, on the side stream:
+    // the copy runs under whatever the context stream is executing; the next step that evaluates the series waits for it
+    if (c->copy_pending) TRM_HIP(c, hipEventSynchronize(c->copy_done));   // the staging buffer is free again
+    if ((size_t)nt * row > c->h_stage_cap) {
+        if (c->h_stage) TRM_HIP(c, hipHostFree(c->h_stage));
+        c->h_stage = nullptr;
+        c->h_stage_cap = 0;
+        TRM_HIP(c, hipHostMalloc(&c->h_stage, (size_t)nt * row, hipHostMallocDefault));
+        c->h_stage_cap = (size_t)nt * row;
+    }
+    std::memcpy(c->h_stage, values, (size_t)nt * row);
+    // the slots written are free ones: never used, or released by trm_series_trim_before -- whose event marks the context
+    // stream's work that may still have been reading them; steps enqueued after the trim cannot see them
+    if (c->order_recorded) TRM_HIP(c, hipStreamWaitEvent(c->copy_stream, c->copy_order, 0));
+    for (int n = 0; n < nt; ++n)
+        TRM_HIP(c, hipMemcpyAsync((char*)sr->d_values + sr->slot((int)held + n) * row, (char*)c->h_stage + (size_t)n * row, row, hipMemcpyHostToDevice, c->copy_stream));
+    TRM_HIP(c, hipEventRecord(c->copy_done, c->copy_stream));
+    c->copy_pending = true;
+    if (sr->pending_from < 0) sr->pending_from = held;
+    sr->times.insert(sr->times.end(), times, times + nt);
+    return TRM_OK;
+}
+
+int trm_series_trim_before(trm_ctx* c, double t) {
+    if (!c) return TRM_EINVAL;
+    bool released = false;
+    for (auto& sr : c->series) {
+        if (sr.indexing == TRM_TIME_CYCLICAL) continue;
+        // keep the node at or before t (the lower bracket of every later evaluation) and at least two levels
+        long drop = 0;
+        while ((long)sr.times.size() - drop > 2 && sr.times[(size_t)drop + 1] <= t) ++drop;
+        if (drop > 0) {
+            sr.times.erase(sr.times.begin(), sr.times.begin() + drop);
+            sr.head = (sr.head + drop) % sr.cap;
+            if (sr.pending_from >= 0) sr.pending_from = std::max<long>(0, sr.pending_from - drop);
+            released = true;
+        }
+    }
+    if (released) {
+        if (hipSetDevice(c->device) != hipSuccess) return fail(c, TRM_EHIP, "trm_series_trim_before: hipSetDevice");
+        if (!c->copy_order) TRM_HIP(c, hipEventCreateWithFlags(&c->copy_order, hipEventDisableTiming));
+        TRM_HIP(c, hipEventRecord(c->copy_order, c->stream));
+        c->order_recorded = true;
+    }
+    return TRM_OK;
+}
+
+int trm_series_info(const trm_ctx* c, int is_bc, int id, int side, int64_t* levels_held, int64_t* capacity, double* t_first, double* t_last) {
+    if (!c) return TRM_EINVAL;
+    const trm_ctx::Series* sr = find_series(const_cast<trm_ctx*>(c), is_bc, id, side);
+    if (!sr) return TRM_EINVAL;
+    if (levels_held) *levels_held = (int64_t)sr->times.size();
+    if (capacity) *capacity = sr->cap;
+    if (t_first) *t_first = sr->times.front();
+    if (t_last) *t_last = sr->times.back();
+    return TRM_OK;
+}
+
+// ---- reset!(state) + reset!(clock) (state_variables.jl:102-120, model_integrator.jl:96-99) -----------------------------------
+int trm_reset(trm_ctx* c) {
+    TRM_ENTER(c);
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
+        // prognostic, auxiliary and tendency fields go to zero; inputs keep their values (they are re-initialised from their
+        // sources), and so do the static root fractions and the user's per-cell forcing
+        if (!c->state.f[f] || is_input_field(f) || f == TRM_FIELD_ROOT_FRACTION || f == TRM_FIELD_VWC_FORCING) continue;
+        TRM_HIP(c, hipMemsetAsync(c->state.f[f], 0, field_elems(c, f) * c->esize, c->stream));
+    }
+    TRM_HIP(c, hipMemsetAsync(c->state.kf_top, 0, (size_t)c->Nh * c->esize, c->stream));
+    if (c->d_top3) TRM_HIP(c, hipMemsetAsync(c->d_top3, 0, 3 * (size_t)c->Nh * c->esize, c->stream));
+    TRM_HIP(c, hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream));
+    c->time = 0.0;
+    c->iteration = 0;
+    c->top_valid = false;
+    c->tend_valid = true;
+    c->closure_consistent = false;
+    return finish(c, TRM_OK);
+}
+
+// ---- output: rows of a field, and the full ring grid (column_ring_grid.jl:102-149) -----------------------------------------
+int trm_download_rows(trm_ctx* c, int field, int row0, int nrows, void* host) {
+    TRM_ENTER(c);
+    if (!host || !valid_field(field) || !c->state.f[field]) return fail(c, TRM_EINVAL, "trm_download_rows: bad argument");
+    if (row0 < 0 || nrows < 1 || row0 + nrows > field_rows(c, field)) return fail(c, TRM_EINVAL, "trm_download_rows: rows out of range");
+    if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
+    int rc = c->precision == TRM_F64 ? stage_rows<double>(c, field, row0, nrows) : stage_rows<float>(c, field, row0, nrows);
+    if (rc) return rc;
+    TRM_HIP(c, hipMemcpyAsync(host, c->d_io, (size_t)nrows * c->Nh * c->esize, hipMemcpyDeviceToHost, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    return TRM_OK;
+}
+
+int trm_set_ring_grid(trm_ctx* c, int64_t num_points, const int64_t* mask_index) {
+    TRM_ENTER(c);
+    if (num_points < c->Nh || num_points >= ((int64_t)1 << 31) || !mask_index) return fail(c, TRM_EINVAL, "trm_set_ring_grid: bad argument");
+    std::vector<int32_t> inv((size_t)num_points, -1), idx((size_t)c->Nh);
+    for (long i = 0; i < c->Nh; ++i) {
+        const int64_t p = mask_index[i];
+        if (p < 0 || p >= num_points || inv[(size_t)p] >= 0 || (i > 0 && p <= mask_index[i - 1]))
+            return fail(c, TRM_EINVAL, "trm_set_ring_grid: mask_index must be strictly increasing grid point indices, one per column");
+        inv[(size_t)p] = (int32_t)i;
+        idx[(size_t)i] = (int32_t)p;
+    }
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    for (void* q : {(void*)c->d_ring_inv, (void*)c->d_ring_idx})
+        if (q) (void)hipFree(q);
+    c->d_ring_inv = c->d_ring_idx = nullptr;
+    TRM_HIP(c, hipMalloc((void**)&c->d_ring_inv, inv.size() * sizeof(int32_t)));
+    TRM_HIP(c, hipMalloc((void**)&c->d_ring_idx, idx.size() * sizeof(int32_t)));
+    TRM_HIP(c, hipMemcpy(c->d_ring_inv, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    TRM_HIP(c, hipMemcpy(c->d_ring_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    c->ring_points = (long)num_points;
+    return TRM_OK;
+}
+
+static int ring_args_ok(trm_ctx* c, int field, int row0, int nrows, const void* buf, const char* who) {
+    if (!c->ring_points) return fail(c, TRM_EINVAL, std::string(who) + ": call trm_set_ring_grid first");
+    if (!buf || !valid_field(field) || !c->state.f[field]) return fail(c, TRM_EINVAL, std::string(who) + ": bad argument");
+    if (row0 < 0 || nrows < 1 || row0 + nrows > field_rows(c, field)) return fail(c, TRM_EINVAL, std::string(who) + ": rows out of range");
+    if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
+    return TRM_OK;
+}
+int trm_download_ring(trm_ctx* c, int field, int row0, int nrows, double fill, void* host) {
+    TRM_ENTER(c);
+    if (int rc = ring_args_ok(c, field, row0, nrows, host, "trm_download_ring")) return rc;
+    return c->precision == TRM_F64 ? scatter_ring_impl<double>(c, field, row0, nrows, fill, host, false) : scatter_ring_impl<float>(c, field, row0, nrows, fill, host, false);
+}
+int trm_scatter_ring_device(trm_ctx* c, int field, int row0, int nrows, double fill, void* dev_out) {
+    TRM_ENTER(c);
+    if (int rc = ring_args_ok(c, field, row0, nrows, dev_out, "trm_scatter_ring_device")) return rc;
+    return c->precision == TRM_F64 ? scatter_ring_impl<double>(c, field, row0, nrows, fill, dev_out, true) : scatter_ring_impl<float>(c, field, row0, nrows, fill, dev_out, true);
+}
+static int gather_ring(trm_ctx* c, int field, const void* full, bool device, const char* who) {
+    if (int rc = ring_args_ok(c, field, 0, (int)field_rows(c, field), full, who)) return rc;
+    if (field == TRM_FIELD_ROOT_FRACTION) return fail(c, TRM_EINVAL, std::string(who) + ": root_fraction is derived from the root distribution parameters");
+    int rc = c->precision == TRM_F64 ? gather_ring_impl<double>(c, field, full, device) : gather_ring_impl<float>(c, field, full, device);
+    if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_consistent = false;
+    if (!rc && field == TRM_FIELD_VWC_FORCING) { c->opt_vwc_field = 1; c->args_valid = false; }
+    c->top_valid = false;
+    if (!rc && is_tendency(field)) c->tend_valid = true;
+    return rc;
+}
+int trm_upload_ring(trm_ctx* c, int field, const void* host_full) {
+    TRM_ENTER(c);
+    return gather_ring(c, field, host_full, false, "trm_upload_ring");
+}
+int trm_gather_ring_device(trm_ctx* c, int field, const void* dev_full) {
+    TRM_ENTER(c);
+    return gather_ring(c, field, dev_full, true, "trm_gather_ring_device");
+}
 
 int trm_initialize(trm_ctx* c) {
     TRM_ENTER(c);
@@ -2210,9 +2555,9 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             if (value < 0 || value > 2) break;
             c->opt_pipeline = value;
             return TRM_OK;
-        case TRM_OPT_PREFETCH_COLUMNS:
-            if (value < -1 || value > (1 << 24)) break;
-            c->opt_prefetch = value;
+        case TRM_OPT_COLUMN_GROUPS:
+            if (value != 1 && value != 2) break;
+            c->opt_groups = value;
             return TRM_OK;
         default: break;
     }
@@ -2229,7 +2574,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_DERIVE_CLOSURE_FIELDS: *value = c->opt_derive; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
-        case TRM_OPT_PREFETCH_COLUMNS: *value = c->opt_prefetch; return TRM_OK;
+        case TRM_OPT_COLUMN_GROUPS: *value = c->opt_groups; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

@@ -189,9 +189,6 @@ template <class NF> struct ColumnArgs {
     // Heun of the vegetation-coupled LandModel: the stage's saturation, liquid fraction, temperature ([Nh][Nzp]) and surface
     // excess water ([Nh]) are stored for the 0-D processes that are evaluated AT the stage (null otherwise)
     NF *stage_sat, *stage_liq, *stage_T, *stage_S;
-    // PROG_EULER: columns ahead of its own that a wave requests into the L2 once its own fields have arrived (0: off), see
-    // prefetch_ahead
-    int prefetch_columns;
 };
 
 
@@ -265,21 +262,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
         }
         bc.flux_U = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
         bc.flux_S = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
-    }
-    if (PROG == PROG_EULER) {
-        // every load of the wave so far has returned past this point (on both sides of the branch below: the wait-count
-        // bookkeeping is per path, and a path that still had a load pending would force a full wait right behind the prefetch)
-        wait_for_loads();
-    }
-    if (PROG == PROG_EULER && a.prefetch_columns > 0) {
-        __shared__ int sink[TRM_STEP_BLOCK];
-        const int col = i + a.prefetch_columns;
-        unsigned pb = ((unsigned)(col < Nh ? col : Nh - 1) * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);
-        asm volatile("" : "+v"(pb));
-        prefetch_line(v.U, pb, sink);
-        prefetch_line(v.sat, pb, sink);
-        if (RICHARDS) prefetch_line(v.psi, pb, sink);
-        if (!DERIVE) { prefetch_line(v.T, pb, sink); prefetch_line(v.liq, pb, sink); }
     }
     // surface_excess_water (and LandModel's surface state) is owned by the column's top lane.  The one-step programs
     // touch it in one short top-lane block at the end; the multi-step program carries it in a register.

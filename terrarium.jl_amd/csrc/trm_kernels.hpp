@@ -364,21 +364,6 @@ TRM_DEV unsigned block_local(unsigned byte_off) {
     return byte_off;
 }
 
-// Cache prefetch for the waves that will run one "round" later.  8 waves per SIMD is the occupancy ceiling and a wave has
-// loads in flight only at its start: on HBM-resident states the step is bound by the bytes in flight, not by the bandwidth
-// (wave life 7.9 us against 6.1 us for the same accesses without arithmetic).  A load-to-LDS (no destination registers, the
-// data lands in a scratch line of LDS nobody reads) brings the lines of a later column group into this XCD's L2 while the
-// wave computes; issued AFTER the wave's own fields have arrived, because vector memory returns in order.  One dword per
-// 8 bytes of a 512-byte column-group segment touches each of its four 128-byte lines.
-// s_waitcnt vmcnt(0) (expcnt / lgkmcnt untouched: simm16 = vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]): every
-// vector memory operation of the wave has completed.  An explicit wait is part of the compiler's own bookkeeping, so no
-// conservative full wait appears behind the prefetch on paths that had issued a different number of loads.
-TRM_DEV void wait_for_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
-template <class NF> TRM_DEV void prefetch_line(const NF* base, unsigned byte_off, int* sink) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + byte_off),
-                                     (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
-}
-
 template <class NF> struct LevelGeom {
     NF zC, psiz, zFlo, dzc, rdzc, rdzf_lo, rdzf_hi, zF_top, dzc_top;
 };

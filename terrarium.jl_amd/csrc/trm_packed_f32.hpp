@@ -147,7 +147,7 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // (Deriving T and liq from (U, sat) instead of reading them, as k_column can, was measured here as well: C5 562 vs 533 us
 // per step -- the packed kernel is not short of bytes -- and is not offered.)
 template <bool RICHARDS, int LPC, int HYD>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf, int prefetch_columns) {
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
     const DevParams<float>& p = p_arg;
@@ -215,18 +215,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, D
             }
             flux_S = sel(is_bot, eS_b, sel(is_top, eS_t, splat(0.0f)));
         }
-    }
-    // ---- cache prefetch for a later wave (trm_column.hpp: prefetch_line), once every load of this wave has returned
-    wait_for_loads();
-    if (prefetch_columns > 0) {
-        __shared__ int sink[TRM_STEP_BLOCK];
-        const int col = i0 + prefetch_columns;
-        // the pair's two columns are adjacent: 2 * Nzp * 4 bytes per lane group; one dword per lane and column suffices
-        unsigned pb0 = ((unsigned)(col < Nh ? col : Nh - 1) * (unsigned)v.Nzp + kk) * 4u;
-        unsigned pb1 = ((unsigned)(col + 1 < Nh ? col + 1 : Nh - 1) * (unsigned)v.Nzp + kk) * 4u;
-        asm volatile("" : "+v"(pb0), "+v"(pb1));
-        for (const float* f : {(const float*)v.U, (const float*)v.sat, (const float*)v.T, (const float*)v.liq}) { prefetch_line(f, pb0, sink); prefetch_line(f, pb1, sink); }
-        if (RICHARDS) { prefetch_line((const float*)v.psi, pb0, sink); prefetch_line((const float*)v.psi, pb1, sink); }
     }
     // ---- heat
     const v2f qT_lo = -((kap + kap_m) * 0.5f) * ((T - T_m) * L.rdzf_lo);

@@ -92,6 +92,19 @@ class FieldTimeSeries:
         if self.values.shape[0] != self.times.size:
             raise ValueError("values must have one row per time")
         self.time_indexing = time_indexing
+        self.window = None          # levels of the device window (None: the whole record is resident)
+
+    def windowed(self, levels):
+        """The same series streamed through a device window of `levels` time levels (Oceananigans' `InMemory(chunk)` backend
+        of a FieldTimeSeries on disk): `run` / `Simulation` then append and trim between library calls
+        (trm_series_append / trm_series_trim_before) instead of holding the whole record in HBM.  `values` may be any
+        array-like that supports slicing along the first axis (a memory-mapped file)."""
+        if self.time_indexing == "cyclical":
+            raise ValueError("a cyclical series is periodic over its whole record and cannot be windowed")
+        self.window = int(levels)
+        if self.window < 3:
+            raise ValueError("the window must hold at least 3 time levels")
+        return self
 
     @classmethod
     def from_function(cls, f, times, time_indexing="linear"):
@@ -163,14 +176,70 @@ class DeviceState:
         if name == "ground_temperature":
             if getattr(self, "vegetation_mode", "off") == "standalone":   # an input of the VegetationModel (no soil)
                 name = "vegetation_ground_temperature"
-            else:                                                          # view of the top soil layer (soil_energy.jl:52-57)
-                return self.get("temperature")[-1]
+            else:                                                          # view of the top soil layer (soil_energy.jl:52-57): one row
+                return self.get_rows("temperature", self.grid.Nz - 1, 1)[0]
         if name == "rainfall_ground" and getattr(self, "vegetation_mode", "off") != "coupled":
             name = "rainfall"          # NoCanopyInterception: alias of rainfall (canopy_interception.jl:11-15)
         rows = self.rows(name)
         a = np.empty((rows, self.grid.Nh), dtype=self.dtype)
         self._check(self._lib.trm_download(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_download")
         return a[0] if rows == 1 else a
+
+    def _alias(self, name):
+        """(field, first row, rows) of a reference variable name that is a view or an alias of another field"""
+        if name == "ground_temperature" and getattr(self, "vegetation_mode", "off") != "standalone":
+            return "temperature", self.grid.Nz - 1, 1
+        if name == "ground_temperature":
+            name = "vegetation_ground_temperature"
+        if name == "rainfall_ground" and getattr(self, "vegetation_mode", "off") != "coupled":
+            name = "rainfall"
+        return name, 0, self.rows(name)
+
+    def get_rows(self, name, row0, nrows) -> np.ndarray:
+        """Rows [row0, row0 + nrows) of a field as `[nrows][Nh]` (trm_download_rows): only these rows cross PCIe."""
+        a = np.empty((nrows, self.grid.Nh), dtype=self.dtype)
+        self._check(self._lib.trm_download_rows(self._ctx, _capi.FIELD[name], int(row0), int(nrows), a.ctypes.data), "trm_download_rows")
+        return a
+
+    # -- ring grid: scatter / gather on the device (column_ring_grid.jl:102-149) ---------------------------------------
+    def set_ring_grid(self, num_points, mask_index):
+        """The columns are the points `mask_index` of a full grid of `num_points` points (trm_set_ring_grid)."""
+        idx = np.ascontiguousarray(mask_index, dtype=np.int64)
+        assert idx.shape == (self.grid.Nh,)
+        self._check(self._lib.trm_set_ring_grid(self._ctx, int(num_points), idx.ctypes.data), "trm_set_ring_grid")
+        self.ring_points = int(num_points)
+
+    def get_ring(self, name, fill=np.nan, row0=None, nrows=None) -> np.ndarray:
+        """`RingGrids.Field(field, grid; fill_value)`: the variable on the full grid, `[num_points]` for one row or
+        `[nrows][num_points]`, scattered on the device (trm_download_ring)."""
+        field, r0, nr = self._alias(name)
+        if row0 is not None:
+            r0, nr = r0 + int(row0), int(nrows if nrows is not None else nr - row0)
+        a = np.empty((nr, self.ring_points), dtype=self.dtype)
+        self._check(self._lib.trm_download_ring(self._ctx, _capi.FIELD[field], r0, nr, float(fill), a.ctypes.data), "trm_download_ring")
+        return a[0] if nr == 1 else a
+
+    def set_ring(self, name, full):
+        """`Oceananigans.Field(ring_field, grid)`: the masked points of a full-grid array `[num_points]` / `[rows][num_points]`
+        become the field, gathered on the device (trm_upload_ring)."""
+        rows = self.rows(name)
+        a = np.empty((rows, self.ring_points), dtype=self.dtype)
+        a[...] = np.asarray(full).reshape(rows, self.ring_points)
+        self._check(self._lib.trm_upload_ring(self._ctx, _capi.FIELD[name], a.ctypes.data), "trm_upload_ring")
+
+    def scatter_ring_to(self, name, device_ptr, fill=np.nan, row0=0, nrows=None):
+        """Scatter rows of a field into a device buffer `[nrows][num_points]` of a coupled model (trm_scatter_ring_device)."""
+        field, r0, nr = self._alias(name)
+        nr = int(nrows) if nrows is not None else nr - int(row0)
+        self._check(self._lib.trm_scatter_ring_device(self._ctx, _capi.FIELD[field], r0 + int(row0), nr, float(fill), C.c_void_p(int(device_ptr))), "trm_scatter_ring_device")
+
+    def gather_ring_from(self, name, device_ptr):
+        """The field from a full-grid device array `[rows][num_points]` of a coupled model (trm_gather_ring_device)."""
+        self._check(self._lib.trm_gather_ring_device(self._ctx, _capi.FIELD[name], C.c_void_p(int(device_ptr))), "trm_gather_ring_device")
+
+    def reset(self):
+        """reset!(state) + reset!(clock) (trm_reset)."""
+        self._check(self._lib.trm_reset(self._ctx), "trm_reset")
 
     def set(self, name, value):
         """set!(field, number | array | function(x, z))"""
@@ -255,6 +324,28 @@ class DeviceState:
         t, v, ti = self._series_args(times, values, time_indexing)
         self._check(self._lib.trm_set_bc_series(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], _capi.BC_KIND[kind],
                                                 t.size, t.ctypes.data, v.ctypes.data, ti), "trm_set_bc_series")
+
+    def _series_id(self, target):
+        """`target`: an input field name, or a (bc variable, side) pair"""
+        if isinstance(target, tuple):
+            return 1, _capi.BC_VAR[target[0]], _capi.SIDE[target[1]]
+        return 0, _capi.FIELD["vegetation_ground_temperature" if target == "ground_temperature" else target], 0
+
+    def series_append(self, target, times, values):
+        """Continues a series with further time levels through the side stream (trm_series_append)."""
+        is_bc, sid, side = self._series_id(target)
+        t, v, _ = self._series_args(times, values, "linear")
+        self._check(self._lib.trm_series_append(self._ctx, is_bc, sid, side, t.size, t.ctypes.data, v.ctypes.data), "trm_series_append")
+
+    def series_trim_before(self, t):
+        """Releases the time levels no evaluation at a time >= t can touch (trm_series_trim_before)."""
+        self._check(self._lib.trm_series_trim_before(self._ctx, float(t)), "trm_series_trim_before")
+
+    def series_info(self, target):
+        is_bc, sid, side = self._series_id(target)
+        n, cap, t0, t1 = C.c_int64(), C.c_int64(), C.c_double(), C.c_double()
+        self._check(self._lib.trm_series_info(self._ctx, is_bc, sid, side, C.byref(n), C.byref(cap), C.byref(t0), C.byref(t1)), "trm_series_info")
+        return dict(levels=int(n.value), capacity=int(cap.value), t_first=t0.value, t_last=t1.value)
 
     def save_state(self): self._check(self._lib.trm_save_state(self._ctx), "trm_save_state")
     def restore_state(self): self._check(self._lib.trm_restore_state(self._ctx), "trm_restore_state")
@@ -377,6 +468,7 @@ class ModelIntegrator:
         self.boundary_conditions = boundary_conditions
         self.initializers = initializers
         self.inputs = inputs  # name -> number | array | f(t) returning an array/number
+        self._next_level = {}  # windowed FieldTimeSeries: the first level of the record that is not on the device yet
 
     @property
     def clock(self):
@@ -406,6 +498,49 @@ class ModelIntegrator:
                     self.state.set_forcing(name, value(t))
                 dyn = True
         return dyn
+
+    # -- windowed series: a record streamed through a fixed device window ------------------------------------------------
+    def _windowed(self):
+        out = [((var, side), v) for (var, side), (kind, v) in self.boundary_conditions.items() if isinstance(v, FieldTimeSeries) and v.window]
+        out += [(name, v) for name, v in self.inputs.items() if isinstance(v, FieldTimeSeries) and v.window]
+        return out
+
+    def _feed(self, t, dt, nsteps):
+        """Moves the device windows forward to time `t` (trim, then append as many levels as the window has room for --
+        the copy runs on a side stream under the steps that follow) and returns how many of the next `nsteps` steps the
+        windows cover.  The last of k steps evaluates its inputs at t + (k - 1) dt, a Heun stage at t + k dt."""
+        ok = nsteps
+        series = self._windowed()
+        if not series:
+            return ok
+        self.state.series_trim_before(t)
+        for target, fts in series:
+            info = self.state.series_info(target)
+            nxt = self._next_level[id(fts)]
+            room = fts.window - info["levels"]
+            if room > 0 and nxt < fts.times.size:
+                hi = min(nxt + room, fts.times.size)
+                self.state.series_append(target, fts.times[nxt:hi], np.asarray(fts.values[nxt:hi]))
+                self._next_level[id(fts)] = hi
+                info = self.state.series_info(target)
+            if self._next_level[id(fts)] < fts.times.size:      # (beyond the end of the record the window IS the record's end)
+                k = int(np.floor((info["t_last"] - t) / dt + 1e-9))
+                if k < 1:
+                    raise ValueError(f"the window of {fts.window} levels of {target} does not cover one step of {dt} s at t = {t}")
+                ok = min(ok, k)
+        return ok
+
+    def _step(self, dt, nsteps, finalize, heun=None):
+        """`nsteps` steps in as few library calls as the device windows of the time series allow (one, without windows)."""
+        heun = isinstance(self.timestepper, Heun) if heun is None else heun
+        stepper = self.state.step_heun if heun else self.state.step
+        if not self._windowed():
+            return stepper(dt, nsteps, finalize=finalize)
+        done = 0
+        while done < nsteps:
+            k = self._feed(self.state.clock()[0], dt, nsteps - done)
+            stepper(dt, k, finalize=finalize and done + k == nsteps)
+            done += k
 
     def _has_time_dependence(self):
         return any(callable(v) for _, v in self.boundary_conditions.values()) or \
@@ -463,13 +598,22 @@ def initialize_integrator(integ: ModelIntegrator):
     """initialize!(integrator) (model_integrator.jl:96-109): reset, inputs, user initializers,
     model initializer, process initializers."""
     st = integ.state
-    st.set_clock(0.0, 0)
+    st.reset()           # reset!(state), reset!(clock): every prognostic / auxiliary / tendency field to zero, clock to 0
     st.clear_series()
+    grid = getattr(integ.model, "grid", None)
+    if hasattr(grid, "mask_index") and not hasattr(st, "ring_points"):
+        st.set_ring_grid(grid.mask.size, grid.mask_index)   # ColumnRingGrid: scatter / gather run on the device
+
+    def head(fts):      # a windowed series starts with the first `window` levels of its record
+        n = fts.times.size if not fts.window else min(fts.window, fts.times.size)
+        integ._next_level[id(fts)] = n
+        return fts.times[:n], np.asarray(fts.values[:n])
+
     for (var, side), (kind, value) in integ.boundary_conditions.items():
         if isinstance(value, RasterInputSource):
             value.attach_boundary(st, var, side, kind)     # a named input variable as boundary value (soil_heat_global_era5.jl:31-44)
         elif isinstance(value, FieldTimeSeries):
-            st.set_bc_series(var, side, kind, value.times, value.values, value.time_indexing)
+            st.set_bc_series(var, side, kind, *head(value), value.time_indexing)
         else:
             st.set_bc(var, side, kind, value(0.0) if callable(value) else value)
     for name, value in integ.inputs.items():
@@ -477,7 +621,7 @@ def initialize_integrator(integ: ModelIntegrator):
             value.name = name
             value.attach(st)      # static raster: set once; time-indexed: device-resident series (ext/TerrariumRastersExt)
         elif isinstance(value, FieldTimeSeries):
-            st.set_forcing_series(name, value.times, value.values, value.time_indexing)
+            st.set_forcing_series(name, *head(value), value.time_indexing)
         else:
             st.set_forcing(name, value(0.0) if callable(value) else value)
     st.update_inputs()   # initialize!(fields, source, clock) = update_inputs! at the start time
@@ -498,10 +642,7 @@ def timestep(integ: ModelIntegrator, dt: Optional[float] = None, finalize: bool 
     """timestep!(integrator, dt; finalize) (model_integrator.jl:124-131)"""
     dt = integ.timestepper.dt if dt is None else float(dt)
     integ._apply_time_dependent(current_time(integ), dt)
-    if isinstance(integ.timestepper, Heun):
-        integ.state.step_heun(dt, 1, finalize)
-    else:
-        integ.state.step(dt, 1, finalize)
+    integ._step(dt, 1, finalize)
 
 
 def run(integ: ModelIntegrator, steps: Optional[int] = None, period: Optional[float] = None, dt: Optional[float] = None):
@@ -513,14 +654,12 @@ def run(integ: ModelIntegrator, steps: Optional[int] = None, period: Optional[fl
         raise ValueError("both `steps` and `period` cannot be specified")
     if steps is None:
         steps = int(period // dt)
-    heun = isinstance(integ.timestepper, Heun)
-    stepper = integ.state.step_heun if heun else integ.state.step
     if integ._has_time_dependence():
         for n in range(steps):
             integ._apply_time_dependent(current_time(integ), dt)
-            stepper(dt, 1, finalize=(n == steps - 1))
+            integ._step(dt, 1, finalize=(n == steps - 1))
     elif steps > 0:
-        stepper(dt, steps, finalize=True)
+        integ._step(dt, steps, finalize=True)
     if steps == 0:
         integ.state.compute_auxiliary()  # run! always ends with compute_auxiliary! (model_integrator.jl:85-86)
     return integ
@@ -556,7 +695,8 @@ def time_step(integ: ModelIntegrator, dt: Optional[float] = None, **kwargs):
 
 
 def reset(integ: ModelIntegrator):
-    """initialize!(integrator) (model_integrator.jl:96-109): clock back to zero, inputs, initializers, process initialisers."""
+    """initialize!(integrator) (model_integrator.jl:96-109): reset!(state) -- every prognostic, auxiliary and tendency field
+    to zero (state_variables.jl:102-120) --, clock back to zero, inputs, initializers, process initialisers."""
     return initialize_integrator(integ)
 
 

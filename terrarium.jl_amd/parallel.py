@@ -53,9 +53,30 @@ def combine(local: np.ndarray, op: str) -> np.ndarray:
     local = np.asarray(local, dtype=np.float64)
     if dist is None or dist.get_world_size() == 1:
         return local
+    if op in ("min", "max"):
+        # Base.minimum / maximum: a NaN on any rank must reach every rank.  The backends' MIN / MAX do not promise that, so
+        # the values travel NaN-free next to a flag that travels with the same operator (the scheme of trm_reduce_global).
+        packed, _ = pack_nan_flags(local, op)
+        t = torch.from_numpy(packed).to(_device())
+        dist.all_reduce(t, op=getattr(dist.ReduceOp, _OPS[op]))
+        return unpack_nan_flags(t.cpu().numpy())
     t = torch.from_numpy(local.copy()).to(_device())
     dist.all_reduce(t, op=getattr(dist.ReduceOp, _OPS[op]))
     return t.cpu().numpy()
+
+
+def pack_nan_flags(values: np.ndarray, op: str):
+    """[values with NaN replaced by the operator's neutral element | flags]: flag = -1 (min) / +1 (max) where the value was
+    NaN, else 0 -- reducing both halves with the same operator leaves a non-zero flag wherever any rank held a NaN."""
+    values = np.asarray(values, dtype=np.float64)
+    nan = np.isnan(values)
+    sentinel, yes = (np.inf, -1.0) if op == "min" else (-np.inf, 1.0)
+    return np.concatenate([np.where(nan, sentinel, values), np.where(nan, yes, 0.0)]), nan
+
+
+def unpack_nan_flags(packed: np.ndarray) -> np.ndarray:
+    n = packed.size // 2
+    return np.where(packed[n:] != 0.0, np.nan, packed[:n])
 
 
 def init_library_communicator(state):

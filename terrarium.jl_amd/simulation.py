@@ -80,9 +80,16 @@ class SnapshotWriter:
         t, it = sim.integrator.state.clock()
         self.times.append(t)
         self.iterations.append(it)
+        st = sim.integrator.state
         for f in self.fields:
-            a = sim.integrator.state.get(f)
-            self.data[f].append(self.ring_grid.scatter(a, self.fill) if self.ring_grid is not None else a)
+            # only the rows the variable consists of cross PCIe (`ground_temperature` = one row of temperature); with a ring
+            # grid the scatter runs on the device (trm_download_ring) and the result arrives as [rows][nlat][nlon]
+            if self.ring_grid is not None and hasattr(st, "ring_points") and st.ring_points == self.ring_grid.mask.size:
+                a = st.get_ring(f, self.fill)
+                self.data[f].append(a.reshape(a.shape[:-1] + self.ring_grid.mask.shape))
+            else:
+                a = st.get(f)
+                self.data[f].append(self.ring_grid.scatter(a, self.fill) if self.ring_grid is not None else a)
 
     def write(self):
         if self.filename:
@@ -136,8 +143,7 @@ class Simulation:
             self.initialized = True
         self.running = True
         host_dependent = integ._has_time_dependence()
-        heun = isinstance(integ.timestepper, _integ.Heun)
-        stepper = integ.state.step_heun if heun else integ.state.step
+        stepper = lambda dt, n, finalize: integ._step(dt, n, finalize)      # (feeds the device windows of streamed series)
         while self.running:
             t, it = integ.state.clock()
             if t >= self.stop_time or it >= self.stop_iteration:
@@ -146,8 +152,14 @@ class Simulation:
             n = min([s.steps_until_next(t, it, self.dt) for s, _ in self._events()] + [10 ** 9])
             n = min(n, self.stop_iteration - it) if math.isfinite(self.stop_iteration) else n
             t_next = min([s.next_time(t) for s, _ in self._events()] + [self.stop_time])
-            whole = int(math.floor((t_next - t) / self.dt + 1e-12)) if math.isfinite(t_next) else n
+            whole = int(math.floor((t_next - t) / self.dt + 1e-9)) if math.isfinite(t_next) else n
             n = int(max(0, min(n, whole)))
+            if math.isfinite(t_next) and abs(t_next - t) <= 1e-9 * self.dt:
+                # The device clock accumulates dt step by step: with a dt that is not exactly representable it can land a few
+                # ulp short of the target.  Oceananigans' `minimum_relative_step` treats that as reached: no sliver step.
+                integ.state.set_clock(t_next, it)
+                self._fire()
+                continue
             if n >= 1:
                 if host_dependent:      # functions of time are evaluated on the host before every step
                     for k in range(n):

@@ -21,7 +21,7 @@ def sample_workload(w, sel):
 
 
 @pytest.mark.parametrize("config,hydraulics,exact", [("richards", "default", True), ("heat", "default", True),
-                                                      ("land", "vg", False)])
+                                                      ("land", "vg", False), ("land", "default", False)])
 def test_n145_full_size_against_sampled_oracle(config, hydraulics, exact):
     lat, lon = W.columns_from_mask("N145")
     assert lat.size == 56951

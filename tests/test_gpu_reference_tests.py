@@ -374,18 +374,99 @@ def test_simulation_driver_with_callbacks_and_ring_output(tmp_path, stepper):
     assert list(f["time"]) == [0.0, 1800.0, 3600.0, 5400.0, 7200.0] and f["ground_temperature"].shape == (5, 144, 288)
     assert np.isnan(f["ground_temperature"][:, ~mask]).all() and np.isfinite(f["ground_temperature"][:, mask]).all()
     assert f["temperature"].shape == (5, 20, 144, 288)
-    # the same trajectory by hand: 13 steps of 600 s and one of 300 s
-    ref = make()
-    trm.run(ref, steps=13, dt=600.0)
-    trm.timestep(ref, 300.0)
-    assert np.array_equal(ref.state.temperature, integ.state.temperature)
-    assert np.array_equal(grid.gather(f["ground_temperature"][-1]), _state_at(make, 12)[-1])
+    # The same trajectory on the ORACLE, stepped by hand: 13 steps of 600 s and the aligned one of 300 s, the snapshots taken
+    # at the iterations the TimeInterval(1800 s) schedule actuates on (0, 3, 6, 9, 12).
+    import oracle
+    o = oracle.Oracle(grid.Nh, grid.thickness, oracle.default_params(), dx=grid.dx)
+    o.set("temperature", T0[None, :] * np.ones((20, 1)))
+    o.set("saturation_water_ice", 0.7)
+    times = 600.0 * np.arange(20)
+    o.set_bc_series("temperature", "top", "value", times, np.stack([T0 + 10 * np.sin(2 * np.pi * t / 86400.0 - lon) for t in times]))
+    o.initialize()
+    step = (lambda dt: o.timestep_heun(dt, True)) if stepper is trm.Heun else (lambda dt: o.timestep(dt, True))
+    snaps = [o.get("temperature")]
+    for n in range(13):
+        step(600.0)
+        if (n + 1) % 3 == 0:
+            snaps.append(o.get("temperature"))
+    step(300.0)
+    assert o.clock()[0] == sim.time
+    assert np.array_equal(integ.state.temperature, o.get("temperature"))
+    assert np.array_equal(integ.state.internal_energy, o.get("internal_energy"))
+    for k, snap in enumerate(snaps):
+        assert np.array_equal(grid.gather(f["temperature"][k]), snap), k
+        assert np.array_equal(grid.gather(f["ground_temperature"][k]), snap[-1]), k
 
 
-def _state_at(make, nsteps):
-    i = make()
-    trm.run(i, steps=nsteps, dt=600.0)
-    return i.state.temperature
+# model_integrator.jl:96-109 + state_variables.jl:102-120: initialize!(integrator) begins with reset!(state) -- every
+# prognostic, auxiliary and tendency field back to zero -- so a re-initialised run repeats a fresh one exactly
+@pytest.mark.parametrize("stepper", [trm.ForwardEuler, trm.Heun])
+def test_reset_of_a_land_model_with_vegetation_equals_a_fresh_integrator(stepper):
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=12), 50)
+    rng = np.random.default_rng(4)
+    u = rng.uniform(-1, 1, 50)
+    zc = grid.z_centers()
+    sat = np.clip(np.minimum(1.0, 0.8 - 0.05 * zc)[:, None] * (1.0 + 0.05 * u)[None, :], 0.05, 1.0)
+    make = lambda: trm.initialize(
+        trm.LandModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=vg_hydrology()), vegetation=trm.VegetationCarbon(), surface_hydrology=trm.SurfaceHydrology.canopy()),
+        stepper(dt=0.5),
+        initializers=dict(temperature=4.0 + 3.0 * u[None, :] * np.ones((12, 1)), saturation_water_ice=sat, carbon_vegetation=1.5 + 0.5 * u,
+                          vegetation_area_fraction=0.5 + 0.3 * u),
+        inputs=dict(air_temperature=6.0 + u, rainfall=2.0e-7 * (u > 0), surface_shortwave_down=300.0, SAI=0.5 + 0.25 * u, CO2=400.0))
+    a, fresh = make(), make()
+    trm.run(a, steps=9)
+    assert np.any(a.state.canopy_water != 0) and np.any(a.state.skin_temperature != fresh.state.skin_temperature)
+    a.state.set("surface_excess_water", 0.01)          # (and something no initializer touches)
+    trm.reset(a)
+    assert a.state.clock() == (0.0, 0) and a.state.status() == 0
+    names = ["internal_energy", "saturation_water_ice", "temperature", "liquid_water_fraction", "pressure_head", "hydraulic_conductivity",
+             "surface_excess_water", "skin_temperature", "canopy_water", "carbon_vegetation", "vegetation_area_fraction", "net_assimilation",
+             "ground_heat_flux", "water_table", "tend_internal_energy", "tend_canopy_water"]
+    for n in names:
+        assert np.array_equal(a.state.get(n), fresh.state.get(n)), n
+    trm.run(a, steps=7)
+    trm.run(fresh, steps=7)
+    for n in names:
+        assert np.array_equal(a.state.get(n), fresh.state.get(n)), n
+
+
+# test/differentiability/soil_energy_diff.jl:28-76 through the C ABI: slopes of the free-water closure by central differences
+# of closure!(state) at U -/+ h (the closure is piecewise linear in U)
+def test_free_water_closure_slopes_on_the_device():
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10), 8)
+    soil = trm.SoilEnergyWaterCarbon(strat=trm.HomogeneousStratigraphy(porosity=trm.ConstantSoilPorosity(mineral_porosity=0.5)))
+    integ = trm.initialize(trm.SoilModel(grid, soil=soil), initializers=dict(saturation_water_ice=1.0))
+    st = integ.state
+    por, sat = 0.5, 1.0
+    Lth = 3.34e8 * sat * por
+    C_thawed = 4.2e6 * por + 2.0e6 * (1 - por)
+    C_frozen = 1.9e6 * por + 2.0e6 * (1 - por)
+    def closure_at(U, sat=1.0):
+        st.set("saturation_water_ice", sat)
+        st.set("internal_energy", U)
+        st.closure()
+        return st.liquid_water_fraction[0, 0], st.temperature[0, 0]
+    h = 1.0e3
+    fd = lambda U, k, **kw: (closure_at(U + h, **kw)[k] - closure_at(U - h, **kw)[k]) / (2 * h)
+    assert fd(-1.0e7, 0) == pytest.approx(1 / Lth, rel=1e-8)             # d liq / d U in the phase change
+    assert fd(-1.0e7, 0, sat=0.0) == 0.0                                  # L_theta = 0
+    assert fd(-Lth - 1.0e7, 1) == pytest.approx(1 / C_frozen, rel=1e-8)   # frozen
+    assert fd(-Lth / 2, 1) == 0.0                                         # phase change
+    assert fd(Lth / 2, 1) == pytest.approx(1 / C_thawed, rel=1e-8)        # thawed
+
+
+# test/inputs/input_forcing.jl:38-54 through the host mirror: a FieldTimeSeries of ones as the bottom heat flux
+def test_forcing_time_series_of_ones_on_the_device():
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=10), 3, dtype=np.float32)
+    t_F = np.arange(0.0, 1.0001, 0.1)
+    bc = trm.GeothermalHeatFlux(trm.FieldTimeSeries(t_F, np.ones((t_F.size, 3))))
+    integ = trm.initialize(trm.SoilModel(grid), trm.ForwardEuler(dt=0.1), boundary_conditions=bc, initializers=dict(temperature=0.0, saturation_water_ice=1.0))
+    st = integ.state
+    assert np.all(st.internal_energy == 0)                                # all(x .≈ 0)
+    dz = trm.zspacings(grid)[:, None]
+    trm.timestep(integ, 0.1)
+    assert np.allclose(np.sum(st.internal_energy.astype(np.float64) * dz, axis=0), 0.1, rtol=1e-5)   # x ≈ 0.1
+    assert st.clock()[0] == pytest.approx(0.1)
 
 
 # ground_resistance_factor.jl:36-56: soil-moisture limited bare-ground evaporation, device vs oracle through a LandModel run

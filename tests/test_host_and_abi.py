@@ -171,7 +171,7 @@ def test_python_constants_match_the_header():
         key = {"asynchronous": "TRM_OPT_ASYNC", "step_kernel": "TRM_OPT_STEP_KERNEL", "write_kf_every_step": "TRM_OPT_WRITE_KF_EVERY_STEP",
                "vwc_forcing_field": "TRM_OPT_VWC_FORCING_FIELD", "packed_f32": "TRM_OPT_PACKED_F32",
                "derive_closure_fields": "TRM_OPT_DERIVE_CLOSURE_FIELDS", "steps_per_launch": "TRM_OPT_STEPS_PER_LAUNCH",
-               "pipeline_parts": "TRM_OPT_PIPELINE_PARTS", "prefetch_columns": "TRM_OPT_PREFETCH_COLUMNS"}[name]
+               "pipeline_parts": "TRM_OPT_PIPELINE_PARTS", "column_groups": "TRM_OPT_COLUMN_GROUPS"}[name]
         assert enum[key] == oid, name
     for code, key in enumerate(("TRM_OK", "TRM_EINVAL", "TRM_EHIP", "TRM_ENOMEM", "TRM_EUNSUPPORTED", "TRM_ESTALE", "TRM_ECOMM")):
         assert enum[key] == code
@@ -220,3 +220,67 @@ def test_exported_interface_helpers():
     zc, zf, dz = trm.znodes(g), trm.znodes(g, "face"), trm.zspacings(g)
     assert zf[-1] == 0.0 and np.all(np.diff(zf) > 0) and np.allclose(np.diff(zf), dz) and np.allclose(zc, (zf[1:] + zf[:-1]) / 2)
     assert trm.get_grid(trm.SoilModel(g)) is g
+
+
+def _build_abi_host(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_host")
+    subprocess.check_call(["gcc", "-O1", "-Wall", "-Werror", "-std=c99", "-o", exe, os.path.join(ROOT, "tests", "abi_host.c"), "-ldl"])
+    return exe
+
+
+def _julia_struct_fields(name):
+    """(field, type) pairs of a Julia struct printed in INTEGRATION.md's shim, in declaration order."""
+    import re
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"(?:mutable )?struct " + name + r"\n(.*?)\n\s*(?:" + name + r"\(\) = new\(\)\n)?end", text, re.S)
+    assert m, name
+    return re.findall(r"(\w+)::(\w+)", m.group(1))
+
+
+def test_c_host_sees_the_struct_layout_the_julia_shim_declares(tmp_path):
+    """tests/abi_host.c -- a plain C program built with gcc against include/terrarium_hip.h that dlopens the library -- prints
+    sizeof / offsetof of trm_grid, trm_params, trm_vegetation_params.  They must equal (a) the layout a Julia `ccall` derives
+    from the structs INTEGRATION.md declares (C layout rules applied to the declared field order and types) and (b) the ctypes
+    mirror the Python tests drive the library through."""
+    import subprocess
+    from terrarium_jl_amd import _capi
+    exe = _build_abi_host(tmp_path)
+    out = subprocess.check_output([exe, "layout", _capi.LIB_PATH], text=True).split("\n")
+    off, size, sizeof, misc = {}, {}, {}, {}
+    for line in out:
+        w = line.split()
+        if not w:
+            continue
+        if w[0] == "sizeof":
+            sizeof[w[1]] = int(w[2])
+        elif w[0] in ("abi_version", "default"):
+            misc[tuple(w[:-1]) if w[0] == "default" else w[0]] = w[1:] if w[0] == "abi_version" else w[-1]
+        else:
+            off.setdefault(w[0], []).append((w[1], int(w[2])))
+            size.setdefault(w[0], {})[w[1]] = int(w[3])
+    assert misc["abi_version"][0] == misc["abi_version"][1]          # the library and the header agree
+    ctype_size = dict(Cint=4, Int64=8, Cdouble=8, Ptr=8)
+    for cstruct, jstruct, ct in (("trm_grid", "TrmGrid", _capi.TrmGrid), ("trm_params", "TrmParams", _capi.TrmParams),
+                                 ("trm_vegetation_params", "TrmVegetationParams", _capi.TrmVegetationParams)):
+        # (a) the Julia declaration: natural alignment, declaration order
+        pos, expect = 0, []
+        for fname, ftype in _julia_struct_fields(jstruct):
+            n = ctype_size[ftype]
+            pos = (pos + n - 1) // n * n
+            expect.append((fname, pos))
+            pos += n
+        assert expect == off[cstruct], (cstruct, [a for a, b in zip(expect, off[cstruct]) if a != b][:3])
+        assert (pos + 7) // 8 * 8 == sizeof[cstruct]
+        # (b) ctypes
+        assert [(f[0], getattr(ct, f[0]).offset) for f in ct._fields_] == off[cstruct]
+        assert C_sizeof(ct) == sizeof[cstruct]
+    # defaults written through the C struct land where the C host reads them
+    assert float(misc[("default", "rho_w")]) == 1000.0 and float(misc[("default", "K_sat")]) == 1.0e-5
+    assert float(misc[("default", "field_capacity")]) == 0.25 and misc[("default", "halo_policy")] == "0" and misc[("default", "reserved")] == "0"
+    assert float(misc[("default", "tau25")]) == 2600.0 and float(misc[("default", "C_can")]) == 0.006
+
+
+def C_sizeof(ct):
+    import ctypes
+    return ctypes.sizeof(ct)

@@ -593,3 +593,45 @@ def test_soil_moisture_evaporation_resistance_limits():
     ref.compute_evaporation()
     beta = beta / ref.get("evaporation_ground")
     assert beta[0] == 0.0 and beta[1] == pytest.approx(0.25, rel=1e-12) and beta[2] == pytest.approx(1.0, abs=1e-12) and beta[3] == 1.0
+
+
+# test/differentiability/soil_energy_diff.jl:28-76 -- the reference pins the slopes of the free-water closure with Enzyme;
+# restated as central finite differences of the same two functions (both are piecewise linear in U, so the difference
+# quotient is the slope up to rounding)
+def test_free_water_closure_slopes():
+    sat, por = 1.0, 0.5
+    Lth = 3.34e8 * sat * por
+    fd = lambda f, U, h=1.0e3: (f(U + h) - f(U - h)) / (2 * h)
+    liq = lambda U, L=Lth: oracle.scalar("liquid_water_fraction", U, L)
+    # liquid_water_fraction: d liq / d U = 1 / L_theta inside the phase change (U = -1e7 > -L_theta)
+    assert fd(liq, -1.0e7) == pytest.approx(1 / Lth, rel=1e-9)
+    # ... and exactly zero when L_theta = 0 (no water: the cell is never in phase change)
+    assert fd(lambda U: liq(U, 0.0), -1.0e7) == 0.0
+    C = 2.0e5
+    T = lambda U: oracle.scalar("energy_to_temperature", U, Lth, C)
+    # energy_to_temperature (the reference's three cases, lines 45-70, with its own values of U)
+    assert fd(T, Lth - 1.0e7) == pytest.approx(1 / C, rel=1e-9)          # "case 1" (U > 0: thawed branch of the function)
+    assert fd(T, -Lth / 2) == 0.0                                        # phase change: T stays at 0
+    assert fd(T, Lth / 2) == pytest.approx(1 / C, rel=1e-9)              # thawed
+    assert fd(T, -Lth - 1.0e7) == pytest.approx(1 / C, rel=1e-9)         # frozen (U < -L_theta): the branch the name promises
+
+
+# test/inputs/input_forcing.jl:38-54 -- a FieldTimeSeries of ones as input source: F ~ 1 at initialisation and after a
+# step of 0.1, and the prognostic that integrates it has moved by 0.1.  The reference's TestModel (tendency = F) is a user
+# model; here the series of ones is the bottom heat flux of a SoilModel, whose column energy integrates it:
+# sum_k U_k dz_k grows by F * dt = 0.1 (compute_z_bcs!: flux * Az / V into the boundary cell, upward positive).
+def test_forcing_time_series_of_ones():
+    thick = trm.ExponentialSpacing(N=10).get_spacing()
+    o = Oracle(3, thick, default_params())
+    o.set("temperature", 0.0)               # U = 0 everywhere: all(x .≈ 0) initially, as in the reference test
+    o.set("saturation_water_ice", 1.0)
+    t_F = np.arange(0.0, 1.0001, 0.1)
+    o.set_bc_series("internal_energy", "bottom", "flux", t_F, np.ones((t_F.size, 3)))
+    o.initialize()
+    o.update_inputs()
+    dz = o.grid()["dzc"][:, None]
+    assert np.all(o.get("internal_energy") == 0.0)
+    o.timestep(0.1)
+    E1 = np.sum(o.get("internal_energy") * dz, axis=0)
+    assert np.allclose(E1, 0.1, rtol=1e-12)                     # x ~ 0.1: the unit flux of the series over one step of 0.1
+    assert o.clock()[0] == pytest.approx(0.1)

@@ -29,6 +29,7 @@ def _worker(rank, world, port, Nh, result_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     rng = np.random.default_rng(3)
     full = rng.normal(size=(5, Nh))                     # the "global" field, identical on every rank
+    full[3, Nh - 1] = np.nan                            # a NaN in the LAST rank's block only: row 3 of min / max must be NaN everywhere
     local = parallel.shard_columns(full, world, rank)  # this rank's block of columns
 
     class FakeState:  # stands in for DeviceState.reduce (which needs a GPU): per-rank partials
@@ -36,7 +37,7 @@ def _worker(rank, world, port, Nh, result_dir):
             if op == "sum":
                 return local.sum(axis=1)
             if op == "min":
-                return local.min(axis=1)
+                return local.min(axis=1)        # (numpy's min / max propagate NaN like Base.minimum / maximum and trm_reduce)
             if op == "max":
                 return local.max(axis=1)
             if op == "hasnan":
@@ -65,13 +66,31 @@ def test_sharded_reductions_world2(tmp_path, Nh):
     for rank in range(world):
         r = np.load(tmp_path / f"rank{rank}.npz")
         full = r["full"]
-        assert np.allclose(r["sum"], full.sum(axis=1), rtol=1e-12)
-        assert np.array_equal(r["min"], full.min(axis=1))
-        assert np.array_equal(r["max"], full.max(axis=1))
-        assert np.all(r["hasnan"] == 0)
-        assert np.allclose(r["vol"], full.sum(), rtol=1e-12)
+        assert np.allclose(r["sum"], full.sum(axis=1), rtol=1e-12, equal_nan=True)
+        # a NaN held by one rank reaches every rank's global minimum / maximum (parallel.combine's sentinel + flag scheme, the
+        # same packing trm_reduce_global uses around its RCCL all-reduce)
+        assert np.isnan(r["min"][3]) and np.isnan(r["max"][3])
+        assert np.array_equal(r["min"], full.min(axis=1), equal_nan=True)
+        assert np.array_equal(r["max"], full.max(axis=1), equal_nan=True)
+        assert list(r["hasnan"]) == [0, 0, 0, 1, 0]
+        assert np.isnan(r["vol"]).all()
         assert int(r["status"][0]) == 2          # rank 1's flag reaches everyone
-        assert np.array_equal(r["gathered"], full)
+        assert np.array_equal(r["gathered"], full, equal_nan=True)
+
+
+def test_nan_flag_packing_of_the_global_min_max():
+    """Host-side unit test of the packing trm_reduce_global and parallel.combine share: NaN -> (neutral element, flag)."""
+    sys.path[:0] = [ROOT]
+    from terrarium_jl_amd import parallel
+    a = np.array([1.0, np.nan, -3.0, np.inf])
+    b = np.array([0.5, 2.0, np.nan, 4.0])
+    for op, red in (("min", np.minimum), ("max", np.maximum)):
+        pa, _ = parallel.pack_nan_flags(a, op)
+        pb, _ = parallel.pack_nan_flags(b, op)
+        assert not np.isnan(pa).any() and not np.isnan(pb).any()          # nothing a backend's MIN / MAX could drop
+        out = parallel.unpack_nan_flags(red(pa, pb))
+        expect = np.array([red(1.0, 0.5), np.nan, np.nan, red(np.inf, 4.0)])
+        assert np.array_equal(out, expect, equal_nan=True)
 
 
 def test_shard_ranges_cover_all_columns():
