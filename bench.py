@@ -24,7 +24,9 @@ sample of the same workload on the host cores) -- never for the measured path.
 import argparse
 import json
 import os
+import shutil
 import socket
+import statistics
 import subprocess
 import sys
 import time
@@ -36,10 +38,15 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 
 import numpy as np
 
-STABLE_STEPS = 150   # see run_timed(): longest stretch the explicit Richards scheme is stepped from one state
-MAX_WARMUP = 100     # ... and the warm-up steps executed before it (config.warmup_executed reports the count)
+# Longest stretch a synthetic state is stepped from one snapshot (see run_timed()).  The explicit Richards scheme at dt = 60 s
+# dries top cells out (sat = 0, psi = -Inf, then NaN -- in the reference as well); the first status flag appears within 250
+# steps of the warmed-up state for C3, 110 for C4-VG and 80 for C4 / C5 (profiles/tools/first_flag.py, profiles/r03/).
+STABLE_STEPS = {"heat": 10 ** 9, "richards": 150, "land": 50, "landveg": 50}
+MAX_WARMUP = 40      # warm-up steps executed before the timed stretches (config.warmup_executed reports the count)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
+# bytes the reference's unfused passes stream per cell and step (count of arrays each kernel reads / writes)
+REFERENCE_ORDER_BYTES_PER_CELL_STEP = {"heat": 140, "richards": 300, "land": 300, "landveg": 300}
 
 WORKLOADS = {
     # name: (description, config, hydraulics, mask/columns, Nz, dtype, replicas)
@@ -123,41 +130,46 @@ def build_workload(W, parallel, name, world, rank, scaling):
     return W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics), desc, config, Nz, dt_name
 
 
-def run_timed(dev, w, config, steps, warmup, spinup_ms, heun, sync, barrier=None):
-    """W untimed warm-up steps, an untimed clock spin-up, then exactly `steps` timed steps (one launch each).
-    Returns (wall seconds of the timed region, device ms of its launches by HIP events on the library's stream,
-    warm-up steps executed)."""
+def run_timed(dev, w, config, steps, warmup, spinup_ms, heun, sync, barrier=None, repeats=1):
+    """W untimed warm-up steps, an untimed clock spin-up, then `repeats` timed regions of exactly `steps` steps each (one
+    launch per step unless the context says otherwise), every region starting from the state the W steps produced (a
+    device-side restore between regions, untimed).  Returns (wall seconds per region, device ms of the region's launches
+    by HIP events on the library's stream per region, warm-up steps executed, whether a region was chunked)."""
     dt = w["dt"]
-    warm = min(warmup, MAX_WARMUP)
+    stable = STABLE_STEPS[config]
+    warm = min(warmup, MAX_WARMUP, stable // 2)
+    step_timed = dev.step_heun_timed if heun else dev.step_timed
     if warm > 0:
         (dev.step_heun if heun else dev.step)(dt, warm, finalize=False)
-    # The explicit Richards scheme at dt = 60 s dries the top cells of this synthetic state to sat = 0 (psi = -Inf, then
-    # NaN) after ~270 steps -- in the reference as well.  Runs longer than STABLE_STEPS therefore go back to a device-side
-    # snapshot of the warmed-up state every STABLE_STEPS steps (a D2D copy inside the timed wall clock, no host data):
-    # every step still does its full work on a valid state.
-    chunked = config != "heat" and steps > STABLE_STEPS
-    if chunked or spinup_ms > 0:
-        dev.save_state()
+    dev.save_state()
+    # Runs longer than the stable stretch go back to the device-side snapshot of the warmed-up state every `stable` steps (a
+    # D2D copy inside the timed wall clock, no host data): every step still does its full work on a valid state.
+    chunked = steps > stable
     # Clock spin-up (untimed, part of the warm-up): an MI355X that comes out of idle needs ~30 ms of sustained load before
-    # its clocks settle (profiles/tools/ramp.py).  A land-surface run is hours of sustained stepping, so the timed region
+    # its clocks settle (profiles/tools/ramp.py).  A land-surface run is hours of sustained stepping, so the timed regions
     # should see the settled clocks: the warmed-up state is stepped and restored until the device has been busy for
-    # --spinup-ms, then restored once more.  The timed K steps start from exactly the state the W steps produced.
+    # --spinup-ms.
     spun = 0.0
     while spun < spinup_ms:
-        spun += (dev.step_heun_timed if heun else dev.step_timed)(dt, STABLE_STEPS, finalize=False)
+        spun += step_timed(dt, min(stable, 150), finalize=False)
         dev.restore_state()
-    (barrier or sync)()
-    t0 = time.perf_counter()
-    ms, done = 0.0, 0
-    while done < steps:
-        n = min(steps - done, STABLE_STEPS) if chunked else steps
-        if chunked and done > 0:
-            dev.restore_state()
-        ms += (dev.step_heun_timed if heun else dev.step_timed)(dt, n, finalize=False)  # n steps = n launches, HIP events on the library's stream
-        done += n
-    sync()
-    (barrier or sync)()
-    return time.perf_counter() - t0, ms, warm, chunked
+    walls, kernels = [], []
+    for _ in range(max(1, repeats)):
+        dev.restore_state()
+        (barrier or sync)()
+        t0 = time.perf_counter()
+        ms, done = 0.0, 0
+        while done < steps:
+            n = min(steps - done, stable)
+            if done > 0:
+                dev.restore_state()
+            ms += step_timed(dt, n, finalize=False)  # n steps, HIP events on the library's stream
+            done += n
+        sync()
+        (barrier or sync)()
+        walls.append(time.perf_counter() - t0)
+        kernels.append(ms)
+    return walls, kernels, warm, chunked
 
 
 def roofline_object(config, Nz, Nh, wordsize, kernel_s, kernel_name, pmc_name=None, workload=None):
@@ -184,27 +196,48 @@ def roofline_object(config, Nz, Nh, wordsize, kernel_s, kernel_name, pmc_name=No
     return r
 
 
+def _median(xs):
+    return float(statistics.median(xs))
+
+
+def measure(dev, w, config, steps, warmup, spinup_ms, heun, sync, barrier, repeats, reduce_max=None):
+    """run_timed + the statistics of the line: per-repeat wall time (max over ranks), median / min / max."""
+    walls, kernels, warm, chunked = run_timed(dev, w, config, steps, warmup, spinup_ms, heun, sync, barrier, repeats)
+    if reduce_max is not None:
+        walls, kernels = reduce_max(walls), reduce_max(kernels)
+    K = max(steps, 1)
+    return dict(wall_s=_median(walls), kernel_ms=_median(kernels), warm=warm, chunked=chunked, repeats=len(walls),
+                ms_per_step=_median(walls) * 1e3 / K, ms_per_step_min=min(walls) * 1e3 / K, ms_per_step_max=max(walls) * 1e3 / K,
+                kernel_us_per_step=_median(kernels) * 1e3 / K, kernel_us_per_step_min=min(kernels) * 1e3 / K)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=10, help="the K-step timed region is repeated this many times (state restored in between, untimed); the line reports the median")
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--kernel", default="fused", choices=["fused", "unfused"])
-    ap.add_argument("--integrator", default="euler", choices=["euler", "heun"], help="ForwardEuler (headline) or Heun (two fused launches per step)")
+    ap.add_argument("--integrator", default="euler", choices=["euler", "heun"], help="ForwardEuler (headline) or Heun (one fused launch per step)")
     ap.add_argument("--series", action="store_true", help="drive the time-dependent boundary value / atmospheric inputs from device-resident time series (forcing feed) instead of constants")
     ap.add_argument("--spinup-ms", type=float, default=200.0, help="untimed device-busy time after the warm-up steps that lets the clocks settle (0: off)")
     ap.add_argument("--skip-kf", action="store_true", help="store hydraulic_conductivity only when finalizing")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the HBM-resident companion measurements (c3x8, c5)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling companion (BASELINE config 4: N145 sharded over the ranks)")
     ap.add_argument("--multistep", type=int, default=50, help="also time the resident-column multi-step kernel with this many steps per launch (temporal blocking; reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
-    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2], help="TRM_OPT_PIPELINE_PARTS (default: the library's auto rule)")
+    ap.add_argument("--pipeline", type=int, default=None, choices=[0, 1, 2], help="TRM_OPT_PIPELINE_PARTS (default: the library's rule)")
+    ap.add_argument("--derive", type=int, default=None, choices=[0, 1, 2, 3], help="TRM_OPT_DERIVE_CLOSURE_FIELDS (default: the library's rule)")
     ap.add_argument("--steps-per-launch", type=int, default=1, help="TRM_OPT_STEPS_PER_LAUNCH of the measured context: 1 (default) = one launch per step, the state streams "
                     "through memory every step -- the per-step HBM roofline; 0 = the library's own choice (what a plain run! gets)")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))     # before torch / the library are touched in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,31 +266,10 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
+    stat_device = "cuda" if backend == "nccl" else "cpu"
 
     import workloads as W
     from terrarium_jl_amd import parallel
-
-    w, desc, config, Nz, dt_name = build_workload(W, parallel, args.workload, world, rank, args.scaling)
-    Nh = w["Nh"]
-    wordsize = 8 if dt_name == "f64" else 4
-
-    dev = W.setup_device(w, device=local_rank)
-    dev.set_option("step_kernel", args.kernel)
-    dev.set_option("steps_per_launch", args.steps_per_launch)
-    if args.pipeline is not None:
-        dev.set_option("pipeline_parts", args.pipeline)
-    if args.series:
-        # the SURVEY 8(d) diurnal cycle sampled every 10 minutes over the run, linear in between
-        DAY = 86400.0
-        nodes = np.arange(0.0, (args.steps + args.warmup + 2) * w["dt"] + 600.0, 600.0)
-        ph = 2 * np.pi * nodes[:, None] / DAY - w["lon"][None, :]
-        if config in ("land", "landveg"):
-            dev.set_forcing_series("air_temperature", nodes, w["T0"][None, :] + 5.0 * np.sin(ph))
-            dev.set_forcing_series("surface_shortwave_down", nodes, np.maximum(0.0, 600.0 * np.sin(ph)))
-        else:
-            dev.set_bc_series("temperature", "top", "value", nodes, w["T0"][None, :] + 10.0 * np.sin(ph))
-    if args.skip_kf:
-        dev.set_option("write_kf_every_step", 0)
 
     def sync():
         torch.cuda.synchronize()
@@ -268,27 +280,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    heun = args.integrator == "heun"
-    elapsed, ms, warm, chunked = run_timed(dev, w, config, args.steps, args.warmup, args.spinup_ms, heun, sync, barrier)
-    status = dev.status()
+    def reduce_max(values):        # per-repeat maximum over the ranks
+        if world == 1:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64, device=stat_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.cpu()]
 
-    # max over ranks, total columns over ranks
-    stats = torch.tensor([elapsed, ms, float(Nh)], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        sm = stats.clone()
-        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        elapsed, ms, total_columns = float(mx[0]), float(mx[1]), float(sm[2])
-        nan_flag = parallel.global_status(status)
-    else:
-        total_columns = float(Nh)
-        nan_flag = status
-    kernel_s = ms * 1e-3 / max(args.steps, 1)            # average duration of one step launch on this GPU
-    value = total_columns * args.steps / elapsed
-    packed = dt_name == "f32" and args.kernel == "fused" and not heun      # (fp32: two columns per lane, default and van Genuchten hydraulics)
+    def reduce_sum(x):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=stat_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0])
+
+    w, desc, config, Nz, dt_name = build_workload(W, parallel, args.workload, world, rank, args.scaling)
+    Nh = w["Nh"]
+    wordsize = 8 if dt_name == "f64" else 4
+
+    def configure(dev, steps_per_launch):
+        dev.set_option("step_kernel", args.kernel)
+        dev.set_option("steps_per_launch", steps_per_launch)
+        if args.pipeline is not None:
+            dev.set_option("pipeline_parts", args.pipeline)
+        if args.derive is not None:
+            dev.set_option("derive_closure_fields", args.derive)
+        if args.skip_kf:
+            dev.set_option("write_kf_every_step", 0)
+
+    dev = W.setup_device(w, device=local_rank)
+    configure(dev, args.steps_per_launch)
+    if args.series:
+        # the SURVEY 8(d) diurnal cycle sampled every 10 minutes over the run, linear in between
+        DAY = 86400.0
+        nodes = np.arange(0.0, (args.steps + args.warmup + 2) * w["dt"] + 600.0, 600.0)
+        ph = 2 * np.pi * nodes[:, None] / DAY - w["lon"][None, :]
+        if config in ("land", "landveg"):
+            dev.set_forcing_series("air_temperature", nodes, w["T0"][None, :] + 5.0 * np.sin(ph))
+            dev.set_forcing_series("surface_shortwave_down", nodes, np.maximum(0.0, 600.0 * np.sin(ph)))
+        else:
+            dev.set_bc_series("temperature", "top", "value", nodes, w["T0"][None, :] + 10.0 * np.sin(ph))
+
+    heun = args.integrator == "heun"
+    m = measure(dev, w, config, args.steps, args.warmup, args.spinup_ms, heun, sync, barrier, args.repeats, reduce_max)
+    status = dev.status()
+    total_columns = reduce_sum(Nh)
+    nan_flag = parallel.global_status(status) if world > 1 else status
+    kernel_s = m["kernel_us_per_step"] * 1e-6            # median duration of one step's launches on the slowest GPU
+    value = total_columns * args.steps / m["wall_s"]
+    packed = dt_name == "f32" and args.kernel == "fused" and not heun and args.steps_per_launch == 1      # (fp32: two columns per lane)
     kernel_name = ("k_step_pk" if packed else "k_column") if args.kernel == "fused" else "unfused sequence"
-    pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series) else None
+    pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series and args.steps_per_launch == 1) else None
 
     out = {
         "metric": "column-steps/sec",
@@ -297,54 +339,66 @@ def main():
         "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed * 1e3 / max(args.steps, 1),
+        "ms_per_step": m["ms_per_step"],
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": dt_name,
         "data": "synthetic forcing and initial state on the reference's ERA5-land mask columns (SURVEY 8(d)); seeded",
-        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": w["dt"], "kernel": args.kernel, "integrator": args.integrator, "series": bool(args.series), "state_restored_every": STABLE_STEPS if chunked else None,
-                   "warmup_executed": warm, "clock_spinup_ms": args.spinup_ms,
+        "config": {"workload": desc, "columns_per_gpu": Nh, "levels": Nz, "dt_s": w["dt"], "kernel": args.kernel, "integrator": args.integrator, "series": bool(args.series),
+                   "steps_per_launch": args.steps_per_launch,
+                   "statistic": f"median of {m['repeats']} timed regions of {args.steps} steps each (max over ranks per region); the state is restored between regions, untimed",
+                   "repeats": m["repeats"], "ms_per_step_min": m["ms_per_step_min"], "ms_per_step_max": m["ms_per_step_max"],
+                   "state_restored_every": STABLE_STEPS[config] if m["chunked"] else None,
+                   "warmup_executed": m["warm"], "clock_spinup_ms": args.spinup_ms,
                    "parallelism": f"columns block-sharded over {n_gpus} GPU(s), no data-path collective",
                    "status_flags": int(nan_flag)},
         "roofline": roofline_object(config, Nz, Nh, wordsize, kernel_s, kernel_name, pmc_name),
     }
+    out["roofline"]["kernel_ms_min"] = m["kernel_us_per_step_min"] * 1e-3
     hung = False
     if world > 1:
         # global diagnostics through the library's own RCCL path (trm_comm_init / trm_status_global), beside torch's.  It runs
-        # in a watchdog thread: should a collective of this never-before-exercised path block, the line is still printed
-        # (with "timeout") and the process leaves through os._exit.
+        # in a watchdog thread: should a collective of this path block, the line is still printed (with "timeout") and the
+        # process leaves through os._exit with a NON-ZERO code -- a hung collective is a defect, not a pass.
         import threading
         box = {}
         th = threading.Thread(target=lambda: box.setdefault("r", abi_global_status(dev, dist, rank, world, local_rank, backend, status)), daemon=True)
         th.start()
         th.join(60.0)
         hung = th.is_alive()
-        out["config"]["abi_global_status"] = "timeout" if hung else box.get("r", "failed")
+        res = {"status": "timeout", "rccl_ranks": None} if hung else box.get("r", {"status": "failed", "rccl_ranks": None})
+        out["config"]["abi_global_status"] = res["status"]
+        out["config"]["rccl_ranks"] = res["rccl_ranks"]
+        if hung:
+            out["config"]["abi_global_status_note"] = ("trm_comm_init / trm_status_global did not return within 60 s; the ranks leave with exit code 3")
     if not hung:
         dev.close()
+    if world > 1 and not hung and not args.no_strong and args.workload == "c3" and args.scaling == "weak":
+        out["strong"] = strong_leg(W, parallel, args, world, rank, local_rank, configure, sync, barrier, reduce_max, reduce_sum)
 
     single = rank == 0 and n_gpus == 1
-    if single and args.multistep > 1 and args.kernel == "fused" and not heun and not args.series:
+    if single and args.multistep > 1 and args.kernel == "fused" and not heun and not args.series and args.steps_per_launch == 1:
         out["multistep"] = multistep_leg(W, w, desc, config, Nz, Nh, wordsize, args, sync, local_rank)
     if single and not args.no_hbm_resident and args.workload == "c3" and args.kernel == "fused" and not heun:
         out["roofline_hbm_resident"] = hbm_resident_leg(W, parallel, args, sync, local_rank)
     if single and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(W, w, args.cpu_seconds)
+        out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if hung:
-        os._exit(0)
+        os._exit(3)
     if world > 1:
         dist.destroy_process_group()
 
 
 def abi_global_status(dev, dist, rank, world, local_rank, backend, local_status):
     """ORs the status word over the ranks inside the library (RCCL, include/terrarium_hip.h: trm_comm_init) and checks it
-    against torch.distributed's answer.  Failures are reported, never fatal: the timed numbers above do not depend on it."""
+    against torch.distributed's answer; reports the world size the library's communicator holds (trm_comm_info).  Failures are
+    reported, never fatal: the timed numbers above do not depend on it."""
     try:
         if backend != "nccl" or not hasattr(dev, "comm_init"):
-            return "skipped"
+            return {"status": "skipped (needs the nccl backend: one rank per device)", "rccl_ranks": None}
         import torch
         uid = dev.comm_unique_id() if rank == 0 else bytes(128)
         t = torch.frombuffer(bytearray(uid), dtype=torch.uint8).cuda()
@@ -353,9 +407,30 @@ def abi_global_status(dev, dist, rank, world, local_rank, backend, local_status)
         flags = dev.status_global()
         ref = torch.tensor([local_status], dtype=torch.int64, device="cuda")
         dist.all_reduce(ref, op=dist.ReduceOp.BOR)
-        return "ok" if int(ref[0]) == flags else f"mismatch: library {flags}, torch {int(ref[0])}"
+        ok = int(ref[0]) == flags
+        return {"status": "ok" if ok else f"mismatch: library {flags}, torch {int(ref[0])}", "rccl_ranks": dev.comm_world()}
     except Exception as e:   # noqa: BLE001 -- diagnostic leg
-        return f"failed: {type(e).__name__}: {e}"
+        return {"status": f"failed: {type(e).__name__}: {e}", "rccl_ranks": None}
+
+
+def strong_leg(W, parallel, args, world, rank, device, configure, sync, barrier, reduce_max, reduce_sum):
+    """BASELINE config 4 at N > 1: the N145 LandModel columns block-sharded over the ranks (7 119 per GPU at N = 8), total work
+    fixed.  Per-step launches and the library's own choice for a plain run! (the resident program), same statistics as the
+    headline.  Launch-latency-limited at this size."""
+    w, desc, config, Nz, dt_name = build_workload(W, parallel, "c4", world, rank, "strong")
+    total = reduce_sum(w["Nh"])
+    res = {"workload": desc + f" -- block-sharded over {world} ranks", "columns_this_rank": w["Nh"], "columns_total": int(total), "scaling": "strong"}
+    steps = min(args.steps, STABLE_STEPS[config])
+    for key, spl in (("per_step", 1), ("library_default", 0)):
+        dev = W.setup_device(w, device=device)
+        configure(dev, spl)
+        m = measure(dev, w, config, steps, min(args.warmup, 10), min(args.spinup_ms, 100.0), False, sync, barrier, args.repeats, reduce_max)
+        st = dev.status()
+        dev.close()
+        res[key] = {"steps_per_launch": spl, "steps": steps, "us_per_step": m["ms_per_step"] * 1e3, "us_per_step_min": m["ms_per_step_min"] * 1e3,
+                    "kernel_us_per_step": m["kernel_us_per_step"], "column_steps_per_s": total * steps / m["wall_s"], "repeats": m["repeats"],
+                    "status_flags": int(parallel.global_status(st))}
+    return res
 
 
 def hbm_resident_leg(W, parallel, args, sync, device):
@@ -370,13 +445,13 @@ def hbm_resident_leg(W, parallel, args, sync, device):
         dev.set_option("steps_per_launch", 1)
         if args.pipeline is not None:
             dev.set_option("pipeline_parts", args.pipeline)
-        elapsed, ms, warm, _ = run_timed(dev, w, config, steps, 5, min(args.spinup_ms, 100.0), False, sync)
+        m = measure(dev, w, config, steps, 5, min(args.spinup_ms, 100.0), False, sync, None, min(args.repeats, 5))
         status = dev.status()
         dev.close()
-        kernel_s = ms * 1e-3 / steps
-        r = roofline_object(config, Nz, w["Nh"], wordsize, kernel_s, "k_step_pk (+ k_surface)" if name == "c5" else "k_column",
+        r = roofline_object(config, Nz, w["Nh"], wordsize, m["kernel_us_per_step"] * 1e-6, "k_step_pk (+ k_surface)" if name == "c5" else "k_column",
                             f"pmc_summary_{name}_fused.json", desc)
-        r.update(steps=steps, warmup_executed=warm, column_steps_per_s=w["Nh"] * steps / elapsed, status_flags=int(status))
+        r.update(steps=steps, repeats=m["repeats"], warmup_executed=m["warm"], column_steps_per_s=w["Nh"] * steps / m["wall_s"],
+                 kernel_ms_min=m["kernel_us_per_step_min"] * 1e-3, status_flags=int(status))
         legs.append(r)
         del w, dev
     first = legs[0]
@@ -386,30 +461,67 @@ def hbm_resident_leg(W, parallel, args, sync, device):
 
 def multistep_leg(W, w, desc, config, Nz, Nh, wordsize, args, sync, device):
     """Temporal blocking ("report it separately and never as the headline fraction"): columns stay in
-    registers for `m` steps per launch, fields are written once per launch."""
-    m = args.multistep
+    registers for `m` steps per launch, fields are written once per launch.  This is what a plain run! gets by default
+    (TRM_OPT_STEPS_PER_LAUNCH = 0)."""
+    mm = args.multistep
     dev = W.setup_device(w, device=device)
-    dev.set_option("steps_per_launch", m)
-    steps = max(m, (args.steps // m) * m)
-    elapsed, ms, warm, _ = run_timed(dev, w, config, steps, args.warmup, args.spinup_ms, False, sync)
+    dev.set_option("steps_per_launch", mm)
+    steps = max(mm, (min(args.steps, STABLE_STEPS[config]) // mm) * mm)
+    m = measure(dev, w, config, steps, args.warmup, args.spinup_ms, False, sync, None, min(args.repeats, 5))
     status = dev.status()
     dev.close()
-    return {"steps_per_launch": m, "steps": steps, "column_steps_per_s": Nh * steps / elapsed, "us_per_step": ms * 1e3 / steps,
+    return {"steps_per_launch": mm, "steps": steps, "repeats": m["repeats"], "column_steps_per_s": Nh * steps / m["wall_s"], "us_per_step": m["kernel_us_per_step"],
             "status_flags": int(status),
             "note": "resident-column multi-step kernel: bit-identical to per-step launches; NOT comparable with the per-step HBM roofline"}
 
 
-def cpu_baseline(W, w, target_seconds):
+def cpu_baseline(args):
+    """The CPU leg runs in a child process of its own (started after all GPU work of this process is done): the OpenMP
+    runtime reads OMP_PROC_BIND / OMP_PLACES when it is loaded, and torch has long loaded one here."""
+    env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", args.workload, "--cpu-seconds", str(args.cpu_seconds)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=max(120.0, 8 * args.cpu_seconds))
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"value": None, "unit": "column-steps/s", "cores": 0, "kind": "port", "sample": f"CPU leg failed (exit {r.returncode}): {r.stderr[-300:]}"}
+        return json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "column-steps/s", "cores": 0, "kind": "port", "sample": "CPU leg timed out"}
+
+
+def julia_probe():
+    """first choice for the CPU leg is the reference's own `timestep!` if `julia` and a depot with Terrarium.jl
+    exist on the box.  Probed, never assumed; nothing can be installed."""
+    exe = shutil.which("julia")
+    if not exe:
+        return {"julia": None, "terrarium_jl": None, "note": "no `julia` on PATH of this box (shutil.which)"}
+    try:
+        r = subprocess.run([exe, "--startup-file=no", "-e", "using Terrarium; print(pkgversion(Terrarium))"], capture_output=True, text=True, timeout=180)
+        ok = r.returncode == 0
+        return {"julia": exe, "terrarium_jl": r.stdout.strip() if ok else None,
+                "note": "Terrarium.jl importable: the reference leg could be timed with it" if ok else f"`using Terrarium` failed: {r.stderr.strip()[-200:]}"}
+    except Exception as e:   # noqa: BLE001
+        return {"julia": exe, "terrarium_jl": None, "note": f"probe failed: {e}"}
+
+
+def cpu_baseline_worker(args):
     """CPU restatement of the reference path (oracle/, reference kernel order) timed on this box's host cores on the same
     workload: whole column set, bounded number of steps.  Headline `value`: one pass per reference kernel with OpenMP over
-    columns, thread count auto-tuned over a few candidates (the reference-order passes are memory-bound and stop scaling
-    long before all hardware threads are busy).  BASELINE.md 4.2's other legs ride along in `legs`: the same driver on one
-    thread, and the cache-blocked ("fused") driver -- every pass over one block of columns at a time -- on one thread
+    columns, thread count auto-tuned over a few candidates, threads bound to cores and spread over the NUMA nodes
+    (OMP_PROC_BIND=spread OMP_PLACES=cores, set by the parent), every array first-touched by the thread that owns its columns
+    (oracle/terrarium_oracle.hpp: FieldVec / first_touch).  BASELINE.md 4.2's other legs ride along in `legs`: the same driver
+    on one thread, and the cache-blocked ("fused") driver -- every pass over one block of columns at a time -- on one thread
     and on the tuned thread count."""
     import oracle
+    import workloads as W
+    from terrarium_jl_amd import parallel
+    w, desc, config, Nz, dt_name = build_workload(W, parallel, args.workload, 1, 0, "weak")
+    target_seconds = args.cpu_seconds
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    candidates = sorted({c for c in (8, 16, 32, 64, 128, avail) if c <= avail} | {min(avail, 8)})
+    candidates = sorted({c for c in (8, 16, 32, 64, 128, 256, avail) if c <= avail} | {min(avail, 8)})
     dt, Nh = w["dt"], w["Nh"]
+    stable = min(STABLE_STEPS[config], 150)
 
     def timed(orc, fn, steps):
         t0 = time.perf_counter()
@@ -419,17 +531,19 @@ def cpu_baseline(W, w, target_seconds):
     ref_order = lambda o, n: o.steps(dt, n)
     blocked = lambda o, n: o.steps_blocked(dt, n, 64)
     budget = target_seconds
+    scan = {}
     best = None
     for threads in candidates:
         oracle.set_threads(threads)
-        orc = W.setup_oracle(w, omp=True)
-        ref_order(orc, 2)  # touch pages / spin up the thread pool
+        orc = W.setup_oracle(w, omp=True)        # (first touch with THIS thread count)
+        ref_order(orc, 2)  # spin up the thread pool
         sec = timed(orc, ref_order, 10)
         budget -= sec
         rate = Nh * 10 / sec
+        scan[threads] = rate
         if best is None or rate > best[1]:
             best = (threads, rate)
-        if budget < target_seconds * 0.6:
+        if budget < target_seconds * 0.5:
             break
     threads = best[0]
     legs = {}
@@ -443,20 +557,29 @@ def cpu_baseline(W, w, target_seconds):
         legs[label] = {"value": Nh * n / sec, "steps": n, "seconds": round(sec, 2)}
         budget -= sec
     oracle.set_threads(threads)
-    chunk, done, spent = 50, 0, 0.0
+    chunk, done, spent = min(50, stable), 0, 0.0
     while spent < max(budget, 2.0) and done < 5000:
-        if done % STABLE_STEPS == 0:      # a fresh state every 150 steps (the explicit Richards scheme dries cells out later)
+        if done % stable == 0:      # a fresh state every stable stretch (the explicit Richards scheme dries cells out later)
             orc = W.setup_oracle(w, omp=True)
             ref_order(orc, 2)
         spent += timed(orc, ref_order, chunk)
         done += chunk
-    legs[f"reference_order_{threads}_threads"] = {"value": Nh * done / spent, "steps": done, "seconds": round(spent, 2)}
-    return {"value": Nh * done / spent, "unit": "column-steps/s", "cores": threads, "kind": "port",
-            "sample": f"all {Nh} columns x {done} steps of the same workload; CPU restatement of the Terrarium.jl "
-                      f"path (not Terrarium.jl itself: Julia is not installed), one pass per reference kernel, OpenMP "
-                      f"over columns with {threads} of {avail} hardware threads (best of {candidates}); {spent:.1f} s; "
-                      f"other legs (column-steps/s): " + ", ".join(f"{k} {v['value']:.3g}" for k, v in legs.items()),
-            "legs": legs}
+    value = Nh * done / spent
+    legs[f"reference_order_{threads}_threads"] = {"value": value, "steps": done, "seconds": round(spent, 2)}
+    bpc = REFERENCE_ORDER_BYTES_PER_CELL_STEP[config]
+    probe = julia_probe()
+    out = {"value": value, "unit": "column-steps/s", "cores": threads, "kind": "port",
+           "sample": f"all {Nh} columns x {done} steps of the same workload; CPU restatement of the Terrarium.jl path (not Terrarium.jl itself: "
+                     f"{probe['note']}), one pass per reference kernel, OpenMP over columns with {threads} of {avail} hardware threads "
+                     f"(best of a scan, column-steps/s: " + ", ".join(f"{k}: {v:.3g}" for k, v in scan.items()) + f"), threads bound "
+                     f"(OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES={os.environ.get('OMP_PLACES')}), arrays first-touched by the owning thread; "
+                     f"{spent:.1f} s; other legs (column-steps/s): " + ", ".join(f"{k} {v['value']:.3g}" for k, v in legs.items()),
+           "streamed_GBps": value * Nz * bpc / 1e9,
+           "streamed_bytes_per_cell_step": bpc,
+           "thread_scan": {str(k): v for k, v in scan.items()},
+           "julia_probe": probe,
+           "legs": legs}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

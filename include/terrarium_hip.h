@@ -174,13 +174,11 @@ enum {
                                     /* interpolates itself, no coupled vegetation), except fp32 contexts on the packed        */
                                     /* two-columns-per-lane kernel; 1: one launch per step (state streams through memory      */
                                     /* every step: what bench.py's headline measures); m > 1: explicit                        */
-    TRM_OPT_PIPELINE_PARTS = 7,     /* LandModel contexts, one launch pair per step (surface processes, soil columns): the   */
+    TRM_OPT_PIPELINE_PARTS = 7      /* LandModel contexts, one launch pair per step (surface processes, soil columns): the   */
                                     /* columns are dealt to two internal streams so that the latency-bound surface launch of  */
                                     /* one half runs under the column launch of the other (columns are independent; results   */
                                     /* are bit-identical).  0: off; 1: whenever a call makes >= 2 such steps; 2 (default):    */
                                     /* the same for contexts of >= 32 768 columns                                             */
-    TRM_OPT_COLUMN_GROUPS = 8       /* (experimental) fused Euler step: 2 = every wave steps two consecutive column groups,  */
-                                    /* the second one's fields requested before the first one's arithmetic; 1 (default): off  */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

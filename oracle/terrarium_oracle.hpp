@@ -40,6 +40,19 @@
 
 namespace trm_oracle {
 
+// Field storage of the timing leg (bench.py cpu_baseline).  std::vector writes every element from the constructing thread, so
+// on a multi-socket host all pages of all fields would sit on ONE NUMA node and the OpenMP passes would stream remotely.
+// FieldVec sizes without writing; Oracle's constructor then first-touches every array inside an `omp parallel for
+// schedule(static)` over the columns -- the decomposition of every compute pass -- so a thread's columns live on its node.
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A> void construct(U* q, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)q) U;      // default-init: no write
+        else ::new ((void*)q) U(std::forward<A>(a)...);
+    }
+};
+template <class NF> using FieldVec = std::vector<NF, NoInitAlloc<NF>>;
+
 // ---------------------------------------------------------------------------
 // Julia Base semantics used by the reference
 // ---------------------------------------------------------------------------
@@ -400,7 +413,7 @@ enum FieldId {
 
 template <class NF> struct Bc {
     int kind = BC_NOFLUX;
-    std::vector<NF> value;  // per column
+    FieldVec<NF> value;  // per column
 };
 
 }  // namespace trm_oracle
@@ -425,15 +438,15 @@ template <class NF> class Oracle {
     long col_hi() const { long h = range_hi(); return h < 0 ? Nh : h; }
 
     // 3-D centre fields with z halos: (Nz+2) x Nh
-    std::vector<NF> U, sat, T, liq, psi, G_U, G_sat;
-    std::vector<NF> Fvwc;        // per-cell vwc_forcing (halo layout); used instead of p.vwc_forcing once set
+    FieldVec<NF> U, sat, T, liq, psi, G_U, G_sat;
+    FieldVec<NF> Fvwc;        // per-cell vwc_forcing (halo layout); used instead of p.vwc_forcing once set
     bool use_Fvwc = false;
     // face field with halos: (Nz+3) x Nh (faces 0..Nz+2)
-    std::vector<NF> Kf;
+    FieldVec<NF> Kf;
     // 2-D
-    std::vector<NF> S, G_S, wt, Ts, ghf, swu, lwu, rnet, Hs, Hl, evap, infil, runoff;
-    std::vector<NF> Tair, pres, wind, qair, rain, swd, lwd;
-    std::vector<NF> albedo_in, emissivity_in;   // PrescribedAlbedo inputs (albedo.jl:8-14)
+    FieldVec<NF> S, G_S, wt, Ts, ghf, swu, lwu, rnet, Hs, Hl, evap, infil, runoff;
+    FieldVec<NF> Tair, pres, wind, qair, rain, swd, lwd;
+    FieldVec<NF> albedo_in, emissivity_in;   // PrescribedAlbedo inputs (albedo.jl:8-14)
     Bc<NF> bc[BCV_COUNT][2];  // [var][0 = bottom, 1 = top]
     bool land_model = false;  // LandModel wiring of ground_heat_flux / infiltration flux BCs
 
@@ -441,33 +454,44 @@ template <class NF> class Oracle {
     // the canopy evapotranspiration fluxes; plant available water per cell (halo layout) and the static root fractions per level
     bool veg_on = false;
     VegetationOracle<NF> veg;
-    std::vector<NF> w_can, G_w_can, I_can, R_can, f_can, rain_ground, E_can, transp, SAI, paw, root_frac;
+    FieldVec<NF> w_can, G_w_can, I_can, R_can, f_can, rain_ground, E_can, transp, SAI, paw;
+    std::vector<NF> root_frac;
 
     Oracle(long nh, int nz, const double* thickness, double dx, const ParamsD& pd_in) : pd(pd_in), p(pd_in), Nh(nh), Nz(nz) {
         g.build(nh, nz, thickness, dx);
         size_t n3 = (size_t)(nz + 2) * nh, nf = (size_t)(nz + 3) * nh, n2 = (size_t)nh;
-        for (auto* v : {&U, &sat, &T, &liq, &psi, &G_U, &G_sat, &Fvwc}) v->assign(n3, NF(0));
-        Kf.assign(nf, NF(0));
-        for (auto* v : {&S, &G_S, &wt, &Ts, &ghf, &swu, &lwu, &rnet, &Hs, &Hl, &evap, &infil, &runoff}) v->assign(n2, NF(0));
+        (void)n3; (void)nf; (void)n2;
+        for (auto* v : {&U, &sat, &T, &liq, &psi, &G_U, &G_sat, &Fvwc}) first_touch(*v, nz + 2, NF(0));
+        first_touch(Kf, nz + 3, NF(0));
+        for (auto* v : {&S, &G_S, &wt, &Ts, &ghf, &swu, &lwu, &rnet, &Hs, &Hl, &evap, &infil, &runoff}) first_touch(*v, 1, NF(0));
         // input defaults (prescribed_atmosphere.jl:90-92,148,221-223)
-        Tair.assign(n2, NF(10));
-        pres.assign(n2, NF(101325));
-        wind.assign(n2, NF(0.1));
-        qair.assign(n2, NF(1.0e-3));
-        rain.assign(n2, NF(0));
-        swd.assign(n2, NF(300));
-        lwd.assign(n2, NF(50));
-        albedo_in.assign(n2, NF(0));
-        emissivity_in.assign(n2, NF(0));
+        first_touch(Tair, 1, NF(10));
+        first_touch(pres, 1, NF(101325));
+        first_touch(wind, 1, NF(0.1));
+        first_touch(qair, 1, NF(1.0e-3));
+        first_touch(rain, 1, NF(0));
+        first_touch(swd, 1, NF(300));
+        first_touch(lwd, 1, NF(50));
+        first_touch(albedo_in, 1, NF(0));
+        first_touch(emissivity_in, 1, NF(0));
         land_model = p.seb != 0;
     }
 
+    // sizes `v` to rows x Nh and writes `x` from the thread that owns each column in the compute passes (static schedule over i)
+    void first_touch(FieldVec<NF>& v, int rows, NF x) {
+        v.resize((size_t)rows * Nh);
+        NF* q = v.data();
+        const long nh = Nh;
+        TRM_OMP_FOR
+        for (long i = 0; i < nh; ++i)
+            for (int k = 0; k < rows; ++k) q[(size_t)k * nh + i] = x;
+    }
     inline size_t C(int k, long i) const { return (size_t)k * Nh + i; }
 
     bool richards() const { return p.flow == FLOW_RICHARDS; }
 
     // ---- field access for the harness (interior only, k = 0 bottom) ---------
-    std::vector<NF>* field3(int id) {
+    FieldVec<NF>* field3(int id) {
         switch (id) {
             case F_INTERNAL_ENERGY: return &U;
             case F_SATURATION: return &sat;
@@ -481,7 +505,7 @@ template <class NF> class Oracle {
             default: return nullptr;
         }
     }
-    std::vector<NF>* field2(int id) {
+    FieldVec<NF>* field2(int id) {
         switch (id) {
             case F_SURFACE_EXCESS_WATER: return &S;
             case F_TEND_SURFACE_EXCESS_WATER: return &G_S;
@@ -529,8 +553,8 @@ template <class NF> class Oracle {
     void enable_vegetation(const VegParamsD& vp) {
         veg = VegetationOracle<NF>(Nh, vp, pd);
         veg_on = true;
-        for (auto* v : {&w_can, &G_w_can, &I_can, &R_can, &f_can, &rain_ground, &E_can, &transp, &SAI}) v->assign((size_t)Nh, NF(0));
-        paw.assign((size_t)(Nz + 2) * Nh, NF(0));
+        for (auto* v : {&w_can, &G_w_can, &I_can, &R_can, &f_can, &rain_ground, &E_can, &transp, &SAI}) first_touch(*v, 1, NF(0));
+        first_touch(paw, Nz + 2, NF(0));
         // root_fraction (root_distribution.jl:51-63): density at the cell centres times the thickness, normalised over the column
         root_frac.assign((size_t)Nz + 2, NF(0));
         NF total = NF(0);
@@ -663,7 +687,7 @@ template <class NF> class Oracle {
         for (const Series& sr : series) {
             double f; long n1, n2;
             interpolating_time_indices(sr.times, sr.indexing, time, f, n1, n2);
-            std::vector<NF>* dst = sr.is_bc ? &bc[sr.var][sr.top].value : field2(sr.field);
+            FieldVec<NF>* dst = sr.is_bc ? &bc[sr.var][sr.top].value : field2(sr.field);
             const NF* v1 = &sr.values[(size_t)n1 * Nh];
             const NF* v2 = &sr.values[(size_t)n2 * Nh];
             if (sr.indexing == TIME_RASTER) {
@@ -693,7 +717,7 @@ template <class NF> class Oracle {
     // Oceananigans z-halo rules: Value -> linear
     // extrapolation through the boundary value with the boundary-face spacing;
     // Gradient -> edge +/- g*Δ; Flux / NoFlux / default -> copy of the edge.
-    void fill_halo(std::vector<NF>& c, int var) {
+    void fill_halo(FieldVec<NF>& c, int var) {
         const Bc<NF>& bt = bc[var][1];
         const Bc<NF>& bb = bc[var][0];
         NF dtop = g.dzf[Nz + 1], dbot = g.dzf[1];
@@ -956,8 +980,8 @@ template <class NF> class Oracle {
     // ---- update_state! (state_variables.jl:72-80) ---------------------------
     void reset_tendencies() {
         const long i0_ = col_lo(), i1_ = col_hi();
-        TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
+            TRM_OMP_FOR
             for (long i = i0_; i < i1_; ++i) { G_U[C(k, i)] = NF(0); G_sat[C(k, i)] = NF(0); }
         std::fill(G_S.begin() + i0_, G_S.begin() + i1_, NF(0));
         if (veg_on) {
@@ -975,7 +999,7 @@ template <class NF> class Oracle {
     }
 
     // ---- explicit_step! (abstract_timestepper.jl:65-141) --------------------
-    void apply_z_flux_bcs(std::vector<NF>& G, int var, const std::vector<NF>* top_field, bool negate_top) {
+    void apply_z_flux_bcs(FieldVec<NF>& G, int var, const FieldVec<NF>* top_field, bool negate_top) {
         // Oceananigans compute_z_bcs!: Flux BCs only; G[1] += F*Az/V, G[Nz] -= F*Az/V
         NF Az = g.dx;  // Flat y => Δy = 1
         NF Vtop = Az * g.dzc[Nz], Vbot = Az * g.dzc[1];
@@ -997,13 +1021,13 @@ template <class NF> class Oracle {
         // (zero tendency); each prognostic is independent of the others here.
         apply_z_flux_bcs(G_U, BCV_INTERNAL_ENERGY, land_model ? &ghf : nullptr, false);  // land_model.jl:56-58
         const long i0_ = col_lo(), i1_ = col_hi();
-        TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
+            TRM_OMP_FOR
             for (long i = i0_; i < i1_; ++i) U[C(k, i)] = U[C(k, i)] + G_U[C(k, i)] * dt;
         if (richards()) {
             apply_z_flux_bcs(G_sat, BCV_SATURATION, land_model ? &infil : nullptr, true);  // land_model.jl:57-61
-            TRM_OMP_FOR2
             for (int k = 1; k <= Nz; ++k)
+                TRM_OMP_FOR
                 for (long i = i0_; i < i1_; ++i) sat[C(k, i)] = sat[C(k, i)] + G_sat[C(k, i)] * dt;
             for (long i = col_lo(); i < col_hi(); ++i) S[i] = S[i] + G_S[i] * dt;
         }
@@ -1080,8 +1104,8 @@ template <class NF> class Oracle {
         NF por = porosity(p), org = organic_fraction(p);
         NF L = p.rho_w * p.Lsl;
         const long i0_ = col_lo(), i1_ = col_hi();
-        TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
+            TRM_OMP_FOR
             for (long i = i0_; i < i1_; ++i) {
                 NF u = U[C(k, i)], s = sat[C(k, i)];
                 NF Ltheta = L * s * por;
@@ -1095,8 +1119,8 @@ template <class NF> class Oracle {
         NF por = porosity(p), org = organic_fraction(p);
         NF L = p.rho_w * p.Lsl;
         const long i0_ = col_lo(), i1_ = col_hi();
-        TRM_OMP_FOR2
         for (int k = 1; k <= Nz; ++k)
+            TRM_OMP_FOR
             for (long i = i0_; i < i1_; ++i) {
                 NF t = T[C(k, i)], s = sat[C(k, i)];
                 NF l = (t >= NF(0)) ? NF(1) : NF(0);

@@ -229,8 +229,8 @@ template <class NF> class VegetationOracle {
     VegParams<NF> p;
     Params<NF> c;   // physical constants + PrescribedAtmosphere parameters (compute_vpd)
     // prognostic (+ tendencies), auxiliaries, inputs: one value per column
-    std::vector<NF> C_veg, nu, G_C_veg, G_nu, LAI_b, phen, LAI, gw_can, lambda_c, An, Rd, GPP, Ra, NPP;
-    std::vector<NF> Tair, pres, qair, swd, CO2, smlf, daily_Rd, Tground;
+    FieldVec<NF> C_veg, nu, G_C_veg, G_nu, LAI_b, phen, LAI, gw_can, lambda_c, An, Rd, GPP, Ra, NPP;
+    FieldVec<NF> Tair, pres, qair, swd, CO2, smlf, daily_Rd, Tground;
     double time = 0.0;
     long long iteration = 0;
 
@@ -246,8 +246,8 @@ template <class NF> class VegetationOracle {
         smlf.assign(nh, NF(1));
         Tground.assign(nh, NF(10));
     }
-    std::vector<NF>* field(int id) {
-        std::vector<NF>* all[] = {&C_veg, &nu, &G_C_veg, &G_nu, &LAI_b, &phen, &LAI, &gw_can, &lambda_c, &An, &Rd, &GPP, &Ra, &NPP,
+    FieldVec<NF>* field(int id) {
+        FieldVec<NF>* all[] = {&C_veg, &nu, &G_C_veg, &G_nu, &LAI_b, &phen, &LAI, &gw_can, &lambda_c, &An, &Rd, &GPP, &Ra, &NPP,
                                   &Tair, &pres, &qair, &swd, &CO2, &smlf, &daily_Rd, &Tground};
         return (id >= 0 && id < 22) ? all[id] : nullptr;
     }

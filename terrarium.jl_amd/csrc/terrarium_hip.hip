@@ -93,7 +93,7 @@ struct trm_ctx {
     int64_t iteration = 0;
     int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
-    int opt_derive = 2, opt_groups = 1;
+    int opt_derive = 2;
     int opt_steps_per_launch = 0;   // 0: chosen by the library (auto_steps_per_launch), 1: one launch per step, m > 1: up to m steps per launch
     // Two-part pipeline of the per-step LandModel path (TRM_OPT_PIPELINE_PARTS): the columns are dealt to two internal streams,
     // each running its own chain of (surface launch, column launch) per step; the latency-bound 0-D surface launch of one part
@@ -861,13 +861,15 @@ template <class NF> struct Ops {
     // on a third; 36 864 columns -6.5 %) -- is neutral for van Genuchten and the LandModel (more arithmetic per byte) and
     // loses on small grids (N72 heat-only: 7.1 vs 6.6 us, latency-bound) and in fp32 (C5 van Genuchten: 754 vs 702 us).
     // AUTO switches on the number format, the bytes one step touches, the hydraulics and the column count.
-    template <bool RICH> static bool derive_now(const trm_ctx* c) {
+    template <bool RICH> static int derive_now(const trm_ctx* c) {
+        // (the coupled vegetation reads T and liq of the whole column from memory every step)
+        if (!c->closure_consistent || c->closure_escaped || coupled(c) || c->opt_derive == 0) return DERIVE_NONE;
+        if (c->opt_derive == 1) return DERIVE_T_LIQ;
+        if (c->opt_derive == 3) return DERIVE_LIQ;
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
         const bool beyond_cache = state_bytes > ((size_t)256 << 20);
         const bool bound_by_bytes = c->Nh >= 24576 && !c->params.seb && (!RICH || hyd(c) == HYD_BC_LINEAR);
-        const bool want = c->opt_derive == 1 || (c->opt_derive == 2 && std::is_same<NF, double>::value && (beyond_cache || bound_by_bytes));
-        // (the coupled vegetation reads T and liq of the whole column from memory every step)
-        return want && c->closure_consistent && !c->closure_escaped && !coupled(c);
+        return (std::is_same<NF, double>::value && (beyond_cache || bound_by_bytes)) ? DERIVE_T_LIQ : DERIVE_NONE;
     }
     // fp32: two columns per lane with packed math (trm_packed_f32.hpp) -- the reference-default hydraulics, and van
     // Genuchten retention with Mualem conductivity
@@ -884,8 +886,14 @@ template <class NF> struct Ops {
             const View<NF>& sv = state_view<NF>(c);
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            if (hyd(c) == HYD_VG_N2) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
-            else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+            const bool dliq = derive_now<RICH>(c) == DERIVE_LIQ;
+            if (hyd(c) == HYD_VG_N2) {
+                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+            } else {
+                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+            }
             TRM_HIP(c, hipGetLastError());
         }
         return TRM_OK;
@@ -987,24 +995,19 @@ template <class NF> struct Ops {
             a.stage_S = (NF*)c->stage.f[TRM_FIELD_SURFACE_EXCESS_WATER];
         }
         const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
-        const bool derive = derive_now<RICH>(c);
+        const int derive = derive_now<RICH>(c);
         if constexpr (PROG == PROG_MULTI) {
             const bool series = !c->series.empty();
-            if (c->params.seb && series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true, true>), grid, block, 0, c->stream, v, p, a);
-            else if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, true, false>), grid, block, 0, c->stream, v, p, a);
-            else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
-            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
+            if (c->params.seb && series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, true>), grid, block, 0, c->stream, v, p, a);
+            else if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, false>), grid, block, 0, c->stream, v, p, a);
+            else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
+            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
         } else if constexpr (PROG == PROG_EULER) {
-            if (c->opt_groups == 2 && H != HYD_GENERIC) {   // (experimental) two column groups per wave, the second one's fields requested early
-                dim3 g2 = grid;
-                g2.x = (grid.x + 1) / 2;
-                if (derive) hipLaunchKernelGGL((k_column_groups<NF, RICH, H, LPC, true, 2>), g2, block, 0, c->stream, v, p, a);
-                else hipLaunchKernelGGL((k_column_groups<NF, RICH, H, LPC, false, 2>), g2, block, 0, c->stream, v, p, a);
-            } else
-            if (derive) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, true, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
-            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+            if (derive == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+            else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
         } else {
-            hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, false, PROG, false>), grid, block, 0, c->stream, v, p, a);
+            hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);
         }
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
@@ -2544,7 +2547,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
         case TRM_OPT_VWC_FORCING_FIELD: c->opt_vwc_field = value != 0; return TRM_OK;
         case TRM_OPT_PACKED_F32: c->opt_packed = value != 0; return TRM_OK;
         case TRM_OPT_DERIVE_CLOSURE_FIELDS:
-            if (value < 0 || value > 2) break;
+            if (value < 0 || value > 3) break;
             c->opt_derive = value;
             return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH:
@@ -2554,10 +2557,6 @@ int trm_set_option(trm_ctx* c, int option, int value) {
         case TRM_OPT_PIPELINE_PARTS:
             if (value < 0 || value > 2) break;
             c->opt_pipeline = value;
-            return TRM_OK;
-        case TRM_OPT_COLUMN_GROUPS:
-            if (value != 1 && value != 2) break;
-            c->opt_groups = value;
             return TRM_OK;
         default: break;
     }
@@ -2574,7 +2573,6 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_DERIVE_CLOSURE_FIELDS: *value = c->opt_derive; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
-        case TRM_OPT_COLUMN_GROUPS: *value = c->opt_groups; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

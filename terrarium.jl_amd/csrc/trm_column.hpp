@@ -42,6 +42,15 @@ template <class NF> struct Tendency { NF gU, gS, Kf_lo, Kc; };
 // quotient x of two distinct floats of the same sign and |U| > |denominator| rounds to >= 1 + 2^-52, so 1 - x < 0
 // and the result is -0.0 without dividing.  Cells in phase change (and L_theta <= eps, sat below 1.4e-24) take the
 // divide -- decided per wave by one ballot.
+enum { DERIVE_NONE = 0, DERIVE_T_LIQ = 1, DERIVE_LIQ = 2 };
+template <class NF> TRM_DEV NF liquid_fraction_wave(const DevParams<NF>& p, NF U, NF sat) {
+    const NF Lth = p.L * sat * p.por;
+    const NF nLth = -Lth;
+    const bool thawed = U >= NF(0), frozen = U < nLth;
+    const bool need_div = !thawed && !(frozen && Lth > Limits<NF>::eps());   // phase change, NaN, vanishing L_theta
+    if (__ballot(need_div) == 0ull) return thawed ? NF(1) : NF(-0.0);
+    return thawed ? NF(1) : boolmul(U >= nLth, NF(1) - safediv(U, nLth));
+}
 template <class NF> TRM_DEV void energy_closure_wave(const DevParams<NF>& p, NF U, NF sat, NF& liq, NF& T, uint32_t& viol) {
     const NF Lth = p.L * sat * p.por;
     const NF nLth = -Lth;
@@ -196,7 +205,7 @@ template <class NF> struct ColumnArgs {
 #ifndef TRM_COLUMN_WAVES_EULER
 #define TRM_COLUMN_WAVES_EULER 1
 #endif
-template <class NF, bool RICHARDS, int HYD, int LPC, bool DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false>
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
@@ -234,9 +243,14 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     c.U = ldg(v.U, cb0);
     c.sat = ldg(v.sat, cb0);
     c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
-    if (DERIVE) {
+    if (DERIVE == DERIVE_T_LIQ) {
         uint32_t viol_in = 0;
         energy_closure_wave(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat, c.liq, c.T, viol_in);   // (its scalars die right here)
+    } else if (DERIVE == DERIVE_LIQ) {
+        // the liquid fraction alone: one compare and, for waves with a cell in phase change, the ballot-guarded divide;
+        // temperature -- the expensive half of the closure (composition, heat capacity, a full divide) -- is read
+        c.T = ldg(v.T, cb0);
+        c.liq = liquid_fraction_wave(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat);
     } else {
         c.T = ldg(v.T, cb0);
         c.liq = ldg(v.liq, cb0);
@@ -440,146 +454,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     }
     // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
     if (viol && ln.act) atomicOr(v_arg.status, viol);
-}
-
-// ---- ForwardEuler, several column groups per wave ----------------------------------------------------------------------
-// k_column<PROG_EULER> with a loop: a wave steps GROUPS consecutive column groups one after the other, and the fields of the
-// NEXT group are requested before the current group's arithmetic starts, so that every wave has loads in flight while it
-// computes.  Why: 8 waves per SIMD is the occupancy ceiling, and a wave of the one-group kernel spends ~2 us of its ~8 us
-// life (HBM-resident states) waiting for its own 3-5 loads with nothing else outstanding -- the bytes in flight per CU are
-// what bounds the step there, not the bandwidth.  Same operations in the same order as k_column<PROG_EULER>: bit-identical.
-// The kernel arguments are re-read from the kernarg segment in every iteration (kernarg_reload): a loop-invariant scalar
-// load would otherwise be hoisted and pin ~200 SGPRs across the loop.
-template <class NF, bool RICHARDS, int HYD, int LPC, bool DERIVE, int GROUPS>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_column_groups(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a_arg) {
-    constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
-    constexpr unsigned off_a = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(ColumnArgs<NF>));
-    constexpr int CPW = 64 / LPC;
-    LaneInfo ln;
-    ln.lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
-    ln.k = ln.lane % LPC;
-    const int sub = ln.lane / LPC;
-    Cell<NF> incoming;
-    {
-        const View<NF>& v = v_arg;
-        const int Nh = (int)v.Nh, Nz = v.Nz;
-        const int col = wave * GROUPS * CPW + sub;
-        const unsigned cb = ((unsigned)(col < Nh ? col : Nh - 1) * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);
-        incoming.U = ldg(v.U, cb);
-        incoming.sat = ldg(v.sat, cb);
-        incoming.psi = RICHARDS ? ldg(v.psi, cb) : NF(0);
-        incoming.T = DERIVE ? NF(0) : ldg(v.T, cb);
-        incoming.liq = DERIVE ? NF(0) : ldg(v.liq, cb);
-    }
-#pragma unroll 1
-    for (int grp = 0; grp < GROUPS; ++grp) {
-        const View<NF>& v = kernarg_reload<View<NF>>(0);
-        const DevParams<NF>& p = kernarg_reload<DevParams<NF>>(off_p);
-        const ColumnArgs<NF>& a = kernarg_reload<ColumnArgs<NF>>(off_a);
-        const int Nz = v.Nz, Nh = (int)v.Nh;
-        ln.is_bot = ln.k == 0;
-        ln.is_top = ln.k == Nz - 1;
-        const LevelGeom<NF> L = level_geom(v, ln.k);
-        const NF dt = a.dt;
-        const int finalize = a.finalize, write_kf = a.write_kf;
-        const bool need_kc = RICHARDS || write_kf;
-        const unsigned kk = (unsigned)(ln.k < Nz ? ln.k : Nz - 1);
-        const int i = (wave * GROUPS + grp) * CPW + sub;
-        const bool colok = i < Nh;
-        ln.act = colok && ln.k < Nz;
-        const int ii = colok ? i : Nh - 1;
-        const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
-        const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + kk) * (unsigned)sizeof(NF);
-        uint32_t viol = 0;
-        bool bad = false;
-        Cell<NF> c = incoming;
-        // ---- boundary inputs of the column (k_column) --------------------------------------------------------------------
-        const bool seb = p.seb != 0;
-        const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
-        ColumnBC<NF> bc;
-        bc.bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0);
-        bc.bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
-        NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
-        NF fU_b = NF(0), fU_t = NF(0), fS_b = NF(0), fS_t = NF(0);
-        const bool hUb = v.bc.kind[0][0] == 2, hSb = RICHARDS && v.bc.kind[1][0] == 2, hUt = seb || v.bc.kind[0][1] == 2,
-                   hSt = RICHARDS && (seb || v.bc.kind[1][1] == 2);
-        if (hUb) fU_b = ldg(bcval(v, 0, 0), ib0);
-        if (hSb) fS_b = ldg(bcval(v, 1, 0), ib0);
-        if (hUt) fU_t = ldg(seb ? v.ghf : bcval(v, 0, 1), ib0);
-        if (hSt) fS_t = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
-        // the next group's fields: requested behind this group's boundary values (vector memory returns in order) and ahead
-        // of its arithmetic
-        if (grp + 1 < GROUPS) {
-            const int col = (wave * GROUPS + grp + 1) * CPW + sub;
-            const unsigned cb = ((unsigned)(col < Nh ? col : Nh - 1) * (unsigned)v.Nzp + kk) * (unsigned)sizeof(NF);
-            incoming.U = ldg(v.U, cb);
-            incoming.sat = ldg(v.sat, cb);
-            incoming.psi = RICHARDS ? ldg(v.psi, cb) : NF(0);
-            incoming.T = DERIVE ? NF(0) : ldg(v.T, cb);
-            incoming.liq = DERIVE ? NF(0) : ldg(v.liq, cb);
-        }
-        if (DERIVE) {
-            uint32_t viol_in = 0;
-            energy_closure_wave(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat, c.liq, c.T, viol_in);
-        }
-        if (hUb) eU_b = flux_term_bottom(fU_b, v.g);
-        if (hSb) eS_b = flux_term_bottom(fS_b, v.g);
-        if (hUt) eU_t = -flux_term_top(fU_t, v.g);
-        if (hSt) eS_t = -flux_term_top(seb ? -fS_t : fS_t, v.g);
-        bc.flux_U = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
-        bc.flux_S = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
-
-        Cell<NF> n;
-        NF z0 = NF(0);
-        const Tendency<NF> t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
-        NF gU = t.gU, gS = t.gS;
-        const NF over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
-        column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
-        NF Kf_out = t.Kf_lo, Kf_out_top = t.Kc;
-        if (finalize && write_kf) {
-            const DevParams<NF>& pf = kernarg_reload<DevParams<NF>>(off_p);
-            const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(pf, n.liq, fractions(pf, n.sat, n.liq, viol));
-            const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
-            const NF Kmin_new = jl_min(Kc_new, Kc_new_m);
-            Kf_out = (ln.is_bot || ln.is_top) ? Kc_new : Kmin_new;
-            Kf_out_top = Kc_new;
-        }
-        if (ln.act) {
-            const View<NF>& vo = kernarg_reload<View<NF>>(0);
-            const unsigned cb = block_local(cb0), ib = block_local(ib0);
-            stg(vo.U, cb, n.U);
-            stg(vo.T, cb, n.T);
-            stg(vo.liq, cb, n.liq);
-            if (RICHARDS) { stg(vo.sat, cb, n.sat); stg(vo.psi, cb, n.psi); }
-            if (finalize) {
-                stg(vo.G_U, cb, gU);
-                if (RICHARDS) stg(vo.G_sat, cb, gS);
-            }
-            if (write_kf) {
-                stg(vo.Kf, cb, Kf_out);
-                if (ln.is_top) stg(vo.Kf_top, ib, Kf_out_top);
-            }
-            if (ln.is_top) {
-                if (RICHARDS) {
-                    NF S = ldg(vo.S, ib);
-                    const NF GS = NF(0) + jl_min(NF(0), S);
-                    S = (S + GS * dt) + over;
-                    stg(vo.S, ib, S);
-                    stg(vo.wt, ib, z0);
-                    if (finalize) stg(vo.G_S, ib, GS);
-                }
-                if (seb) {
-                    stg(vo.top_T, ib, n.T);
-                    stg(vo.top_sat, ib, n.sat);
-                    stg(vo.top_liq, ib, n.liq);
-                    stg(vo.Ts, ib, ldg(vo.Ts, ib) + NF(0) * dt);
-                }
-            }
-            viol |= bad ? 1u : 0u;
-        }
-        if (viol && ln.act) atomicOr(v_arg.status, viol);
-    }
 }
 
 // ---- Heun with every boundary kind -------------------------------------------------------------------------------------

@@ -77,6 +77,20 @@ TRM_DEV v2f conductivity_linear2(const DevParams<float>& p, const Frac2& f) {
     const v2f theta_sat = f.water + f.ice + f.air;
     return div2(f.water * p.K_sat, theta_sat);
 }
+// liquid fraction of the free-water closure on both components (liquid_fraction_wave, trm_column.hpp)
+TRM_DEV v2f liquid_fraction2(const DevParams<float>& p, v2f U, v2f sat) {
+    const v2f Lth = sat * p.L * p.por;
+    const v2f nLth = -Lth;
+    const float eps = Limits<float>::eps();
+    const M2 thawed = ge(U, splat(0.0f)), frozen0 = lt(U, nLth);
+    const bool needx = !thawed.x && !(frozen0.x && Lth.x > eps), needy = !thawed.y && !(frozen0.y && Lth.y > eps);
+    if (__ballot(needx || needy) == 0ull) return sel(thawed, splat(1.0f), splat(-0.0f));
+    const v2f den = nLth + eps;
+    const v2f sd = v2f{(nLth.x == 0.0f) ? Limits<float>::inf() : div_nr(U.x, den.x), (nLth.y == 0.0f) ? Limits<float>::inf() : div_nr(U.y, den.y)};
+    const v2f x = splat(1.0f) - sd;
+    const v2f bm = v2f{(U.x >= nLth.x) ? x.x : copysign_(0.0f, x.x), (U.y >= nLth.y) ? x.y : copysign_(0.0f, x.y)};
+    return sel(thawed, splat(1.0f), bm);
+}
 // energy_closure (trm_device.hpp) on both components
 TRM_DEV void energy_closure2(const DevParams<float>& p, v2f U, v2f sat, v2f& liq, v2f& T, uint32_t& viol) {
     const v2f Lth = sat * p.L * p.por;   // (p.L * sat) * por: multiplication by the scalar commutes bit for bit
@@ -146,7 +160,9 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // grid: one wave per 2 * (64 / LPC) columns
 // (Deriving T and liq from (U, sat) instead of reading them, as k_column can, was measured here as well: C5 562 vs 533 us
 // per step -- the packed kernel is not short of bytes -- and is not offered.)
-template <bool RICHARDS, int LPC, int HYD>
+// DERIVE_LIQ: the incoming liquid fraction is re-derived from (U, sat) instead of being read (legal when the stored fields
+// are the closure of the stored state, trm_ctx::closure_consistent): one of the five field reads less.
+template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
@@ -172,7 +188,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, D
 
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
     const v2f psi = RICHARDS ? ld2(v.psi, cb0, cb1) : splat(0.0f);
-    const v2f T = ld2(v.T, cb0, cb1), liq = ld2(v.liq, cb0, cb1);
+    const v2f T = ld2(v.T, cb0, cb1);
+    const v2f liq = DERIVE_LIQ ? liquid_fraction2(kernarg_reload<DevParams<float>>(off_p), U, sat) : ld2(v.liq, cb0, cb1);
 
     uint32_t viol_old = 0;   // (bounds of the incoming state were flagged by the launch that produced it)
     const Frac2 f = fractions2(p, sat, liq, viol_old);

@@ -129,26 +129,6 @@ def test_default_steps_per_launch_is_the_resident_program_and_bit_identical(conf
     assert a.status() == b.status()
 
 
-@pytest.mark.parametrize("config,hydraulics,dtype,Nz", CONFIGS)
-def test_two_column_groups_per_wave_equals_one_bitwise(config, hydraulics, dtype, Nz):
-    """TRM_OPT_COLUMN_GROUPS = 2 (experimental): k_column_groups steps two consecutive column groups per wave, the second
-    one's fields requested before the first one's arithmetic -- same bits as the one-group program, ragged column counts,
-    with and without the derivation of T / liq."""
-    lat, lon = small_columns(203)
-    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
-    a, b = W.setup_device(w), W.setup_device(w)
-    a.set_option("column_groups", 2)
-    for d in (a, b):
-        d.set_option("packed_f32", 0)
-        d.set_option("derive_closure_fields", 1)
-        d.step(w["dt"], 1, finalize=False)
-        d.step(w["dt"], 17, finalize=False)
-        d.step(w["dt"], 1, finalize=True)
-    for n in all_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else []):
-        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
-    assert a.status() == b.status() and a.clock() == b.clock()
-
-
 PIPELINE_CONFIGS = [("land", "default", np.float64, 32, 131), ("land", "vg", np.float64, 50, 257), ("land", "default", np.float32, 64, 203),
                     ("land", "vg", np.float32, 40, 129), ("landveg", "vg", np.float64, 32, 200), ("richards", "default", np.float64, 32, 131)]
 

@@ -145,5 +145,9 @@ def test_bench_contract_json_line():
     assert m["steps_per_launch"] == 50 and m["status_flags"] == 0 and m["column_steps_per_s"] > d["value"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 1e5 and "sample" in c
+    assert c["streamed_GBps"] > 1.0 and "julia" in c["julia_probe"] and len(c["thread_scan"]) >= 1
+    # statistics of the line: median over repeated timed regions, min / max beside it
+    assert d["config"]["repeats"] == 10 and d["config"]["ms_per_step_min"] <= d["ms_per_step"] <= d["config"]["ms_per_step_max"]
+    assert d["config"]["steps_per_launch"] == 1 and r["kernel_ms_min"] <= r["kernel_ms"] <= d["ms_per_step"] * 1.02
     # value = whole-job columns x steps / wall time
     assert abs(d["value"] - 56951 * 20 / (d["ms_per_step"] * 1e-3 * 20)) / d["value"] < 1e-6
