@@ -478,7 +478,7 @@ def multistep_leg(W, w, desc, config, Nz, Nh, wordsize, args, sync, device):
 def cpu_baseline(args):
     """The CPU leg runs in a child process of its own (started after all GPU work of this process is done): the OpenMP
     runtime reads OMP_PROC_BIND / OMP_PLACES when it is loaded, and torch has long loaded one here."""
-    env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores")
+    env = dict(os.environ, OMP_PROC_BIND="spread", OMP_PLACES="cores", OMP_WAIT_POLICY="passive")
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", args.workload, "--cpu-seconds", str(args.cpu_seconds)]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=max(120.0, 8 * args.cpu_seconds))
@@ -488,6 +488,25 @@ def cpu_baseline(args):
         return json.loads(line[-1])
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "column-steps/s", "cores": 0, "kind": "port", "sample": "CPU leg timed out"}
+
+
+def cpu_share():
+    """CPUs this process may actually use: the cgroup quota (a GPU box hands a 1-GPU job 16 of its 256 hardware threads' worth of
+    CPU time) bounded by the affinity mask.  Threads beyond the quota only fight over it."""
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:              # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = q / per if q > 0 else None
+        except (OSError, ValueError):
+            pass
+    return avail, quota
 
 
 def julia_probe():
@@ -518,8 +537,9 @@ def cpu_baseline_worker(args):
     from terrarium_jl_amd import parallel
     w, desc, config, Nz, dt_name = build_workload(W, parallel, args.workload, 1, 0, "weak")
     target_seconds = args.cpu_seconds
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    candidates = sorted({c for c in (8, 16, 32, 64, 128, 256, avail) if c <= avail} | {min(avail, 8)})
+    avail, quota = cpu_share()
+    limit = min(avail, 128 if quota is None else max(8, int(2 * quota + 0.5)))
+    candidates = sorted({c for c in (4, 8, 16, 32, 64, 128) if c <= limit} | {min(limit, 8)})
     dt, Nh = w["dt"], w["Nh"]
     stable = min(STABLE_STEPS[config], 150)
 
@@ -543,7 +563,7 @@ def cpu_baseline_worker(args):
         scan[threads] = rate
         if best is None or rate > best[1]:
             best = (threads, rate)
-        if budget < target_seconds * 0.5:
+        if budget < target_seconds * 0.5 or rate < 0.8 * best[1]:      # (past the knee: more threads only fight over the cores)
             break
     threads = best[0]
     legs = {}
@@ -570,13 +590,15 @@ def cpu_baseline_worker(args):
     probe = julia_probe()
     out = {"value": value, "unit": "column-steps/s", "cores": threads, "kind": "port",
            "sample": f"all {Nh} columns x {done} steps of the same workload; CPU restatement of the Terrarium.jl path (not Terrarium.jl itself: "
-                     f"{probe['note']}), one pass per reference kernel, OpenMP over columns with {threads} of {avail} hardware threads "
+                     f"{probe['note']}), one pass per reference kernel, OpenMP over columns with {threads} threads ({avail} hardware threads in the "
+                     f"affinity mask, cgroup CPU quota {'none' if quota is None else round(quota, 1)}) "
                      f"(best of a scan, column-steps/s: " + ", ".join(f"{k}: {v:.3g}" for k, v in scan.items()) + f"), threads bound "
                      f"(OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES={os.environ.get('OMP_PLACES')}), arrays first-touched by the owning thread; "
                      f"{spent:.1f} s; other legs (column-steps/s): " + ", ".join(f"{k} {v['value']:.3g}" for k, v in legs.items()),
            "streamed_GBps": value * Nz * bpc / 1e9,
            "streamed_bytes_per_cell_step": bpc,
            "thread_scan": {str(k): v for k, v in scan.items()},
+           "hardware_threads": avail, "cgroup_cpu_quota": quota,
            "julia_probe": probe,
            "legs": legs}
     print(json.dumps(out), flush=True)

@@ -165,8 +165,8 @@ enum {
                                     /* closure of the stored internal_energy / saturation (the library wrote them), a fused   */
                                     /* Euler step can re-derive them in registers instead of reading them: 2 of 5 field reads */
                                     /* less, bit-identical results.  0: never; 1: whenever legal; 2 (default): for fp64 states  */
-                                    /* beyond the 256 MiB Infinity Cache, and for the reference-default hydraulics / heat-only  */
-                                    /* on grids of >= 24 576 columns: where it was measured to win                */
+                                    /* beyond the 256 MiB Infinity Cache or of >= 24 576 columns: where it was measured to win  */
+                                    /* (DESIGN 4.1); 3: the liquid fraction alone (one read less; measured between 0 and 1)     */
     TRM_OPT_STEPS_PER_LAUNCH = 6,   /* trm_step keeps every column in registers for up to m steps per launch and writes the */
                                     /* fields once per launch (temporal blocking of run!'s loop, model_integrator.jl:72-88;  */
                                     /* bit-identical to m = 1).  0 (default): the library chooses -- 50 wherever the program  */
@@ -182,8 +182,9 @@ enum {
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
-                                /* wavefront shuffles for the vertical stencil (Nz <= 64; deeper columns take */
-                                /* the unfused kernels)                                                       */
+                                /* wavefront shuffles for the vertical stencil (Nz <= 64; two levels per lane */
+                                /* for 65 ... 128 levels with the branch-free boundary kinds, ForwardEuler;   */
+                                /* anything deeper takes the unfused kernels)                                 */
     TRM_KERNEL_UNFUSED = 1      /* one launch per reference kernel, in the reference's order (A/B comparator) */
 };
 

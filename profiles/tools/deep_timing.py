@@ -1,0 +1,28 @@
+"""Per-cell time of the fused Euler step on deep columns (two levels per lane, Nz = 65 ... 128) against Nz = 64 (one level per
+lane) and against the reference-order kernels: python profiles/tools/deep_timing.py"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import numpy as np
+import workloads as W
+lat, lon = W.columns_from_mask("N145")
+out = {}
+for config in ("heat", "richards"):
+    for Nz, kernel in ((64, "fused"), (100, "fused"), (128, "fused"), (100, "unfused")):
+        w = W.make_workload(config, lat, lon, Nz)
+        d = W.setup_device(w)
+        d.set_option("step_kernel", kernel)
+        d.step(w["dt"], 10, finalize=False)
+        d.save_state()
+        ts = []
+        for _ in range(5):
+            d.restore_state()
+            d.step_timed(w["dt"], 50, finalize=False)
+            d.restore_state()
+            ts.append(d.step_timed(w["dt"], 50, finalize=False) * 1e3 / 50)
+        us = float(np.median(ts))
+        out[f"{config}_Nz{Nz}_{kernel}"] = {"us_per_step": round(us, 2), "ps_per_cell": round(us * 1e6 / (lat.size * Nz), 2), "status": d.status()}
+        d.close()
+for config in ("heat", "richards"):
+    out[f"{config}_per_cell_ratio_100_vs_64"] = round(out[f"{config}_Nz100_fused"]["ps_per_cell"] / out[f"{config}_Nz64_fused"]["ps_per_cell"], 3)
+print(json.dumps(out))

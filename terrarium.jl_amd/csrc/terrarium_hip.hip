@@ -4,6 +4,7 @@
 #include "trm_kernels.hpp"
 #include "trm_packed_f32.hpp"
 #include "trm_column.hpp"
+#include "trm_column_deep.hpp"
 #include "trm_vegetation.hpp"
 
 #include <dlfcn.h>
@@ -855,12 +856,12 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     // Deriving T and liq in registers saves 2 of 11 field accesses and costs ~40 instructions per cell.  Measured on MI355X
-    // (profiles/tools/derive_crossover.py, ab_step.py; fp64): it wins once an fp64 state streams from HBM (8 x N145: 223 vs
-    // 240 us); with the state in the Infinity Cache it wins where the step is bound by the bytes it moves -- the
-    // reference-default hydraulics and heat-only from ~28 000 columns up (N145: 26.0-26.2 vs 27.7-28.4 us on two boxes, equal
-    // on a third; 36 864 columns -6.5 %) -- is neutral for van Genuchten and the LandModel (more arithmetic per byte) and
-    // loses on small grids (N72 heat-only: 7.1 vs 6.6 us, latency-bound) and in fp32 (C5 van Genuchten: 754 vs 702 us).
-    // AUTO switches on the number format, the bytes one step touches, the hydraulics and the column count.
+    // (profiles/r03/exp4_ab_derive.log, interleaved medians on one box; fp64): 8 x N145 (HBM-resident) 215 vs 261 us, N145
+    // 25.1 vs 27.3 us with the reference-default hydraulics, 33.6 vs 35.1 (LandModel), 34.4 vs 35.6 (LandModel, van Genuchten);
+    // it loses on small grids (N72 heat-only: 7.1 vs 6.6 us, latency-bound) and for the packed fp32 kernel, which is not short of
+    // bytes (C5: liquid fraction alone 523 vs 500 us, both 562 vs 533).  Deriving the liquid fraction alone (mode 3: one read
+    // less, the temperature divide saved) sits between the two everywhere (8 x N145: 238 us) and is kept as an option only.
+    // AUTO (2): fp64 states beyond the Infinity Cache, or of >= 24 576 columns.
     template <bool RICH> static int derive_now(const trm_ctx* c) {
         // (the coupled vegetation reads T and liq of the whole column from memory every step)
         if (!c->closure_consistent || c->closure_escaped || coupled(c) || c->opt_derive == 0) return DERIVE_NONE;
@@ -868,8 +869,8 @@ template <class NF> struct Ops {
         if (c->opt_derive == 3) return DERIVE_LIQ;
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
         const bool beyond_cache = state_bytes > ((size_t)256 << 20);
-        const bool bound_by_bytes = c->Nh >= 24576 && !c->params.seb && (!RICH || hyd(c) == HYD_BC_LINEAR);
-        return (std::is_same<NF, double>::value && (beyond_cache || bound_by_bytes)) ? DERIVE_T_LIQ : DERIVE_NONE;
+        const bool large = c->Nh >= 24576;
+        return (std::is_same<NF, double>::value && (beyond_cache || large)) ? DERIVE_T_LIQ : DERIVE_NONE;
     }
     // fp32: two columns per lane with packed math (trm_packed_f32.hpp) -- the reference-default hydraulics, and van
     // Genuchten retention with Mualem conductivity
@@ -1022,9 +1023,29 @@ template <class NF> struct Ops {
         }
         return rc;
     }
+    // columns of 65 ... 128 levels: two levels per lane, one column per wavefront (trm_column_deep.hpp)
+    static bool deep_columns(const trm_ctx* c) { return c->Nz > 64 && c->Nz <= 128; }
+    template <bool RICH, int H> static int launch_deep(trm_ctx* c, double dt, int finalize) {
+        const LaunchArgs<NF>& la = launch_args<NF>(c);
+        ColumnArgs<NF> a{};
+        a.dt = (NF)dt;
+        a.finalize = finalize;
+        a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
+        a.nsteps = 1;
+        const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
+        hipLaunchKernelGGL((k_column_deep<NF, RICH, H>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
     // one fused ForwardEuler step (the state's surface processes have run)
     static int wave_step(trm_ctx* c, double dt, int finalize) {
         int rc = TRM_OK;
+        if (deep_columns(c)) {
+            if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H>(c, dt, finalize))); }
+            else { TRM_BY_HYD(c, rc = (launch_deep<false, H>(c, dt, finalize))); }
+            if (!rc) c->closure_consistent = true;
+            return rc;
+        }
         const bool deep = c->Nz > 32;
         if (packed_path(c)) {
             if (richards(c)) rc = deep ? launch_packed<true, 64>(c, dt, finalize) : launch_packed<true, 32>(c, dt, finalize);
@@ -1104,11 +1125,12 @@ template <class NF> struct Ops {
     }
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
-        // the fused kernels map one soil level to one lane: columns deeper than 64 levels take the reference-order kernels
-        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64;
+        // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
+        // deeper takes the reference-order kernels
+        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || (deep_columns(c) && !generic_bcs(c) && !coupled(c)));
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
-        const bool program_ok = fused && !generic_bcs(c) && series_fit_program(c) && !coupled(c);
+        const bool program_ok = fused && c->Nz <= 64 && !generic_bcs(c) && series_fit_program(c) && !coupled(c);
         const int spl = !program_ok ? 1 : (c->opt_steps_per_launch > 0 ? c->opt_steps_per_launch : auto_steps_per_launch(c));
         bool piped = false, first_piped = false;
         int n = 0, rc = TRM_OK;

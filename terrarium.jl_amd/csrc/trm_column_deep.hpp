@@ -1,0 +1,312 @@
+// trm_column_deep.hpp -- the fused ForwardEuler step for columns of 65 ... 128 levels: TWO soil levels per lane.
+//
+// The reference's own saturation-adjustment test steps a UniformSpacing(N = 100) column (test/soil/soil_hydrology_tests.jl:
+// 93-123); with one level per lane such grids fell to the reference-order kernels (four times the per-cell time).  Here lane l
+// of a wavefront holds levels 2l ("a") and 2l + 1 ("b") of ONE column: a column is one contiguous 16-byte-per-lane access
+// per field, the k - 1 neighbour of a is the previous lane's b (one DPP shift), of b the lane's own a (free); likewise
+// upwards.  Ballots come in pairs (a cells, b cells).  Every operation is the one k_column<PROG_EULER> / the reference-order
+// kernels perform on the cell, in the same order: results are bit-identical (tests/test_gpu_deep_columns.py).
+// Scope: the branch-free boundary kinds (as k_column), Euler, no derivation of T / liq; anything else keeps the unfused path.
+#pragma once
+#include "trm_column.hpp"
+
+namespace trm {
+
+template <class NF> struct Two { NF a, b; };
+// level k - 1 / k + 1 of both cells of a lane
+template <class NF> TRM_DEV Two<NF> below(const Two<NF>& x) { return Two<NF>{shift_up(x.b), x.a}; }
+template <class NF> TRM_DEV Two<NF> above(const Two<NF>& x) { return Two<NF>{x.b, shift_dn(x.a)}; }
+template <class NF> TRM_DEV Two<NF> ld2cells(const NF* base, unsigned byte_off) {
+    // (one 16-byte access for fp64 pairs, 8 bytes for fp32: the two levels are adjacent in the z-fastest layout)
+    struct alignas(2 * sizeof(NF)) Raw { NF a, b; };
+    const Raw r = *reinterpret_cast<const Raw*>(reinterpret_cast<const char*>(base) + byte_off);
+    return Two<NF>{r.a, r.b};
+}
+struct DeepLane { int lane, ka, kb; bool act_a, act_b, bot_a, top_a, top_b; };
+
+// broadcast of a per-level value from level q (lane q / 2, cell q % 2) to the wave
+template <class NF> TRM_DEV NF from_level(const Two<NF>& x, int q) {
+    const NF va = __shfl(x.a, q >> 1, 64), vb = __shfl(x.b, q >> 1, 64);
+    return (q & 1) ? vb : va;
+}
+// bit q of the result = the predicate of level q (a cells are the even levels, b cells the odd ones), as two 64-bit halves
+struct Mask128 { unsigned long long lo, hi; };
+TRM_DEV Mask128 level_mask(bool pa, bool pb) {
+    const unsigned long long A = __ballot(pa), B = __ballot(pb);
+    // interleave: level 2l <- A bit l, level 2l + 1 <- B bit l
+    auto spread = [](unsigned long long x) {   // bits 0..31 of x to the even positions of a 64-bit word
+        x &= 0xffffffffull;
+        x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+        x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+        x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+        x = (x | (x << 2)) & 0x3333333333333333ull;
+        x = (x | (x << 1)) & 0x5555555555555555ull;
+        return x;
+    };
+    Mask128 m;
+    m.lo = spread(A) | (spread(B) << 1);
+    m.hi = spread(A >> 32) | (spread(B >> 32) << 1);
+    return m;
+}
+TRM_DEV bool any(const Mask128& m) { return (m.lo | m.hi) != 0ull; }
+TRM_DEV int lowest(const Mask128& m) { return m.lo ? __builtin_ctzll(m.lo) : 64 + __builtin_ctzll(m.hi); }
+TRM_DEV int highest(const Mask128& m) { return m.hi ? 127 - __builtin_clzll(m.hi) : 63 - __builtin_clzll(m.lo); }
+TRM_DEV bool any_above(const Mask128& m, int q) {   // a bit at a level > q
+    if (q >= 127) return false;
+    if (q >= 63) return (m.hi >> (q - 63)) != 0ull;
+    return (m.lo >> (q + 1)) != 0ull || m.hi != 0ull;
+}
+TRM_DEV bool any_below(const Mask128& m, int q) {   // a bit at a level < q
+    if (q <= 0) return false;
+    if (q <= 64) return (q == 64 ? m.lo : (m.lo & ((1ull << q) - 1ull))) != 0ull;
+    return m.lo != 0ull || (m.hi & ((1ull << (q - 64)) - 1ull)) != 0ull;
+}
+
+// adjust_saturation_profile! (soil_hydrology.jl:185-219), two levels per lane: repair_saturation() of trm_kernels.hpp with the
+// level sets as 128-bit masks and the cell of level q addressed as (lane q / 2, cell q % 2)
+template <class NF>
+TRM_DEV NF repair_saturation_deep(Two<NF>& s, const DeepLane& ln, int Nz, const Two<NF>& dzc, const Two<NF>& rdzc, NF dzc_top) {
+    const bool over_a = ln.act_a && !ln.top_a && s.a > NF(1), over_b = ln.act_b && !ln.top_b && s.b > NF(1);
+    const bool under_a = ln.act_a && !ln.bot_a && s.a < NF(0), under_b = ln.act_b && s.b < NF(0);
+    const Mask128 any_over = level_mask(over_a, over_b);
+    const Mask128 any_bad = level_mask(over_a || under_a, over_b || under_b);
+    s.a = ln.bot_a ? s.a : s.a + NF(0);
+    s.b = s.b + NF(0);
+    if (any(any_bad)) {
+        // thickness of the cells above / below (the edge cells keep their own, as neighbour_dz() does)
+        const Two<NF> dz_up = above(dzc), rdz_up = above(rdzc), dz_dn = below(dzc), rdz_dn = below(rdzc);
+        const bool edge_up_a = ln.ka >= Nz - 1, edge_up_b = ln.kb >= Nz - 1;
+        const Two<NF> nb_dz_up{edge_up_a ? dzc.a : dz_up.a, edge_up_b ? dzc.b : dz_up.b}, nb_rdz_up{edge_up_a ? rdzc.a : rdz_up.a, edge_up_b ? rdzc.b : rdz_up.b};
+        const Two<NF> nb_dz_dn{ln.bot_a ? dzc.a : dz_dn.a, dz_dn.b}, nb_rdz_dn{ln.bot_a ? rdzc.a : rdz_dn.a, rdz_dn.b};
+        if (any(any_over)) {
+            NF carry = NF(0);
+            for (int q = lowest(any_over); q < Nz - 1; ++q) {
+                Two<NF> cout{NF(0), NF(0)};
+                if (ln.ka == q) {
+                    s.a = s.a + carry;
+                    const NF e = jl_max(s.a - NF(1), NF(0));
+                    s.a = s.a - e;
+                    cout.a = div_const(e * dzc.a, nb_dz_up.a, nb_rdz_up.a);
+                }
+                if (ln.kb == q) {
+                    s.b = s.b + carry;
+                    const NF e = jl_max(s.b - NF(1), NF(0));
+                    s.b = s.b - e;
+                    cout.b = div_const(e * dzc.b, nb_dz_up.b, nb_rdz_up.b);
+                }
+                carry = from_level(cout, q);
+                if (!any_above(any_over, q) && __ballot(!(carry == NF(0))) == 0ull) break;
+            }
+            if (ln.top_a) s.a = s.a + carry;
+            if (ln.top_b) s.b = s.b + carry;
+        }
+        const bool under2_a = ln.act_a && !ln.bot_a && !(jl_max(-s.a, NF(0)) == NF(0));
+        const bool under2_b = ln.act_b && !(jl_max(-s.b, NF(0)) == NF(0));
+        const Mask128 any_under = level_mask(under2_a, under2_b);
+        if (any(any_under)) {
+            NF pend = NF(0);
+            for (int q = highest(any_under); q >= 1; --q) {
+                Two<NF> pout{NF(0), NF(0)};
+                if (ln.ka == q) {
+                    s.a = s.a - pend;
+                    const NF d = jl_max(-s.a, NF(0));
+                    s.a = s.a + d;
+                    pout.a = div_const(d * dzc.a, nb_dz_dn.a, nb_rdz_dn.a);
+                }
+                if (ln.kb == q) {
+                    s.b = s.b - pend;
+                    const NF d = jl_max(-s.b, NF(0));
+                    s.b = s.b + d;
+                    pout.b = div_const(d * dzc.b, nb_dz_dn.b, nb_rdz_dn.b);
+                }
+                pend = from_level(pout, q);
+                if (!any_below(any_under, q) && __ballot(!(pend == NF(0))) == 0ull) break;
+            }
+            if (ln.bot_a) s.a = s.a - pend;
+        }
+    }
+    // surface overflow joins surface_excess_water (the top cell); bottom clamp (the bottom cell)
+    const NF e_a = ln.top_a ? jl_max(s.a - NF(1), NF(0)) : NF(0), e_b = ln.top_b ? jl_max(s.b - NF(1), NF(0)) : NF(0);
+    s.a = s.a - e_a;
+    s.b = s.b - e_b;
+    s.a = ln.bot_a ? jl_max(s.a, NF(0)) : s.a;
+    return (e_a + e_b) * dzc_top;      // (one of the two is the top cell's excess, the other +0)
+}
+
+template <class NF, bool RICHARDS, int HYD>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
+    constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+    const View<NF>& v = v_arg;
+    const DevParams<NF>& p = p_arg;
+    DeepLane ln;
+    ln.lane = threadIdx.x & 63;
+    const int i = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);      // one column per wave
+    const int Nz = v.Nz, Nh = (int)v.Nh;
+    ln.ka = 2 * ln.lane;
+    ln.kb = ln.ka + 1;
+    const bool colok = i < Nh;
+    ln.act_a = colok && ln.ka < Nz;
+    ln.act_b = colok && ln.kb < Nz;
+    ln.bot_a = ln.ka == 0;
+    ln.top_a = ln.ka == Nz - 1;
+    ln.top_b = ln.kb == Nz - 1;
+    const bool is_top_lane = ln.top_a || ln.top_b;
+    const int ii = colok ? i : Nh - 1;
+    // Lanes beyond the top load the column's last pair again (an aligned 2-word access inside the column's pitch) and store
+    // nothing.  With an odd number of levels the top lane's b cell is the first padding word: read, never stored, and nothing
+    // of it reaches a real cell (the top cell takes its upper face, conductivities and fluxes from the boundary formulas).
+    const int last_pair = (Nz - 1) & ~1;
+    const int ka_ld = ln.ka <= last_pair ? ln.ka : last_pair;
+    const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
+    const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)ka_ld) * (unsigned)sizeof(NF);
+    const NF dt = a.dt;
+    const int finalize = a.finalize, write_kf = a.write_kf;
+    const bool need_kc = RICHARDS || write_kf;
+    uint32_t viol_a = 0, viol_b = 0;    // (per cell: only real cells report)
+    bool bad = false;
+
+    // per-level geometry of both cells (the level records of trm_kernels.hpp: level_geom)
+    const LevelGeom<NF> La = level_geom(v, ln.ka), Lb = level_geom(v, ln.kb);
+    const Two<NF> dzc{La.dzc, Lb.dzc}, rdzc{La.rdzc, Lb.rdzc};
+
+    // ---- the column comes in ---------------------------------------------------------------------------------------
+    const Two<NF> U = ld2cells(v.U, cb0), sat = ld2cells(v.sat, cb0), T = ld2cells(v.T, cb0), liq = ld2cells(v.liq, cb0);
+    const Two<NF> psi = RICHARDS ? ld2cells(v.psi, cb0) : Two<NF>{NF(0), NF(0)};
+    const bool seb = p.seb != 0;
+    const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
+    const NF bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0), bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
+    NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
+    if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib0), v.g);
+    if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib0), v.g);
+    if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib0), v.g);
+    if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
+        const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
+        eS_t = -flux_term_top(seb ? -fS : fS, v.g);
+    }
+    const Two<NF> flux_U{ln.bot_a ? eU_b : (ln.top_a ? eU_t : NF(0)), ln.top_b ? eU_t : NF(0)};
+    const Two<NF> flux_S{ln.bot_a ? eS_b : (ln.top_a ? eS_t : NF(0)), ln.top_b ? eS_t : NF(0)};
+
+    // ---- compute_auxiliary! + compute_tendencies! (column_tendencies, trm_column.hpp, per cell) -----------------------
+    uint32_t viol_old = 0;
+    const Frac<NF> fa = fractions(p, sat.a, liq.a, viol_old), fb = fractions(p, sat.b, liq.b, viol_old);
+    const Two<NF> kap{conductivity(p, fa), conductivity(p, fb)};
+    const Two<NF> Kc{need_kc ? conductivity_hydraulic<NF, HYD, false>(p, liq.a, fa) : NF(0), need_kc ? conductivity_hydraulic<NF, HYD, false>(p, liq.b, fb) : NF(0)};
+    const Two<NF> T_dn = below(T), kap_dn = below(kap);
+    // temperature halos of the edge cells
+    auto ext_b = [&](NF Tc) { return vTb ? Tc + div_const(Tc - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot) : Tc; };
+    auto ext_t = [&](NF Tc) { return vTt ? Tc + div_const(bTt - Tc, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top : Tc; };
+    auto halo_kap = [&](NF kc, NF lq, uint32_t& vl) { return (!RICHARDS && p.halo_policy != 1) ? conductivity(p, fractions(p, NF(0), lq, vl)) : kc; };
+    const NF T_m_a = ln.bot_a ? ext_b(T.a) : T_dn.a, T_m_b = T_dn.b;
+    const NF kap_halo_a = halo_kap(kap.a, liq.a, viol_a), kap_halo_b = halo_kap(kap.b, liq.b, viol_b);
+    const NF kap_m_a = ln.bot_a ? kap_halo_a : kap_dn.a, kap_m_b = kap_dn.b;
+    const Two<NF> qT_lo{-(NF(0.5) * (kap.a + kap_m_a)) * ((T.a - T_m_a) * La.rdzf_lo), -(NF(0.5) * (kap.b + kap_m_b)) * ((T.b - T_m_b) * Lb.rdzf_lo)};
+    const Two<NF> qT_up = above(qT_lo);
+    const NF qT_hi_a = ln.top_a ? -(NF(0.5) * (kap_halo_a + kap.a)) * ((ext_t(T.a) - T.a) * La.rdzf_hi) : qT_up.a;
+    const NF qT_hi_b = ln.top_b ? -(NF(0.5) * (kap_halo_b + kap.b)) * ((ext_t(T.b) - T.b) * Lb.rdzf_hi) : qT_up.b;
+    Two<NF> gU{NF(0) + (-((qT_hi_a - qT_lo.a) * La.rdzc)), NF(0) + (-((qT_hi_b - qT_lo.b) * Lb.rdzc))};
+    Two<NF> gS{NF(0), NF(0)}, Kf_lo{NF(0), NF(0)};
+    if (need_kc) {   // face conductivities (soil_hydrology.jl:145-163)
+        const Two<NF> Kc_dn = below(Kc);
+        const NF Kmin_a = jl_min(Kc.a, Kc_dn.a), Kmin_b = jl_min(Kc.b, Kc_dn.b);
+        Kf_lo.a = (ln.bot_a || ln.top_a) ? Kc.a : Kmin_a;
+        Kf_lo.b = ln.top_b ? Kc.b : Kmin_b;
+    }
+    if (RICHARDS) {  // Darcy fluxes (soil_hydrology_rre.jl:95-131)
+        const Two<NF> Kf_dn = below(Kf_lo), Kf_up = above(Kf_lo), psi_dn = below(psi);
+        const NF Kf_m_a = ln.bot_a ? NF(0) : Kf_dn.a, Kf_m_b = Kf_dn.b;
+        const NF Kf_p_a = ln.top_a ? Kc.a : Kf_up.a, Kf_p_b = ln.top_b ? Kc.b : Kf_up.b;
+        const NF psi_m_a = ln.bot_a ? psi.a : psi_dn.a, psi_m_b = psi_dn.b;
+        const NF g_lo_a = (psi.a - psi_m_a) * La.rdzf_lo, g_lo_b = (psi.b - psi_m_b) * Lb.rdzf_lo;
+        const Two<NF> qW_lo{-upwind_conductivity(g_lo_a, Kf_m_a, Kf_lo.a, Kf_p_a) * g_lo_a, -upwind_conductivity(g_lo_b, Kf_m_b, Kf_lo.b, Kf_p_b) * g_lo_b};
+        const Two<NF> qW_up = above(qW_lo);
+        const NF qW_t_a = -jl_min(Kc.a, NF(0)) * (psi.a - psi.a), qW_t_b = -jl_min(Kc.b, NF(0)) * (psi.b - psi.b);
+        const NF qW_hi_a = ln.top_a ? qW_t_a : qW_up.a, qW_hi_b = ln.top_b ? qW_t_b : qW_up.b;
+        const NF dth_a = -((qW_hi_a - qW_lo.a) * La.rdzc) + NF(0) + p.vwc_forcing, dth_b = -((qW_hi_b - qW_lo.b) * Lb.rdzc) + NF(0) + p.vwc_forcing;
+        gS.a = NF(0) + div_const(dth_a, p.por, p.rpor);
+        gS.b = NF(0) + div_const(dth_b, p.por, p.rpor);
+    }
+    // ---- compute_z_bcs! + explicit_step! + hydrology closure (column_advance) -------------------------------------------
+    gU.a += flux_U.a; gU.b += flux_U.b;
+    Two<NF> Un{U.a + gU.a * dt, U.b + gU.b * dt};
+    bad = bad || (ln.act_a && is_nan(Un.a)) || (ln.act_b && is_nan(Un.b));
+    Two<NF> sn = sat;
+    NF z0 = NF(0), over = NF(0);
+    if (RICHARDS) {
+        gS.a += flux_S.a; gS.b += flux_S.b;
+        sn.a = sat.a + gS.a * dt;
+        sn.b = sat.b + gS.b * dt;
+        bad = bad || (ln.act_a && is_nan(sn.a)) || (ln.act_b && is_nan(sn.b));
+        over = repair_saturation_deep<NF>(sn, ln, Nz, dzc, rdzc, v.g.dzc_top);
+        // compute_water_table! (soil_hydrology.jl:170-175): lower face of the first unsaturated cell from the bottom
+        const Mask128 unsat = level_mask(ln.act_a && sn.a < NF(1), ln.act_b && sn.b < NF(1));
+        const Two<NF> zFlo{La.zFlo, Lb.zFlo};
+        const int first = any(unsat) ? lowest(unsat) : -1;
+        const NF z_first = from_level(zFlo, first >= 0 ? first : 0);
+        z0 = first >= 0 ? z_first : v.g.zF_top;
+    }
+    // ---- closures (column_closure): (U, sat) -> (T, liq, psi), parameters fetched afresh -----------------------------------
+    Two<NF> ln_, Tn, psin{NF(0), NF(0)};
+    {
+        const DevParams<NF>& p2 = kernarg_reload<DevParams<NF>>(off_p);
+        // (one ballot decision for the wave's phase-change divide per cell set, as energy_closure_wave)
+        energy_closure_wave(p2, Un.a, sn.a, ln_.a, Tn.a, viol_a);
+        energy_closure_wave(p2, Un.b, sn.b, ln_.b, Tn.b, viol_b);
+        if (RICHARDS) {
+            psin.a = pressure_head<NF, HYD>(p2, sn.a, La.zC, La.psiz, z0);
+            psin.b = pressure_head<NF, HYD>(p2, sn.b, Lb.zC, Lb.psiz, z0);
+        }
+    }
+    Two<NF> Kf_out = Kf_lo;
+    NF Kf_out_top = ln.top_a ? Kc.a : Kc.b;
+    if (finalize && write_kf) {
+        const DevParams<NF>& pf = kernarg_reload<DevParams<NF>>(off_p);
+        const Two<NF> Kn{conductivity_hydraulic<NF, HYD, false>(pf, ln_.a, fractions(pf, sn.a, ln_.a, viol_a)),
+                         conductivity_hydraulic<NF, HYD, false>(pf, ln_.b, fractions(pf, sn.b, ln_.b, viol_b))};
+        const Two<NF> Kn_dn = below(Kn);
+        const NF Kmin_a = jl_min(Kn.a, Kn_dn.a), Kmin_b = jl_min(Kn.b, Kn_dn.b);
+        Kf_out.a = (ln.bot_a || ln.top_a) ? Kn.a : Kmin_a;
+        Kf_out.b = ln.top_b ? Kn.b : Kmin_b;
+        Kf_out_top = ln.top_a ? Kn.a : Kn.b;
+    }
+    // ---- the column goes out -------------------------------------------------------------------------------------------
+    const View<NF>& vo = kernarg_reload<View<NF>>(0);
+    auto store_cell = [&](bool act, unsigned cb_, NF u, NF t, NF l, NF s, NF ps, NF kf, NF gu, NF gs) {
+        if (!act) return;
+        const unsigned cb = block_local(cb_);
+        stg(vo.U, cb, u);
+        stg(vo.T, cb, t);
+        stg(vo.liq, cb, l);
+        if (RICHARDS) { stg(vo.sat, cb, s); stg(vo.psi, cb, ps); }
+        if (finalize) {
+            stg(vo.G_U, cb, gu);
+            if (RICHARDS) stg(vo.G_sat, cb, gs);
+        }
+        if (write_kf) stg(vo.Kf, cb, kf);
+    };
+    const unsigned cba = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)ln.ka) * (unsigned)sizeof(NF), cbb = cba + (unsigned)sizeof(NF);
+    store_cell(ln.act_a, cba, Un.a, Tn.a, ln_.a, sn.a, psin.a, Kf_out.a, gU.a, gS.a);
+    store_cell(ln.act_b, cbb, Un.b, Tn.b, ln_.b, sn.b, psin.b, Kf_out.b, gU.b, gS.b);
+    if (colok && is_top_lane) {
+        const unsigned ib = block_local(ib0);
+        const NF Tt = ln.top_a ? Tn.a : Tn.b, st = ln.top_a ? sn.a : sn.b, lt = ln.top_a ? ln_.a : ln_.b;
+        if (write_kf) stg(vo.Kf_top, ib, Kf_out_top);
+        if (RICHARDS) {
+            NF S = ldg(vo.S, ib);
+            const NF GS = NF(0) + jl_min(NF(0), S);
+            S = (S + GS * dt) + over;
+            stg(vo.S, ib, S);
+            stg(vo.wt, ib, z0);
+            if (finalize) stg(vo.G_S, ib, GS);
+        }
+        if (seb) {
+            stg(vo.top_T, ib, Tt);
+            stg(vo.top_sat, ib, st);
+            stg(vo.top_liq, ib, lt);
+            stg(vo.Ts, ib, ldg(vo.Ts, ib) + NF(0) * dt);
+        }
+    }
+    const uint32_t viol = (ln.act_a ? viol_a : 0u) | (ln.act_b ? viol_b : 0u) | (bad ? 1u : 0u);
+    if (viol) atomicOr(v_arg.status, viol);
+}
+
+}  // namespace trm

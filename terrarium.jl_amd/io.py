@@ -82,6 +82,39 @@ class Dataset:
         if self.shape is None or self.dtype is None or self.layout is None:
             raise Hdf5FormatError(f"{name}: not a dataset (dataspace / datatype / layout message missing)")
 
+    def _fill(self):
+        """What storage that was never written reads as: the variable's `_FillValue` (NetCDF-4 stores it as the HDF5 fill
+        value too), else 0."""
+        fv = self.attrs.get("_FillValue")
+        try:
+            return np.asarray(fv, dtype=self.dtype).reshape(-1)[0] if fv is not None else self.dtype.type(0)
+        except (TypeError, ValueError):
+            return self.dtype.type(0)
+
+    def read_cf(self) -> np.ndarray:
+        """`read()` with the CF packing conventions applied, as Rasters.jl / NCDatasets.jl do by default on the reference side
+        (examples/simulations/soil_heat_global_era5.jl reads ERA5 files through `Raster(...)`, `replace_missing(..., NaN)`):
+        `_FillValue` / `missing_value` become NaN, then `value * scale_factor + add_offset` in float64.  Classic ERA5
+        downloads are int16-packed: without this the raw integers would be taken for the physical values.  A variable without
+        any of these attributes is returned as stored."""
+        raw = self.read()
+        a = self.attrs
+        packed = any(k in a for k in ("scale_factor", "add_offset"))
+        missing = [a[k] for k in ("_FillValue", "missing_value") if k in a and not isinstance(a[k], str)]
+        if not packed and not missing:
+            return raw
+        out = raw.astype(np.float64)
+        if missing:
+            bad = np.zeros(raw.shape, dtype=bool)
+            for m in missing:
+                for v in np.asarray(m).reshape(-1):
+                    bad |= (raw == v) if not (isinstance(v, np.floating) and np.isnan(v)) else np.isnan(out)
+        if packed:
+            out = out * float(np.asarray(a.get("scale_factor", 1.0)).reshape(-1)[0]) + float(np.asarray(a.get("add_offset", 0.0)).reshape(-1)[0])
+        if missing:
+            out[bad] = np.nan
+        return out
+
     def read(self) -> np.ndarray:
         f, kind = self.file, self.layout[0]
         count = int(np.prod(self.shape, dtype=np.int64)) if self.shape else 1
@@ -91,7 +124,7 @@ class Dataset:
         elif kind == "contiguous":
             addr, size = self.layout[1], self.layout[2]
             if addr == UNDEF:
-                return np.zeros(self.shape, self.dtype)      # never written: fill value 0
+                return np.full(self.shape, self._fill(), self.dtype)      # never written: the fill value
             raw = f.buf[f.base + addr:f.base + addr + nbytes]
         else:
             return self._read_chunked()
@@ -118,7 +151,7 @@ class Dataset:
         f = self.file
         _, btree, chunk = self.layout
         rank = len(self.shape)
-        out = np.zeros(self.shape, self.dtype)
+        out = np.full(self.shape, self._fill(), self.dtype)       # chunks that were never allocated read as the fill value
         if btree == UNDEF:
             return out
         cshape = chunk[:rank]
@@ -436,7 +469,7 @@ class RasterInputSource:
         """Reads `variable` (dimensions [time,] y, x in file order) and its time coordinate from a NetCDF-4 file."""
         f = Hdf5File(path)
         ds = f[variable]
-        data = ds.read()
+        data = ds.read_cf()      # scale_factor / add_offset / _FillValue applied, as Rasters does by default
         mask_ndim = np.asarray(grid.mask).ndim
         times = None
         if data.ndim == mask_ndim + 1:

@@ -17,7 +17,7 @@ DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
 def land_mask_from_netcdf(path: str, variable: str = "lsm", threshold: float = 0.5) -> np.ndarray:
     """`Raster(path; name = :lsm)[Ti(1)] .> 0.5` (examples/simulations/soil_heat_global.jl:30-37): boolean [nlat][nlon]."""
-    lsm = _io.Hdf5File(path)[variable].read()
+    lsm = _io.Hdf5File(path)[variable].read_cf()    # (packed int16 masks unpack to 0..1; missing values -> NaN -> not land)
     while lsm.ndim > 2:
         lsm = lsm[0]            # the leading time axis has one entry
     return lsm > threshold

@@ -46,8 +46,12 @@ def _datatype(dtype):
 
 
 def _attribute(name, text):
-    val = text.encode() + b"\0"
     nm = name.encode() + b"\0"
+    if not isinstance(text, str):                                   # a numeric attribute (scale_factor, _FillValue, ...): scalar
+        arr = np.asarray(text)
+        val, dt, ds = arr.tobytes(), _datatype(arr.dtype), bytes([2, 0, 0, 0])
+        return bytes([3, 0]) + struct.pack("<HHH", len(nm), len(dt), len(ds)) + bytes([0]) + nm + dt + ds + val
+    val = text.encode() + b"\0"
     dt, ds = _datatype(f"S{len(val)}"), bytes([2, 0, 0, 0])        # scalar dataspace
     return bytes([3, 0]) + struct.pack("<HHH", len(nm), len(dt), len(ds)) + bytes([0]) + nm + dt + ds + val
 

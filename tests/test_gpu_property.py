@@ -4,6 +4,7 @@ heat + Richards with the reference-default hydraulics), to 1e-10 on van Genuchte
 the round-end run sees the same cases."""
 import numpy as np
 import pytest
+hypothesis = pytest.importorskip("hypothesis")
 from hypothesis import event, given, settings, strategies as st, HealthCheck
 
 import oracle

@@ -122,3 +122,38 @@ def test_oracle_raster_interpolation_rule():
         o.set_clock(t)
         o.update_inputs()
         assert np.array_equal(o.get("air_temperature"), expect), t
+
+
+def test_cf_packing_is_applied_like_rasters_does(tmp_path):
+    """Classic ERA5 downloads are int16-packed (scale_factor / add_offset / _FillValue / missing_value).  Rasters.jl /
+    NCDatasets.jl unpack by default on the reference side (and the ERA5 example calls replace_missing(..., NaN)); the reader's
+    read_cf() does the same, RasterInputSource.from_netcdf and land_mask_from_netcdf go through it.  Chunks that were never
+    allocated read as the fill value, i.e. missing."""
+    from hdf5_writer import Writer
+    rng = np.random.default_rng(9)
+    scale, offset, fill = 0.0125, 273.15, np.int16(-32767)
+    raw = rng.integers(-3000, 3000, size=(3, 12, 16)).astype(np.int16)
+    raw[1, 4, 5] = fill
+    raw[2, 0, 0] = fill
+    w = Writer()
+    w.dataset("t2m", raw, layout="chunked", chunks=(1, 8, 8), deflate=True, shuffle=True,
+              attrs=dict(scale_factor=np.float64(scale), add_offset=np.float64(offset), _FillValue=fill, missing_value=fill, units="K"))
+    w.dataset("time", np.arange(3, dtype=np.float64), attrs=dict(units="hours since 2020-01-01 00:00:00"))
+    lsm = (rng.random((1, 12, 16)) * 65534 - 32767).astype(np.int16)
+    w.dataset("lsm", lsm, attrs=dict(scale_factor=np.float64(1 / 65534), add_offset=np.float64(0.5)))
+    w.dataset("plain", np.arange(6, dtype=np.float32).reshape(2, 3))
+    path = tmp_path / "era5_packed.nc"
+    path.write_bytes(w.tobytes())
+    f = tio.Hdf5File(str(path))
+    got = f["t2m"].read_cf()
+    expect = raw.astype(np.float64) * scale + offset
+    expect[raw == fill] = np.nan
+    assert got.dtype == np.float64 and np.array_equal(got, expect, equal_nan=True) and np.isnan(got[1, 4, 5]) and np.isnan(got[2, 0, 0])
+    assert np.array_equal(f["t2m"].read(), raw)                              # the stored values stay available
+    assert f["plain"].read_cf().dtype == np.float32                          # nothing to unpack: returned as stored
+    mask = rng.random((12, 16)) > 0.5
+    grid = trm.ColumnRingGrid(trm.UniformSpacing(dz=0.5, N=5), mask)
+    src = tio.RasterInputSource.from_netcdf(grid, str(path), "t2m", name="air_temperature")
+    assert np.array_equal(src.times, 3600.0 * np.arange(3)) and np.array_equal(src.columns(), grid.gather(expect), equal_nan=True)
+    land = trm.masks.land_mask_from_netcdf(str(path))
+    assert np.array_equal(land, (lsm[0].astype(np.float64) / 65534 + 0.5) > 0.5)
