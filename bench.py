@@ -426,6 +426,8 @@ def strong_leg(W, parallel, args, world, rank, device, configure, sync, barrier,
         configure(dev, spl)
         m = measure(dev, w, config, steps, min(args.warmup, 10), min(args.spinup_ms, 100.0), False, sync, barrier, args.repeats, reduce_max)
         st = dev.status()
+        if os.environ.get("TRM_BENCH_DEBUG"):
+            print(f"[rank {rank}] strong {key}: columns {w['Nh']} status {st} kernel us/step {m['kernel_us_per_step']:.2f} wall {m['ms_per_step'] * 1e3:.2f}", file=sys.stderr, flush=True)
         dev.close()
         res[key] = {"steps_per_launch": spl, "steps": steps, "us_per_step": m["ms_per_step"] * 1e3, "us_per_step_min": m["ms_per_step_min"] * 1e3,
                     "kernel_us_per_step": m["kernel_us_per_step"], "column_steps_per_s": total * steps / m["wall_s"], "repeats": m["repeats"],

@@ -174,11 +174,12 @@ enum {
                                     /* interpolates itself, no coupled vegetation), except fp32 contexts on the packed        */
                                     /* two-columns-per-lane kernel; 1: one launch per step (state streams through memory      */
                                     /* every step: what bench.py's headline measures); m > 1: explicit                        */
-    TRM_OPT_PIPELINE_PARTS = 7      /* LandModel contexts, one launch pair per step (surface processes, soil columns): the   */
-                                    /* columns are dealt to two internal streams so that the latency-bound surface launch of  */
-                                    /* one half runs under the column launch of the other (columns are independent; results   */
-                                    /* are bit-identical).  0: off; 1: whenever a call makes >= 2 such steps; 2 (default):    */
-                                    /* the same for contexts of >= 32 768 columns                                             */
+    TRM_OPT_PIPELINE_PARTS = 7      /* bare-ground LandModel, one launch per step and half: the columns are dealt to two      */
+                                    /* halves and every launch covers the soil columns of one half AND the 0-D surface         */
+                                    /* processes (land_model.jl:79-88) of the other, so that the latency-bound surface chain  */
+                                    /* runs under the column program (columns are independent; bit-identical results).        */
+                                    /* Applies to calls of >= 2 steps with constant inputs and the branch-free boundary kinds. */
+                                    /* 0: off; 1: whenever legal; 2 (default): for contexts of >= 16 384 columns              */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

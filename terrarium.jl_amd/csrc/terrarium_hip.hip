@@ -96,14 +96,11 @@ struct trm_ctx {
     int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
     int opt_derive = 2;
     int opt_steps_per_launch = 0;   // 0: chosen by the library (auto_steps_per_launch), 1: one launch per step, m > 1: up to m steps per launch
-    // Two-part pipeline of the per-step LandModel path (TRM_OPT_PIPELINE_PARTS): the columns are dealt to two internal streams,
-    // each running its own chain of (surface launch, column launch) per step; the latency-bound 0-D surface launch of one part
-    // runs under the column launch of the other.  Columns are independent, so the parts never synchronise inside a call.
+    // Two halves of the columns (TRM_OPT_PIPELINE_PARTS): the per-step LandModel path runs the latency-bound 0-D surface
+    // processes of one half in the same launch as the soil columns of the other (k_land_euler).  Columns are independent.
     int opt_pipeline = 2;           // 0: off, 1: whenever legal, 2: auto (column threshold)
     int part = -1;                  // part the launch helpers currently address (-1: all columns)
     long part_lo[2] = {0, 0}, part_n[2] = {0, 0};
-    hipStream_t pipe_stream[2] = {nullptr, nullptr};
-    hipEvent_t pipe_fork = nullptr, pipe_join[2] = {nullptr, nullptr}, pipe_stagger = nullptr;
     // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
     // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
     // `args_valid` and the next launch rebuilds them.
@@ -412,14 +409,11 @@ dim3 wave_grid(const trm_ctx* c, int lpc) {
     long waves = (ncols(c) + (64 / lpc) - 1) / (64 / lpc);
     return dim3((unsigned)((waves + 3) / 4), 1, 1);
 }
-// addresses one pipeline part (its columns, its stream) for the lifetime of the scope
+// addresses one part of the columns for the lifetime of the scope
 struct PartScope {
     trm_ctx* c;
-    hipStream_t stream;
-    PartScope(trm_ctx* ctx, int q) : c(ctx), stream(ctx->stream) {
-        if (q >= 0) { c->part = q; c->stream = c->pipe_stream[q]; }
-    }
-    ~PartScope() { c->part = -1; c->stream = stream; }
+    PartScope(trm_ctx* ctx, int q) : c(ctx) { c->part = q; }
+    ~PartScope() { c->part = -1; }
 };
 
 // Time interpolation indices of a series at time t -- Oceananigans' FieldTimeSeries indexing (Linear / Clamp /
@@ -832,7 +826,8 @@ template <class NF> struct Ops {
         std::vector<NF> per_level((size_t)c->Nz);
         for (int k = 0; k < c->Nz; ++k) per_level[k] = R[k] / total;
         if (!c->d_rootf) TRM_HIP(c, hipMalloc(&c->d_rootf, (size_t)c->Nz * sizeof(NF)));
-        TRM_HIP(c, hipMemcpy(c->d_rootf, per_level.data(), (size_t)c->Nz * sizeof(NF), hipMemcpyHostToDevice));
+        TRM_HIP(c, hipMemcpyAsync(c->d_rootf, per_level.data(), (size_t)c->Nz * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
         std::vector<NF> host((size_t)c->Nz * c->Nh);
         for (int k = 0; k < c->Nz; ++k)
             for (long i = 0; i < c->Nh; ++i) host[(size_t)k * c->Nh + i] = R[k] / total;
@@ -1074,48 +1069,98 @@ template <class NF> struct Ops {
         if (std::is_same<NF, float>::value && packed_path(c)) return 1;
         return 50;
     }
-    // ---- two-part pipeline of the per-step LandModel path -----------------------------------------------------------
-    static bool pipeline_now(const trm_ctx* c, int steps_left) {
-        if (c->opt_pipeline == 0 || steps_left < 2 || c->part_n[1] <= 0) return false;
-        return c->opt_pipeline == 1 || (c->params.seb && c->Nh >= 32768);
+    // ---- LandModel, per-step path: the surface processes of one half of the columns UNDER the column program of the other ----
+    // (k_land_euler / k_land_pk, trm_column.hpp: one stream, two launches per step as before, each covering the soil columns
+    // of one half and the 0-D surface processes of the other)
+    static bool interleave_now(trm_ctx* c, int steps_left) {
+        if (c->opt_pipeline == 0 || steps_left < 2 || !c->params.seb || !richards(c) || coupled(c) || c->part_n[1] <= 0) return false;
+        if (!c->series.empty() || generic_bcs(c) || c->Nz > 64) return false;      // (inputs constant over the call; one level per lane)
+        if (std::is_same<NF, float>::value && !packed_path(c)) return false;        // (fp32 off the packed kernel: not instantiated)
+        return c->opt_pipeline == 1 || c->Nh >= 16384;
     }
-    static int pipeline_fork(trm_ctx* c) {
-        for (int q = 0; q < 2; ++q)
-            if (!c->pipe_stream[q]) {
-                TRM_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[q], hipStreamNonBlocking));
-                TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_join[q], hipEventDisableTiming));
+    // columns of part `qcol` step; the surface processes of part `qsurf` run beside them for ITS next column step
+    template <bool RICH, int H, int LPC> static int launch_land(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) {
+        const LaunchArgs<NF>& la = launch_args<NF>(c);
+        const View<NF>&vc = la.part[qcol], &vs = la.part[qsurf];
+        const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+        const unsigned sblocks = (unsigned)((c->part_n[qsurf] + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK);
+        const dim3 block(TRM_STEP_BLOCK);
+        if constexpr (std::is_same<NF, float>::value) {
+            const long pairs = (c->part_n[qcol] + 1) / 2;
+            const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
+            const dim3 grid(sblocks + (unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
+            if (top_arrays) hipLaunchKernelGGL((k_land_pk<RICH, LPC, H, true>), grid, block, 0, c->stream, vc, la.p, (float)dt, finalize, wkf, vs, (int)sblocks);
+            else hipLaunchKernelGGL((k_land_pk<RICH, LPC, H, false>), grid, block, 0, c->stream, vc, la.p, (float)dt, finalize, wkf, vs, (int)sblocks);
+        } else {
+            ColumnArgs<NF> a{};
+            a.dt = (NF)dt;
+            a.finalize = finalize;
+            a.write_kf = wkf;
+            a.nsteps = 1;
+            a.bcT_bot_stage = la.w.bcT_bot;
+            a.bcT_top_stage = la.w.bcT_top;
+            const long waves = (c->part_n[qcol] + (64 / LPC) - 1) / (64 / LPC);
+            const dim3 grid(sblocks + (unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
+            const bool derive = derive_now<RICH>(c) == DERIVE_T_LIQ;
+#define TRM_LAND(D, T) hipLaunchKernelGGL((k_land_euler<NF, RICH, H, LPC, D, T>), grid, block, 0, c->stream, vc, la.p, a, vs, (int)sblocks)
+            if (derive) { if (top_arrays) TRM_LAND(DERIVE_T_LIQ, true); else TRM_LAND(DERIVE_T_LIQ, false); }
+            else { if (top_arrays) TRM_LAND(DERIVE_NONE, true); else TRM_LAND(DERIVE_NONE, false); }
+#undef TRM_LAND
+        }
+        TRM_HIP(c, hipGetLastError());
+        return TRM_OK;
+    }
+    static int land_launch(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) {
+        int rc = TRM_OK;
+        const bool deep = c->Nz > 32;
+        if constexpr (std::is_same<NF, float>::value) {
+            if (hyd(c) == HYD_VG_N2) rc = deep ? launch_land<true, HYD_VG_N2, 64>(c, qcol, qsurf, dt, finalize, top_arrays) : launch_land<true, HYD_VG_N2, 32>(c, qcol, qsurf, dt, finalize, top_arrays);
+            else rc = deep ? launch_land<true, HYD_BC_LINEAR, 64>(c, qcol, qsurf, dt, finalize, top_arrays) : launch_land<true, HYD_BC_LINEAR, 32>(c, qcol, qsurf, dt, finalize, top_arrays);
+        } else {
+            TRM_BY_HYD(c, rc = deep ? (launch_land<true, H, 64>(c, qcol, qsurf, dt, finalize, top_arrays)) : (launch_land<true, H, 32>(c, qcol, qsurf, dt, finalize, top_arrays)));
+        }
+        return rc;
+    }
+    // `nsteps` >= 2 ForwardEuler steps of a bare-ground LandModel with constant inputs:
+    //     surf(A, 0) | col(A, 0) + surf(B, 0) | col(B, 0) + surf(A, 1) | ... | col(A, N-1) + surf(B, N-1) | col(B, N-1)
+    static int land_steps_interleaved(trm_ctx* c, double dt, int nsteps, int finalize) {
+        const bool top0 = c->top_valid, cc0 = c->closure_consistent;
+        int rc;
+        {   // the state's surface processes for half A
+            PartScope scope(c, 0);
+            c->top_valid = top0;
+            rc = surface(c, c->state, true);
+        }
+        for (int n = 0; n < nsteps && !rc; ++n) {
+            const int fin = (finalize && n == nsteps - 1) ? 1 : 0;
+            const bool tops = (n == 0) ? top0 : !c->top_escaped;     // what a surface evaluation of an UNSTEPPED / stepped half reads
+            c->closure_consistent = (n == 0) ? cc0 : true;
+            rc = land_launch(c, 0, 1, dt, fin, tops);
+            if (rc) break;
+            if (n < nsteps - 1) {
+                rc = land_launch(c, 1, 0, dt, 0, !c->top_escaped);   // (half A has just been stepped: its top arrays are current)
+            } else {
+                PartScope scope(c, 1);
+                rc = wave_step(c, dt, fin);
             }
-        if (!c->pipe_fork) {
-            TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_fork, hipEventDisableTiming));
-            TRM_HIP(c, hipEventCreateWithFlags(&c->pipe_stagger, hipEventDisableTiming));
+            c->time += dt;
+            c->iteration += 1;
         }
-        if (c->copy_pending) {   // levels appended on the side stream: both parts are ordered behind the copy through the fork
-            TRM_HIP(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
-            for (auto& o : c->series) o.pending_from = -1;
-        }
-        TRM_HIP(c, hipEventRecord(c->pipe_fork, c->stream));
-        for (int q = 0; q < 2; ++q) TRM_HIP(c, hipStreamWaitEvent(c->pipe_stream[q], c->pipe_fork, 0));
-        return TRM_OK;
-    }
-    static int pipeline_join(trm_ctx* c) {
-        for (int q = 0; q < 2; ++q) {
-            TRM_HIP(c, hipEventRecord(c->pipe_join[q], c->pipe_stream[q]));
-            TRM_HIP(c, hipStreamWaitEvent(c->stream, c->pipe_join[q], 0));
-        }
-        return TRM_OK;
+        c->closure_consistent = !rc;
+        c->tend_valid = finalize != 0;
+        c->top_valid = !rc && !c->top_escaped;
+        if (!rc && finalize) rc = surface(c, c->state, true);
+        return rc;
     }
     // One fused ForwardEuler step of the columns the launch helpers currently address: update_inputs!, the 0-D surface
     // processes as their own small launch in front of the column kernel (LandModel), and once more after it when finalizing.
     // (+ the 0-D prognostics' step of the coupled vegetation; the per-cell plant_available_water field is materialised with the
     // other per-cell auxiliaries: by the finalizing launch, or every step under TRM_OPT_WRITE_KF_EVERY_STEP)
-    // stagger: +1 = record the stagger event after the surface launch, -1 = wait for it first (first pipelined step only)
-    static int fused_step(trm_ctx* c, double dt, int fin, int stagger = 0) {
-        if (stagger < 0) TRM_HIP(c, hipStreamWaitEvent(c->stream, c->pipe_stagger, 0));
+    static int fused_step(trm_ctx* c, double dt, int fin) {
         int rc = update_inputs(c, c->state, c->time);
         if (rc) return rc;
         if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt, c->opt_write_kf != 0);
         else if (c->params.seb) rc = surface(c, c->state, true);
-        if (stagger > 0) TRM_HIP(c, hipEventRecord(c->pipe_stagger, c->stream));
         if (!rc) rc = wave_step(c, dt, fin);
         c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
         c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
@@ -1132,10 +1177,9 @@ template <class NF> struct Ops {
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
         const bool program_ok = fused && c->Nz <= 64 && !generic_bcs(c) && series_fit_program(c) && !coupled(c);
         const int spl = !program_ok ? 1 : (c->opt_steps_per_launch > 0 ? c->opt_steps_per_launch : auto_steps_per_launch(c));
-        bool piped = false, first_piped = false;
         int n = 0, rc = TRM_OK;
         while (n < nsteps && !rc) {
-            const int m = std::min(spl, nsteps - n);
+            int m = std::min(spl, nsteps - n);
             const int fin = (finalize && n + m == nsteps) ? 1 : 0;
             if (!fused) {
                 rc = update_inputs(c, c->state, c->time);
@@ -1144,24 +1188,18 @@ template <class NF> struct Ops {
                 if (!rc) rc = unfused_step(c, dt, fin);
                 if (!rc) c->closure_consistent = true;   // closure! has just run
             } else if (m > 1) {
-                if (piped) { rc = pipeline_join(c); piped = false; if (rc) break; }
                 rc = c->series.empty() ? update_inputs(c, c->state, c->time) : upload_series_rows(c, dt, m);
                 if (!rc) rc = column_program<PROG_MULTI>(c, dt, fin, m);
                 if (!rc) c->closure_consistent = true;
                 c->tend_valid = fin != 0;
                 c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
-            } else if (piped || pipeline_now(c, nsteps - n)) {
-                if (!piped) { rc = pipeline_fork(c); if (rc) break; piped = first_piped = true; }
-                // every part sees the flags as they stood before this step
-                const bool top0 = c->top_valid, cc0 = c->closure_consistent;
-                for (int q = 0; q < 2 && !rc; ++q) {
-                    PartScope scope(c, q);
-                    c->top_valid = top0;
-                    c->closure_consistent = cc0;
-                    rc = fused_step(c, dt, fin, first_piped ? (q == 0 ? 1 : -1) : 0);
-                }
-                first_piped = false;
+            } else if (interleave_now(c, nsteps - n)) {
+                // every remaining step of the call in one go (the clock is ticked inside)
+                m = nsteps - n;
+                rc = land_steps_interleaved(c, dt, m, finalize);
+                n += m;
+                continue;
             } else {
                 rc = fused_step(c, dt, fin);
             }
@@ -1170,7 +1208,6 @@ template <class NF> struct Ops {
             c->iteration += m;
             n += m;
         }
-        if (piped) { const int rj = pipeline_join(c); if (!rc) rc = rj; }
         return rc;
     }
 
@@ -1335,18 +1372,23 @@ int finish(trm_ctx* c, int rc) {
     return TRM_OK;
 }
 
+// The zero fills run on the CONTEXT stream and are waited for.  A plain hipMemset goes to the null stream, which the context's
+// non-blocking stream does not synchronise with: under load (two processes time-slicing one device) a fill could land AFTER a
+// later upload / copy on the context stream had written the buffer and wipe it -- seen once as a NaN state in a shared-device
+// rehearsal of the N > 1 bench.
 int alloc_fields(trm_ctx* c, FieldSet& s) {
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
         if (is_lazy_field(f) && c->veg_mode == TRM_VEGETATION_OFF) continue;
         if (s.f[f]) continue;
         size_t bytes = field_elems(c, f) * c->esize;
         TRM_HIP(c, hipMalloc(&s.f[f], bytes));
-        TRM_HIP(c, hipMemset(s.f[f], 0, bytes));
+        TRM_HIP(c, hipMemsetAsync(s.f[f], 0, bytes, c->stream));
     }
     if (!s.kf_top) {
         TRM_HIP(c, hipMalloc(&s.kf_top, (size_t)c->Nh * c->esize));
-        TRM_HIP(c, hipMemset(s.kf_top, 0, (size_t)c->Nh * c->esize));
+        TRM_HIP(c, hipMemsetAsync(s.kf_top, 0, (size_t)c->Nh * c->esize, c->stream));
     }
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
     return TRM_OK;
 }
 
@@ -1355,7 +1397,8 @@ template <class NF> int upload_grid(trm_ctx* c, const double* thickness) {
     g.build(c->Nz, thickness);
     auto up = [&](void** d, const std::vector<NF>& h) -> int {
         TRM_HIP(c, hipMalloc(d, h.size() * sizeof(NF)));
-        TRM_HIP(c, hipMemcpy(*d, h.data(), h.size() * sizeof(NF), hipMemcpyHostToDevice));
+        TRM_HIP(c, hipMemcpyAsync(*d, h.data(), h.size() * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
         return TRM_OK;
     };
     int rc;
@@ -1386,7 +1429,8 @@ template <class NF> int upload_grid(trm_ctx* c, const double* thickness) {
 
 template <class NF> int fill_row(trm_ctx* c, int field, double value) {
     std::vector<NF> h((size_t)c->Nh, (NF)value);
-    TRM_HIP(c, hipMemcpy(c->state.f[field], h.data(), h.size() * sizeof(NF), hipMemcpyHostToDevice));
+    TRM_HIP(c, hipMemcpyAsync(c->state.f[field], h.data(), h.size() * sizeof(NF), hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
     return TRM_OK;
 }
 
@@ -1800,9 +1844,10 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     hip(hipMalloc((void**)&c->d_status, sizeof(uint32_t)), "hipMalloc(status)");
     hip(hipMalloc(&c->d_zero, (size_t)c->Nh * c->esize), "hipMalloc(zero)");
     if (c->params.seb) hip(hipMalloc(&c->d_top3, 3 * (size_t)c->Nh * c->esize), "hipMalloc(top cells)");
-    if (rc == TRM_OK) hip(hipMemset(c->d_zero, 0, (size_t)c->Nh * c->esize), "hipMemset(zero)");
+    if (rc == TRM_OK) hip(hipMemsetAsync(c->d_zero, 0, (size_t)c->Nh * c->esize, c->stream), "hipMemset(zero)");
     if (rc) return bail(rc);
-    hip(hipMemset(c->d_status, 0, sizeof(uint32_t)), "hipMemset(status)");
+    hip(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream), "hipMemset(status)");
+    hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
     if ((rc = alloc_fields(c, c->state))) return bail(rc);
     rc = c->precision == TRM_F64 ? upload_grid<double>(c, g->thickness) : upload_grid<float>(c, g->thickness);
     if (rc) return bail(rc);
@@ -1844,18 +1889,13 @@ int trm_destroy(trm_ctx* c) {
         if (q) (void)hipFree(q);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
-    for (int q = 0; q < 2; ++q) {
-        if (c->pipe_stream[q]) { (void)hipStreamSynchronize(c->pipe_stream[q]); (void)hipStreamDestroy(c->pipe_stream[q]); }
-        if (c->pipe_join[q]) (void)hipEventDestroy(c->pipe_join[q]);
-    }
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     if (c->copy_order) (void)hipEventDestroy(c->copy_order);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     for (void* q : {(void*)c->d_ring_inv, (void*)c->d_ring_idx, c->d_ring})
         if (q) (void)hipFree(q);
-    if (c->pipe_fork) (void)hipEventDestroy(c->pipe_fork);
-    if (c->pipe_stagger) (void)hipEventDestroy(c->pipe_stagger);
+
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->args && c->args_free) c->args_free(c->args);
     delete c;
@@ -1963,7 +2003,8 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
         float* d = (float*)h.data();
         for (long i = 0; i < c->Nh; ++i) d[i] = (float)scalar;
     }
-    TRM_HIP(c, hipMemcpy(c->bc_value[var][side], h.data(), bytes, hipMemcpyHostToDevice));
+    TRM_HIP(c, hipMemcpyAsync(c->bc_value[var][side], h.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
     return TRM_OK;
 }
 
@@ -1996,7 +2037,8 @@ int add_series(trm_ctx* c, trm_ctx::Series&& sr, int nt, const double* times, co
     sr.head = 0;
     size_t bytes = (size_t)nt * (size_t)c->Nh * c->esize;
     TRM_HIP(c, hipMalloc(&sr.d_values, bytes));
-    TRM_HIP(c, hipMemcpy(sr.d_values, values, bytes, hipMemcpyHostToDevice));
+    TRM_HIP(c, hipMemcpyAsync(sr.d_values, values, bytes, hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
     c->series.push_back(std::move(sr));
     return TRM_OK;
 }
@@ -2026,7 +2068,8 @@ int trm_set_bc_series(trm_ctx* c, int var, int side, int kind, int nt, const dou
     c->args_valid = false;
     if (!c->bc_value[var][side]) {
         TRM_HIP(c, hipMalloc(&c->bc_value[var][side], (size_t)c->Nh * c->esize));
-        TRM_HIP(c, hipMemset(c->bc_value[var][side], 0, (size_t)c->Nh * c->esize));
+        TRM_HIP(c, hipMemsetAsync(c->bc_value[var][side], 0, (size_t)c->Nh * c->esize, c->stream));
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
     }
     return TRM_OK;
 }
@@ -2194,8 +2237,10 @@ int trm_set_ring_grid(trm_ctx* c, int64_t num_points, const int64_t* mask_index)
     c->d_ring_inv = c->d_ring_idx = nullptr;
     TRM_HIP(c, hipMalloc((void**)&c->d_ring_inv, inv.size() * sizeof(int32_t)));
     TRM_HIP(c, hipMalloc((void**)&c->d_ring_idx, idx.size() * sizeof(int32_t)));
-    TRM_HIP(c, hipMemcpy(c->d_ring_inv, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    TRM_HIP(c, hipMemcpy(c->d_ring_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    TRM_HIP(c, hipMemcpyAsync(c->d_ring_inv, inv.data(), inv.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
+    TRM_HIP(c, hipMemcpyAsync(c->d_ring_idx, idx.data(), idx.size() * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));
     c->ring_points = (long)num_points;
     return TRM_OK;
 }

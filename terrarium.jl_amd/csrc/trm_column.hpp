@@ -205,10 +205,12 @@ template <class NF> struct ColumnArgs {
 #ifndef TRM_COLUMN_WAVES_EULER
 #define TRM_COLUMN_WAVES_EULER 1
 #endif
+// The program itself, as a device function: `k_column` below is its launch; `k_land_euler` runs it beside the surface processes
+// of OTHER columns in one launch.  Its kernel must pass (View, DevParams, ColumnArgs) as its first three arguments: the program
+// re-reads them from the kernarg segment at those offsets (kernarg_reload).  `block`: index of the 256-thread workgroup among
+// those that run the program.
 template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK)
-    __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
-    k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
+TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, const ColumnArgs<NF>& a, unsigned block) {
     // (kernarg layout: the arguments in order, each at its natural alignment)
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
     const View<NF>& v = v_arg;
@@ -218,7 +220,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     constexpr int CPW = 64 / LPC;
     LaneInfo ln;
     ln.lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int wave = (int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6);
     ln.k = ln.lane % LPC;
     const int sub = ln.lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
@@ -454,6 +456,34 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     }
     // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
     if (viol && ln.act) atomicOr(v_arg.status, viol);
+}
+
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK)
+    __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
+    k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES>(v_arg, p_arg, a, blockIdx.x);
+}
+
+// ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the
+// OTHER half (land_model.jl:79-88: evaporation, runoff, the surface energy balance twice -- k_surface).  The surface launch
+// is a latency-bound chain of ~450 dependent fp64 instructions on one wave per SIMD (5.4 us at N145, 16 % of the step); its
+// result is needed by the columns' explicit step, and the columns' new top cells by the next surface evaluation -- a strict
+// chain per column, but columns are independent: with the columns dealt to two halves A and B the launches
+//     surf(A, 0) | col(A, 0) + surf(B, 0) | col(B, 0) + surf(A, 1) | col(A, 1) + surf(B, 1) | ...
+// keep that chain for every column while each surface evaluation runs UNDER the column program of the other half.  The
+// surface workgroups come first in the grid so that they are dispatched at once.  Same operations per column as the
+// k_surface / k_column pair: bit-identical results.
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, bool TOP_ARRAYS>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK)
+    __attribute__((amdgpu_waves_per_eu(HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5, 8)))
+    k_land_euler(View<NF> v_col, DevParams<NF> p_arg, ColumnArgs<NF> a, View<NF> v_surf, int surface_blocks) {
+    if ((int)blockIdx.x < surface_blocks) {
+        const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < v_surf.Nh) surface_program<NF, RICHARDS, HYD, true, TOP_ARRAYS>(v_surf, p_arg, i);
+        return;
+    }
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG_EULER, false, false>(v_col, p_arg, a, blockIdx.x - (unsigned)surface_blocks);
 }
 
 // ---- Heun with every boundary kind -------------------------------------------------------------------------------------

@@ -110,9 +110,7 @@ template <class NF, int HYD> __global__ void k_hydraulics(View<NF> v, DevParams<
 // hydraulic_conductivity field -- used in front of the fused step kernel, which does not
 // materialise K before the surface processes run.
 // TOP_ARRAYS (with FROM_STATE): the top cell's (T, sat, liq) come from the compact per-column arrays the fused step wrote.
-template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= v.Nh) return;
+template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> TRM_DEV void surface_program(const View<NF>& v, const DevParams<NF>& p, long i) {
     const long top = i * v.Nzp + (v.Nz - 1);
     SebIn<NF> in = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i], NF(0), NF(0), NF(0)};
     seb_radiation_inputs(p, v.albedo, v.emissivity, (unsigned)i * (unsigned)sizeof(NF), in);
@@ -129,6 +127,10 @@ template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __
     surface_processes(p, in, v.Ts[i], T_top, sat_top, liq_top, Kf_top, v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
     v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
     v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
+}
+template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < v.Nh) surface_program<NF, RICHARDS, HYD, FROM_STATE, TOP_ARRAYS>(v, p, i);
 }
 
 // compute_tendencies_kernel! for SoilHydrology{RichardsEq} (soil_hydrology_rre.jl:150-162) and

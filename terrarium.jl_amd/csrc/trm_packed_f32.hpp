@@ -163,7 +163,7 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // DERIVE_LIQ: the incoming liquid fraction is re-derived from (U, sat) instead of being read (legal when the stored fields
 // are the closure of the stored state, trm_ctx::closure_consistent): one of the five field reads less.
 template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
+TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p_arg, float dt, int finalize, int write_kf, unsigned block) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
     const DevParams<float>& p = p_arg;
@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, D
     typedef float NF;
     constexpr int CPW = 64 / LPC;   // column PAIRS per wave
     const int lane = threadIdx.x & 63;
-    const int wave = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int wave = (int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int k = lane % LPC, sub = lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
     const bool is_bot = k == 0, is_top = k == Nz - 1;
@@ -331,6 +331,21 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, D
     // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
     const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u);
     if (flags) atomicOr(v.status, flags);
+}
+template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
+    step_pk_program<RICHARDS, LPC, HYD, DERIVE_LIQ>(v_arg, p_arg, dt, finalize, write_kf, blockIdx.x);
+}
+// LandModel in fp32: the packed column step of one half of the columns beside the surface processes of the other half in one
+// launch (k_land_euler, trm_column.hpp).  (View, DevParams) first: step_pk_program re-reads them from the kernarg segment.
+template <bool RICHARDS, int LPC, int HYD, bool TOP_ARRAYS>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_land_pk(View<float> v_col, DevParams<float> p_arg, float dt, int finalize, int write_kf, View<float> v_surf, int surface_blocks) {
+    if ((int)blockIdx.x < surface_blocks) {
+        const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < v_surf.Nh) surface_program<float, RICHARDS, HYD, true, TOP_ARRAYS>(v_surf, p_arg, i);
+        return;
+    }
+    step_pk_program<RICHARDS, LPC, HYD, false>(v_col, p_arg, dt, finalize, write_kf, blockIdx.x - (unsigned)surface_blocks);
 }
 
 }  // namespace trm

@@ -130,36 +130,52 @@ def test_default_steps_per_launch_is_the_resident_program_and_bit_identical(conf
 
 
 PIPELINE_CONFIGS = [("land", "default", np.float64, 32, 131), ("land", "vg", np.float64, 50, 257), ("land", "default", np.float32, 64, 203),
-                    ("land", "vg", np.float32, 40, 129), ("landveg", "vg", np.float64, 32, 200), ("richards", "default", np.float64, 32, 131)]
+                    ("land", "vg", np.float32, 40, 129), ("land", "default", np.float64, 20, 64), ("land", "vg", np.float64, 32, 65)]
 
 
+@pytest.mark.parametrize("derive", [0, 1])
 @pytest.mark.parametrize("config,hydraulics,dtype,Nz,Nh", PIPELINE_CONFIGS)
-def test_two_part_pipeline_equals_single_stream_bitwise(config, hydraulics, dtype, Nz, Nh):
-    """TRM_OPT_PIPELINE_PARTS = 1: the per-step LandModel path on two internal streams, half the columns each (the seam on a
-    multiple of 64 columns, ragged second half), with a device-resident forcing series evaluated per part -- same bits as the
-    single-stream path, fields, diagnostics, tendencies, inputs and status."""
+def test_land_halves_interleaved_equal_the_launch_pair_bitwise(config, hydraulics, dtype, Nz, Nh, derive):
+    """TRM_OPT_PIPELINE_PARTS = 1: every launch steps the soil columns of one half of the context and evaluates the surface
+    processes of the other half (k_land_euler / k_land_pk; the seam on a multiple of 64 columns, ragged second half) --
+    same bits as k_surface + k_column per step: fields, diagnostics, tendencies, status, clock; with and without the
+    derivation of T / liq, starting from a state the user has touched (top arrays invalid) and from a stepped one."""
     lat, lon = small_columns(Nh)
     w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
     a, b = W.setup_device(w), W.setup_device(w)
     a.set_option("pipeline_parts", 1)
     b.set_option("pipeline_parts", 0)
-    tt = 600.0 * np.arange(4)
-    ph = 2 * np.pi * tt[:, None] / 86400.0 - w["lon"][None, :]
-    nsteps = 9 if config != "landveg" else 6
     for d in (a, b):
-        if config != "richards":
-            d.set_forcing_series("air_temperature", tt * (w["dt"] / 60.0), w["T0"][None, :] + 5.0 * np.sin(ph), "linear")
-        else:
-            d.set_bc_series("temperature", "top", "value", tt, w["T0"][None, :] + 10.0 * np.sin(ph), "linear")
-        d.step(w["dt"], nsteps, finalize=False)
-        d.step(w["dt"], 1, finalize=False)       # (a single step never forks)
+        d.set_option("derive_closure_fields", derive)
+        d.step(w["dt"], 9, finalize=False)       # from the initial state: the first surface evaluations read the fields
+        d.step(w["dt"], 1, finalize=False)       # (a single step never interleaves)
+        d.step(w["dt"], 2, finalize=False)       # from a stepped state: they read the top-cell arrays
+        T = d.get("temperature")
+        d.set("temperature", T)                  # an upload invalidates the top-cell arrays and the closure bookkeeping
         d.step(w["dt"], 3, finalize=True)
     assert a.clock() == b.clock()
     names = all_fields(w) + ["tend_internal_energy", "tend_saturation_water_ice", "tend_surface_excess_water"]
-    names += ["air_temperature"] if config != "richards" else []
     for n in names:
         assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
     assert a.status() == b.status()
+
+
+def test_land_interleaving_falls_back_where_it_does_not_apply():
+    """Series-fed inputs, the coupled vegetation and a SoilModel keep the launch pair / the single launch; results equal."""
+    lat, lon = small_columns(150)
+    for config, hyd in (("land", "default"), ("landveg", "vg"), ("richards", "default")):
+        w = W.make_workload(config, lat, lon, 32, hydraulics=hyd)
+        a, b = W.setup_device(w), W.setup_device(w)
+        a.set_option("pipeline_parts", 1)
+        b.set_option("pipeline_parts", 0)
+        tt = 600.0 * np.arange(4) * (w["dt"] / 60.0)
+        ph = 2 * np.pi * tt[:, None] / 86400.0 - w["lon"][None, :]
+        for d in (a, b):
+            if config == "land":
+                d.set_forcing_series("air_temperature", tt, w["T0"][None, :] + 5.0 * np.sin(ph), "linear")
+            d.step(w["dt"], 7, finalize=True)
+        for n in all_fields(w):
+            assert np.array_equal(a.get(n), b.get(n), equal_nan=True), (config, n)
 
 
 def test_multistep_with_repair_and_overflow_matches_oracle():
