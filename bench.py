@@ -301,8 +301,11 @@ def main():
     def configure(dev, steps_per_launch):
         dev.set_option("step_kernel", args.kernel)
         dev.set_option("steps_per_launch", steps_per_launch)
-        if args.pipeline is not None:
-            dev.set_option("pipeline_parts", args.pipeline)
+        # The roofline legs measure ONE column kernel per step over all columns of the context (what `roofline` prices and what the
+        # rocprof row shows).  The library's interleaved LandModel launches (TRM_OPT_PIPELINE_PARTS: half the columns + the surface
+        # processes of the other half per launch; on by itself from 262 144 columns, -1 ... -2 % at C5 size) are therefore
+        # switched off unless asked for; `land_interleaved` reports them beside the C5 leg.
+        dev.set_option("pipeline_parts", args.pipeline if args.pipeline is not None else 0)
         if args.derive is not None:
             dev.set_option("derive_closure_fields", args.derive)
         if args.skip_kf:
@@ -445,15 +448,23 @@ def hbm_resident_leg(W, parallel, args, sync, device):
         wordsize = 8 if dt_name == "f64" else 4
         dev = W.setup_device(w, device=device)
         dev.set_option("steps_per_launch", 1)
-        if args.pipeline is not None:
-            dev.set_option("pipeline_parts", args.pipeline)
+        dev.set_option("pipeline_parts", args.pipeline if args.pipeline is not None else 0)
         m = measure(dev, w, config, steps, 5, min(args.spinup_ms, 100.0), False, sync, None, min(args.repeats, 5))
         status = dev.status()
+        interleaved = None
+        if config == "land" and args.pipeline is None:     # the library's own choice at this size, reported beside the roofline leg
+            dev.set_option("pipeline_parts", 2)
+            dev.restore_state()            # back to the warmed-up state the first measurement started from
+            mi = measure(dev, w, config, steps, 0, 0.0, False, sync, None, min(args.repeats, 5))
+            interleaved = {"us_per_step": mi["kernel_us_per_step"], "column_steps_per_s": w["Nh"] * steps / mi["wall_s"], "status_flags": int(dev.status()),
+                           "note": "TRM_OPT_PIPELINE_PARTS = 2 (library default): k_land_pk, half the columns + the other half's surface processes per launch"}
         dev.close()
         r = roofline_object(config, Nz, w["Nh"], wordsize, m["kernel_us_per_step"] * 1e-6, "k_step_pk (+ k_surface)" if name == "c5" else "k_column",
                             f"pmc_summary_{name}_fused.json", desc)
         r.update(steps=steps, repeats=m["repeats"], warmup_executed=m["warm"], column_steps_per_s=w["Nh"] * steps / m["wall_s"],
                  kernel_ms_min=m["kernel_us_per_step_min"] * 1e-3, status_flags=int(status))
+        if interleaved:
+            r["land_interleaved"] = interleaved
         legs.append(r)
         del w, dev
     first = legs[0]

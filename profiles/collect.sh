@@ -10,7 +10,7 @@
 # Output: gpurun_out/prof_<round>/ (scratch); copy kernel_stats_* / pmc_summary_* / bench_*.json into profiles/<round>/.
 ROUND=${1:-r03}
 COMMIT=${2:-unknown}
-run() { T=$1; shift; timeout -k 10 $T "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT $GRAFT_REPO_ROOT/profiles/$ROUND
@@ -26,10 +26,10 @@ for wl in c3 c3x8 c5 c4 c4vg c5vg c2 c3vg c4vgveg; do
   python profiles/summarize_pmc.py $OUT/pmc_${wl} $wl $COMMIT > $OUT/pmc_summary_${wl}_fused.json
   cp $OUT/pmc_summary_${wl}_fused.json profiles/$ROUND/
   echo pmc $wl done
-  T="python bench.py --workload $wl --no-cpu-baseline --no-hbm-resident --multistep 0 --steps $K --warmup 10 --repeats 10"
-  run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- $T > $OUT/bench_trace_$wl.json 2> $OUT/trace_$wl.err
+  CMD="python bench.py --workload $wl --no-cpu-baseline --no-hbm-resident --multistep 0 --steps $K --warmup 10 --repeats 10"
+  run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -- $CMD > $OUT/bench_trace_$wl.json 2> $OUT/trace_$wl.err
   find $OUT/trace_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_$wl.csv \;
-  run 300 $T > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
+  run 300 $CMD > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
   echo trace + bench $wl done
 done
 run 300 python bench.py --integrator heun --no-cpu-baseline --no-hbm-resident --multistep 0 > $OUT/bench_c3_heun.json 2>/dev/null

@@ -22,14 +22,21 @@ SIZES = {"c3": 56951, "c3x8": 455608, "c5": 812500, "c5vg": 812500, "c4": 56951,
 def collect(directory, kernel):
     sums = {}
     names = set()
+    rows = []
     for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as f:
-            for row in csv.DictReader(f):
-                if kernel not in row.get("Kernel_Name", ""):
-                    continue
-                names.add(row["Kernel_Name"].split("(")[0])
-                key = (row["Counter_Name"], row["Dispatch_Id"])
-                sums[key] = sums.get(key, 0.0) + float(row["Counter_Value"])
+            rows += [row for row in csv.DictReader(f) if kernel in row.get("Kernel_Name", "")]
+    # one template instance only: the one launched most often (the first launch of a context runs the non-deriving instance)
+    freq = {}
+    for row in rows:
+        freq[row["Kernel_Name"]] = freq.get(row["Kernel_Name"], 0) + 1
+    dominant = max(freq, key=freq.get) if freq else None
+    for row in rows:
+        if row["Kernel_Name"] != dominant:
+            continue
+        names.add(row["Kernel_Name"].split("(")[0])
+        key = (row["Counter_Name"], row["Dispatch_Id"])
+        sums[key] = sums.get(key, 0.0) + float(row["Counter_Value"])
     per_counter = {}
     for (name, _), v in sums.items():
         per_counter.setdefault(name, []).append(v)

@@ -1,6 +1,6 @@
 # round 3, first GPU call: the new defaults (resident program for nsteps > 1, two-part pipeline) -- tests, then A/B
 # A step that runs into its time limit ends the script (no further GPU work after a hang).
-run() { T=$1; shift; timeout -k 10 $T "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
 L=gpurun_out/exp1_ab.log; : > $L
 run 300 python -m pytest tests/test_gpu_column_programs.py -q -x -W ignore::DeprecationWarning > gpurun_out/exp1_tests.log 2>&1; tail -3 gpurun_out/exp1_tests.log
 AB="python profiles/tools/ab_options.py"

@@ -1,6 +1,6 @@
 # round 3, GPU call 2: (a) first step at which the synthetic states raise a status flag, (b) L2 prefetch-ahead A/B,
 # (c) two-part pipeline with a single context in the process and more hardware queues
-run() { T=$1; shift; timeout -k 10 $T "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
 L=gpurun_out/exp2_ab.log; : > $L
 run 300 python -m pytest tests/test_gpu_column_programs.py tests/test_gpu_parity.py -q -x -W ignore::DeprecationWarning > gpurun_out/exp2_tests.log 2>&1; tail -3 gpurun_out/exp2_tests.log
 run 300 python profiles/tools/first_flag.py c3 c3vg c4 c4vg c5 >> $L 2>&1

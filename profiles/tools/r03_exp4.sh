@@ -1,5 +1,5 @@
 # round 3, GPU call 4: full GPU suite after the kernel clean-up, liquid-fraction-only derivation A/B, the driver's bench line
-run() { T=$1; shift; timeout -k 10 $T "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
 L=gpurun_out/exp4_ab.log; : > $L
 run 900 python -m pytest tests -m gpu -q -x -W ignore::DeprecationWarning > gpurun_out/exp4_full.log 2>&1; tail -5 gpurun_out/exp4_full.log
 AB="python profiles/tools/ab_options.py"

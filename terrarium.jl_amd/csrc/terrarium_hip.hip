@@ -1028,7 +1028,8 @@ template <class NF> struct Ops {
         a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
         a.nsteps = 1;
         const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
-        hipLaunchKernelGGL((k_column_deep<NF, RICH, H>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+        if (derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+        else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }

@@ -133,8 +133,12 @@ TRM_DEV NF repair_saturation_deep(Two<NF>& s, const DeepLane& ln, int Nz, const 
     return (e_a + e_b) * dzc_top;      // (one of the two is the top cell's excess, the other +0)
 }
 
-template <class NF, bool RICHARDS, int HYD>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
+#ifndef TRM_DEEP_WAVES
+#define TRM_DEEP_WAVES 1
+#endif
+template <class NF, bool RICHARDS, int HYD, bool DERIVE = false>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(TRM_DEEP_WAVES, 8)))
+    k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
@@ -170,8 +174,18 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_column_deep(View<NF> v_arg, 
     const Two<NF> dzc{La.dzc, Lb.dzc}, rdzc{La.rdzc, Lb.rdzc};
 
     // ---- the column comes in ---------------------------------------------------------------------------------------
-    const Two<NF> U = ld2cells(v.U, cb0), sat = ld2cells(v.sat, cb0), T = ld2cells(v.T, cb0), liq = ld2cells(v.liq, cb0);
+    const Two<NF> U = ld2cells(v.U, cb0), sat = ld2cells(v.sat, cb0);
     const Two<NF> psi = RICHARDS ? ld2cells(v.psi, cb0) : Two<NF>{NF(0), NF(0)};
+    Two<NF> T, liq;
+    if (DERIVE) {   // (T, liq) of the incoming state re-derived from (U, sat) instead of being read (k_column: DERIVE_T_LIQ)
+        uint32_t viol_in = 0;
+        const DevParams<NF>& pd = kernarg_reload<DevParams<NF>>(off_p);
+        energy_closure_wave(pd, U.a, sat.a, liq.a, T.a, viol_in);
+        energy_closure_wave(pd, U.b, sat.b, liq.b, T.b, viol_in);
+    } else {
+        T = ld2cells(v.T, cb0);
+        liq = ld2cells(v.liq, cb0);
+    }
     const bool seb = p.seb != 0;
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
     const NF bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0), bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);

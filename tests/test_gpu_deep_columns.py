@@ -32,6 +32,7 @@ def test_deep_columns_fused_equals_reference_order_kernels_bitwise(config, hydra
     if config == "richards":
         w["bcs"][("saturation_water_ice", "top")] = ("flux", np.full(lat.size, -1.0e-7))
     a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("derive_closure_fields", 1 if Nz % 2 else 0)     # (with and without T / liq derived in registers)
     b.set_option("step_kernel", "unfused")
     nsteps = 30 if config != "land" else 20
     for d in (a, b):
