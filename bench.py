@@ -302,9 +302,8 @@ def main():
         dev.set_option("step_kernel", args.kernel)
         dev.set_option("steps_per_launch", steps_per_launch)
         # The roofline legs measure ONE column kernel per step over all columns of the context (what `roofline` prices and what the
-        # rocprof row shows).  The library's interleaved LandModel launches (TRM_OPT_PIPELINE_PARTS: half the columns + the surface
-        # processes of the other half per launch; on by itself from 262 144 columns, -1 ... -2 % at C5 size) are therefore
-        # switched off unless asked for; `land_interleaved` reports them beside the C5 leg.
+        # rocprof row shows): the interleaved LandModel launches (TRM_OPT_PIPELINE_PARTS: half the columns + the surface processes
+        # of the other half per launch; off by default) stay off unless asked for; `land_interleaved` reports them beside the C5 leg.
         dev.set_option("pipeline_parts", args.pipeline if args.pipeline is not None else 0)
         if args.derive is not None:
             dev.set_option("derive_closure_fields", args.derive)
@@ -452,12 +451,12 @@ def hbm_resident_leg(W, parallel, args, sync, device):
         m = measure(dev, w, config, steps, 5, min(args.spinup_ms, 100.0), False, sync, None, min(args.repeats, 5))
         status = dev.status()
         interleaved = None
-        if config == "land" and args.pipeline is None:     # the library's own choice at this size, reported beside the roofline leg
-            dev.set_option("pipeline_parts", 2)
+        if config == "land" and args.pipeline is None:     # the interleaved launches at this size, reported beside the roofline leg
+            dev.set_option("pipeline_parts", 1)
             dev.restore_state()            # back to the warmed-up state the first measurement started from
             mi = measure(dev, w, config, steps, 0, 0.0, False, sync, None, min(args.repeats, 5))
             interleaved = {"us_per_step": mi["kernel_us_per_step"], "column_steps_per_s": w["Nh"] * steps / mi["wall_s"], "status_flags": int(dev.status()),
-                           "note": "TRM_OPT_PIPELINE_PARTS = 2 (library default): k_land_pk, half the columns + the other half's surface processes per launch"}
+                           "note": "TRM_OPT_PIPELINE_PARTS = 1: k_land_pk, half the columns + the other half's surface processes per launch (off by default: no gain measured)"}
         dev.close()
         r = roofline_object(config, Nz, w["Nh"], wordsize, m["kernel_us_per_step"] * 1e-6, "k_step_pk (+ k_surface)" if name == "c5" else "k_column",
                             f"pmc_summary_{name}_fused.json", desc)

@@ -179,8 +179,9 @@ enum {
                                     /* processes (land_model.jl:79-88) of the other, so that the latency-bound surface chain  */
                                     /* runs under the column program (columns are independent; bit-identical results).        */
                                     /* Applies to calls of >= 2 steps with constant inputs and the branch-free boundary kinds. */
-                                    /* 0: off; 1: whenever legal; 2 (default): for contexts of >= 262 144 columns, where it    */
-                                    /* was measured to win (1-2 %; it loses 10 % at N145: DESIGN 4.3)                          */
+                                    /* 0: off; 1: whenever legal; 2 (default): the library's rule -- currently never: measured  */
+                                    /* within +-2 % at 812 500 columns and +10 % at N145 (every launch carries ~4 us of fixed    */
+                                    /* cost)                                                                         */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

@@ -1077,10 +1077,11 @@ template <class NF> struct Ops {
         if (c->opt_pipeline == 0 || steps_left < 2 || !c->params.seb || !richards(c) || coupled(c) || c->part_n[1] <= 0) return false;
         if (!c->series.empty() || generic_bcs(c) || c->Nz > 64) return false;      // (inputs constant over the call; one level per lane)
         if (std::is_same<NF, float>::value && !packed_path(c)) return false;        // (fp32 off the packed kernel: not instantiated)
-        // Measured (profiles/r03/exp6_ab_land_interleaved.log): -1.0 % (C5) and -1.6 % (C5-VG) at 812 500 columns, but +10 % at
-        // N145 and on its shards -- every launch carries ~4 us of fixed cost, and two half-size column launches pay it twice
-        // where the k_surface launch they absorb was little more than that fixed cost itself.  AUTO: very large contexts only.
-        return c->opt_pipeline == 1 || c->Nh >= 262144;
+        // Measured (profiles/r03/exp6_ab_land_interleaved.log, bench_default.json: land_interleaved): within +-2 % at 812 500 columns
+        // (492 vs 497, 503 vs 511 us on one box; 523 vs 512 on another), +10 % at N145 and on its shards -- every launch carries ~4 us
+        // of fixed cost, and two half-size column launches pay it twice where the k_surface launch they absorb was little more than
+        // that fixed cost itself.  Not a win anywhere it was measured: AUTO (2) leaves it off; 1 forces it.
+        return c->opt_pipeline == 1;
     }
     // columns of part `qcol` step; the surface processes of part `qsurf` run beside them for ITS next column step
     template <bool RICH, int H, int LPC> static int launch_land(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) {
