@@ -281,6 +281,14 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     }
     // surface_excess_water (and LandModel's surface state) is owned by the column's top lane.  The one-step programs
     // touch it in one short top-lane block at the end; the multi-step program carries it in a register.
+    // Both are READ HERE, with the other inputs of the column: vector memory retires in order, loads and stores through the one
+    // counter, so a load issued behind the field stores would hold the whole wave until every one of its stores had been
+    // acknowledged -- the wave's last act before it frees its slot.
+    NF S_in = NF(0), Ts_in = NF(0), S_stage_out = NF(0);
+    if (PROG != PROG_MULTI) {
+        if (RICHARDS) S_in = ldg(v.S, ib0);
+        if (seb) Ts_in = ldg(v.Ts, ib0);
+    }
     NF S = NF(0);
     SurfaceRegs<NF> sf;
     if (PROG == PROG_MULTI) {
@@ -408,6 +416,23 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         Kf_out = (ln.is_bot || ln.is_top) ? Kc_new : Kmin_new;
         Kf_out_top = Kc_new;
     }
+    // surface_excess_water and the skin temperature after the step, formed BEFORE the first store is issued: every loaded value
+    // has been consumed by then, and nothing is waited for behind the stores (see S_in above)
+    NF Ts_new = NF(0);
+    if (PROG != PROG_MULTI) {
+        if (RICHARDS) {
+            // tendency min(0, S) once per column (SURVEY C-3), Euler / Heun update, overflow
+            S = S_in;
+            GS_out = NF(0) + jl_min(NF(0), S);
+            if (PROG == PROG_HEUN) {
+                S_stage_out = (S + GS_out * dt) + over_stage;
+                GS_out = (GS_out + (NF(0) + jl_min(NF(0), S_stage_out))) / NF(2);
+            }
+            S = (S + GS_out * dt) + over;
+        }
+        Ts_new = Ts_in + NF(0) * dt;   // zero-tendency prognostic skin_temperature
+        asm volatile("" : "+v"(S), "+v"(GS_out), "+v"(Ts_new), "+v"(S_stage_out));
+    }
     // ---- the column goes out: 6 coalesced stores ---------------------------------------------------------------------------
     if (ln.act) {
         const View<NF>& v = kernarg_reload<View<NF>>(0);
@@ -426,17 +451,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         }
         if (ln.is_top) {
             if (RICHARDS) {
-                // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler / Heun update, overflow
-                if (PROG != PROG_MULTI) {
-                    S = ldg(v.S, ib);
-                    GS_out = NF(0) + jl_min(NF(0), S);
-                    if (PROG == PROG_HEUN) {
-                        const NF S_stage = (S + GS_out * dt) + over_stage;
-                        if (a.stage_S) stg(a.stage_S, ib, S_stage);
-                        GS_out = (GS_out + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
-                    }
-                    S = (S + GS_out * dt) + over;
-                }
+                if (PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage_out);
                 stg(v.S, ib, S);
                 stg(v.wt, ib, z0);
                 if (finalize) stg(v.G_S, ib, GS_out);
@@ -448,7 +463,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
                 if (SEB_INLINE) {
                     stg(v.Ts, ib, sf.out.Ts);
                 } else {
-                    stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);   // zero-tendency prognostic skin_temperature
+                    stg(v.Ts, ib, Ts_new);
                 }
             }
         }
@@ -611,6 +626,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         bc.flux_U = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
         bc.flux_S = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
     }
+    // (read with the other inputs, not behind the field stores: see column_program)
+    const NF S_in = RICHARDS ? ldg(v.S, ib0) : NF(0), Ts_in = seb ? ldg(v.Ts, ib0) : NF(0);
     // stage 1
     const Tendency<NF> t = column_tendencies_generic<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, ii, cb0, need_kc, viol);
     NF gU = t.gU, gS = t.gS, z0s, z0;
@@ -652,7 +669,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         }
         if (ln.is_top) {
             if (RICHARDS) {
-                NF S = ldg(vo.S, ib);
+                NF S = S_in;
                 NF GS = NF(0) + jl_min(NF(0), S);
                 const NF S_stage = (S + GS * dt) + over_stage;
                 GS = (GS + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
@@ -665,7 +682,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
                 stg(vo.top_T, ib, n.T);
                 stg(vo.top_sat, ib, n.sat);
                 stg(vo.top_liq, ib, n.liq);
-                stg(vo.Ts, ib, ldg(vo.Ts, ib) + NF(0) * dt);
+                stg(vo.Ts, ib, Ts_in + NF(0) * dt);
             }
         }
         viol |= bad ? 1u : 0u;

@@ -197,6 +197,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
         eS_t = -flux_term_top(seb ? -fS : fS, v.g);
     }
+    // (read with the other inputs, not behind the field stores: see column_program)
+    const NF S_in = RICHARDS ? ldg(v.S, ib0) : NF(0), Ts_in = seb ? ldg(v.Ts, ib0) : NF(0);
     const Two<NF> flux_U{ln.bot_a ? eU_b : (ln.top_a ? eU_t : NF(0)), ln.top_b ? eU_t : NF(0)};
     const Two<NF> flux_S{ln.bot_a ? eS_b : (ln.top_a ? eS_t : NF(0)), ln.top_b ? eS_t : NF(0)};
 
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         const NF Tt = ln.top_a ? Tn.a : Tn.b, st = ln.top_a ? sn.a : sn.b, lt = ln.top_a ? ln_.a : ln_.b;
         if (write_kf) stg(vo.Kf_top, ib, Kf_out_top);
         if (RICHARDS) {
-            NF S = ldg(vo.S, ib);
+            NF S = S_in;
             const NF GS = NF(0) + jl_min(NF(0), S);
             S = (S + GS * dt) + over;
             stg(vo.S, ib, S);
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
             stg(vo.top_T, ib, Tt);
             stg(vo.top_sat, ib, st);
             stg(vo.top_liq, ib, lt);
-            stg(vo.Ts, ib, ldg(vo.Ts, ib) + NF(0) * dt);
+            stg(vo.Ts, ib, Ts_in + NF(0) * dt);
         }
     }
     const uint32_t viol = (ln.act_a ? viol_a : 0u) | (ln.act_b ? viol_b : 0u) | (bad ? 1u : 0u);

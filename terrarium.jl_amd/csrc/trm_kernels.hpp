@@ -560,6 +560,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v_arg, De
     const NF T = ldg(v.T, cb), liq = ldg(v.liq, cb);
     const NF psi = RICHARDS ? ldg(v.psi, cb) : NF(0);
     const NF U0 = U, sat0 = sat;
+    // (read with the other inputs: a load behind a store would hold the wave until that store is acknowledged -- loads and
+    // stores retire through the one in-order counter)
+    const NF Ts_in = p.seb ? ldg(v.Ts, ib0) : NF(0);
 
     // (composition bounds of the incoming state were flagged by the launch that produced it)
     uint32_t viol_old = 0;
@@ -672,7 +675,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v_arg, De
     }
     if (act && is_top && p.seb) {   // zero-tendency prognostic skin_temperature
         const unsigned ib = block_local(ib0);
-        stg(v.Ts, ib, ldg(v.Ts, ib) + NF(0) * dt);
+        stg(v.Ts, ib, Ts_in + NF(0) * dt);
     }
     // ---- closures: (U, sat) -> (T, liq, psi), parameters fetched afresh (see kernarg_reload) ----------------------
     NF ln, Tn;

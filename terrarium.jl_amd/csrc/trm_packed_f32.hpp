@@ -233,6 +233,11 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
             flux_S = sel(is_bot, eS_b, sel(is_top, eS_t, splat(0.0f)));
         }
     }
+    // surface_excess_water and the skin temperature of the two columns: READ HERE, with the other inputs.  Vector memory retires in
+    // order, loads and stores through the one counter: a load issued behind a store holds the whole wave until that store has
+    // been acknowledged by memory (the top-lane block used to do that three times per wave).
+    const v2f S_in = RICHARDS ? ld2(v.S, ib0, ib1) : splat(0.0f);
+    const v2f Ts_in = seb ? ld2(v.Ts, ib0, ib1) : splat(0.0f);
     // ---- heat
     const v2f qT_lo = -((kap + kap_m) * 0.5f) * ((T - T_m) * L.rdzf_lo);
     const v2f qT_sh = dn2(qT_lo);
@@ -265,7 +270,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     // ---- explicit Euler update
     const v2f Unew = U + gU * dt;
     bool bad = (act0 && is_nan(Unew.x)) || (act1 && is_nan(Unew.y));
-    v2f snew = sat, z0 = splat(0.0f);
+    v2f snew = sat, z0 = splat(0.0f), GS_top = splat(0.0f), S_out = splat(0.0f);
     if (RICHARDS) {
         snew = sat + gS * dt;
         bad = bad || (act0 && is_nan(snew.x)) || (act1 && is_nan(snew.y));
@@ -274,28 +279,9 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         const float over1 = repair_saturation<NF, LPC>(v, sy, k, Nz, act1, is_bot, is_top, L);
         snew = v2f{sx, sy};
         z0 = v2f{water_table<NF, LPC>(sx, act0, lane, L), water_table<NF, LPC>(sy, act1, lane, L)};
-        if (is_top && k < Nz) {
-            if (act0) {
-                float S = ldg(v.S, ib0);
-                const float GS = 0.0f + jl_min(0.0f, S);
-                if (finalize) stg(v.G_S, ib0, GS);
-                S = S + GS * dt;
-                stg(v.S, ib0, S + over0);
-                stg(v.wt, ib0, z0.x);
-            }
-            if (act1) {
-                float S = ldg(v.S, ib1);
-                const float GS = 0.0f + jl_min(0.0f, S);
-                if (finalize) stg(v.G_S, ib1, GS);
-                S = S + GS * dt;
-                stg(v.S, ib1, S + over1);
-                stg(v.wt, ib1, z0.y);
-            }
-        }
-    }
-    if (is_top && seb) {   // zero-tendency prognostic skin_temperature
-        if (act0) stg(v.Ts, ib0, ldg(v.Ts, ib0) + 0.0f * dt);
-        if (act1) stg(v.Ts, ib1, ldg(v.Ts, ib1) + 0.0f * dt);
+        // surface_excess_water: tendency min(0, S) once per column, Euler update, overflow (stored with everything else below)
+        GS_top = v2f{0.0f + jl_min(0.0f, S_in.x), 0.0f + jl_min(0.0f, S_in.y)};
+        S_out = v2f{(S_in.x + GS_top.x * dt) + over0, (S_in.y + GS_top.y * dt) + over1};
     }
     // ---- closures
     v2f ln, Tn;
@@ -309,9 +295,18 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         Kf_out = sel(is_bot || is_top, Kc_new, Kmin_new);
         Kf_out_top = Kc_new;
     }
-    auto store = [&](bool act, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft, float gu, float gs) {
+    auto store = [&](bool act, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft, float gu, float gs,
+                     float S_new, float GS, float wt, float Ts_old /* already stepped */) {
         if (!act) return;
         const unsigned cb = block_local(cb_), ib = block_local(ib_);   // keeps the saddr form inside this block
+        if (is_top) {   // the column's 0-D state (top lane)
+            if (RICHARDS) {
+                if (finalize) stg(v.G_S, ib, GS);
+                stg(v.S, ib, S_new);
+                stg(v.wt, ib, wt);
+            }
+            if (seb) stg(v.Ts, ib, Ts_old);
+        }
         if (finalize) {   // state.tendencies of the last step (k_step_wave)
             stg(v.G_U, cb, gu);
             if (RICHARDS) stg(v.G_sat, cb, gs);
@@ -326,8 +321,11 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
             if (is_top) stg(v.Kf_top, ib, kft);
         }
     };
-    store(act0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x);
-    store(act1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y, gU.y, gS.y);
+    // every loaded value has been consumed before the first store is issued (nothing is waited for behind the stores)
+    v2f Ts_new = Ts_in + splat(0.0f) * dt;     // zero-tendency prognostic skin_temperature
+    asm volatile("" : "+v"(Ts_new), "+v"(S_out), "+v"(GS_top));
+    store(act0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x, S_out.x, GS_top.x, z0.x, Ts_new.x);
+    store(act1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y, gU.y, gS.y, S_out.y, GS_top.y, z0.y, Ts_new.y);
     // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
     const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u);
     if (flags) atomicOr(v.status, flags);
