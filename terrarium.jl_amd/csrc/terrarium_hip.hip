@@ -116,6 +116,11 @@ struct trm_ctx {
     void* d_series_table = nullptr;
     void* d_series_rows = nullptr;
     size_t series_rows_cap = 0;
+    // pinned staging for them: a ring, so that a launch never waits for the stream -- only for the copy that used the same
+    // staging buffer four launches ago
+    struct RowStage { void* h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
+    RowStage row_stage[4];
+    int row_stage_next = 0;
     bool args_valid = false;
     void* args = nullptr;   // LaunchArgs<NF>*, owned
     void (*args_free)(void*) = nullptr;
@@ -926,9 +931,24 @@ template <class NF> struct Ops {
     // slot table + [nsteps][nseries] rows for a multi-step launch that starts at the context clock
     static int upload_series_rows(trm_ctx* c, double dt, int nsteps) {
         const int ns = (int)c->series.size();
-        SeriesTable<NF> tb;
+        const size_t nrows = (size_t)nsteps * ns, need = sizeof(SeriesTable<NF>) + nrows * sizeof(SeriesRow);
+        trm_ctx::RowStage& st = c->row_stage[c->row_stage_next];
+        c->row_stage_next = (c->row_stage_next + 1) % 4;
+        if (st.pending) {
+            TRM_HIP(c, hipEventSynchronize(st.done));
+            st.pending = false;
+        }
+        if (!st.done) TRM_HIP(c, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+        if (need > st.cap) {
+            if (st.h) TRM_HIP(c, hipHostFree(st.h));
+            st.h = nullptr;
+            st.cap = 0;
+            TRM_HIP(c, hipHostMalloc(&st.h, need, hipHostMallocDefault));
+            st.cap = need;
+        }
+        SeriesTable<NF>& tb = *(SeriesTable<NF>*)st.h;
+        SeriesRow* rows = (SeriesRow*)((char*)st.h + sizeof(SeriesTable<NF>));
         std::memset(&tb, 0, sizeof(tb));
-        std::vector<SeriesRow> rows((size_t)nsteps * ns);
         for (int j = 0; j < ns; ++j) {
             auto& sr = c->series[j];
             const int slot = series_slot(c, sr);
@@ -956,17 +976,19 @@ template <class NF> struct Ops {
             }
         }
         if (!c->d_series_table) TRM_HIP(c, hipMalloc(&c->d_series_table, sizeof(SeriesTable<double>)));
-        if (rows.size() * sizeof(SeriesRow) > c->series_rows_cap) {
-            if (c->d_series_rows) TRM_HIP(c, hipFree(c->d_series_rows));
+        if (nrows * sizeof(SeriesRow) > c->series_rows_cap) {
+            if (c->d_series_rows) TRM_HIP(c, hipFree(c->d_series_rows));   // (waits for the launches that read it)
             c->d_series_rows = nullptr;
             c->series_rows_cap = 0;
-            TRM_HIP(c, hipMalloc(&c->d_series_rows, rows.size() * sizeof(SeriesRow)));
-            c->series_rows_cap = rows.size() * sizeof(SeriesRow);
+            TRM_HIP(c, hipMalloc(&c->d_series_rows, nrows * sizeof(SeriesRow)));
+            c->series_rows_cap = nrows * sizeof(SeriesRow);
         }
-        // (synchronous copies from pageable memory: the buffers may be reused as soon as the calls return)
+        // in stream order behind the previous launch (which reads the device copies) and in front of the next one; the host
+        // does not wait
         TRM_HIP(c, hipMemcpyAsync(c->d_series_table, &tb, sizeof(tb), hipMemcpyHostToDevice, c->stream));
-        TRM_HIP(c, hipMemcpyAsync(c->d_series_rows, rows.data(), rows.size() * sizeof(SeriesRow), hipMemcpyHostToDevice, c->stream));
-        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        TRM_HIP(c, hipMemcpyAsync(c->d_series_rows, rows, nrows * sizeof(SeriesRow), hipMemcpyHostToDevice, c->stream));
+        TRM_HIP(c, hipEventRecord(st.done, c->stream));
+        st.pending = true;
         return TRM_OK;
     }
     template <bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
@@ -1898,6 +1920,11 @@ int trm_destroy(trm_ctx* c) {
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
     if (c->copy_order) (void)hipEventDestroy(c->copy_order);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto& st : c->row_stage) {
+        if (st.pending) (void)hipEventSynchronize(st.done);
+        if (st.done) (void)hipEventDestroy(st.done);
+        if (st.h) (void)hipHostFree(st.h);
+    }
     for (void* q : {(void*)c->d_ring_inv, (void*)c->d_ring_idx, c->d_ring})
         if (q) (void)hipFree(q);
 

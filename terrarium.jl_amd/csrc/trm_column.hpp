@@ -28,7 +28,7 @@ enum { PROG_EULER = 0, PROG_HEUN = 1, PROG_MULTI = 2 };
 
 template <class NF> struct Cell { NF U, sat, T, liq, psi; };
 // what one lane knows about its place in the column
-struct LaneInfo { int lane, k; bool is_bot, is_top, act; };
+struct LaneInfo { int lane, k; bool is_bot, is_top, act; unsigned long long m_act; };   // m_act: the wave's ballot of act
 // boundary inputs of this lane's column (every lane of a column holds the same values)
 template <class NF> struct ColumnBC {
     NF bTb, bTt;            // temperature boundary values (used when the Value condition is set)
@@ -43,20 +43,24 @@ template <class NF> struct Tendency { NF gU, gS, Kf_lo, Kc; };
 // and the result is -0.0 without dividing.  Cells in phase change (and L_theta <= eps, sat below 1.4e-24) take the
 // divide -- decided per wave by one ballot.
 enum { DERIVE_NONE = 0, DERIVE_T_LIQ = 1, DERIVE_LIQ = 2 };
+// a lane needs the divide when it is in phase change, NaN, or its L_theta vanishes: !thawed && !(frozen && L_theta > eps) --
+// combined on the scalar unit from three ballots (the lane-wise boolean expression costs 8 vector instructions)
+TRM_DEV bool no_lane_divides(bool thawed, bool frozen, bool latent_resolved) {
+    const unsigned long long need = ~wave_ballot(thawed) & ~(wave_ballot(frozen) & wave_ballot(latent_resolved)) & wave_ballot(true);
+    return need == 0ull;
+}
 template <class NF> TRM_DEV NF liquid_fraction_wave(const DevParams<NF>& p, NF U, NF sat) {
     const NF Lth = p.L * sat * p.por;
     const NF nLth = -Lth;
     const bool thawed = U >= NF(0), frozen = U < nLth;
-    const bool need_div = !thawed && !(frozen && Lth > Limits<NF>::eps());   // phase change, NaN, vanishing L_theta
-    if (__ballot(need_div) == 0ull) return thawed ? NF(1) : NF(-0.0);
+    if (no_lane_divides(thawed, frozen, Lth > Limits<NF>::eps())) return thawed ? NF(1) : NF(-0.0);
     return thawed ? NF(1) : boolmul(U >= nLth, NF(1) - safediv(U, nLth));
 }
 template <class NF> TRM_DEV void energy_closure_wave(const DevParams<NF>& p, NF U, NF sat, NF& liq, NF& T, uint32_t& viol) {
     const NF Lth = p.L * sat * p.por;
     const NF nLth = -Lth;
     const bool thawed = U >= NF(0), frozen = U < nLth;
-    const bool need_div = !thawed && !(frozen && Lth > Limits<NF>::eps());   // phase change, NaN, vanishing L_theta
-    if (__ballot(need_div) == 0ull) {
+    if (no_lane_divides(thawed, frozen, Lth > Limits<NF>::eps())) {
         liq = thawed ? NF(1) : NF(-0.0);
     } else {
         liq = thawed ? NF(1) : boolmul(U >= nLth, NF(1) - safediv(U, nLth));
@@ -135,16 +139,16 @@ TRM_DEV NF column_advance(const View<NF>& v, const LevelGeom<NF>& L, const LaneI
                           NF U0, NF sat0, NF& gU, NF& gS, NF dt, Cell<NF>& n, NF& z0, bool& bad) {
     gU += bc.flux_U;
     n.U = U0 + gU * dt;
-    bad = bad || (ln.act && is_nan(n.U));
+    if (!RICHARDS) bad = bad || (ln.act && is_nan(n.U));
     n.sat = sat0;
     z0 = NF(0);
     NF over = NF(0);
     if (RICHARDS) {
         gS += bc.flux_S;
         NF snew = sat0 + gS * dt;
-        bad = bad || (ln.act && is_nan(snew));
-        over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.act, ln.is_bot, ln.is_top, L);
-        z0 = water_table<NF, LPC>(snew, ln.act, ln.lane, L);
+        bad = bad || (ln.act && __builtin_isunordered(n.U, snew));   // either one NaN: one compare
+        over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.m_act, ln.is_bot, ln.is_top, L);
+        z0 = water_table<NF, LPC>(snew, ln.m_act, ln.lane, L);
         n.sat = snew;
     }
     return over;
@@ -234,6 +238,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     const int i = wave * CPW + sub;
     const bool colok = i < Nh;
     ln.act = colok && ln.k < Nz;
+    ln.m_act = wave_ballot(colok) & wave_ballot(ln.k < Nz);
     const int ii = colok ? i : Nh - 1;
     const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);
@@ -599,6 +604,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const int i = wave * CPW + sub;
     const bool colok = i < Nh;
     ln.act = colok && ln.k < Nz;
+    ln.m_act = wave_ballot(colok) & wave_ballot(ln.k < Nz);
     const int ii = colok ? i : Nh - 1;
     const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);

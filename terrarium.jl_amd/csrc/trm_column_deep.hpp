@@ -32,7 +32,7 @@ template <class NF> TRM_DEV NF from_level(const Two<NF>& x, int q) {
 // bit q of the result = the predicate of level q (a cells are the even levels, b cells the odd ones), as two 64-bit halves
 struct Mask128 { unsigned long long lo, hi; };
 TRM_DEV Mask128 level_mask(bool pa, bool pb) {
-    const unsigned long long A = __ballot(pa), B = __ballot(pb);
+    const unsigned long long A = wave_ballot(pa), B = wave_ballot(pb);
     // interleave: level 2l <- A bit l, level 2l + 1 <- B bit l
     auto spread = [](unsigned long long x) {   // bits 0..31 of x to the even positions of a 64-bit word
         x &= 0xffffffffull;
@@ -95,7 +95,7 @@ TRM_DEV NF repair_saturation_deep(Two<NF>& s, const DeepLane& ln, int Nz, const 
                     cout.b = div_const(e * dzc.b, nb_dz_up.b, nb_rdz_up.b);
                 }
                 carry = from_level(cout, q);
-                if (!any_above(any_over, q) && __ballot(!(carry == NF(0))) == 0ull) break;
+                if (!any_above(any_over, q) && wave_ballot(!(carry == NF(0))) == 0ull) break;
             }
             if (ln.top_a) s.a = s.a + carry;
             if (ln.top_b) s.b = s.b + carry;
@@ -120,7 +120,7 @@ TRM_DEV NF repair_saturation_deep(Two<NF>& s, const DeepLane& ln, int Nz, const 
                     pout.b = div_const(d * dzc.b, nb_dz_dn.b, nb_rdz_dn.b);
                 }
                 pend = from_level(pout, q);
-                if (!any_below(any_under, q) && __ballot(!(pend == NF(0))) == 0ull) break;
+                if (!any_below(any_under, q) && wave_ballot(!(pend == NF(0))) == 0ull) break;
             }
             if (ln.bot_a) s.a = s.a - pend;
         }

@@ -17,6 +17,9 @@ namespace trm {
 // Julia Base float semantics the reference relies on
 // ---------------------------------------------------------------------------
 template <class NF> TRM_HD bool is_nan(NF x) { return x != x; }
+// the wave's predicate mask straight from the compare (s_and with exec); HIP's __ballot takes the predicate through a vector
+// register (v_cndmask 0/1 + v_cmp_ne)
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 template <class NF> TRM_HD bool sign_bit(NF x) { return __builtin_signbit(x); }
 TRM_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 TRM_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

@@ -398,12 +398,14 @@ template <class NF> TRM_DEV NeighbourDz<NF> neighbour_dz(const View<NF>& v, int 
 // overflow and the bottom clamp, all lane-local.  Otherwise both passes run as lane-serial loops.
 // Returns excess * dz_top in the TOP lane (0 elsewhere): the column's overflow into surface_excess_water.
 template <class NF, int LPC>
-TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, bool act, bool is_bot, bool is_top, const LevelGeom<NF>& L) {
+TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, unsigned long long m_act, bool is_bot, bool is_top,
+                             const LevelGeom<NF>& L) {
     // (max(s - 1, 0) != 0  <=>  s > 1  and  max(-s, 0) != 0  <=>  s < 0, NaN included: both sides false)
-    const bool over = act && !is_top && snew > NF(1);
-    const bool under = act && !is_bot && snew < NF(0);
-    const unsigned long long any_over = __ballot(over);
-    const unsigned long long any_bad = __ballot(over || under);
+    // Every ballot is taken of ONE compare and the masks are combined on the scalar unit: the ballot of a conjunction goes
+    // through a vector register (v_cndmask 0/1 + v_cmp_ne).  m_act: the wave's mask of lanes that hold a cell.
+    const unsigned long long m_top = wave_ballot(is_top), m_bot = wave_ballot(is_bot);
+    const unsigned long long any_over = wave_ballot(snew > NF(1)) & m_act & ~m_top;
+    const unsigned long long any_bad = any_over | (wave_ballot(snew < NF(0)) & m_act & ~m_bot);
     // every cell but the bottom one receives `+ carry` / `+ deficit`; with nothing to move that is `+ 0`
     // (idempotent, and absorbed by a later non-zero addend), so apply it once up front
     snew = is_bot ? snew : snew + NF(0);
@@ -436,12 +438,11 @@ TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, bool ac
                     cout = div_const(e * L.dzc, nb.dzc_up, nb.rdzc_up);
                 }
                 carry = shfl_from<NF, LPC>(cout, q);
-                if ((lv >> (q + 1)) == 0ull && __ballot(!(carry == NF(0))) == 0ull) break;
+                if ((lv >> (q + 1)) == 0ull && wave_ballot(!(carry == NF(0))) == 0ull) break;
             }
             if (is_top) snew = snew + carry;
         }
-        const bool under2 = act && !is_bot && !(jl_max(-snew, NF(0)) == NF(0));
-        const unsigned long long any_under = __ballot(under2);
+        const unsigned long long any_under = wave_ballot(!(jl_max(-snew, NF(0)) == NF(0))) & m_act & ~m_bot;
         if (any_under != 0ull) {
             const unsigned long long lv = level_bits<LPC>(any_under);
             NF pend = NF(0);
@@ -454,7 +455,7 @@ TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, bool ac
                     pout = div_const(d * L.dzc, nb.dzc_dn, nb.rdzc_dn);
                 }
                 pend = shfl_from<NF, LPC>(pout, q);
-                if ((lv & ((1ull << q) - 1ull)) == 0ull && __ballot(!(pend == NF(0))) == 0ull) break;
+                if ((lv & ((1ull << q) - 1ull)) == 0ull && wave_ballot(!(pend == NF(0))) == 0ull) break;
             }
             if (is_bot) snew = snew - pend;
         }
@@ -467,8 +468,8 @@ TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, bool ac
 }
 // compute_water_table! (soil_hydrology.jl:170-175, kernel_utils.jl:7-16): lower face of the first
 // unsaturated cell from the bottom, the surface if there is none.
-template <class NF, int LPC> TRM_DEV NF water_table(NF sat, bool act, int lane, const LevelGeom<NF>& L) {
-    const unsigned long long unsat = __ballot(act && sat < NF(1)) & group_mask<LPC>(lane);
+template <class NF, int LPC> TRM_DEV NF water_table(NF sat, unsigned long long m_act, int lane, const LevelGeom<NF>& L) {
+    const unsigned long long unsat = wave_ballot(sat < NF(1)) & m_act & group_mask<LPC>(lane);
     const int first = unsat ? (__ffsll((long long)unsat) - 1) % LPC : -1;
     const NF z_first = shfl_from<NF, LPC>(L.zFlo, first >= 0 ? first : 0);
     return first >= 0 ? z_first : L.zF_top;
@@ -489,13 +490,13 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
     const long c = (i < v.Nh ? i : v.Nh - 1) * v.Nzp + (k < Nz ? k : Nz - 1);
     NF s = v.sat[c];
     if (WITH_ADJUST) {
-        NF over = repair_saturation<NF, LPC>(v, s, k, Nz, act, is_bot, is_top, L);
+        NF over = repair_saturation<NF, LPC>(v, s, k, Nz, wave_ballot(act), is_bot, is_top, L);
         if (act) {
             v.sat[c] = s;
             if (is_top) v.S[i] += over;
         }
     }
-    NF z0 = water_table<NF, LPC>(s, act, lane, L);
+    NF z0 = water_table<NF, LPC>(s, wave_ballot(act), lane, L);
     if (act) {
         if (is_bot) v.wt[i] = z0;
         if (WITH_PSI) v.psi[c] = pressure_head<NF, HYD>(p, s, L.zC, L.psiz, z0);
@@ -660,8 +661,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_wave(View<NF> v_arg, De
     if (RICHARDS) {
         snew = sat0 + gS * dt;
         bad = bad || (act && is_nan(snew));
-        const NF over = repair_saturation<NF, LPC>(v, snew, k, Nz, act, is_bot, is_top, L);
-        z0 = water_table<NF, LPC>(snew, act, lane, L);
+        const unsigned long long m_act = wave_ballot(act);
+        const NF over = repair_saturation<NF, LPC>(v, snew, k, Nz, m_act, is_bot, is_top, L);
+        z0 = water_table<NF, LPC>(snew, m_act, lane, L);
         if (act && is_top) {
             // surface_excess_water: tendency min(0, S) once per column (SURVEY C-3), Euler update, overflow
             const unsigned ib = block_local(ib0);

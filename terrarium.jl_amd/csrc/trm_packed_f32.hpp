@@ -84,7 +84,7 @@ TRM_DEV v2f liquid_fraction2(const DevParams<float>& p, v2f U, v2f sat) {
     const float eps = Limits<float>::eps();
     const M2 thawed = ge(U, splat(0.0f)), frozen0 = lt(U, nLth);
     const bool needx = !thawed.x && !(frozen0.x && Lth.x > eps), needy = !thawed.y && !(frozen0.y && Lth.y > eps);
-    if (__ballot(needx || needy) == 0ull) return sel(thawed, splat(1.0f), splat(-0.0f));
+    if (wave_ballot(needx || needy) == 0ull) return sel(thawed, splat(1.0f), splat(-0.0f));
     const v2f den = nLth + eps;
     const v2f sd = v2f{(nLth.x == 0.0f) ? Limits<float>::inf() : div_nr(U.x, den.x), (nLth.y == 0.0f) ? Limits<float>::inf() : div_nr(U.y, den.y)};
     const v2f x = splat(1.0f) - sd;
@@ -101,7 +101,7 @@ TRM_DEV void energy_closure2(const DevParams<float>& p, v2f U, v2f sat, v2f& liq
     const float eps = Limits<float>::eps();
     const M2 thawed = ge(U, splat(0.0f)), frozen0 = lt(U, nLth);
     const bool needx = !thawed.x && !(frozen0.x && Lth.x > eps), needy = !thawed.y && !(frozen0.y && Lth.y > eps);
-    if (__ballot(needx || needy) == 0ull) {
+    if (wave_ballot(needx || needy) == 0ull) {
         liq = sel(thawed, splat(1.0f), splat(-0.0f));
     } else {
         const v2f den = nLth + eps;
@@ -275,10 +275,11 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         snew = sat + gS * dt;
         bad = bad || (act0 && is_nan(snew.x)) || (act1 && is_nan(snew.y));
         float sx = snew.x, sy = snew.y;
-        const float over0 = repair_saturation<NF, LPC>(v, sx, k, Nz, act0, is_bot, is_top, L);
-        const float over1 = repair_saturation<NF, LPC>(v, sy, k, Nz, act1, is_bot, is_top, L);
+        const unsigned long long m_lev = wave_ballot(k < Nz), m_act0 = wave_ballot(i0 < Nh) & m_lev, m_act1 = wave_ballot(i1 < Nh) & m_lev;
+        const float over0 = repair_saturation<NF, LPC>(v, sx, k, Nz, m_act0, is_bot, is_top, L);
+        const float over1 = repair_saturation<NF, LPC>(v, sy, k, Nz, m_act1, is_bot, is_top, L);
         snew = v2f{sx, sy};
-        z0 = v2f{water_table<NF, LPC>(sx, act0, lane, L), water_table<NF, LPC>(sy, act1, lane, L)};
+        z0 = v2f{water_table<NF, LPC>(sx, m_act0, lane, L), water_table<NF, LPC>(sy, m_act1, lane, L)};
         // surface_excess_water: tendency min(0, S) once per column, Euler update, overflow (stored with everything else below)
         GS_top = v2f{0.0f + jl_min(0.0f, S_in.x), 0.0f + jl_min(0.0f, S_in.y)};
         S_out = v2f{(S_in.x + GS_top.x * dt) + over0, (S_in.y + GS_top.y * dt) + over1};
