@@ -28,7 +28,7 @@ from .models import (PhysicalConstants, SoilThermalConductivities, SoilHeatCapac
                      StaticExponentialRootDistribution, FieldCapacityLimitedPAW, VegetationCarbon, VegetationModel, flatten_vegetation)
 from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, PrescribedBottomTemperature,
                          GroundHeatFlux, GeothermalHeatFlux, InfiltrationFlux, ImpermeableBoundary, FreeDrainage,
-                         merge_boundary_conditions, DeviceState, ModelIntegrator, FieldTimeSeries, InputSource, InputSources, initialize, initialize_integrator,
+                         merge_boundary_conditions, DeviceState, ModelIntegrator, FieldTimeSeries, StateFunction, InputSource, InputSources, initialize, initialize_integrator,
                          timestep, run, current_time, compute_auxiliary, compute_tendencies, closure, invclosure,
                          update_state, default_dt, is_adaptive, iteration, time_step, reset, get_grid, znodes, zspacings)
 from ._capi import TerrariumHipError

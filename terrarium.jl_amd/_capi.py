@@ -87,6 +87,27 @@ class TerrariumHipError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP / HSA runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7) and
+    libhsa-runtime64.so; the library is linked against /opt/rocm's libamdhip64.so.7.  Loaded after torch, the library binds
+    to torch's copy (same SONAME) and both see the device; loaded BEFORE torch, the process ends up with two HSA runtimes
+    and the second one finds no GPU ("No HIP GPUs are available").  So, when PyTorch is installed and no HIP runtime is in
+    the process yet, torch's copy is loaded first -- without importing torch."""
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass    # (the library's own runpath still finds /opt/rocm's runtime)
+
+
 def lib():
     """Load libterrarium_hip.so; raise loudly if it has not been built."""
     global _lib
@@ -96,6 +117,7 @@ def lib():
         raise TerrariumHipError(
             f"{LIB_PATH} is missing: build it with `make -C terrarium.jl_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     L.trm_abi_version.restype = i32

@@ -457,6 +457,49 @@ class DeviceState:
         self._check(self._lib.trm_synchronize(self._ctx), "trm_synchronize")
 
 
+# ---- state-dependent forcings and boundary values ------------------------------------
+class StateFunction:
+    """A boundary value, input or `vwc_forcing` that depends on the model STATE: the mirror of the reference's user
+    `Forcing` in discrete form (src/forcings.jl:13-15, `forcing(i, j, k, grid, clock, fields)`) and of boundary conditions
+    that read `fields` (src/boundary_conditions.jl:25-28, `getbc(..., clock, fields)`).
+
+    `func(fields, clock, parameters)` is evaluated ON THE DEVICE before every step, vectorised over all columns (the
+    reference evaluates the scalar form per cell inside the tendency kernel: the same values at the same state):
+      fields.<name>   a torch view of the library's own buffer, zero-copy -- `[num_columns, rows]` for 3-D fields (level k of
+                      column i at [i, k], k = 0 the bottom cell), `[num_columns]` for 2-D fields
+      clock           `.time`, `.iteration`
+    and returns a tensor (or number) that broadcasts to the target: `[num_columns, Nz]` for `vwc_forcing`, `[num_columns]`
+    for a boundary value or an input.  Evaluation and the step share one stream, so nothing waits on the host.
+    ForwardEuler only: Heun's second stage would need the function at the stage's state, inside the fused launch."""
+
+    def __init__(self, func, parameters=None):
+        self.func = func
+        self.parameters = parameters
+
+
+class _Clock:
+    def __init__(self, time, iteration):
+        self.time, self.iteration = time, iteration
+
+
+class _DeviceFields:
+    """`fields` of a StateFunction: attribute access -> torch view of the field's device buffer (cached)."""
+
+    def __init__(self, state, torch):
+        object.__setattr__(self, "_state", state)
+        object.__setattr__(self, "_torch", torch)
+        object.__setattr__(self, "_views", {})
+
+    def __getattr__(self, name):
+        if name not in self._views:
+            field, row0, rows = self._state._alias(name)      # (e.g. ground_temperature = the top row of temperature)
+            t = self._torch.as_tensor(self._state.device_array(field), device=f"cuda:{int(self._state.grid.device)}")
+            if t.dim() == 2:
+                t = t[:, row0] if (field != name and rows == 1) else t[:, row0:row0 + rows]
+            self._views[name] = t
+        return self._views[name]
+
+
 # ---- integrator -------------------------------------------------------------------
 class ModelIntegrator:
     """src/timesteppers/model_integrator.jl:10-37"""
@@ -469,6 +512,7 @@ class ModelIntegrator:
         self.initializers = initializers
         self.inputs = inputs  # name -> number | array | f(t) returning an array/number
         self._next_level = {}  # windowed FieldTimeSeries: the first level of the record that is not on the device yet
+        self._sf = None        # StateFunction targets: [(function, destination view)], bound by initialize_integrator
 
     @property
     def clock(self):
@@ -481,7 +525,7 @@ class ModelIntegrator:
         Heun evaluates its stage at the ticked stage clock (heun.jl:52-59: tick!(stage.clock) then update_state!(stage)),
         so under Heun a function f is handed over as the two-node series [(t, f(t)), (t + dt, f(t + dt))]: the library
         evaluates it at t for the state and at t + dt for the stage (both nodes are hit exactly)."""
-        dyn = False
+        dyn = self._apply_state_functions(t)
         heun = isinstance(self.timestepper, Heun) and dt is not None
         for (var, side), (kind, value) in self.boundary_conditions.items():
             if callable(value):
@@ -498,6 +542,54 @@ class ModelIntegrator:
                     self.state.set_forcing(name, value(t))
                 dyn = True
         return dyn
+
+    # -- state-dependent functions: evaluated by torch on the library's stream, written into the library's buffers ----------
+    def _state_functions(self):
+        out = [(("bc", var, side, kind), v) for (var, side), (kind, v) in self.boundary_conditions.items() if isinstance(v, StateFunction)]
+        out += [(("input", name), v) for name, v in self.inputs.items() if isinstance(v, StateFunction)]
+        forcing = getattr(getattr(getattr(self.model, "soil", None), "hydrology", None), "vwc_forcing", None)
+        if isinstance(forcing, StateFunction):
+            out.append((("vwc_forcing",), forcing))
+        return out
+
+    def _bind_state_functions(self):
+        """Allocates the targets and puts the library on a torch stream (called by initialize_integrator)."""
+        fns = self._state_functions()
+        self._sf = []
+        if not fns:
+            return
+        if isinstance(self.timestepper, Heun):
+            raise NotImplementedError("a StateFunction needs the stage's state at Heun's second stage: use ForwardEuler")
+        import torch  # device memory / stream plumbing of the host mirror
+        st = self.state
+        dev = f"cuda:{int(st.grid.device)}"
+        if getattr(self, "_sf_stream", None) is None:
+            self._sf_stream = torch.cuda.Stream(device=dev)
+            st.set_stream(self._sf_stream.cuda_stream)
+        self._sf_fields = _DeviceFields(st, torch)
+        for target, fn in fns:
+            if target[0] == "bc":
+                _, var, side, kind = target
+                st.set_bc(var, side, kind, np.zeros(st.grid.Nh, dtype=st.dtype))
+                dest = torch.as_tensor(st.bc_device_array(var, side), device=dev)
+            elif target[0] == "input":
+                st.set_forcing(target[1], 0.0)
+                dest = getattr(self._sf_fields, target[1])
+            else:
+                st.set("vwc_forcing", np.zeros((st.grid.Nz, st.grid.Nh), dtype=st.dtype))
+                dest = self._sf_fields.vwc_forcing
+            self._sf.append((fn, dest))
+
+    def _apply_state_functions(self, t):
+        if not self._sf:
+            return False
+        import torch
+        clock = _Clock(t, self.state.clock()[1])
+        with torch.cuda.stream(self._sf_stream):
+            for fn, dest in self._sf:
+                out = fn.func(self._sf_fields, clock, fn.parameters)
+                dest.copy_(torch.as_tensor(out, device=dest.device, dtype=dest.dtype).expand_as(dest))
+        return True
 
     # -- windowed series: a record streamed through a fixed device window ------------------------------------------------
     def _windowed(self):
@@ -543,7 +635,7 @@ class ModelIntegrator:
             done += k
 
     def _has_time_dependence(self):
-        return any(callable(v) for _, v in self.boundary_conditions.values()) or \
+        return bool(self._sf) or any(callable(v) for _, v in self.boundary_conditions.values()) or \
             any(callable(v) for v in self.inputs.values())
 
 
@@ -614,7 +706,7 @@ def initialize_integrator(integ: ModelIntegrator):
             value.attach_boundary(st, var, side, kind)     # a named input variable as boundary value (soil_heat_global_era5.jl:31-44)
         elif isinstance(value, FieldTimeSeries):
             st.set_bc_series(var, side, kind, *head(value), value.time_indexing)
-        else:
+        elif not isinstance(value, StateFunction):
             st.set_bc(var, side, kind, value(0.0) if callable(value) else value)
     for name, value in integ.inputs.items():
         if isinstance(value, RasterInputSource):
@@ -622,12 +714,13 @@ def initialize_integrator(integ: ModelIntegrator):
             value.attach(st)      # static raster: set once; time-indexed: device-resident series (ext/TerrariumRastersExt)
         elif isinstance(value, FieldTimeSeries):
             st.set_forcing_series(name, *head(value), value.time_indexing)
-        else:
+        elif not isinstance(value, StateFunction):
             st.set_forcing(name, value(0.0) if callable(value) else value)
+    integ._bind_state_functions()
     st.update_inputs()   # initialize!(fields, source, clock) = update_inputs! at the start time
     soil = getattr(integ.model, "soil", None)
     forcing = getattr(getattr(soil, "hydrology", None), "vwc_forcing", None)
-    if forcing is not None and not isinstance(forcing, (int, float)):
+    if forcing is not None and not isinstance(forcing, (int, float, StateFunction)):
         st.set("vwc_forcing", forcing)   # per-cell user forcing (soil_hydrology.jl:37-38)
     for name, value in integ.initializers.items():
         st.set(name, value)

@@ -197,8 +197,9 @@ class RichardsEq:
 @dataclass
 class SoilHydrology:
     """soil_hydrology.jl:21-53.  `vwc_forcing` [1/s]: a number (spatially constant source/sink), a per-cell array
-    `[Nz][Nh]` / vertical profile `[Nz]`, or a function (x, z) evaluated once per cell (an Oceananigans `Forcing`
-    that depends on position only); forcings that depend on the evolving fields do not cross the C ABI."""
+    `[Nz][Nh]` / vertical profile `[Nz]`, a function (x, z) evaluated once per cell (an Oceananigans `Forcing`
+    that depends on position only), or a `StateFunction(func(fields, clock, parameters))` -- a forcing that depends on
+    the evolving fields (forcings.jl:13-15), evaluated on the device before every step into the per-cell forcing field."""
     vertical_flow: Union[NoFlow, RichardsEq] = field(default_factory=NoFlow)
     hydraulic_properties: Union[ConstantSoilHydraulics, SoilHydraulicsSURFEX] = field(default_factory=ConstantSoilHydraulics)
     vwc_forcing: Optional[object] = None

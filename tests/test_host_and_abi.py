@@ -284,3 +284,21 @@ def test_c_host_sees_the_struct_layout_the_julia_shim_declares(tmp_path):
 def C_sizeof(ct):
     import ctypes
     return ctypes.sizeof(ct)
+
+
+def test_loading_the_library_first_leaves_one_hip_runtime_for_torch():
+    """PyTorch-ROCm bundles its own libamdhip64.so / libhsa-runtime64.so; the loader makes the library bind to that copy even
+    when nothing imported torch yet, so a later `import torch` does not bring a second runtime into the process (which then
+    finds no GPU).  No GPU needed: only the loaded objects are inspected."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import terrarium_jl_amd as trm\n"
+            "assert 'torch' not in sys.modules\n"
+            "trm._capi.lib()\n"
+            "import torch\n"
+            "maps = open('/proc/self/maps').read().split('\\n')\n"
+            "print(len({l.split()[-1] for l in maps if 'libamdhip64' in l}), len({l.split()[-1] for l in maps if 'libhsa-runtime64' in l}))\n") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-2:] == ["1", "1"], out.stdout
