@@ -136,6 +136,10 @@ TRM_DEV NF repair_saturation_deep(Two<NF>& s, const DeepLane& ln, int Nz, const 
 #ifndef TRM_DEEP_WAVES
 #define TRM_DEEP_WAVES 1
 #endif
+// word w of the level record at byte offset `rec` of the level table (see level_geom)
+template <class NF> TRM_DEV NF level_word(const View<NF>& v, unsigned rec, int w) {
+    return *reinterpret_cast<const NF*>(reinterpret_cast<const char*>(v.lvl) + rec + (unsigned)w * (unsigned)sizeof(NF));
+}
 template <class NF, bool RICHARDS, int HYD, bool DERIVE = false>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(TRM_DEEP_WAVES, 8)))
     k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
@@ -169,8 +173,16 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     uint32_t viol_a = 0, viol_b = 0;    // (per cell: only real cells report)
     bool bad = false;
 
-    // per-level geometry of both cells (the level records of trm_kernels.hpp: level_geom)
-    const LevelGeom<NF> La = level_geom(v, ln.ka), Lb = level_geom(v, ln.kb);
+    // per-level geometry of both cells (the level records of trm_kernels.hpp: level_geom).  Only what the tendencies and the
+    // repair need is fetched here (thickness, its reciprocal, the face reciprocals); zC, psiz and zFlo serve the water table and
+    // the pressure head at the END of the program and are fetched there (level_word): 12 registers less across the stencil.
+    struct EarlyGeom { NF dzc, rdzc, rdzf_lo, rdzf_hi; };
+    auto early = [&](int k) {
+        const int kk = k < Nz ? k : Nz - 1;
+        const NF* q = reinterpret_cast<const NF*>(reinterpret_cast<const char*>(v.lvl) + (unsigned)kk * (unsigned)sizeof(LevelPack<NF>));
+        return EarlyGeom{q[3], q[4], q[5], q[6]};
+    };
+    const EarlyGeom La = early(ln.ka), Lb = early(ln.kb);
     const Two<NF> dzc{La.dzc, Lb.dzc}, rdzc{La.rdzc, Lb.rdzc};
 
     // ---- the column comes in ---------------------------------------------------------------------------------------
@@ -189,18 +201,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const bool seb = p.seb != 0;
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
     const NF bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0), bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
-    NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
-    if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib0), v.g);
-    if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib0), v.g);
-    if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib0), v.g);
-    if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
-        const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
-        eS_t = -flux_term_top(seb ? -fS : fS, v.g);
-    }
-    // (read with the other inputs, not behind the field stores: see column_program)
-    const NF S_in = RICHARDS ? ldg(v.S, ib0) : NF(0), Ts_in = seb ? ldg(v.Ts, ib0) : NF(0);
-    const Two<NF> flux_U{ln.bot_a ? eU_b : (ln.top_a ? eU_t : NF(0)), ln.top_b ? eU_t : NF(0)};
-    const Two<NF> flux_S{ln.bot_a ? eS_b : (ln.top_a ? eS_t : NF(0)), ln.top_b ? eS_t : NF(0)};
 
     // ---- compute_auxiliary! + compute_tendencies! (column_tendencies, trm_column.hpp, per cell) -----------------------
     uint32_t viol_old = 0;
@@ -242,20 +242,37 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         gS.b = NF(0) + div_const(dth_b, p.por, p.rpor);
     }
     // ---- compute_z_bcs! + explicit_step! + hydrology closure (column_advance) -------------------------------------------
+    // The boundary flux terms and the 0-D inputs are fetched HERE: after the stencil (its registers are free again), in front
+    // of every store (no load sits behind a store: see column_program).
+    unsigned ib_late = ib0;
+    asm volatile("" : "+v"(ib_late));
+    NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
+    if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib_late), v.g);
+    if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib_late), v.g);
+    if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib_late), v.g);
+    if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
+        const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib_late);
+        eS_t = -flux_term_top(seb ? -fS : fS, v.g);
+    }
+    const NF S_in = RICHARDS ? ldg(v.S, ib_late) : NF(0), Ts_in = seb ? ldg(v.Ts, ib_late) : NF(0);
+    const Two<NF> flux_U{ln.bot_a ? eU_b : (ln.top_a ? eU_t : NF(0)), ln.top_b ? eU_t : NF(0)};
+    const Two<NF> flux_S{ln.bot_a ? eS_b : (ln.top_a ? eS_t : NF(0)), ln.top_b ? eS_t : NF(0)};
     gU.a += flux_U.a; gU.b += flux_U.b;
     Two<NF> Un{U.a + gU.a * dt, U.b + gU.b * dt};
     bad = bad || (ln.act_a && is_nan(Un.a)) || (ln.act_b && is_nan(Un.b));
     Two<NF> sn = sat;
     NF z0 = NF(0), over = NF(0);
+    unsigned late_a = (unsigned)(ln.ka < Nz ? ln.ka : Nz - 1) * (unsigned)sizeof(LevelPack<NF>), late_b = (unsigned)(ln.kb < Nz ? ln.kb : Nz - 1) * (unsigned)sizeof(LevelPack<NF>);
     if (RICHARDS) {
         gS.a += flux_S.a; gS.b += flux_S.b;
         sn.a = sat.a + gS.a * dt;
         sn.b = sat.b + gS.b * dt;
         bad = bad || (ln.act_a && is_nan(sn.a)) || (ln.act_b && is_nan(sn.b));
         over = repair_saturation_deep<NF>(sn, ln, Nz, dzc, rdzc, v.g.dzc_top);
+        asm volatile("" : "+v"(late_a), "+v"(late_b));   // (the late geometry is addressed from here on: not hoisted above the stencil)
         // compute_water_table! (soil_hydrology.jl:170-175): lower face of the first unsaturated cell from the bottom
         const Mask128 unsat = level_mask(ln.act_a && sn.a < NF(1), ln.act_b && sn.b < NF(1));
-        const Two<NF> zFlo{La.zFlo, Lb.zFlo};
+        const Two<NF> zFlo{level_word(v, late_a, 2), level_word(v, late_b, 2)};
         const int first = any(unsat) ? lowest(unsat) : -1;
         const NF z_first = from_level(zFlo, first >= 0 ? first : 0);
         z0 = first >= 0 ? z_first : v.g.zF_top;
@@ -268,8 +285,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         energy_closure_wave(p2, Un.a, sn.a, ln_.a, Tn.a, viol_a);
         energy_closure_wave(p2, Un.b, sn.b, ln_.b, Tn.b, viol_b);
         if (RICHARDS) {
-            psin.a = pressure_head<NF, HYD>(p2, sn.a, La.zC, La.psiz, z0);
-            psin.b = pressure_head<NF, HYD>(p2, sn.b, Lb.zC, Lb.psiz, z0);
+            psin.a = pressure_head<NF, HYD>(p2, sn.a, level_word(v, late_a, 0), level_word(v, late_a, 1), z0);
+            psin.b = pressure_head<NF, HYD>(p2, sn.b, level_word(v, late_b, 0), level_word(v, late_b, 1), z0);
         }
     }
     Two<NF> Kf_out = Kf_lo;
