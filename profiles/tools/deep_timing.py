@@ -5,8 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
 import numpy as np
 import workloads as W
-lat, lon = W.columns_from_mask("N145")
-out = {}
+mask = sys.argv[1] if len(sys.argv) > 1 else "N145"   # N72: 14 017 columns -- every state of the comparison fits the Infinity Cache
+lat, lon = W.columns_from_mask(mask)
+out = {"mask": mask, "columns": int(lat.size)}
 for config in ("heat", "richards"):
     for Nz, kernel in ((64, "fused"), (100, "fused"), (128, "fused"), (100, "unfused")):
         w = W.make_workload(config, lat, lon, Nz)
