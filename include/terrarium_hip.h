@@ -186,8 +186,8 @@ enum {
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
                                 /* wavefront shuffles for the vertical stencil (Nz <= 64; two levels per lane */
-                                /* for 65 ... 128 levels with the branch-free boundary kinds, ForwardEuler;   */
-                                /* anything deeper takes the unfused kernels)                                 */
+                                /* for 65 ... 128 levels with the branch-free boundary kinds, ForwardEuler    */
+                                /* and Heun; anything deeper takes the unfused kernels)                       */
     TRM_KERNEL_UNFUSED = 1      /* one launch per reference kernel, in the reference's order (A/B comparator) */
 };
 
@@ -411,8 +411,8 @@ int trm_invclosure(trm_ctx* ctx);
  * step has run.  TRM_KERNEL_UNFUSED materialises them at every step. */
 int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* Same for Heun (heun.jl:37-71): with TRM_KERNEL_FUSED and Nz <= 64 ONE launch per step (both stages on the column held in
- * registers; the stage never touches memory; every boundary kind), four for TRM_VEGETATION_COUPLED; otherwise the
- * reference-order kernels on a second copy of the state. */
+ * registers; the stage never touches memory; every boundary kind), four for TRM_VEGETATION_COUPLED; ONE launch for 65 ... 128
+ * levels with the branch-free boundary kinds as well; otherwise the reference-order kernels on a second copy of the state. */
 int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
 /* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
 int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);

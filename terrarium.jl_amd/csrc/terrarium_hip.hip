@@ -1042,18 +1042,35 @@ template <class NF> struct Ops {
     }
     // columns of 65 ... 128 levels: two levels per lane, one column per wavefront (trm_column_deep.hpp)
     static bool deep_columns(const trm_ctx* c) { return c->Nz > 64 && c->Nz <= 128; }
-    template <bool RICH, int H> static int launch_deep(trm_ctx* c, double dt, int finalize) {
+    template <bool RICH, int H, int PROG = PROG_EULER> static int launch_deep(trm_ctx* c, double dt, int finalize) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         ColumnArgs<NF> a{};
         a.dt = (NF)dt;
         a.finalize = finalize;
         a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
         a.nsteps = 1;
+        a.bcT_bot_stage = la.w.bcT_bot;      // Heun: the stage's temperature boundary values (evaluated at t + dt)
+        a.bcT_top_stage = la.w.bcT_top;
         const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
-        if (derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
-        else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+        if (derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+        else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
+    }
+    // Heun of deep columns: the sequence of heun_step_fused with k_column_deep<PROG_HEUN> as the column program
+    static int heun_step_deep(trm_ctx* c, double dt, int finalize) {
+        int rc = update_inputs(c, c->state, c->time);
+        if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
+        if (!rc && c->params.seb) rc = surface(c, c->state, true);
+        if (!rc) {
+            if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H, PROG_HEUN>(c, dt, finalize))); }
+            else { TRM_BY_HYD(c, rc = (launch_deep<false, H, PROG_HEUN>(c, dt, finalize))); }
+        }
+        if (!rc) c->closure_consistent = true;
+        c->tend_valid = finalize != 0;
+        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+        if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
+        return rc;
     }
     // one fused ForwardEuler step (the state's surface processes have run)
     static int wave_step(trm_ctx* c, double dt, int finalize) {
@@ -1367,6 +1384,7 @@ template <class NF> struct Ops {
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && deep_columns(c) && !generic_bcs(c) && !coupled(c)) return heun_step_deep(c, dt, finalize);
         c->top_valid = false;
         c->tend_valid = true;
         c->closure_consistent = true;   // (ends with closure!)

@@ -6,7 +6,8 @@
 // per field, the k - 1 neighbour of a is the previous lane's b (one DPP shift), of b the lane's own a (free); likewise
 // upwards.  Ballots come in pairs (a cells, b cells).  Every operation is the one k_column<PROG_EULER> / the reference-order
 // kernels perform on the cell, in the same order: results are bit-identical (tests/test_gpu_deep_columns.py).
-// Scope: the branch-free boundary kinds (as k_column), Euler, no derivation of T / liq; anything else keeps the unfused path.
+// Scope: the branch-free boundary kinds (as k_column), ForwardEuler and Heun (both stages in registers, one launch), with the
+// derivation of T / liq; generic boundary kinds, the coupled vegetation and Nz > 128 keep the reference-order kernels.
 #pragma once
 #include "trm_column.hpp"
 
@@ -140,9 +141,12 @@ TRM_DEV NF repair_saturation_deep(Two<NF>& s, const DeepLane& ln, int Nz, const 
 template <class NF> TRM_DEV NF level_word(const View<NF>& v, unsigned rec, int w) {
     return *reinterpret_cast<const NF*>(reinterpret_cast<const char*>(v.lvl) + rec + (unsigned)w * (unsigned)sizeof(NF));
 }
-template <class NF, bool RICHARDS, int HYD, bool DERIVE = false>
+// PROG: PROG_EULER, or PROG_HEUN -- both stages of the reference's Heun (heun.jl:37-71) on the column in registers, one launch
+// per step, the sequence of column_program<PROG_HEUN> (trm_column.hpp) cell by cell.
+template <class NF, bool RICHARDS, int HYD, bool DERIVE = false, int PROG = PROG_EULER>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(TRM_DEEP_WAVES, 8)))
     k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
+    static_assert(PROG == PROG_EULER || PROG == PROG_HEUN, "deep columns: Euler and Heun");
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
@@ -175,7 +179,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
 
     // per-level geometry of both cells (the level records of trm_kernels.hpp: level_geom).  Only what the tendencies and the
     // repair need is fetched here (thickness, its reciprocal, the face reciprocals); zC, psiz and zFlo serve the water table and
-    // the pressure head at the END of the program and are fetched there (level_word): 12 registers less across the stencil.
+    // the pressure head at the END of a stage and are fetched there (level_word): 12 registers less across the stencil.
     struct EarlyGeom { NF dzc, rdzc, rdzf_lo, rdzf_hi; };
     auto early = [&](int k) {
         const int kk = k < Nz ? k : Nz - 1;
@@ -202,47 +206,94 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
     const NF bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0), bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
 
-    // ---- compute_auxiliary! + compute_tendencies! (column_tendencies, trm_column.hpp, per cell) -----------------------
-    uint32_t viol_old = 0;
-    const Frac<NF> fa = fractions(p, sat.a, liq.a, viol_old), fb = fractions(p, sat.b, liq.b, viol_old);
-    const Two<NF> kap{conductivity(p, fa), conductivity(p, fb)};
-    const Two<NF> Kc{need_kc ? conductivity_hydraulic<NF, HYD, false>(p, liq.a, fa) : NF(0), need_kc ? conductivity_hydraulic<NF, HYD, false>(p, liq.b, fb) : NF(0)};
-    const Two<NF> T_dn = below(T), kap_dn = below(kap);
-    // temperature halos of the edge cells
-    auto ext_b = [&](NF Tc) { return vTb ? Tc + div_const(Tc - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot) : Tc; };
-    auto ext_t = [&](NF Tc) { return vTt ? Tc + div_const(bTt - Tc, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top : Tc; };
-    auto halo_kap = [&](NF kc, NF lq, uint32_t& vl) { return (!RICHARDS && p.halo_policy != 1) ? conductivity(p, fractions(p, NF(0), lq, vl)) : kc; };
-    const NF T_m_a = ln.bot_a ? ext_b(T.a) : T_dn.a, T_m_b = T_dn.b;
-    const NF kap_halo_a = halo_kap(kap.a, liq.a, viol_a), kap_halo_b = halo_kap(kap.b, liq.b, viol_b);
-    const NF kap_m_a = ln.bot_a ? kap_halo_a : kap_dn.a, kap_m_b = kap_dn.b;
-    const Two<NF> qT_lo{-(NF(0.5) * (kap.a + kap_m_a)) * ((T.a - T_m_a) * La.rdzf_lo), -(NF(0.5) * (kap.b + kap_m_b)) * ((T.b - T_m_b) * Lb.rdzf_lo)};
-    const Two<NF> qT_up = above(qT_lo);
-    const NF qT_hi_a = ln.top_a ? -(NF(0.5) * (kap_halo_a + kap.a)) * ((ext_t(T.a) - T.a) * La.rdzf_hi) : qT_up.a;
-    const NF qT_hi_b = ln.top_b ? -(NF(0.5) * (kap_halo_b + kap.b)) * ((ext_t(T.b) - T.b) * Lb.rdzf_hi) : qT_up.b;
-    Two<NF> gU{NF(0) + (-((qT_hi_a - qT_lo.a) * La.rdzc)), NF(0) + (-((qT_hi_b - qT_lo.b) * Lb.rdzc))};
-    Two<NF> gS{NF(0), NF(0)}, Kf_lo{NF(0), NF(0)};
-    if (need_kc) {   // face conductivities (soil_hydrology.jl:145-163)
-        const Two<NF> Kc_dn = below(Kc);
-        const NF Kmin_a = jl_min(Kc.a, Kc_dn.a), Kmin_b = jl_min(Kc.b, Kc_dn.b);
-        Kf_lo.a = (ln.bot_a || ln.top_a) ? Kc.a : Kmin_a;
-        Kf_lo.b = ln.top_b ? Kc.b : Kmin_b;
-    }
-    if (RICHARDS) {  // Darcy fluxes (soil_hydrology_rre.jl:95-131)
-        const Two<NF> Kf_dn = below(Kf_lo), Kf_up = above(Kf_lo), psi_dn = below(psi);
-        const NF Kf_m_a = ln.bot_a ? NF(0) : Kf_dn.a, Kf_m_b = Kf_dn.b;
-        const NF Kf_p_a = ln.top_a ? Kc.a : Kf_up.a, Kf_p_b = ln.top_b ? Kc.b : Kf_up.b;
-        const NF psi_m_a = ln.bot_a ? psi.a : psi_dn.a, psi_m_b = psi_dn.b;
-        const NF g_lo_a = (psi.a - psi_m_a) * La.rdzf_lo, g_lo_b = (psi.b - psi_m_b) * Lb.rdzf_lo;
-        const Two<NF> qW_lo{-upwind_conductivity(g_lo_a, Kf_m_a, Kf_lo.a, Kf_p_a) * g_lo_a, -upwind_conductivity(g_lo_b, Kf_m_b, Kf_lo.b, Kf_p_b) * g_lo_b};
-        const Two<NF> qW_up = above(qW_lo);
-        const NF qW_t_a = -jl_min(Kc.a, NF(0)) * (psi.a - psi.a), qW_t_b = -jl_min(Kc.b, NF(0)) * (psi.b - psi.b);
-        const NF qW_hi_a = ln.top_a ? qW_t_a : qW_up.a, qW_hi_b = ln.top_b ? qW_t_b : qW_up.b;
-        const NF dth_a = -((qW_hi_a - qW_lo.a) * La.rdzc) + NF(0) + p.vwc_forcing, dth_b = -((qW_hi_b - qW_lo.b) * Lb.rdzc) + NF(0) + p.vwc_forcing;
-        gS.a = NF(0) + div_const(dth_a, p.por, p.rpor);
-        gS.b = NF(0) + div_const(dth_b, p.por, p.rpor);
-    }
-    // ---- compute_z_bcs! + explicit_step! + hydrology closure (column_advance) -------------------------------------------
-    // The boundary flux terms and the 0-D inputs are fetched HERE: after the stencil (its registers are free again), in front
+    // ---- compute_auxiliary! + compute_tendencies! (column_tendencies, trm_column.hpp, per cell) of a (T, liq, sat, psi) ----
+    struct Tend { Two<NF> gU, gS, Kf_lo, Kc; };
+    auto tendencies = [&](const View<NF>& v, const DevParams<NF>& p, const Two<NF>& T, const Two<NF>& liq, const Two<NF>& sat, const Two<NF>& psi,
+                          NF bTb, NF bTt, bool need_kc, uint32_t& viol_a, uint32_t& viol_b) {
+        uint32_t viol_old = 0;
+        const Frac<NF> fa = fractions(p, sat.a, liq.a, viol_old), fb = fractions(p, sat.b, liq.b, viol_old);
+        const Two<NF> kap{conductivity(p, fa), conductivity(p, fb)};
+        const Two<NF> Kc{need_kc ? conductivity_hydraulic<NF, HYD, false>(p, liq.a, fa) : NF(0), need_kc ? conductivity_hydraulic<NF, HYD, false>(p, liq.b, fb) : NF(0)};
+        const Two<NF> T_dn = below(T), kap_dn = below(kap);
+        // temperature halos of the edge cells
+        auto ext_b = [&](NF Tc) { return vTb ? Tc + div_const(Tc - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot) : Tc; };
+        auto ext_t = [&](NF Tc) { return vTt ? Tc + div_const(bTt - Tc, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top : Tc; };
+        auto halo_kap = [&](NF kc, NF lq, uint32_t& vl) { return (!RICHARDS && p.halo_policy != 1) ? conductivity(p, fractions(p, NF(0), lq, vl)) : kc; };
+        const NF T_m_a = ln.bot_a ? ext_b(T.a) : T_dn.a, T_m_b = T_dn.b;
+        const NF kap_halo_a = halo_kap(kap.a, liq.a, viol_a), kap_halo_b = halo_kap(kap.b, liq.b, viol_b);
+        const NF kap_m_a = ln.bot_a ? kap_halo_a : kap_dn.a, kap_m_b = kap_dn.b;
+        const Two<NF> qT_lo{-(NF(0.5) * (kap.a + kap_m_a)) * ((T.a - T_m_a) * La.rdzf_lo), -(NF(0.5) * (kap.b + kap_m_b)) * ((T.b - T_m_b) * Lb.rdzf_lo)};
+        const Two<NF> qT_up = above(qT_lo);
+        const NF qT_hi_a = ln.top_a ? -(NF(0.5) * (kap_halo_a + kap.a)) * ((ext_t(T.a) - T.a) * La.rdzf_hi) : qT_up.a;
+        const NF qT_hi_b = ln.top_b ? -(NF(0.5) * (kap_halo_b + kap.b)) * ((ext_t(T.b) - T.b) * Lb.rdzf_hi) : qT_up.b;
+        Tend t;
+        t.gU = Two<NF>{NF(0) + (-((qT_hi_a - qT_lo.a) * La.rdzc)), NF(0) + (-((qT_hi_b - qT_lo.b) * Lb.rdzc))};
+        t.gS = Two<NF>{NF(0), NF(0)};
+        t.Kf_lo = Two<NF>{NF(0), NF(0)};
+        t.Kc = Kc;
+        if (need_kc) {   // face conductivities (soil_hydrology.jl:145-163)
+            const Two<NF> Kc_dn = below(Kc);
+            const NF Kmin_a = jl_min(Kc.a, Kc_dn.a), Kmin_b = jl_min(Kc.b, Kc_dn.b);
+            t.Kf_lo.a = (ln.bot_a || ln.top_a) ? Kc.a : Kmin_a;
+            t.Kf_lo.b = ln.top_b ? Kc.b : Kmin_b;
+        }
+        if (RICHARDS) {  // Darcy fluxes (soil_hydrology_rre.jl:95-131)
+            const Two<NF> Kf_lo = t.Kf_lo;
+            const Two<NF> Kf_dn = below(Kf_lo), Kf_up = above(Kf_lo), psi_dn = below(psi);
+            const NF Kf_m_a = ln.bot_a ? NF(0) : Kf_dn.a, Kf_m_b = Kf_dn.b;
+            const NF Kf_p_a = ln.top_a ? Kc.a : Kf_up.a, Kf_p_b = ln.top_b ? Kc.b : Kf_up.b;
+            const NF psi_m_a = ln.bot_a ? psi.a : psi_dn.a, psi_m_b = psi_dn.b;
+            const NF g_lo_a = (psi.a - psi_m_a) * La.rdzf_lo, g_lo_b = (psi.b - psi_m_b) * Lb.rdzf_lo;
+            const Two<NF> qW_lo{-upwind_conductivity(g_lo_a, Kf_m_a, Kf_lo.a, Kf_p_a) * g_lo_a, -upwind_conductivity(g_lo_b, Kf_m_b, Kf_lo.b, Kf_p_b) * g_lo_b};
+            const Two<NF> qW_up = above(qW_lo);
+            const NF qW_t_a = -jl_min(Kc.a, NF(0)) * (psi.a - psi.a), qW_t_b = -jl_min(Kc.b, NF(0)) * (psi.b - psi.b);
+            const NF qW_hi_a = ln.top_a ? qW_t_a : qW_up.a, qW_hi_b = ln.top_b ? qW_t_b : qW_up.b;
+            const NF dth_a = -((qW_hi_a - qW_lo.a) * La.rdzc) + NF(0) + p.vwc_forcing, dth_b = -((qW_hi_b - qW_lo.b) * Lb.rdzc) + NF(0) + p.vwc_forcing;
+            t.gS.a = NF(0) + div_const(dth_a, p.por, p.rpor);
+            t.gS.b = NF(0) + div_const(dth_b, p.por, p.rpor);
+        }
+        return t;
+    };
+    // ---- compute_z_bcs! + explicit_step! + hydrology closure's repair and water table (column_advance) of the STATE's (U, sat)
+    unsigned late_a = (unsigned)(ln.ka < Nz ? ln.ka : Nz - 1) * (unsigned)sizeof(LevelPack<NF>), late_b = (unsigned)(ln.kb < Nz ? ln.kb : Nz - 1) * (unsigned)sizeof(LevelPack<NF>);
+    auto advance = [&](Two<NF>& gU, Two<NF>& gS, const Two<NF>& flux_U, const Two<NF>& flux_S, Two<NF>& Un, Two<NF>& sn, NF& z0) {
+        gU.a += flux_U.a; gU.b += flux_U.b;
+        Un = Two<NF>{U.a + gU.a * dt, U.b + gU.b * dt};
+        bad = bad || (ln.act_a && is_nan(Un.a)) || (ln.act_b && is_nan(Un.b));
+        sn = sat;
+        z0 = NF(0);
+        NF over = NF(0);
+        if (RICHARDS) {
+            gS.a += flux_S.a; gS.b += flux_S.b;
+            sn.a = sat.a + gS.a * dt;
+            sn.b = sat.b + gS.b * dt;
+            bad = bad || (ln.act_a && is_nan(sn.a)) || (ln.act_b && is_nan(sn.b));
+            over = repair_saturation_deep<NF>(sn, ln, Nz, dzc, rdzc, v.g.dzc_top);
+            asm volatile("" : "+v"(late_a), "+v"(late_b));   // (the late geometry is addressed from here on: not hoisted above the stencil)
+            // compute_water_table! (soil_hydrology.jl:170-175): lower face of the first unsaturated cell from the bottom
+            const Mask128 unsat = level_mask(ln.act_a && sn.a < NF(1), ln.act_b && sn.b < NF(1));
+            const Two<NF> zFlo{level_word(v, late_a, 2), level_word(v, late_b, 2)};
+            const int first = any(unsat) ? lowest(unsat) : -1;
+            const NF z_first = from_level(zFlo, first >= 0 ? first : 0);
+            z0 = first >= 0 ? z_first : v.g.zF_top;
+        }
+        return over;
+    };
+    // ---- closures (column_closure): (U, sat) -> (T, liq, psi), parameters fetched afresh -----------------------------------
+    auto closure = [&](const Two<NF>& Un, const Two<NF>& sn, NF z0, Two<NF>& ln_, Two<NF>& Tn, Two<NF>& psin) {
+        const DevParams<NF>& p2 = kernarg_reload<DevParams<NF>>(off_p);
+        // (one ballot decision for the wave's phase-change divide per cell set, as energy_closure_wave)
+        energy_closure_wave(p2, Un.a, sn.a, ln_.a, Tn.a, viol_a);
+        energy_closure_wave(p2, Un.b, sn.b, ln_.b, Tn.b, viol_b);
+        psin = Two<NF>{NF(0), NF(0)};
+        if (RICHARDS) {
+            psin.a = pressure_head<NF, HYD>(p2, sn.a, level_word(v, late_a, 0), level_word(v, late_a, 1), z0);
+            psin.b = pressure_head<NF, HYD>(p2, sn.b, level_word(v, late_b, 0), level_word(v, late_b, 1), z0);
+        }
+    };
+
+    Tend t = tendencies(v, p, T, liq, sat, psi, bTb, bTt, need_kc, viol_a, viol_b);   // tendencies at the STATE (hydraulic_conductivity comes from here)
+    // The boundary flux terms and the 0-D inputs are fetched HERE: after the first stencil (its registers are free again), in front
     // of every store (no load sits behind a store: see column_program).
     unsigned ib_late = ib0;
     asm volatile("" : "+v"(ib_late));
@@ -257,39 +308,30 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const NF S_in = RICHARDS ? ldg(v.S, ib_late) : NF(0), Ts_in = seb ? ldg(v.Ts, ib_late) : NF(0);
     const Two<NF> flux_U{ln.bot_a ? eU_b : (ln.top_a ? eU_t : NF(0)), ln.top_b ? eU_t : NF(0)};
     const Two<NF> flux_S{ln.bot_a ? eS_b : (ln.top_a ? eS_t : NF(0)), ln.top_b ? eS_t : NF(0)};
-    gU.a += flux_U.a; gU.b += flux_U.b;
-    Two<NF> Un{U.a + gU.a * dt, U.b + gU.b * dt};
-    bad = bad || (ln.act_a && is_nan(Un.a)) || (ln.act_b && is_nan(Un.b));
-    Two<NF> sn = sat;
-    NF z0 = NF(0), over = NF(0);
-    unsigned late_a = (unsigned)(ln.ka < Nz ? ln.ka : Nz - 1) * (unsigned)sizeof(LevelPack<NF>), late_b = (unsigned)(ln.kb < Nz ? ln.kb : Nz - 1) * (unsigned)sizeof(LevelPack<NF>);
-    if (RICHARDS) {
-        gS.a += flux_S.a; gS.b += flux_S.b;
-        sn.a = sat.a + gS.a * dt;
-        sn.b = sat.b + gS.b * dt;
-        bad = bad || (ln.act_a && is_nan(sn.a)) || (ln.act_b && is_nan(sn.b));
-        over = repair_saturation_deep<NF>(sn, ln, Nz, dzc, rdzc, v.g.dzc_top);
-        asm volatile("" : "+v"(late_a), "+v"(late_b));   // (the late geometry is addressed from here on: not hoisted above the stencil)
-        // compute_water_table! (soil_hydrology.jl:170-175): lower face of the first unsaturated cell from the bottom
-        const Mask128 unsat = level_mask(ln.act_a && sn.a < NF(1), ln.act_b && sn.b < NF(1));
-        const Two<NF> zFlo{level_word(v, late_a, 2), level_word(v, late_b, 2)};
-        const int first = any(unsat) ? lowest(unsat) : -1;
-        const NF z_first = from_level(zFlo, first >= 0 ? first : 0);
-        z0 = first >= 0 ? z_first : v.g.zF_top;
+
+    Two<NF> gU = t.gU, gS = t.gS, Un, sn, ln_, Tn, psin;
+    NF z0 = NF(0), over = NF(0), over_stage = NF(0);
+    if (PROG == PROG_HEUN) {
+        // stage 1: Euler predictor with the state's boundary fluxes and its closures (the stage never leaves the registers)
+        const Two<NF> G1U = t.gU, G1S = t.gS;
+        Two<NF> Us, ss, ls, Ts, ps;
+        NF z0s;
+        over_stage = advance(gU, gS, flux_U, flux_S, Us, ss, z0s);
+        closure(Us, ss, z0s, ls, Ts, ps);
+        // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
+        const NF bTb2 = vTb ? ldg(a.bcT_bot_stage, ib_late) : NF(0), bTt2 = vTt ? ldg(a.bcT_top_stage, ib_late) : NF(0);
+        uint32_t vs_a = 0, vs_b = 0;
+        const Tend t2 = tendencies(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), Ts, ls, ss, ps, bTb2, bTt2, RICHARDS, vs_a, vs_b);
+        viol_a |= vs_a; viol_b |= vs_b;
+        // average_tendencies! (heun.jl:27-35), then the step of the STATE with its own boundary fluxes
+        gU = Two<NF>{(G1U.a + t2.gU.a) / NF(2), (G1U.b + t2.gU.b) / NF(2)};
+        gS = RICHARDS ? Two<NF>{(G1S.a + t2.gS.a) / NF(2), (G1S.b + t2.gS.b) / NF(2)} : Two<NF>{NF(0), NF(0)};
     }
-    // ---- closures (column_closure): (U, sat) -> (T, liq, psi), parameters fetched afresh -----------------------------------
-    Two<NF> ln_, Tn, psin{NF(0), NF(0)};
-    {
-        const DevParams<NF>& p2 = kernarg_reload<DevParams<NF>>(off_p);
-        // (one ballot decision for the wave's phase-change divide per cell set, as energy_closure_wave)
-        energy_closure_wave(p2, Un.a, sn.a, ln_.a, Tn.a, viol_a);
-        energy_closure_wave(p2, Un.b, sn.b, ln_.b, Tn.b, viol_b);
-        if (RICHARDS) {
-            psin.a = pressure_head<NF, HYD>(p2, sn.a, level_word(v, late_a, 0), level_word(v, late_a, 1), z0);
-            psin.b = pressure_head<NF, HYD>(p2, sn.b, level_word(v, late_b, 0), level_word(v, late_b, 1), z0);
-        }
-    }
-    Two<NF> Kf_out = Kf_lo;
+    over = advance(gU, gS, flux_U, flux_S, Un, sn, z0);
+    closure(Un, sn, z0, ln_, Tn, psin);
+
+    Two<NF> Kf_out = t.Kf_lo;
+    const Two<NF> Kc = t.Kc;
     NF Kf_out_top = ln.top_a ? Kc.a : Kc.b;
     if (finalize && write_kf) {
         const DevParams<NF>& pf = kernarg_reload<DevParams<NF>>(off_p);
@@ -301,13 +343,24 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         Kf_out.b = ln.top_b ? Kn.b : Kmin_b;
         Kf_out_top = ln.top_a ? Kn.a : Kn.b;
     }
+    // surface_excess_water after the step, formed before the first store (column_program)
+    NF S = NF(0), GS = NF(0);
+    if (RICHARDS) {
+        S = S_in;
+        GS = NF(0) + jl_min(NF(0), S);
+        if (PROG == PROG_HEUN) {
+            const NF S_stage = (S + GS * dt) + over_stage;
+            GS = (GS + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
+        }
+        S = (S + GS * dt) + over;
+    }
     // ---- the column goes out -------------------------------------------------------------------------------------------
     const View<NF>& vo = kernarg_reload<View<NF>>(0);
-    auto store_cell = [&](bool act, unsigned cb_, NF u, NF t, NF l, NF s, NF ps, NF kf, NF gu, NF gs) {
+    auto store_cell = [&](bool act, unsigned cb_, NF u, NF t_, NF l, NF s, NF ps, NF kf, NF gu, NF gs) {
         if (!act) return;
         const unsigned cb = block_local(cb_);
         stg(vo.U, cb, u);
-        stg(vo.T, cb, t);
+        stg(vo.T, cb, t_);
         stg(vo.liq, cb, l);
         if (RICHARDS) { stg(vo.sat, cb, s); stg(vo.psi, cb, ps); }
         if (finalize) {
@@ -324,9 +377,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         const NF Tt = ln.top_a ? Tn.a : Tn.b, st = ln.top_a ? sn.a : sn.b, lt = ln.top_a ? ln_.a : ln_.b;
         if (write_kf) stg(vo.Kf_top, ib, Kf_out_top);
         if (RICHARDS) {
-            NF S = S_in;
-            const NF GS = NF(0) + jl_min(NF(0), S);
-            S = (S + GS * dt) + over;
             stg(vo.S, ib, S);
             stg(vo.wt, ib, z0);
             if (finalize) stg(vo.G_S, ib, GS);

@@ -86,3 +86,40 @@ def test_deep_columns_with_generic_boundary_kinds_keep_the_reference_order_kerne
         d.set_bc("temperature", "bottom", "gradient", 0.01)
         d.step(w["dt"], 12, finalize=True)
     assert np.array_equal(a.get("temperature"), b.get("temperature"))
+
+
+# heun.jl:37-71 on deep columns: both stages of k_column_deep<PROG_HEUN> in registers, one launch per step -- bit for bit the
+# reference-order (staged) Heun and the oracle's, incl. boundary series evaluated at t for the state and t + dt for the stage
+HEUN_CASES = [("heat", "default", np.float64, 100, 60), ("richards", "default", np.float64, 100, 75), ("richards", "vg", np.float64, 127, 9),
+              ("land", "default", np.float64, 96, 40), ("richards", "default", np.float32, 128, 33), ("land", "vg", np.float32, 65, 21)]
+
+
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz,Nh", HEUN_CASES)
+def test_deep_columns_heun_in_one_launch_equals_the_staged_heun_bitwise(config, hydraulics, dtype, Nz, Nh):
+    lat, lon = small_columns(Nh)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    if config == "richards":
+        w["bcs"][("saturation_water_ice", "top")] = ("flux", np.full(lat.size, -1.0e-7))
+    a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("derive_closure_fields", 1 if Nz % 2 else 0)
+    b.set_option("step_kernel", "unfused")
+    o = W.setup_oracle(w) if (dtype == np.float64 and hydraulics == "default" and config != "land") else None
+    if config != "land":      # a time-dependent top temperature: the stage takes its value at t + dt
+        times = w["dt"] * np.arange(0, 16)
+        vals = np.stack([w["T0"] + 10.0 * np.sin(2 * np.pi * t / 86400.0 - lon) + 0.01 * t / w["dt"] for t in times])
+        for d in (a, b) + ((o,) if o is not None else ()):
+            d.set_bc_series("temperature", "top", "value", times, vals)
+    nsteps = 12
+    for d in (a, b):
+        d.step_heun(w["dt"], 1, finalize=False)
+        d.step_heun(w["dt"], nsteps - 2, finalize=False)
+        d.step_heun(w["dt"], 1, finalize=True)
+    names = W.compared_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else [])
+    for n in names:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status() and a.clock() == b.clock()
+    if o is not None:
+        for k in range(nsteps):
+            o.timestep_heun(w["dt"], True)
+        for n in W.compared_fields(w):
+            assert np.array_equal(a.get(n), o.get(n)), n
