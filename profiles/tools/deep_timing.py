@@ -24,6 +24,23 @@ for config in ("heat", "richards"):
         us = float(np.median(ts))
         out[f"{config}_Nz{Nz}_{kernel}"] = {"us_per_step": round(us, 2), "ps_per_cell": round(us * 1e6 / (lat.size * Nz), 2), "status": d.status()}
         d.close()
+# Nz = 100: the resident multi-step program (the library default for nsteps > 1) and Heun in one launch against the staged Heun
+for config in ("heat", "richards"):
+    w = W.make_workload(config, lat, lon, 100)
+    for name, spl, kernel, heun in (("multistep", 0, "fused", False), ("heun_fused", 1, "fused", True), ("heun_unfused", 1, "unfused", True)):
+        d = W.setup_device(w, steps_per_launch=spl)
+        d.set_option("step_kernel", kernel)
+        step = d.step_heun_timed if heun else d.step_timed
+        d.step(w["dt"], 10, finalize=False)
+        d.save_state()
+        ts = []
+        for _ in range(5):
+            d.restore_state()
+            step(w["dt"], 50, finalize=False)
+            d.restore_state()
+            ts.append(step(w["dt"], 50, finalize=False) * 1e3 / 50)
+        out[f"{config}_Nz100_{name}"] = {"us_per_step": round(float(np.median(ts)), 2), "status": d.status()}
+        d.close()
 for config in ("heat", "richards"):
     out[f"{config}_per_cell_ratio_100_vs_64"] = round(out[f"{config}_Nz100_fused"]["ps_per_cell"] / out[f"{config}_Nz64_fused"]["ps_per_cell"], 3)
 print(json.dumps(out))

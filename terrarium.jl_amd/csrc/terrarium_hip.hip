@@ -1042,13 +1042,13 @@ template <class NF> struct Ops {
     }
     // columns of 65 ... 128 levels: two levels per lane, one column per wavefront (trm_column_deep.hpp)
     static bool deep_columns(const trm_ctx* c) { return c->Nz > 64 && c->Nz <= 128; }
-    template <bool RICH, int H, int PROG = PROG_EULER> static int launch_deep(trm_ctx* c, double dt, int finalize) {
+    template <bool RICH, int H, int PROG = PROG_EULER> static int launch_deep(trm_ctx* c, double dt, int finalize, int nsteps = 1) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         ColumnArgs<NF> a{};
         a.dt = (NF)dt;
         a.finalize = finalize;
         a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
-        a.nsteps = 1;
+        a.nsteps = nsteps;
         a.bcT_bot_stage = la.w.bcT_bot;      // Heun: the stage's temperature boundary values (evaluated at t + dt)
         a.bcT_top_stage = la.w.bcT_top;
         const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
@@ -1056,6 +1056,13 @@ template <class NF> struct Ops {
         else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
+    }
+    // the resident multi-step program on deep columns (no surface energy balance, no series: see step())
+    static int deep_program(trm_ctx* c, double dt, int finalize, int nsteps) {
+        int rc = TRM_OK;
+        if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H, PROG_MULTI>(c, dt, finalize, nsteps))); }
+        else { TRM_BY_HYD(c, rc = (launch_deep<false, H, PROG_MULTI>(c, dt, finalize, nsteps))); }
+        return rc;
     }
     // Heun of deep columns: the sequence of heun_step_fused with k_column_deep<PROG_HEUN> as the column program
     static int heun_step_deep(trm_ctx* c, double dt, int finalize) {
@@ -1106,7 +1113,7 @@ template <class NF> struct Ops {
     // against 6.4-12.5 on N72 / 7 119-column shards, 13.6 against 26 at N145.  fp32 contexts whose per-step path is the
     // packed kernel (two columns per lane) keep it: the program runs the scalar fp32 instructions at the fp64 issue rate.
     static int auto_steps_per_launch(trm_ctx* c) {
-        if (std::is_same<NF, float>::value && packed_path(c)) return 1;
+        if (std::is_same<NF, float>::value && packed_path(c) && !deep_columns(c)) return 1;   // (deep columns never take the packed kernel)
         return 50;
     }
     // ---- LandModel, per-step path: the surface processes of one half of the columns UNDER the column program of the other ----
@@ -1219,7 +1226,9 @@ template <class NF> struct Ops {
         const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || (deep_columns(c) && !generic_bcs(c) && !coupled(c)));
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
-        const bool program_ok = fused && c->Nz <= 64 && !generic_bcs(c) && series_fit_program(c) && !coupled(c);
+        // (columns of 65 ... 128 levels: contexts without the surface energy balance and without series)
+        const bool program_ok = fused && !generic_bcs(c) && !coupled(c) &&
+                                ((c->Nz <= 64 && series_fit_program(c)) || (deep_columns(c) && !c->params.seb && c->series.empty()));
         const int spl = !program_ok ? 1 : (c->opt_steps_per_launch > 0 ? c->opt_steps_per_launch : auto_steps_per_launch(c));
         int n = 0, rc = TRM_OK;
         while (n < nsteps && !rc) {
@@ -1233,7 +1242,7 @@ template <class NF> struct Ops {
                 if (!rc) c->closure_consistent = true;   // closure! has just run
             } else if (m > 1) {
                 rc = c->series.empty() ? update_inputs(c, c->state, c->time) : upload_series_rows(c, dt, m);
-                if (!rc) rc = column_program<PROG_MULTI>(c, dt, fin, m);
+                if (!rc) rc = deep_columns(c) ? deep_program(c, dt, fin, m) : column_program<PROG_MULTI>(c, dt, fin, m);
                 if (!rc) c->closure_consistent = true;
                 c->tend_valid = fin != 0;
                 c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;

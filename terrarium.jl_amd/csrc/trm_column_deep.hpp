@@ -146,7 +146,8 @@ template <class NF> TRM_DEV NF level_word(const View<NF>& v, unsigned rec, int w
 template <class NF, bool RICHARDS, int HYD, bool DERIVE = false, int PROG = PROG_EULER>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(TRM_DEEP_WAVES, 8)))
     k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
-    static_assert(PROG == PROG_EULER || PROG == PROG_HEUN, "deep columns: Euler and Heun");
+    // PROG_MULTI: a.nsteps ForwardEuler steps on the resident column (contexts without the surface energy balance and without
+    // time series: constants between the steps), fields written once per launch -- column_program<PROG_MULTI>'s loop.
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
@@ -190,8 +191,8 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const Two<NF> dzc{La.dzc, Lb.dzc}, rdzc{La.rdzc, Lb.rdzc};
 
     // ---- the column comes in ---------------------------------------------------------------------------------------
-    const Two<NF> U = ld2cells(v.U, cb0), sat = ld2cells(v.sat, cb0);
-    const Two<NF> psi = RICHARDS ? ld2cells(v.psi, cb0) : Two<NF>{NF(0), NF(0)};
+    Two<NF> U = ld2cells(v.U, cb0), sat = ld2cells(v.sat, cb0);
+    Two<NF> psi = RICHARDS ? ld2cells(v.psi, cb0) : Two<NF>{NF(0), NF(0)};
     Two<NF> T, liq;
     if (DERIVE) {   // (T, liq) of the incoming state re-derived from (U, sat) instead of being read (k_column: DERIVE_T_LIQ)
         uint32_t viol_in = 0;
@@ -329,6 +330,25 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     }
     over = advance(gU, gS, flux_U, flux_S, Un, sn, z0);
     closure(Un, sn, z0, ln_, Tn, psin);
+    NF S_multi = S_in, GS_multi = NF(0);
+    if (PROG == PROG_MULTI) {
+        if (RICHARDS) {   // surface_excess_water carried in the register: tendency min(0, S), Euler update, overflow -- per step
+            GS_multi = NF(0) + jl_min(NF(0), S_multi);
+            S_multi = (S_multi + GS_multi * dt) + over;
+        }
+        for (int step = 1; step < a.nsteps; ++step) {
+            // (the loop reads its kernel arguments afresh every iteration, see kernarg_reload)
+            U = Un; sat = sn; T = Tn; liq = ln_; psi = psin;
+            t = tendencies(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), T, liq, sat, psi, bTb, bTt, need_kc, viol_a, viol_b);
+            gU = t.gU; gS = t.gS;
+            over = advance(gU, gS, flux_U, flux_S, Un, sn, z0);
+            closure(Un, sn, z0, ln_, Tn, psin);
+            if (RICHARDS) {
+                GS_multi = NF(0) + jl_min(NF(0), S_multi);
+                S_multi = (S_multi + GS_multi * dt) + over;
+            }
+        }
+    }
 
     Two<NF> Kf_out = t.Kf_lo;
     const Two<NF> Kc = t.Kc;
@@ -345,7 +365,10 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     }
     // surface_excess_water after the step, formed before the first store (column_program)
     NF S = NF(0), GS = NF(0);
-    if (RICHARDS) {
+    if (RICHARDS && PROG == PROG_MULTI) {
+        S = S_multi;
+        GS = GS_multi;
+    } else if (RICHARDS) {
         S = S_in;
         GS = NF(0) + jl_min(NF(0), S);
         if (PROG == PROG_HEUN) {

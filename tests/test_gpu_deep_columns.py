@@ -123,3 +123,27 @@ def test_deep_columns_heun_in_one_launch_equals_the_staged_heun_bitwise(config, 
             o.timestep_heun(w["dt"], True)
         for n in W.compared_fields(w):
             assert np.array_equal(a.get(n), o.get(n)), n
+
+
+# model_integrator.jl:72-88 (run!'s loop) on deep columns: the resident multi-step program of k_column_deep -- the library's default
+# for nsteps > 1 without the surface energy balance and without series -- equals one launch per step bit for bit
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz,Nh", [("heat", "default", np.float64, 100, 70), ("richards", "default", np.float64, 100, 90),
+                                                            ("richards", "vg", np.float64, 65, 17), ("richards", "default", np.float32, 128, 40)])
+def test_deep_columns_multistep_program_equals_per_step_launches_bitwise(config, hydraulics, dtype, Nz, Nh):
+    lat, lon = small_columns(Nh)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    if config == "richards":
+        w["bcs"][("saturation_water_ice", "top")] = ("flux", np.full(lat.size, -2.0e-7))
+    a, b, c = W.setup_device(w, steps_per_launch=0), W.setup_device(w, steps_per_launch=1), W.setup_device(w, steps_per_launch=7)
+    for d in (a, b, c):
+        d.step(w["dt"], 23, finalize=False)
+        d.step(w["dt"], 10, finalize=True)
+    names = W.compared_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water", "surface_excess_water", "water_table"] if config != "heat" else [])
+    for n in names:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+        assert np.array_equal(c.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status() == c.status() and a.clock() == b.clock() == c.clock()
+    # the default really is the program: one launch for 40 steps is much shorter than 40 launches
+    a.synchronize(); b.synchronize()
+    ta, tb = a.step_timed(w["dt"], 40, finalize=False), b.step_timed(w["dt"], 40, finalize=False)
+    assert ta < 0.8 * tb, (ta, tb)
