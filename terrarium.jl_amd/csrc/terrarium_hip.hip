@@ -2403,6 +2403,21 @@ int trm_step(trm_ctx* c, double dt, int nsteps, int finalize) {
     return finish(c, DISPATCH(c, step(c, dt, nsteps, finalize)));
 }
 
+namespace {
+// The timed entry points return as soon as the stop event has completed: the host POLLS it (a blocking wait is woken by an
+// interrupt some 10-20 us later, which a caller's wall clock around a short run of steps would see).
+int wait_polling(trm_ctx* c, hipEvent_t ev) {
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) {
+            (void)hipGetLastError();   // (hipErrorNotReady of the polls is not an error: do not leave it for the next launch check)
+            return TRM_OK;
+        }
+        if (e != hipErrorNotReady) TRM_HIP(c, e);
+    }
+}
+}  // namespace
+
 int trm_step_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
     TRM_ENTER(c);
     if (nsteps < 0 || !ms) return fail(c, TRM_EINVAL, "trm_step_timed: bad argument");
@@ -2410,7 +2425,7 @@ int trm_step_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
     int rc = DISPATCH(c, step(c, dt, nsteps, finalize));
     if (rc) return rc;
     TRM_HIP(c, hipEventRecord(c->ev1, c->stream));
-    TRM_HIP(c, hipEventSynchronize(c->ev1));
+    if (int rw = wait_polling(c, c->ev1)) return rw;
     TRM_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return TRM_OK;
 }
@@ -2450,7 +2465,7 @@ int trm_step_heun_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* 
     c->opt_async = async;
     if (rc) return rc;
     TRM_HIP(c, hipEventRecord(c->ev1, c->stream));
-    TRM_HIP(c, hipEventSynchronize(c->ev1));
+    if (int rw = wait_polling(c, c->ev1)) return rw;
     TRM_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return TRM_OK;
 }
