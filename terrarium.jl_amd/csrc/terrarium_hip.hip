@@ -27,6 +27,7 @@ namespace {
 struct FieldSet {
     void* f[TRM_FIELD_COUNT];
     void* kf_top;  // top face (face Nz) of the hydraulic_conductivity Face field, [Nh]
+    void* raw[TRM_FIELD_COUNT];   // the allocations behind f[] (f = raw + the field's skew, see alloc_fields)
 };
 
 }  // namespace
@@ -1430,12 +1431,28 @@ int finish(trm_ctx* c, int rc) {
 // non-blocking stream does not synchronise with: under load (two processes time-slicing one device) a fill could land AFTER a
 // later upload / copy on the context stream had written the buffer and wipe it -- seen once as a NaN state in a shared-device
 // rehearsal of the N > 1 bench.
+// Every field starts (field id mod 32) x 16 640 bytes into its own allocation.  hipMalloc hands out identically aligned blocks, so
+// column i of every field of the step (nine streams) would sit at the same offset modulo any power of two -- the same HBM
+// channel and bank for all of them at the moment a wave touches them.  65 x 256 B moves each field by an odd number of 256-byte
+// interleave units: measured -3.7 ... -4.7 % on the HBM-resident fp64 step (8 x N145: 210.7 -> 200.9 us, 218.1 -> 209.9 on another
+// box), -3 % at C5, nothing on the cache-resident ones (profiles/r03/exp15*_skew.log).  TRM_FIELD_SKEW (bytes, a multiple of 256)
+// overrides it for experiments.
+size_t field_skew_bytes() {
+    static const size_t v = [] {
+        const char* e = std::getenv("TRM_FIELD_SKEW");
+        const size_t s = e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)16640;
+        return s - s % 256;
+    }();
+    return v;
+}
 int alloc_fields(trm_ctx* c, FieldSet& s) {
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
         if (is_lazy_field(f) && c->veg_mode == TRM_VEGETATION_OFF) continue;
         if (s.f[f]) continue;
         size_t bytes = field_elems(c, f) * c->esize;
-        TRM_HIP(c, hipMalloc(&s.f[f], bytes));
+        const size_t skew = field_skew_bytes() * (size_t)(f % 32);
+        TRM_HIP(c, hipMalloc(&s.raw[f], bytes + skew));
+        s.f[f] = (char*)s.raw[f] + skew;
         TRM_HIP(c, hipMemsetAsync(s.f[f], 0, bytes, c->stream));
     }
     if (!s.kf_top) {
@@ -1924,9 +1941,9 @@ int trm_destroy(trm_ctx* c) {
     (void)trm_comm_destroy(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
-        if (c->state.f[f]) (void)hipFree(c->state.f[f]);
-        if (c->stage.f[f]) (void)hipFree(c->stage.f[f]);
-        if (c->saved.f[f]) (void)hipFree(c->saved.f[f]);
+        if (c->state.f[f]) (void)hipFree(c->state.raw[f]);
+        if (c->stage.f[f]) (void)hipFree(c->stage.raw[f]);
+        if (c->saved.f[f]) (void)hipFree(c->saved.raw[f]);
     }
     if (c->state.kf_top) (void)hipFree(c->state.kf_top);
     if (c->stage.kf_top) (void)hipFree(c->stage.kf_top);
