@@ -482,7 +482,7 @@ template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool 
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
-    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES>(v_arg, p_arg, a, blockIdx.x);
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
 }
 
 // ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the

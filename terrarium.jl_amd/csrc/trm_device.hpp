@@ -20,6 +20,22 @@ template <class NF> TRM_HD bool is_nan(NF x) { return x != x; }
 // the wave's predicate mask straight from the compare (s_and with exec); HIP's __ballot takes the predicate through a vector
 // register (v_cndmask 0/1 + v_cmp_ne)
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b mod 8).  xcd_block<true> makes every XCD work on
+// ONE contiguous eighth of the columns instead of every eighth workgroup-sized chunk.  Measured twice, same build, two boxes
+// (profiles/r03/exp16_xcd_remap.log, exp16b_xcd_remap_pk.log): the packed fp32 step at C5 454.2 -> 437.4 us on one box and
+// 452.3 -> 483.6 us on the other; the fp64 column program +1.6 % at 8 x N145, +2 % at C3.  A lever whose sign depends on the
+// box is not a default: both off (TRM_XCD_REMAP / TRM_XCD_REMAP_PK = 1 build the variants).
+#ifndef TRM_XCD_REMAP
+#define TRM_XCD_REMAP 0
+#endif
+#ifndef TRM_XCD_REMAP_PK
+#define TRM_XCD_REMAP_PK 0
+#endif
+template <bool ON> __device__ __forceinline__ unsigned xcd_block(unsigned b, unsigned nb) {
+    if (!ON) return b;
+    const unsigned per = nb / 8u, rem = nb % 8u, x = b % 8u, j = b / 8u;
+    return x * per + (x < rem ? x : rem) + j;
+}
 template <class NF> TRM_HD bool sign_bit(NF x) { return __builtin_signbit(x); }
 TRM_HD double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 TRM_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }

@@ -333,7 +333,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
 }
 template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
-    step_pk_program<RICHARDS, LPC, HYD, DERIVE_LIQ>(v_arg, p_arg, dt, finalize, write_kf, blockIdx.x);
+    step_pk_program<RICHARDS, LPC, HYD, DERIVE_LIQ>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x));
 }
 // LandModel in fp32: the packed column step of one half of the columns beside the surface processes of the other half in one
 // launch (k_land_euler, trm_column.hpp).  (View, DevParams) first: step_pk_program re-reads them from the kernarg segment.
