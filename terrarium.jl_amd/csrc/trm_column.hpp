@@ -457,10 +457,13 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         if (ln.is_top) {
             if (RICHARDS) {
                 if (PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage_out);
+#ifndef TRM_DIAG_NO_2D_STORES
                 stg(v.S, ib, S);
                 stg(v.wt, ib, z0);
+#endif
                 if (finalize) stg(v.G_S, ib, GS_out);
             }
+#ifndef TRM_DIAG_NO_TOP_STORES
             if (seb) {   // the next surface energy balance reads these
                 stg(v.top_T, ib, n.T);
                 stg(v.top_sat, ib, n.sat);
@@ -471,6 +474,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
                     stg(v.Ts, ib, Ts_new);
                 }
             }
+#endif
         }
         viol |= bad ? 1u : 0u;
     }
