@@ -147,3 +147,28 @@ def test_library_loaded_before_torch_shares_one_hip_runtime():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-2:] == ["1", "1"], out.stdout
+
+
+def test_simulation_driver_with_a_state_function_and_an_aligned_last_step():
+    """Simulation(integrator; dt, stop_time) (model_integrator.jl:39-66) over a boundary value that reads the state: the driver
+    evaluates it before every step, the aligned (shortened) last step included; the oracle is stepped by hand the same way"""
+    Nz, Nh, dt = 12, 33, 600.0
+    u = columns(Nh)
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
+    bc = trm.PrescribedSurfaceTemperature("Ts", trm.StateFunction(lambda f, clock, p: 0.25 * f.temperature[:, -1] + (4.0 + 1.0e-4 * clock.time)))
+    T_init = (1.0 + 3.0 * u)[None, :] * np.ones((Nz, 1))
+    integ = trm.initialize(trm.SoilModel(grid), trm.ForwardEuler(dt=dt), boundary_conditions=bc, initializers=dict(temperature=T_init, saturation_water_ice=0.6))
+    sim = trm.Simulation(integ, dt=dt, stop_time=4.5 * dt)          # 4 steps of 600 s and one of 300 s
+    seen = []
+    sim.add_callback(lambda s: seen.append((s.iteration, s.time)), trm.IterationInterval(2), name="progress")
+    trm.run_simulation(sim)
+    assert sim.time == 4.5 * dt and sim.iteration == 5 and seen == [(0, 0.0), (2, 2 * dt), (4, 4 * dt)]
+    o = oracle_like(integ)
+    o.set("temperature", T_init)
+    o.set("saturation_water_ice", 0.6)
+    o.initialize()
+    for step_dt in (dt, dt, dt, dt, 0.5 * dt):
+        o.set_bc("temperature", "top", "value", 0.25 * o.get("temperature")[-1] + (4.0 + 1.0e-4 * o.clock()[0]))
+        o.timestep(step_dt, True)
+    for name in ("internal_energy", "temperature", "liquid_water_fraction"):
+        assert np.array_equal(integ.state.get(name), o.get(name)), name
