@@ -1110,13 +1110,11 @@ template <class NF> struct Ops {
         return rc;
     }
     // TRM_OPT_STEPS_PER_LAUNCH = 0: run!'s loop (model_integrator.jl:72-88) is exactly trm_step(ctx, dt, nsteps, 0), so the
-    // resident-column program is what a plain call gets whenever it is legal.  Measured: 1.9-4.4 us per step
-    // against 6.4-12.5 on N72 / 7 119-column shards, 13.6 against 26 at N145.  fp32 contexts whose per-step path is the
-    // packed kernel (two columns per lane) keep it: the program runs the scalar fp32 instructions at the fp64 issue rate.
-    static int auto_steps_per_launch(trm_ctx* c) {
-        if (std::is_same<NF, float>::value && packed_path(c) && !deep_columns(c)) return 1;   // (deep columns never take the packed kernel)
-        return 50;
-    }
+    // resident-column program is what a plain call gets whenever it is legal.  Measured: 2.0-4.6 us per step
+    // against 6.8-12 on N72 / 7 119-column shards, 12.3 against 24-26 at N145 -- and for fp32 contexts whose per-step path is
+    // the packed kernel as well: C5 371 against 447-451 us, C5-VG 479 against 489, a 12 696-column fp32 shard 7.3 against 13.3
+    // (r3: the rule used to keep the packed kernel there).
+    static int auto_steps_per_launch(trm_ctx*) { return 50; }
     // ---- LandModel, per-step path: the surface processes of one half of the columns UNDER the column program of the other ----
     // (k_land_euler / k_land_pk, trm_column.hpp: one stream, two launches per step as before, each covering the soil columns
     // of one half and the 0-D surface processes of the other)
