@@ -171,9 +171,9 @@ enum {
                                     /* fields once per launch (temporal blocking of run!'s loop, model_integrator.jl:72-88;  */
                                     /* bit-identical to m = 1).  0 (default): the library chooses -- 50 wherever the program  */
                                     /* is legal (branch-free boundary kinds, constants or device-resident series the program  */
-                                    /* interpolates itself, no coupled vegetation), except fp32 contexts on the packed        */
-                                    /* two-columns-per-lane kernel; 1: one launch per step (state streams through memory      */
-                                    /* every step: what bench.py's headline measures); m > 1: explicit                        */
+                                    /* interpolates itself, no coupled vegetation; fp32 contexts included); 1: one launch per */
+                                    /* step (state streams through memory every step: what bench.py's headline measures);     */
+                                    /* m > 1: explicit                                                                          */
     TRM_OPT_PIPELINE_PARTS = 7      /* bare-ground LandModel, one launch per step and half: the columns are dealt to two      */
                                     /* halves and every launch covers the soil columns of one half AND the 0-D surface         */
                                     /* processes (land_model.jl:79-88) of the other, so that the latency-bound surface chain  */
