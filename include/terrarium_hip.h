@@ -186,8 +186,8 @@ enum {
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
                                 /* wavefront shuffles for the vertical stencil (Nz <= 64; two levels per lane */
-                                /* for 65 ... 128 levels with the branch-free boundary kinds, ForwardEuler    */
-                                /* and Heun; anything deeper takes the unfused kernels)                       */
+                                /* for 65 ... 128 levels: ForwardEuler with every boundary kind, Heun with    */
+                                /* the branch-free ones; anything deeper takes the unfused kernels)           */
     TRM_KERNEL_UNFUSED = 1      /* one launch per reference kernel, in the reference's order (A/B comparator) */
 };
 

@@ -1043,7 +1043,7 @@ template <class NF> struct Ops {
     }
     // columns of 65 ... 128 levels: two levels per lane, one column per wavefront (trm_column_deep.hpp)
     static bool deep_columns(const trm_ctx* c) { return c->Nz > 64 && c->Nz <= 128; }
-    template <bool RICH, int H, int PROG = PROG_EULER> static int launch_deep(trm_ctx* c, double dt, int finalize, int nsteps = 1) {
+    template <bool RICH, int H, int PROG = PROG_EULER, bool GENERIC = false> static int launch_deep(trm_ctx* c, double dt, int finalize, int nsteps = 1) {
         const LaunchArgs<NF>& la = launch_args<NF>(c);
         ColumnArgs<NF> a{};
         a.dt = (NF)dt;
@@ -1053,7 +1053,8 @@ template <class NF> struct Ops {
         a.bcT_bot_stage = la.w.bcT_bot;      // Heun: the stage's temperature boundary values (evaluated at t + dt)
         a.bcT_top_stage = la.w.bcT_top;
         const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
-        if (derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+        if constexpr (GENERIC) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+        else if (derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
         else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
         TRM_HIP(c, hipGetLastError());
         return TRM_OK;
@@ -1084,7 +1085,10 @@ template <class NF> struct Ops {
     static int wave_step(trm_ctx* c, double dt, int finalize) {
         int rc = TRM_OK;
         if (deep_columns(c)) {
-            if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H>(c, dt, finalize))); }
+            if (generic_bcs(c)) {
+                if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H, PROG_EULER, true>(c, dt, finalize))); }
+                else { TRM_BY_HYD(c, rc = (launch_deep<false, H, PROG_EULER, true>(c, dt, finalize))); }
+            } else if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H>(c, dt, finalize))); }
             else { TRM_BY_HYD(c, rc = (launch_deep<false, H>(c, dt, finalize))); }
             if (!rc) c->closure_consistent = true;
             return rc;
@@ -1222,7 +1226,7 @@ template <class NF> struct Ops {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
         // deeper takes the reference-order kernels
-        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || (deep_columns(c) && !generic_bcs(c) && !coupled(c)));
+        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || (deep_columns(c) && !coupled(c)));
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
         // (columns of 65 ... 128 levels: contexts without the surface energy balance and without series)

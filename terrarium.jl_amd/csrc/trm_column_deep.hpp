@@ -6,8 +6,8 @@
 // per field, the k - 1 neighbour of a is the previous lane's b (one DPP shift), of b the lane's own a (free); likewise
 // upwards.  Ballots come in pairs (a cells, b cells).  Every operation is the one k_column<PROG_EULER> / the reference-order
 // kernels perform on the cell, in the same order: results are bit-identical (tests/test_gpu_deep_columns.py).
-// Scope: the branch-free boundary kinds (as k_column), ForwardEuler and Heun (both stages in registers, one launch), with the
-// derivation of T / liq; generic boundary kinds, the coupled vegetation and Nz > 128 keep the reference-order kernels.
+// Scope: ForwardEuler (every boundary kind: GENERIC), Heun (both stages in registers, one launch) and the multi-step program with
+// the branch-free kinds, with the derivation of T / liq; the coupled vegetation and Nz > 128 keep the reference-order kernels.
 #pragma once
 #include "trm_column.hpp"
 
@@ -143,9 +143,12 @@ template <class NF> TRM_DEV NF level_word(const View<NF>& v, unsigned rec, int w
 }
 // PROG: PROG_EULER, or PROG_HEUN -- both stages of the reference's Heun (heun.jl:37-71) on the column in registers, one launch
 // per step, the sequence of column_program<PROG_HEUN> (trm_column.hpp) cell by cell.
-template <class NF, bool RICHARDS, int HYD, bool DERIVE = false, int PROG = PROG_EULER>
+// GENERIC: every boundary kind (Value / Gradient on temperature, liquid fraction, saturation, pressure head) and the per-cell
+// vwc_forcing field, with the halo formulas of column_tendencies_generic (trm_column.hpp) on the edge cells.
+template <class NF, bool RICHARDS, int HYD, bool DERIVE = false, int PROG = PROG_EULER, bool GENERIC = false>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(TRM_DEEP_WAVES, 8)))
     k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
+    static_assert(!GENERIC || PROG == PROG_EULER, "generic boundary kinds on deep columns: ForwardEuler");
     // PROG_MULTI: a.nsteps ForwardEuler steps on the resident column (contexts without the surface energy balance and without
     // time series: constants between the steps), fields written once per launch -- column_program<PROG_MULTI>'s loop.
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
@@ -220,13 +223,50 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         auto ext_b = [&](NF Tc) { return vTb ? Tc + div_const(Tc - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot) : Tc; };
         auto ext_t = [&](NF Tc) { return vTt ? Tc + div_const(bTt - Tc, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top : Tc; };
         auto halo_kap = [&](NF kc, NF lq, uint32_t& vl) { return (!RICHARDS && p.halo_policy != 1) ? conductivity(p, fractions(p, NF(0), lq, vl)) : kc; };
-        const NF T_m_a = ln.bot_a ? ext_b(T.a) : T_dn.a, T_m_b = T_dn.b;
-        const NF kap_halo_a = halo_kap(kap.a, liq.a, viol_a), kap_halo_b = halo_kap(kap.b, liq.b, viol_b);
-        const NF kap_m_a = ln.bot_a ? kap_halo_a : kap_dn.a, kap_m_b = kap_dn.b;
+        NF T_m_a, kap_m_a, T_h_a = NF(0), T_h_b = NF(0), kap_h_a = NF(0), kap_h_b = NF(0), psi_hb = NF(0), psi_ht_a = NF(0), psi_ht_b = NF(0);
+        const NF T_m_b = T_dn.b, kap_m_b = kap_dn.b;
+        if constexpr (GENERIC) {
+            // halo cells of the edge cells from the boundary kinds (column_tendencies_generic): divergent branches of the two
+            // edge lanes only
+            const bool same_bot = v.bc.kind[3][0] != 1 && v.bc.kind[3][0] != 3 && (RICHARDS ? (v.bc.kind[1][0] != 1 && v.bc.kind[1][0] != 3) : p.halo_policy == 1);
+            const bool same_top = v.bc.kind[3][1] != 1 && v.bc.kind[3][1] != 3 && (RICHARDS ? (v.bc.kind[1][1] != 1 && v.bc.kind[1][1] != 3) : p.halo_policy == 1);
+            T_m_a = T_dn.a;
+            kap_m_a = kap_dn.a;
+            if (ln.bot_a) {
+                T_m_a = halo_bottom(v.bc.kind[2][0], bcval(v, 2, 0), ii, T.a, v.g);
+                kap_m_a = kap.a;
+                if (!same_bot) {
+                    const NF lh = halo_bottom(v.bc.kind[3][0], bcval(v, 3, 0), ii, liq.a, v.g);
+                    const NF sh = sat_halo<NF, RICHARDS>(v, p, 0, ii, sat.a);
+                    kap_m_a = conductivity(p, fractions(p, sh, lh, viol_a));
+                }
+                if (RICHARDS) psi_hb = halo_bottom(v.bc.kind[4][0], bcval(v, 4, 0), ii, psi.a, v.g);
+            }
+            auto top_halo = [&](bool is_top, NF Tc, NF lq, NF sc, NF psic, NF kapc, NF& T_h, NF& kap_h, NF& psi_ht, uint32_t& vl) {
+                if (!is_top) return;
+                T_h = halo_top(v.bc.kind[2][1], bcval(v, 2, 1), ii, Tc, v.g);
+                kap_h = kapc;
+                if (!same_top) {
+                    const NF lh = halo_top(v.bc.kind[3][1], bcval(v, 3, 1), ii, lq, v.g);
+                    const NF sh = sat_halo<NF, RICHARDS>(v, p, 1, ii, sc);
+                    kap_h = conductivity(p, fractions(p, sh, lh, vl));
+                }
+                if (RICHARDS) psi_ht = halo_top(v.bc.kind[4][1], bcval(v, 4, 1), ii, psic, v.g);
+            };
+            top_halo(ln.top_a, T.a, liq.a, sat.a, psi.a, kap.a, T_h_a, kap_h_a, psi_ht_a, viol_a);
+            top_halo(ln.top_b, T.b, liq.b, sat.b, psi.b, kap.b, T_h_b, kap_h_b, psi_ht_b, viol_b);
+        } else {
+            T_m_a = ln.bot_a ? ext_b(T.a) : T_dn.a;
+            kap_h_a = halo_kap(kap.a, liq.a, viol_a);
+            kap_h_b = halo_kap(kap.b, liq.b, viol_b);
+            kap_m_a = ln.bot_a ? kap_h_a : kap_dn.a;
+            T_h_a = ext_t(T.a);
+            T_h_b = ext_t(T.b);
+        }
         const Two<NF> qT_lo{-(NF(0.5) * (kap.a + kap_m_a)) * ((T.a - T_m_a) * La.rdzf_lo), -(NF(0.5) * (kap.b + kap_m_b)) * ((T.b - T_m_b) * Lb.rdzf_lo)};
         const Two<NF> qT_up = above(qT_lo);
-        const NF qT_hi_a = ln.top_a ? -(NF(0.5) * (kap_halo_a + kap.a)) * ((ext_t(T.a) - T.a) * La.rdzf_hi) : qT_up.a;
-        const NF qT_hi_b = ln.top_b ? -(NF(0.5) * (kap_halo_b + kap.b)) * ((ext_t(T.b) - T.b) * Lb.rdzf_hi) : qT_up.b;
+        const NF qT_hi_a = ln.top_a ? -(NF(0.5) * (kap_h_a + kap.a)) * ((T_h_a - T.a) * La.rdzf_hi) : qT_up.a;
+        const NF qT_hi_b = ln.top_b ? -(NF(0.5) * (kap_h_b + kap.b)) * ((T_h_b - T.b) * Lb.rdzf_hi) : qT_up.b;
         Tend t;
         t.gU = Two<NF>{NF(0) + (-((qT_hi_a - qT_lo.a) * La.rdzc)), NF(0) + (-((qT_hi_b - qT_lo.b) * Lb.rdzc))};
         t.gS = Two<NF>{NF(0), NF(0)};
@@ -243,13 +283,26 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
             const Two<NF> Kf_dn = below(Kf_lo), Kf_up = above(Kf_lo), psi_dn = below(psi);
             const NF Kf_m_a = ln.bot_a ? NF(0) : Kf_dn.a, Kf_m_b = Kf_dn.b;
             const NF Kf_p_a = ln.top_a ? Kc.a : Kf_up.a, Kf_p_b = ln.top_b ? Kc.b : Kf_up.b;
-            const NF psi_m_a = ln.bot_a ? psi.a : psi_dn.a, psi_m_b = psi_dn.b;
+            const NF psi_m_a = ln.bot_a ? (GENERIC ? psi_hb : psi.a) : psi_dn.a, psi_m_b = psi_dn.b;
             const NF g_lo_a = (psi.a - psi_m_a) * La.rdzf_lo, g_lo_b = (psi.b - psi_m_b) * Lb.rdzf_lo;
             const Two<NF> qW_lo{-upwind_conductivity(g_lo_a, Kf_m_a, Kf_lo.a, Kf_p_a) * g_lo_a, -upwind_conductivity(g_lo_b, Kf_m_b, Kf_lo.b, Kf_p_b) * g_lo_b};
             const Two<NF> qW_up = above(qW_lo);
-            const NF qW_t_a = -jl_min(Kc.a, NF(0)) * (psi.a - psi.a), qW_t_b = -jl_min(Kc.b, NF(0)) * (psi.b - psi.b);
+            NF qW_t_a, qW_t_b, F_a = p.vwc_forcing, F_b = p.vwc_forcing;
+            if constexpr (GENERIC) {
+                // boundary face above the top cell with the halo cell's pressure head; the user forcing per cell when the field is set
+                const NF g_t_a = (psi_ht_a - psi.a) * La.rdzf_hi, g_t_b = (psi_ht_b - psi.b) * Lb.rdzf_hi;
+                qW_t_a = -upwind_conductivity(g_t_a, Kf_lo.a, Kc.a, NF(0)) * g_t_a;
+                qW_t_b = -upwind_conductivity(g_t_b, Kf_lo.b, Kc.b, NF(0)) * g_t_b;
+                if (v.Fvwc) {
+                    const Two<NF> F = ld2cells(v.Fvwc, cb0);
+                    F_a = F.a; F_b = F.b;
+                }
+            } else {
+                qW_t_a = -jl_min(Kc.a, NF(0)) * (psi.a - psi.a);
+                qW_t_b = -jl_min(Kc.b, NF(0)) * (psi.b - psi.b);
+            }
             const NF qW_hi_a = ln.top_a ? qW_t_a : qW_up.a, qW_hi_b = ln.top_b ? qW_t_b : qW_up.b;
-            const NF dth_a = -((qW_hi_a - qW_lo.a) * La.rdzc) + NF(0) + p.vwc_forcing, dth_b = -((qW_hi_b - qW_lo.b) * Lb.rdzc) + NF(0) + p.vwc_forcing;
+            const NF dth_a = -((qW_hi_a - qW_lo.a) * La.rdzc) + NF(0) + F_a, dth_b = -((qW_hi_b - qW_lo.b) * Lb.rdzc) + NF(0) + F_b;
             t.gS.a = NF(0) + div_const(dth_a, p.por, p.rpor);
             t.gS.b = NF(0) + div_const(dth_b, p.por, p.rpor);
         }

@@ -77,15 +77,48 @@ def test_saturation_adjustment_on_the_reference_grid_inside_the_fused_step():
         assert np.array_equal(st.get(n), o.get(n)), n
 
 
-def test_deep_columns_with_generic_boundary_kinds_keep_the_reference_order_kernels():
-    lat, lon = small_columns(20)
-    w = W.make_workload("heat", lat, lon, 80)
+# Value / Flux / Gradient boundary kinds on every variable that carries them (the reference's FreeDrainage() is a Gradient condition on
+# the pressure head) and the per-cell vwc_forcing field: the GENERIC instance of k_column_deep, against the reference-order kernels
+# and the oracle, bit for bit
+@pytest.mark.parametrize("config,dtype,Nz,Nh", [("richards", np.float64, 100, 83), ("richards", np.float64, 127, 11), ("heat", np.float64, 80, 20),
+                                                 ("richards", np.float32, 66, 40), ("land", np.float64, 96, 30)])
+def test_deep_columns_with_generic_boundary_kinds_run_fused_and_equal_the_reference_order_kernels(config, dtype, Nz, Nh):
+    lat, lon = small_columns(Nh)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype)
+    rng = np.random.default_rng(7)
+    if config == "heat":
+        w["bcs"][("temperature", "bottom")] = ("gradient", 0.01)
+        w["bcs"][("liquid_water_fraction", "top")] = ("gradient", 0.1)
+    else:
+        w["bcs"].update({("temperature", "bottom"): ("value", w["T0"] - 1.0), ("internal_energy", "bottom"): ("flux", np.full(Nh, 0.05)),
+                         ("pressure_head", "bottom"): ("gradient", 0.0), ("liquid_water_fraction", "top"): ("gradient", 0.1)})
+        if config == "richards":
+            w["bcs"][("saturation_water_ice", "top")] = ("flux", -1.0e-8 * rng.random(Nh))
+            w["bcs"][("pressure_head", "top")] = ("value", np.full(Nh, -0.3))
     a, b = W.setup_device(w), W.setup_device(w)
     b.set_option("step_kernel", "unfused")
+    o = W.setup_oracle(w) if (dtype == np.float64 and config != "land") else None
+    if config != "heat":        # a root-zone sink that differs per cell and column (soil_hydrology.jl:37-38)
+        zc = a.z_centers()
+        F = (-2.0e-7 * np.exp(zc / 0.5)[:, None] * (1.0 + 0.5 * np.cos(np.arange(Nh)))[None, :]).astype(dtype)
+        for d in (a, b) + ((o,) if o is not None else ()):
+            d.set("vwc_forcing", F)
+    nsteps = 25
     for d in (a, b):
-        d.set_bc("temperature", "bottom", "gradient", 0.01)
-        d.step(w["dt"], 12, finalize=True)
-    assert np.array_equal(a.get("temperature"), b.get("temperature"))
+        d.step(w["dt"], 1, finalize=False)
+        d.step(w["dt"], nsteps - 2, finalize=False)
+        d.step(w["dt"], 1, finalize=True)
+    names = W.compared_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else [])
+    for n in names:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status() and a.clock() == b.clock()
+    if o is not None:
+        o.run(w["dt"], nsteps)
+        for n in W.compared_fields(w):
+            assert np.array_equal(a.get(n), o.get(n)), n
+    # it really is the fused kernel: one launch per step against a dozen
+    ta, tb = a.step_timed(w["dt"], 20, finalize=False), b.step_timed(w["dt"], 20, finalize=False)
+    assert ta < 0.6 * tb, (ta, tb)
 
 
 # heun.jl:37-71 on deep columns: both stages of k_column_deep<PROG_HEUN> in registers, one launch per step -- bit for bit the
