@@ -1,0 +1,30 @@
+# round 3, GPU call 20b: staged per-column outputs as a run-time choice (auto rule: HBM-resident states and large LandModels), in the
+# fp64 column program and the packed fp32 step.  Full suite with the rule, full suite with staging forced everywhere, then A/B
+# against the previous build
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run 900 python -m pytest tests -m gpu -q -x -W ignore::DeprecationWarning > gpurun_out/exp20b_tests_auto.log 2>&1; tail -2 gpurun_out/exp20b_tests_auto.log
+TRM_STAGED_SMALL=1 run 900 python -m pytest tests -m gpu -q -x -W ignore::DeprecationWarning > gpurun_out/exp20b_tests_forced.log 2>&1; tail -2 gpurun_out/exp20b_tests_forced.log
+L=gpurun_out/exp20b_staged_auto.log; : > $L
+AB="python profiles/tools/ab_options.py"
+for round in 1 2 3; do
+  for B in new prev; do
+    if [ $B = new ]; then unset TRM_LIBRARY; else export TRM_LIBRARY=$PWD/build/variants/libtrm_prev.so; fi
+    run 300 $AB c5 $B: --steps 30 --reps 5 >> $L 2>&1
+    run 300 $AB c5vg $B: --steps 30 --reps 5 >> $L 2>&1
+    run 300 $AB c4 $B: --steps 50 >> $L 2>&1
+    run 300 $AB c3 $B: >> $L 2>&1
+    run 300 $AB c3x8 $B: --steps 60 --reps 5 >> $L 2>&1
+    run 300 $AB c2 $B: >> $L 2>&1
+  done
+done
+python - <<'PY'
+import json
+rows = {}
+for line in open("gpurun_out/exp20b_staged_auto.log"):
+    if line.startswith("{"):
+        d = json.loads(line)
+        for k, v in d["us_per_step"].items():
+            rows.setdefault(d["workload"], {}).setdefault(k, []).append(v["median"])
+for wl, r in rows.items():
+    print(wl, r, "new/prev", round(sum(r["new"]) / sum(r["prev"]), 3))
+PY

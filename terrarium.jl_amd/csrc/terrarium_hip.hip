@@ -349,6 +349,7 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
             void* val = (&s == &c->stage && c->bc_value_stage[a][b]) ? c->bc_value_stage[a][b] : c->bc_value[a][b];
             v.bc.value[a][b] = val ? val : c->d_zero;
         }
+    fill_small_table(v);
     return v;
 }
 
@@ -370,6 +371,7 @@ template <class NF> View<NF> sub_view(const View<NF>& v, long lo, long n) {
     for (int a = 0; a < TRM_BCV_COUNT; ++a)
         for (int b = 0; b < 2; ++b)
             if (s.bc.value[a][b]) s.bc.value[a][b] = (const NF*)s.bc.value[a][b] + lo;
+    fill_small_table(s);
     return s;
 }
 
@@ -873,6 +875,20 @@ template <class NF> struct Ops {
         const bool large = c->Nh >= 24576;
         return (std::is_same<NF, double>::value && (beyond_cache || large)) ? DERIVE_T_LIQ : DERIVE_NONE;
     }
+    // The per-column outputs of the column program through the workgroup's staging table (ColumnArgs::staged) or as direct 2-lane
+    // stores.  Measured (profiles/r03/exp20_staged_small_stores.log, same box, alternating): staged wins where the state streams
+    // from HBM (8 x N145: 201.7 vs 212.9 us, -5.3 %) and on the LandModel with its seven outputs (C4 33.7 vs 34.4), it loses
+    // where the step is launch- and latency-bound (C3 25.2 vs 24.7, N72 heat-only 7.3 vs 6.7): the barrier in front of the
+    // staged store.  TRM_STAGED_SMALL = 0 / 1 in the environment forces it (experiments).
+    // The packed fp32 step does not gain (C5 472 vs 468 us, C5-VG 500 vs 487; exp20b): staging is off there unless forced.
+    template <bool RICH> static int staged_now(const trm_ctx* c, bool packed = false) {
+        static const int forced = [] { const char* e = std::getenv("TRM_STAGED_SMALL"); return e ? std::atoi(e) : -1; }();
+        if (forced >= 0) return forced != 0;
+        if (packed) return 0;
+        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
+        const bool beyond_cache = state_bytes > ((size_t)256 << 20);
+        return (beyond_cache || (c->params.seb != 0 && c->Nh >= 24576)) ? 1 : 0;
+    }
     // fp32: two columns per lane with packed math (trm_packed_f32.hpp) -- the reference-default hydraulics, and van
     // Genuchten retention with Mualem conductivity
     static bool packed_path(trm_ctx* c) {
@@ -889,12 +905,13 @@ template <class NF> struct Ops {
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
             const bool dliq = derive_now<RICH>(c) == DERIVE_LIQ;
+            const int staged = staged_now<RICH>(c, true);
             if (hyd(c) == HYD_VG_N2) {
-                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
-                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
+                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
             } else {
-                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
-                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf);
+                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
+                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
             }
             TRM_HIP(c, hipGetLastError());
         }
@@ -1001,6 +1018,7 @@ template <class NF> struct Ops {
         a.finalize = finalize;
         a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
         a.nsteps = nsteps;
+        a.staged = staged_now<RICH>(c);
         a.bcT_bot_stage = la.w.bcT_bot;
         a.bcT_top_stage = la.w.bcT_top;
         a.series = (const SeriesTable<NF>*)c->d_series_table;

@@ -193,6 +193,7 @@ template <class NF> TRM_DEV NF series_value(const SeriesTable<NF>* tb, const Ser
 template <class NF> struct ColumnArgs {
     NF dt;
     int finalize, write_kf, nsteps;
+    int staged;   // the per-column outputs leave through the workgroup's staging table (store_small_outputs) instead of directly
     // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
     const NF *bcT_bot_stage, *bcT_top_stage;
     // multi-step program with time series: the slot table and [nsteps][nseries] rows
@@ -450,13 +451,31 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             stg(v.G_U, cb, gU_out);
             if (RICHARDS) stg(v.G_sat, cb, gS_out);
         }
-        if (write_kf) {
-            stg(v.Kf, cb, Kf_out);
-            if (ln.is_top) stg(v.Kf_top, ib, Kf_out_top);
-        }
-        if (ln.is_top) {
+        if (write_kf) stg(v.Kf, cb, Kf_out);
+        if (ln.is_top && RICHARDS && PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage_out);
+        if (ln.is_top && a.staged) {
+            // The per-column outputs (up to eight 8-byte values: top face of K, surface excess water, water table, its tendency,
+            // the top cell for the next surface energy balance, the skin temperature) go to the workgroup's staging table: one
+            // wave writes them below, 64 contiguous bytes per array and workgroup in a single instruction, instead of eight
+            // stores of two active lanes each -- eight partially written cache lines per wave (profiles/r03/exp17, 19, 20).
+            const int cib = (int)(threadIdx.x >> 6) * CPW + sub;      // column within the workgroup
+            const int cpb = (int)(blockDim.x >> 6) * CPW;
+            NF* st = small_stage<NF>();
+            if (write_kf) st[SMALL_KF_TOP * cpb + cib] = Kf_out_top;
             if (RICHARDS) {
-                if (PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage_out);
+                st[SMALL_S * cpb + cib] = S;
+                st[SMALL_WT * cpb + cib] = z0;
+                if (finalize) st[SMALL_G_S * cpb + cib] = GS_out;
+            }
+            if (seb) {   // the next surface energy balance reads these
+                st[SMALL_TOP_T * cpb + cib] = n.T;
+                st[SMALL_TOP_SAT * cpb + cib] = n.sat;
+                st[SMALL_TOP_LIQ * cpb + cib] = n.liq;
+                st[SMALL_TS * cpb + cib] = SEB_INLINE ? sf.out.Ts : Ts_new;
+            }
+        } else if (ln.is_top) {
+            if (write_kf) stg(v.Kf_top, ib, Kf_out_top);
+            if (RICHARDS) {
 #ifndef TRM_DIAG_NO_2D_STORES
                 stg(v.S, ib, S);
                 stg(v.wt, ib, z0);
@@ -468,15 +487,17 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
                 stg(v.top_T, ib, n.T);
                 stg(v.top_sat, ib, n.sat);
                 stg(v.top_liq, ib, n.liq);
-                if (SEB_INLINE) {
-                    stg(v.Ts, ib, sf.out.Ts);
-                } else {
-                    stg(v.Ts, ib, Ts_new);
-                }
+                stg(v.Ts, ib, SEB_INLINE ? sf.out.Ts : Ts_new);
             }
 #endif
         }
         viol |= bad ? 1u : 0u;
+    }
+    if (a.staged) {
+        const unsigned enabled = (write_kf ? 1u << SMALL_KF_TOP : 0u) | (RICHARDS ? (1u << SMALL_S) | (1u << SMALL_WT) : 0u) |
+                                 ((RICHARDS && finalize) ? 1u << SMALL_G_S : 0u) |
+                                 (seb ? (1u << SMALL_TOP_T) | (1u << SMALL_TOP_SAT) | (1u << SMALL_TOP_LIQ) | (1u << SMALL_TS) : 0u);
+        store_small_outputs<NF>(enabled, (int)(blockDim.x >> 6) * CPW, block, Nh);
     }
     // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
     if (viol && ln.act) atomicOr(v_arg.status, viol);

@@ -57,7 +57,15 @@ template <class NF> struct View {
     // grid (device arrays): zC[Nz], zF[Nz+1], dzc[Nz], rdzc[Nz], rdzf[Nz+1] (face f lies below cell f),
     // psiz[Nz] = zC - z_surface (elevation head)
     const NF *zC, *zF, *dzc, *rdzc, *rdzf, *psiz;
+    // the per-column outputs of the column program in the order of its staged store (column_program, SMALL_*): Kf_top, S, wt,
+    // G_S, top_T, top_sat, top_liq, Ts -- the same pointers as above, as a table a lane can index
+    NF* small[8];
 };
+enum { SMALL_KF_TOP = 0, SMALL_S, SMALL_WT, SMALL_G_S, SMALL_TOP_T, SMALL_TOP_SAT, SMALL_TOP_LIQ, SMALL_TS, SMALL_COUNT };
+template <class NF> inline void fill_small_table(View<NF>& v) {
+    v.small[SMALL_KF_TOP] = v.Kf_top; v.small[SMALL_S] = v.S; v.small[SMALL_WT] = v.wt; v.small[SMALL_G_S] = v.G_S;
+    v.small[SMALL_TOP_T] = v.top_T; v.small[SMALL_TOP_SAT] = v.top_sat; v.small[SMALL_TOP_LIQ] = v.top_liq; v.small[SMALL_TS] = v.Ts;
+}
 
 template <class NF> TRM_DEV const NF* bcval(const View<NF>& v, int var, int side) { return (const NF*)v.bc.value[var][side]; }
 
@@ -532,6 +540,28 @@ template <class T> TRM_DEV const T& kernarg_reload(unsigned offset) {
     asm volatile("" : "+s"(kp));
     return *(const T*)(kp + offset);
 }
+
+// Staging table of a workgroup's per-column outputs: [SMALL_COUNT][columns per workgroup] (at most 8 x 16 values).
+template <class NF> TRM_DEV NF* small_stage() {
+    __shared__ NF table[SMALL_COUNT * 16];
+    return table;
+}
+// After a barrier, lane l of the workgroup's first waves stores entry l of the table: array l / cpb, column l % cpb of the
+// workgroup -- every array receives one contiguous run of cpb values from a single instruction.  The array pointers come from
+// the kernel argument segment (View::small), indexed per lane.  `enabled`: bit per array (wave-uniform).
+template <class NF> TRM_DEV void store_small_outputs(unsigned enabled, int cpb, unsigned block, int Nh) {
+    __syncthreads();
+    const int l = (int)threadIdx.x;
+    if (l < SMALL_COUNT * cpb) {
+        const int slot = l / cpb, col = l - slot * cpb;
+        const long i = (long)block * cpb + col;
+        if (i < Nh && ((enabled >> slot) & 1u)) {
+            NF* const* tbl = kernarg_reload<View<NF>>(0).small;
+            tbl[slot][i] = small_stage<NF>()[l];
+        }
+    }
+}
+
 constexpr unsigned round_up_to(unsigned x, unsigned a) { return (x + a - 1) / a * a; }
 
 template <class NF, bool RICHARDS, int HYD, int LPC>

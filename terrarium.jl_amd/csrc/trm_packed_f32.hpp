@@ -163,7 +163,7 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // DERIVE_LIQ: the incoming liquid fraction is re-derived from (U, sat) instead of being read (legal when the stored fields
 // are the closure of the stored state, trm_ctx::closure_consistent): one of the five field reads less.
 template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
-TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p_arg, float dt, int finalize, int write_kf, unsigned block) {
+TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p_arg, float dt, int finalize, int write_kf, unsigned block, int staged = 0) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
     const DevParams<float>& p = p_arg;
@@ -296,11 +296,26 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         Kf_out = sel(is_bot || is_top, Kc_new, Kmin_new);
         Kf_out_top = Kc_new;
     }
-    auto store = [&](bool act, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft, float gu, float gs,
+    const int cpb = (int)(blockDim.x >> 6) * CPW * 2;      // columns per workgroup
+    auto store = [&](bool act, int cib, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft, float gu, float gs,
                      float S_new, float GS, float wt, float Ts_old /* already stepped */) {
         if (!act) return;
         const unsigned cb = block_local(cb_), ib = block_local(ib_);   // keeps the saddr form inside this block
-        if (is_top) {   // the column's 0-D state (top lane)
+        if (is_top && staged) {   // the column's 0-D outputs through the workgroup's staging table (store_small_outputs, trm_column.hpp)
+            float* st = small_stage<float>();
+            if (write_kf) st[SMALL_KF_TOP * cpb + cib] = kft;
+            if (RICHARDS) {
+                if (finalize) st[SMALL_G_S * cpb + cib] = GS;
+                st[SMALL_S * cpb + cib] = S_new;
+                st[SMALL_WT * cpb + cib] = wt;
+            }
+            if (seb) {
+                st[SMALL_TS * cpb + cib] = Ts_old;
+                st[SMALL_TOP_T * cpb + cib] = t;
+                st[SMALL_TOP_SAT * cpb + cib] = s;
+                st[SMALL_TOP_LIQ * cpb + cib] = l;
+            }
+        } else if (is_top) {   // the column's 0-D state (top lane)
             if (RICHARDS) {
                 if (finalize) stg(v.G_S, ib, GS);
                 stg(v.S, ib, S_new);
@@ -316,24 +331,31 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         stg(v.T, cb, t);
         stg(v.liq, cb, l);
         if (RICHARDS) { stg(v.sat, cb, s); stg(v.psi, cb, ps); }
-        if (is_top && seb) { stg(v.top_T, ib, t); stg(v.top_sat, ib, s); stg(v.top_liq, ib, l); }
+        if (is_top && seb && !staged) { stg(v.top_T, ib, t); stg(v.top_sat, ib, s); stg(v.top_liq, ib, l); }
         if (write_kf) {
             stg(v.Kf, cb, kf);
-            if (is_top) stg(v.Kf_top, ib, kft);
+            if (is_top && !staged) stg(v.Kf_top, ib, kft);
         }
     };
     // every loaded value has been consumed before the first store is issued (nothing is waited for behind the stores)
     v2f Ts_new = Ts_in + splat(0.0f) * dt;     // zero-tendency prognostic skin_temperature
     asm volatile("" : "+v"(Ts_new), "+v"(S_out), "+v"(GS_top));
-    store(act0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x, S_out.x, GS_top.x, z0.x, Ts_new.x);
-    store(act1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y, gU.y, gS.y, S_out.y, GS_top.y, z0.y, Ts_new.y);
+    const int cib0 = ((int)(threadIdx.x >> 6) * CPW + sub) * 2;
+    store(act0, cib0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x, S_out.x, GS_top.x, z0.x, Ts_new.x);
+    store(act1, cib0 + 1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y, gU.y, gS.y, S_out.y, GS_top.y, z0.y, Ts_new.y);
+    if (staged) {
+        const unsigned enabled = (write_kf ? 1u << SMALL_KF_TOP : 0u) | (RICHARDS ? (1u << SMALL_S) | (1u << SMALL_WT) : 0u) |
+                                 ((RICHARDS && finalize) ? 1u << SMALL_G_S : 0u) |
+                                 (seb ? (1u << SMALL_TOP_T) | (1u << SMALL_TOP_SAT) | (1u << SMALL_TOP_LIQ) | (1u << SMALL_TS) : 0u);
+        store_small_outputs<float>(enabled, cpb, block, Nh);
+    }
     // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
     const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u);
     if (flags) atomicOr(v.status, flags);
 }
 template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
-__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf) {
-    step_pk_program<RICHARDS, LPC, HYD, DERIVE_LIQ>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x));
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf, int staged) {
+    step_pk_program<RICHARDS, LPC, HYD, DERIVE_LIQ>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x), staged);
 }
 // LandModel in fp32: the packed column step of one half of the columns beside the surface processes of the other half in one
 // launch (k_land_euler, trm_column.hpp).  (View, DevParams) first: step_pk_program re-reads them from the kernarg segment.
