@@ -320,3 +320,20 @@ def test_divide_sequences_fp32():
     K_expected = ((f(p.K_sat) * water) / ((water + ice) + air)).astype(f)
     Kc = d.get("hydraulic_conductivity")
     assert np.array_equal(Kc[0], K_expected[0]) and np.array_equal(Kc[-1], K_expected[-1])
+
+
+def test_staged_per_column_outputs_forced_on_small_grids():
+    """The column programs store their per-column outputs either directly or through the workgroup's staging table
+    (ColumnArgs::staged; the library stages HBM-resident fp64 states and large LandModels).  TRM_STAGED_SMALL=1 forces the
+    staged path for every context: the parity and program tests of this file and the LandModel parity cases must pass unchanged
+    (the variable is read once per process, hence the child process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRM_STAGED_SMALL="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_column_programs.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
+                          "-m", "gpu", "-q", "-x", "-W", "ignore::DeprecationWarning", "-k", "not staged_per_column_outputs and not hypothesis",
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
