@@ -165,8 +165,9 @@ enum {
                                     /* closure of the stored internal_energy / saturation (the library wrote them), a fused   */
                                     /* Euler step can re-derive them in registers instead of reading them: 2 of 5 field reads */
                                     /* less, bit-identical results.  0: never; 1: whenever legal; 2 (default): for fp64 states  */
-                                    /* beyond the 256 MiB Infinity Cache or of >= 24 576 columns: where it was measured to win  */
-                                    /* (DESIGN 4.1); 3: the liquid fraction alone (one read less; measured between 0 and 1)     */
+                                    /* beyond the 256 MiB Infinity Cache or of >= 24 576 columns, and the liquid fraction alone */
+                                    /* for fp32 states beyond the cache on the packed kernel: where it was measured to win      */
+                                    /* (DESIGN 4.1, 4.3); 3: the liquid fraction alone (one read less)                          */
     TRM_OPT_STEPS_PER_LAUNCH = 6,   /* trm_step keeps every column in registers for up to m steps per launch and writes the */
                                     /* fields once per launch (temporal blocking of run!'s loop, model_integrator.jl:72-88;  */
                                     /* bit-identical to m = 1).  0 (default): the library chooses -- 50 wherever the program  */

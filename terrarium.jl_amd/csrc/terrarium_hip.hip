@@ -864,7 +864,8 @@ template <class NF> struct Ops {
     // it loses on small grids (N72 heat-only: 7.1 vs 6.6 us, latency-bound) and for the packed fp32 kernel, which is not short of
     // bytes (C5: liquid fraction alone 523 vs 500 us, both 562 vs 533).  Deriving the liquid fraction alone (mode 3: one read
     // less, the temperature divide saved) sits between the two everywhere (8 x N145: 238 us) and is kept as an option only.
-    // AUTO (2): fp64 states beyond the Infinity Cache, or of >= 24 576 columns.
+    // AUTO (2): fp64 states beyond the Infinity Cache, or of >= 24 576 columns; fp32 states beyond the cache on the packed kernel:
+    // the liquid fraction alone (the numbers above for the packed kernel predate the store ordering of round 3; see below).
     template <bool RICH> static int derive_now(const trm_ctx* c) {
         // (the coupled vegetation reads T and liq of the whole column from memory every step)
         if (!c->closure_consistent || c->closure_escaped || coupled(c) || c->opt_derive == 0) return DERIVE_NONE;
@@ -873,7 +874,10 @@ template <class NF> struct Ops {
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
         const bool beyond_cache = state_bytes > ((size_t)256 << 20);
         const bool large = c->Nh >= 24576;
-        return (std::is_same<NF, double>::value && (beyond_cache || large)) ? DERIVE_T_LIQ : DERIVE_NONE;
+        // fp32 on the packed kernel, HBM-resident: the liquid fraction alone (r3, re-measured on the final kernels,
+        // profiles/r03/exp21_derive_liq_fp32.log: C5 443.7 vs 457.9 us, C5-VG 472.5 vs 476.3; before the store ordering it lost)
+        if (std::is_same<NF, float>::value) return (beyond_cache && packed_path(const_cast<trm_ctx*>(c))) ? DERIVE_LIQ : DERIVE_NONE;
+        return (beyond_cache || large) ? DERIVE_T_LIQ : DERIVE_NONE;
     }
     // The per-column outputs of the column program through the workgroup's staging table (ColumnArgs::staged) or as direct 2-lane
     // stores.  Measured (profiles/r03/exp20_staged_small_stores.log, same box, alternating): staged wins where the state streams
