@@ -908,15 +908,18 @@ template <class NF> struct Ops {
             const View<NF>& sv = state_view<NF>(c);
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            const bool dliq = derive_now<RICH>(c) == DERIVE_LIQ;
+            const int derive = derive_now<RICH>(c);
             const int staged = staged_now<RICH>(c, true);
-            if (hyd(c) == HYD_VG_N2) {
-                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
-                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_VG_N2>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
-            } else {
-                if (dliq) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR, true>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
-                else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYD_BC_LINEAR>), pg, dim3(TRM_STEP_BLOCK), 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);
-            }
+            const dim3 blk(TRM_STEP_BLOCK);
+#define TRM_LAUNCH_PK(HYDV)                                                                                                                        \
+    do {                                                                                                                                           \
+        if (derive == DERIVE_T_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_T_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
+        else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
+        else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_NONE>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);     \
+    } while (0)
+            if (hyd(c) == HYD_VG_N2) TRM_LAUNCH_PK(HYD_VG_N2);
+            else TRM_LAUNCH_PK(HYD_BC_LINEAR);
+#undef TRM_LAUNCH_PK
             TRM_HIP(c, hipGetLastError());
         }
         return TRM_OK;

@@ -42,7 +42,6 @@ template <class NF> struct Tendency { NF gU, gS, Kf_lo, Kc; };
 // quotient x of two distinct floats of the same sign and |U| > |denominator| rounds to >= 1 + 2^-52, so 1 - x < 0
 // and the result is -0.0 without dividing.  Cells in phase change (and L_theta <= eps, sat below 1.4e-24) take the
 // divide -- decided per wave by one ballot.
-enum { DERIVE_NONE = 0, DERIVE_T_LIQ = 1, DERIVE_LIQ = 2 };
 // a lane needs the divide when it is in phase change, NaN, or its L_theta vanishes: !thawed && !(frozen && L_theta > eps) --
 // combined on the scalar unit from three ballots (the lane-wise boolean expression costs 8 vector instructions)
 TRM_DEV bool no_lane_divides(bool thawed, bool frozen, bool latent_resolved) {

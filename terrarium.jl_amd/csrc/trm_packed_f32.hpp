@@ -162,7 +162,7 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // per step -- the packed kernel is not short of bytes -- and is not offered.)
 // DERIVE_LIQ: the incoming liquid fraction is re-derived from (U, sat) instead of being read (legal when the stored fields
 // are the closure of the stored state, trm_ctx::closure_consistent): one of the five field reads less.
-template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
+template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE>
 TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p_arg, float dt, int finalize, int write_kf, unsigned block, int staged = 0) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
@@ -188,8 +188,14 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
 
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
     const v2f psi = RICHARDS ? ld2(v.psi, cb0, cb1) : splat(0.0f);
-    const v2f T = ld2(v.T, cb0, cb1);
-    const v2f liq = DERIVE_LIQ ? liquid_fraction2(kernarg_reload<DevParams<float>>(off_p), U, sat) : ld2(v.liq, cb0, cb1);
+    v2f T, liq;
+    if (DERIVE == DERIVE_T_LIQ) {      // both re-derived from (U, sat): two field reads less (k_column: DERIVE_T_LIQ)
+        uint32_t viol_in = 0;
+        energy_closure2(kernarg_reload<DevParams<float>>(off_p), U, sat, liq, T, viol_in);
+    } else {
+        T = ld2(v.T, cb0, cb1);
+        liq = DERIVE == DERIVE_LIQ ? liquid_fraction2(kernarg_reload<DevParams<float>>(off_p), U, sat) : ld2(v.liq, cb0, cb1);
+    }
 
     uint32_t viol_old = 0;   // (bounds of the incoming state were flagged by the launch that produced it)
     const Frac2 f = fractions2(p, sat, liq, viol_old);
@@ -353,9 +359,9 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u);
     if (flags) atomicOr(v.status, flags);
 }
-template <bool RICHARDS, int LPC, int HYD, bool DERIVE_LIQ = false>
+template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf, int staged) {
-    step_pk_program<RICHARDS, LPC, HYD, DERIVE_LIQ>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x), staged);
+    step_pk_program<RICHARDS, LPC, HYD, DERIVE>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x), staged);
 }
 // LandModel in fp32: the packed column step of one half of the columns beside the surface processes of the other half in one
 // launch (k_land_euler, trm_column.hpp).  (View, DevParams) first: step_pk_program re-reads them from the kernarg segment.
@@ -366,7 +372,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_land_pk(View<float> v_col, D
         if (i < v_surf.Nh) surface_program<float, RICHARDS, HYD, true, TOP_ARRAYS>(v_surf, p_arg, i);
         return;
     }
-    step_pk_program<RICHARDS, LPC, HYD, false>(v_col, p_arg, dt, finalize, write_kf, blockIdx.x - (unsigned)surface_blocks);
+    step_pk_program<RICHARDS, LPC, HYD, DERIVE_NONE>(v_col, p_arg, dt, finalize, write_kf, blockIdx.x - (unsigned)surface_blocks);
 }
 
 }  // namespace trm
