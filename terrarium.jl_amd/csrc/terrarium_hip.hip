@@ -884,6 +884,14 @@ template <class NF> struct Ops {
     // from HBM (8 x N145: 201.7 vs 212.9 us, -5.3 %) and on the LandModel with its seven outputs (C4 33.7 vs 34.4), it loses
     // where the step is launch- and latency-bound (C3 25.2 vs 24.7, N72 heat-only 7.3 vs 6.7): the barrier in front of the
     // staged store.  TRM_STAGED_SMALL = 0 / 1 in the environment forces it (experiments).
+    // The per-column inputs of the column program through the scalar memory path: cache-resident states (see column_program).
+    // TRM_SCALAR_INPUTS = 0 / 1 in the environment forces it (experiments, tests).
+    template <bool RICH> static int scalar_inputs_now(const trm_ctx* c) {
+        static const int forced = [] { const char* e = std::getenv("TRM_SCALAR_INPUTS"); return e ? std::atoi(e) : -1; }();
+        if (forced >= 0) return forced != 0;
+        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
+        return state_bytes <= ((size_t)256 << 20) ? 1 : 0;
+    }
     // The packed fp32 step does not gain (C5 472 vs 468 us, C5-VG 500 vs 487; exp20b): staging is off there unless forced.
     template <bool RICH> static int staged_now(const trm_ctx* c, bool packed = false) {
         static const int forced = [] { const char* e = std::getenv("TRM_STAGED_SMALL"); return e ? std::atoi(e) : -1; }();
@@ -1026,6 +1034,7 @@ template <class NF> struct Ops {
         a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
         a.nsteps = nsteps;
         a.staged = staged_now<RICH>(c);
+        a.scalar_in = scalar_inputs_now<RICH>(c);
         a.bcT_bot_stage = la.w.bcT_bot;
         a.bcT_top_stage = la.w.bcT_top;
         a.series = (const SeriesTable<NF>*)c->d_series_table;

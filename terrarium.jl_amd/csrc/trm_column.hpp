@@ -192,6 +192,7 @@ template <class NF> TRM_DEV NF series_value(const SeriesTable<NF>* tb, const Ser
 template <class NF> struct ColumnArgs {
     NF dt;
     int finalize, write_kf, nsteps;
+    int scalar_in; // the per-column inputs come through the scalar memory path (sld) instead of vector loads
     int staged;   // the per-column outputs leave through the workgroup's staging table (store_small_outputs) instead of directly
     // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
     const NF *bcT_bot_stage, *bcT_top_stage;
@@ -266,18 +267,31 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     const bool seb = p.seb != 0;
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
     ColumnBC<NF> bc;
-    bc.bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0);
-    bc.bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
+    // The per-column inputs (boundary values, LandModel's ground heat flux / infiltration, the 0-D fields) come through the
+    // scalar memory path (sld): one s_load per column of the wave, selected per half-wave -- where the state is cache-resident
+    // (ColumnArgs::scalar_in; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
+    // 8 x N145 200.8 -> 208.0: from HBM the scalar cache's 64-byte lines for 16 useful bytes cost more than the vector path).
+    const int col_w0 = __builtin_amdgcn_readfirstlane(wave * CPW);
+    const int jc0 = col_w0 < Nh ? col_w0 : Nh - 1, jc1 = col_w0 + 1 < Nh ? col_w0 + 1 : Nh - 1;
+    auto col_ld = [&](const NF* ptr) -> NF {
+        if (!a.scalar_in) return ldg(ptr, ib0);     // (wave-uniform choice: ColumnArgs::scalar_in)
+        const NF x0 = sld(ptr, jc0);
+        if (CPW == 1) return x0;
+        const NF x1 = sld(ptr, jc1);
+        return sub ? x1 : x0;
+    };
+    bc.bTb = vTb ? col_ld(bcval(v, 2, 0)) : NF(0);
+    bc.bTt = vTt ? col_ld(bcval(v, 2, 1)) : NF(0);
     {   // flux conditions: edge terms, 0 unless a condition is set; kept by the edge lanes
         NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
-        if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib0), v.g);
-        if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib0), v.g);
+        if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(col_ld(bcval(v, 0, 0)), v.g);
+        if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(col_ld(bcval(v, 1, 0)), v.g);
         if (!SEB_INLINE) {
             // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before
             // this launch.  Top terms enter with a minus sign.
-            if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib0), v.g);
+            if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(col_ld(seb ? v.ghf : bcval(v, 0, 1)), v.g);
             if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
-                const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib0);
+                const NF fS = col_ld(seb ? v.infil : bcval(v, 1, 1));
                 eS_t = -flux_term_top(seb ? -fS : fS, v.g);
             }
         }
@@ -291,8 +305,8 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     // acknowledged -- the wave's last act before it frees its slot.
     NF S_in = NF(0), Ts_in = NF(0), S_stage_out = NF(0);
     if (PROG != PROG_MULTI) {
-        if (RICHARDS) S_in = ldg(v.S, ib0);
-        if (seb) Ts_in = ldg(v.Ts, ib0);
+        if (RICHARDS) S_in = col_ld(v.S);
+        if (seb) Ts_in = col_ld(v.Ts);
     }
     NF S = NF(0);
     SurfaceRegs<NF> sf;
