@@ -917,7 +917,10 @@ template <class NF> struct Ops {
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
             const int derive = derive_now<RICH>(c);
-            const int staged = staged_now<RICH>(c, true);
+            // (bit 0: staged outputs; bit 1: per-column inputs through the scalar memory path -- on: C5 450.4 -> 447.0 us, C5-VG
+            // 486.6 -> 482.5, a 12 696-column shard 15.3 -> 15.0, profiles/r03/exp27; TRM_SCALAR_INPUTS_PK = 0 turns it off)
+            static const int scalar_pk = [] { const char* e = std::getenv("TRM_SCALAR_INPUTS_PK"); return e ? std::atoi(e) : 1; }();
+            const int staged = staged_now<RICH>(c, true) | (scalar_pk ? 2 : 0);
             const dim3 blk(TRM_STEP_BLOCK);
 #define TRM_LAUNCH_PK(HYDV)                                                                                                                        \
     do {                                                                                                                                           \

@@ -185,6 +185,21 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const unsigned ib0 = (unsigned)j0 * 4u, ib1 = (unsigned)j1 * 4u;
     const unsigned cb0 = ((unsigned)j0 * (unsigned)v.Nzp + kk) * 4u, cb1 = ((unsigned)j1 * (unsigned)v.Nzp + kk) * 4u;
     uint32_t viol = 0;
+    // `staged`: bit 0 -- the per-column outputs through the workgroup's staging table; bit 1 -- the per-column inputs through the
+    // scalar memory path (sld, trm_kernels.hpp): the four columns of the wave (two per half-wave) from s_loads, selected per
+    // half-wave, instead of two vector loads per input in which every lane of a column reads the same address
+    const bool scalar_in = (staged & 2) != 0;
+    staged &= 1;
+    const int pair_w0 = __builtin_amdgcn_readfirstlane(wave * CPW) * 2;
+    auto clampi = [&](int i) { return i < Nh ? i : Nh - 1; };
+    const int q0 = clampi(pair_w0), q1 = clampi(pair_w0 + 1), q2 = clampi(pair_w0 + 2), q3 = clampi(pair_w0 + 3);
+    auto col_ld2 = [&](const float* ptr) -> v2f {
+        if (!scalar_in) return ld2(ptr, ib0, ib1);
+        const float a0 = sld(ptr, q0), a1 = sld(ptr, q1);
+        if (CPW == 1) return v2f{a0, a1};
+        const float a2 = sld(ptr, q2), a3 = sld(ptr, q3);
+        return v2f{sub ? a2 : a0, sub ? a3 : a1};
+    };
 
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
     const v2f psi = RICHARDS ? ld2(v.psi, cb0, cb1) : splat(0.0f);
@@ -208,11 +223,11 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
     v2f T_ext_b = T, T_ext_t = T;
     if (vTb) {
-        const v2f b = ld2(bcval(v, 2, 0), ib0, ib1);
+        const v2f b = col_ld2(bcval(v, 2, 0));
         T_ext_b = T + div_const2(T - b, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
     }
     if (vTt) {
-        const v2f b = ld2(bcval(v, 2, 1), ib0, ib1);
+        const v2f b = col_ld2(bcval(v, 2, 1));
         T_ext_t = T + div_const2(b - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
     }
     const v2f T_m = sel(is_bot, T_ext_b, T_sh);
@@ -225,15 +240,15 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     {
         const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
         v2f eU_b = splat(0.0f), eU_t = splat(0.0f);
-        if (fUb) eU_b = div_const2(ld2(bcval(v, 0, 0), ib0, ib1) * v.g.Az, v.g.V_bot, v.g.rV_bot);
-        if (fUt) eU_t = -div_const2(ld2(seb ? v.ghf : bcval(v, 0, 1), ib0, ib1) * v.g.Az, v.g.V_top, v.g.rV_top);
+        if (fUb) eU_b = div_const2(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
+        if (fUt) eU_t = -div_const2(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top);
         flux_U = sel(is_bot, eU_b, sel(is_top, eU_t, splat(0.0f)));
         if (RICHARDS) {
             const bool fSb = v.bc.kind[1][0] == 2, fSt = seb || v.bc.kind[1][1] == 2;
             v2f eS_b = splat(0.0f), eS_t = splat(0.0f);
-            if (fSb) eS_b = div_const2(ld2(bcval(v, 1, 0), ib0, ib1) * v.g.Az, v.g.V_bot, v.g.rV_bot);
+            if (fSb) eS_b = div_const2(col_ld2(bcval(v, 1, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
             if (fSt) {
-                const v2f fS = ld2(seb ? v.infil : bcval(v, 1, 1), ib0, ib1);
+                const v2f fS = col_ld2(seb ? v.infil : bcval(v, 1, 1));
                 eS_t = -div_const2((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top);
             }
             flux_S = sel(is_bot, eS_b, sel(is_top, eS_t, splat(0.0f)));
@@ -242,8 +257,8 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     // surface_excess_water and the skin temperature of the two columns: READ HERE, with the other inputs.  Vector memory retires in
     // order, loads and stores through the one counter: a load issued behind a store holds the whole wave until that store has
     // been acknowledged by memory (the top-lane block used to do that three times per wave).
-    const v2f S_in = RICHARDS ? ld2(v.S, ib0, ib1) : splat(0.0f);
-    const v2f Ts_in = seb ? ld2(v.Ts, ib0, ib1) : splat(0.0f);
+    const v2f S_in = RICHARDS ? col_ld2(v.S) : splat(0.0f);
+    const v2f Ts_in = seb ? col_ld2(v.Ts) : splat(0.0f);
     // ---- heat
     const v2f qT_lo = -((kap + kap_m) * 0.5f) * ((T - T_m) * L.rdzf_lo);
     const v2f qT_sh = dn2(qT_lo);
