@@ -339,7 +339,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             stg(a.stage_T, cb, s.T);
         }
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
-        const NF bTb2 = vTb ? ldg(a.bcT_bot_stage, ib0) : NF(0), bTt2 = vTt ? ldg(a.bcT_top_stage, ib0) : NF(0);
+        const NF bTb2 = vTb ? col_ld(a.bcT_bot_stage) : NF(0), bTt2 = vTt ? col_ld(a.bcT_top_stage) : NF(0);
         uint32_t viol_stage = 0;
         const Tendency<NF> t2 = column_tendencies<NF, RICHARDS, HYD, LPC>(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), L, ln, s, bTb2, bTt2, RICHARDS, viol_stage);
         viol |= viol_stage;
