@@ -917,10 +917,7 @@ template <class NF> struct Ops {
             const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
             dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
             const int derive = derive_now<RICH>(c);
-            // (bit 0: staged outputs; bit 1: per-column inputs through the scalar memory path -- on: C5 450.4 -> 447.0 us, C5-VG
-            // 486.6 -> 482.5, a 12 696-column shard 15.3 -> 15.0, profiles/r03/exp27; TRM_SCALAR_INPUTS_PK = 0 turns it off)
-            static const int scalar_pk = [] { const char* e = std::getenv("TRM_SCALAR_INPUTS_PK"); return e ? std::atoi(e) : 1; }();
-            const int staged = staged_now<RICH>(c, true) | (scalar_pk ? 2 : 0);
+            const int staged = staged_now<RICH>(c, true);
             const dim3 blk(TRM_STEP_BLOCK);
 #define TRM_LAUNCH_PK(HYDV)                                                                                                                        \
     do {                                                                                                                                           \
@@ -1036,8 +1033,6 @@ template <class NF> struct Ops {
         a.finalize = finalize;
         a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
         a.nsteps = nsteps;
-        a.staged = staged_now<RICH>(c);
-        a.scalar_in = scalar_inputs_now<RICH>(c);
         a.bcT_bot_stage = la.w.bcT_bot;
         a.bcT_top_stage = la.w.bcT_top;
         a.series = (const SeriesTable<NF>*)c->d_series_table;
@@ -1059,7 +1054,14 @@ template <class NF> struct Ops {
             else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
             else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
         } else if constexpr (PROG == PROG_EULER) {
-            if (derive == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+            // with the derivation (every large or HBM-resident fp64 state): how the per-column outputs leave / inputs arrive
+            if (derive == DERIVE_T_LIQ) {
+                const int staged = staged_now<RICH>(c), scalar_in = scalar_inputs_now<RICH>(c);
+                if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
+                else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
+                else if (scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
+                else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, false>), grid, block, 0, c->stream, v, p, a);
+            }
             else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
             else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
         } else {
@@ -1954,6 +1956,9 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     hip(hipMalloc((void**)&c->d_status, sizeof(uint32_t)), "hipMalloc(status)");
     hip(hipMalloc(&c->d_zero, (size_t)c->Nh * c->esize), "hipMalloc(zero)");
     if (c->params.seb) hip(hipMalloc(&c->d_top3, 3 * (size_t)c->Nh * c->esize), "hipMalloc(top cells)");
+    // (tests: TRM_DERIVE_DEFAULT = 1 makes small grids take the instances with the derivation, where the staged outputs and the
+    // input paths are compiled in -- the value a context starts with for TRM_OPT_DERIVE_CLOSURE_FIELDS)
+    if (const char* e = std::getenv("TRM_DERIVE_DEFAULT")) c->opt_derive = std::atoi(e);
     if (rc == TRM_OK) hip(hipMemsetAsync(c->d_zero, 0, (size_t)c->Nh * c->esize, c->stream), "hipMemset(zero)");
     if (rc) return bail(rc);
     hip(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream), "hipMemset(status)");

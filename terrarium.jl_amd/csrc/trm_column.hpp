@@ -192,8 +192,6 @@ template <class NF> TRM_DEV NF series_value(const SeriesTable<NF>* tb, const Ser
 template <class NF> struct ColumnArgs {
     NF dt;
     int finalize, write_kf, nsteps;
-    int scalar_in; // the per-column inputs come through the scalar memory path (sld) instead of vector loads
-    int staged;   // the per-column outputs leave through the workgroup's staging table (store_small_outputs) instead of directly
     // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
     const NF *bcT_bot_stage, *bcT_top_stage;
     // multi-step program with time series: the slot table and [nsteps][nseries] rows
@@ -214,7 +212,9 @@ template <class NF> struct ColumnArgs {
 // of OTHER columns in one launch.  Its kernel must pass (View, DevParams, ColumnArgs) as its first three arguments: the program
 // re-reads them from the kernarg segment at those offsets (kernarg_reload).  `block`: index of the 256-thread workgroup among
 // those that run the program.
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false>
+// STAGED / SCALAR_IN: how the per-column outputs leave and the per-column inputs arrive (see below) -- compile-time: as
+// wave-uniform run-time branches they cost the field loads their back-to-back issue (profiles/r03/exp28: 8 x N145 +7 %).
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true>
 TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, const ColumnArgs<NF>& a, unsigned block) {
     // (kernarg layout: the arguments in order, each at its natural alignment)
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
@@ -269,12 +269,12 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     ColumnBC<NF> bc;
     // The per-column inputs (boundary values, LandModel's ground heat flux / infiltration, the 0-D fields) come through the
     // scalar memory path (sld): one s_load per column of the wave, selected per half-wave -- where the state is cache-resident
-    // (ColumnArgs::scalar_in; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
+    // (SCALAR_IN, chosen per launch; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
     // 8 x N145 200.8 -> 208.0: from HBM the scalar cache's 64-byte lines for 16 useful bytes cost more than the vector path).
     const int col_w0 = __builtin_amdgcn_readfirstlane(wave * CPW);
     const int jc0 = col_w0 < Nh ? col_w0 : Nh - 1, jc1 = col_w0 + 1 < Nh ? col_w0 + 1 : Nh - 1;
     auto col_ld = [&](const NF* ptr) -> NF {
-        if (!a.scalar_in) return ldg(ptr, ib0);     // (wave-uniform choice: ColumnArgs::scalar_in)
+        if (!SCALAR_IN) return ldg(ptr, ib0);
         const NF x0 = sld(ptr, jc0);
         if (CPW == 1) return x0;
         const NF x1 = sld(ptr, jc1);
@@ -466,7 +466,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         }
         if (write_kf) stg(v.Kf, cb, Kf_out);
         if (ln.is_top && RICHARDS && PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage_out);
-        if (ln.is_top && a.staged) {
+        if (ln.is_top && STAGED) {
             // The per-column outputs (up to eight 8-byte values: top face of K, surface excess water, water table, its tendency,
             // the top cell for the next surface energy balance, the skin temperature) go to the workgroup's staging table: one
             // wave writes them below, 64 contiguous bytes per array and workgroup in a single instruction, instead of eight
@@ -506,7 +506,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         }
         viol |= bad ? 1u : 0u;
     }
-    if (a.staged) {
+    if (STAGED) {
         const unsigned enabled = (write_kf ? 1u << SMALL_KF_TOP : 0u) | (RICHARDS ? (1u << SMALL_S) | (1u << SMALL_WT) : 0u) |
                                  ((RICHARDS && finalize) ? 1u << SMALL_G_S : 0u) |
                                  (seb ? (1u << SMALL_TOP_T) | (1u << SMALL_TOP_SAT) | (1u << SMALL_TOP_LIQ) | (1u << SMALL_TS) : 0u);
@@ -516,11 +516,11 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     if (viol && ln.act) atomicOr(v_arg.status, viol);
 }
 
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false>
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
-    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES, STAGED, SCALAR_IN>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
 }
 
 // ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the

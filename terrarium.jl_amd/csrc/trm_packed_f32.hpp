@@ -185,16 +185,14 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const unsigned ib0 = (unsigned)j0 * 4u, ib1 = (unsigned)j1 * 4u;
     const unsigned cb0 = ((unsigned)j0 * (unsigned)v.Nzp + kk) * 4u, cb1 = ((unsigned)j1 * (unsigned)v.Nzp + kk) * 4u;
     uint32_t viol = 0;
-    // `staged`: bit 0 -- the per-column outputs through the workgroup's staging table; bit 1 -- the per-column inputs through the
-    // scalar memory path (sld, trm_kernels.hpp): the four columns of the wave (two per half-wave) from s_loads, selected per
-    // half-wave, instead of two vector loads per input in which every lane of a column reads the same address
-    const bool scalar_in = (staged & 2) != 0;
+    // The per-column inputs come through the scalar memory path (sld, trm_kernels.hpp): the four columns of the wave (two per
+    // half-wave) from s_loads, selected per half-wave, instead of two vector loads per input in which every lane of a column reads
+    // the same address (profiles/r03/exp27: C5 450.4 -> 447.0 us, a 12 696-column shard 15.3 -> 15.0).
     staged &= 1;
     const int pair_w0 = __builtin_amdgcn_readfirstlane(wave * CPW) * 2;
     auto clampi = [&](int i) { return i < Nh ? i : Nh - 1; };
     const int q0 = clampi(pair_w0), q1 = clampi(pair_w0 + 1), q2 = clampi(pair_w0 + 2), q3 = clampi(pair_w0 + 3);
     auto col_ld2 = [&](const float* ptr) -> v2f {
-        if (!scalar_in) return ld2(ptr, ib0, ib1);
         const float a0 = sld(ptr, q0), a1 = sld(ptr, q1);
         if (CPW == 1) return v2f{a0, a1};
         const float a2 = sld(ptr, q2), a3 = sld(ptr, q3);

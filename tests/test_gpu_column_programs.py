@@ -333,7 +333,9 @@ def test_staged_per_column_outputs_forced_on_small_grids():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # (and the per-column inputs by vector loads, ColumnArgs::scalar_in = 0: what HBM-resident states take -- the small grids of the
     # suite otherwise run with direct stores and the scalar memory path)
-    env = dict(os.environ, TRM_STAGED_SMALL="1", TRM_SCALAR_INPUTS="0")
+    # Both are compiled into the instances that derive T / liq (every large fp64 state): TRM_DERIVE_DEFAULT=1 makes the small
+    # grids of the suite take those.
+    env = dict(os.environ, TRM_STAGED_SMALL="1", TRM_SCALAR_INPUTS="0", TRM_DERIVE_DEFAULT="1")
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_column_programs.py"), os.path.join(root, "tests", "test_gpu_parity.py"),
                           "-m", "gpu", "-q", "-x", "-W", "ignore::DeprecationWarning", "-k", "not staged_per_column_outputs and not hypothesis",
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
