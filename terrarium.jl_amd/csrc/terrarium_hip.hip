@@ -879,7 +879,7 @@ template <class NF> struct Ops {
         if (std::is_same<NF, float>::value) return (beyond_cache && packed_path(const_cast<trm_ctx*>(c))) ? DERIVE_LIQ : DERIVE_NONE;
         return (beyond_cache || large) ? DERIVE_T_LIQ : DERIVE_NONE;
     }
-    // The per-column outputs of the column program through the workgroup's staging table (ColumnArgs::staged) or as direct 2-lane
+    // The per-column outputs of the column program through the workgroup's staging table (template parameter STAGED) or as direct 2-lane
     // stores.  Measured (profiles/r03/exp20_staged_small_stores.log, same box, alternating): staged wins where the state streams
     // from HBM (8 x N145: 201.7 vs 212.9 us, -5.3 %) and on the LandModel with its seven outputs (C4 33.7 vs 34.4), it loses
     // where the step is launch- and latency-bound (C3 25.2 vs 24.7, N72 heat-only 7.3 vs 6.7): the barrier in front of the

@@ -324,7 +324,7 @@ def test_divide_sequences_fp32():
 
 def test_staged_per_column_outputs_forced_on_small_grids():
     """The column programs store their per-column outputs either directly or through the workgroup's staging table
-    (ColumnArgs::staged; the library stages HBM-resident fp64 states and large LandModels).  TRM_STAGED_SMALL=1 forces the
+    (template parameter STAGED of the deriving instances; the library stages HBM-resident fp64 states and large LandModels).  TRM_STAGED_SMALL=1 forces the
     staged path for every context: the parity and program tests of this file and the LandModel parity cases must pass unchanged
     (the variable is read once per process, hence the child process)."""
     import os
