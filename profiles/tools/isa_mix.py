@@ -1,5 +1,5 @@
 """Opcode-class mix of one kernel in a device assembly listing (static count over the whole kernel body, cold paths included):
-   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math --cuda-device-only -S -o /tmp/trm.s terrarium_hip.hip
+   make -C terrarium.jl_amd/csrc asm F=trm_launch_column_f64_euler_rich   (-> build/obj/<F>.s; any trm_launch_*.hip)
    python profiles/tools/isa_mix.py /tmp/trm.s _ZN3trm8k_columnIdLb1ELi0ELi32ELi1ELi0ELb0ELb0E"""
 import collections
 import re

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Static resource usage (VGPRs, SGPRs, occupancy, scratch, static VALU count) of the step kernels from the device ISA:
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -S --cuda-device-only -o /tmp/trm.s terrarium.jl_amd/csrc/terrarium_hip.hip
+    make -C terrarium.jl_amd/csrc asm F=trm_launch_column_f64_euler_rich   (-> build/obj/<F>.s; any trm_launch_*.hip)
     python profiles/tools/kernel_resources.py /tmp/trm.s [filter ...]"""
 import re
 import subprocess

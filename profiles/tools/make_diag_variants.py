@@ -67,7 +67,8 @@ def main():
         with open(path, "w") as f:
             f.write(fn(text))
         so = os.path.join(out, f"libtrm_{name}.so")
-        subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + sys.argv[1:] + ["-shared", "-o", so, os.path.join(work, "terrarium.jl_amd", "csrc", "terrarium_hip.hip")])
+        subprocess.check_call(["make", "-C", os.path.join(work, "terrarium.jl_amd", "csrc"), "-s", "-j8", "OUT=" + so, "OBJDIR=" + os.path.join(work, "obj"),
+                               "EXTRA=" + " ".join(sys.argv[1:])])
         print("built", so)
 
 

@@ -1,5 +1,9 @@
 #!/bin/bash
-# usage: mkvar.sh NAME SRCDIR [extra flags] -> build/variants/lib_NAME.so
+# usage: mkvar.sh NAME SRCDIR [extra compiler flags] -> build/variants/lib_NAME.so
+# SRCDIR: a copy of terrarium.jl_amd/csrc (with ../../include beside it as in the tree), or the tree's own csrc.  The translation
+# units compile in parallel into build/variants/obj_NAME/.
 name=$1; src=$2; shift 2
-mkdir -p /root/repo/build/variants
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I/root/repo/include -I/root/repo/terrarium.jl_amd/csrc "$@" -shared -o /root/repo/build/variants/lib_$name.so $src/terrarium_hip.hip 2>&1 | grep -E "error" -A5
+root=$(cd "$(dirname "$0")/../.." && pwd)
+mkdir -p $root/build/variants
+make -C $src -s -j8 OUT=$root/build/variants/lib_$name.so OBJDIR=$root/build/variants/obj_$name EXTRA="$*" 2>&1 | grep -E "error" -A5
+ls -la $root/build/variants/lib_$name.so

@@ -1,169 +1,27 @@
-// terrarium_hip.hip -- context management and the C ABI of libterrarium_hip.so
-// (include/terrarium_hip.h).  gfx950 only; no CPU fallback.
-#include "../../include/terrarium_hip.h"
-#include "trm_kernels.hpp"
-#include "trm_packed_f32.hpp"
-#include "trm_column.hpp"
-#include "trm_column_deep.hpp"
-#include "trm_vegetation.hpp"
+// terrarium_hip.hip -- context management, the step sequences and the C ABI of libterrarium_hip.so
+// (include/terrarium_hip.h).  gfx950 only; no CPU fallback.  The kernel instantiations live in the trm_launch_*.hip files
+// (trm_host.hpp declares their launchers); this file launches only the small data-movement kernels (transposition, ring
+// scatter / gather, reductions).
+#include "trm_host.hpp"
 
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types only: the library is opened lazily by trm_comm_init (no link-time dependency)
-
-#include <cmath>
-#include <limits>
-#include <type_traits>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <algorithm>
-#include <string>
-#include <vector>
 
 using namespace trm;
+using namespace trmh;
 
 namespace {
-
-struct FieldSet {
-    void* f[TRM_FIELD_COUNT];
-    void* kf_top;  // top face (face Nz) of the hydraulic_conductivity Face field, [Nh]
-    void* raw[TRM_FIELD_COUNT];   // the allocations behind f[] (f = raw + the field's skew, see alloc_fields)
-};
-
+thread_local std::string g_create_error;
 }  // namespace
 
-struct trm_ctx {
-    int precision = TRM_F64;
-    long Nh = 0;
-    int Nz = 0, Nzp = 0, device = 0;  // Nzp: level pitch of the z-fastest device layout
-    size_t esize = 8;
-    trm_params params;
-    hipStream_t own_stream = nullptr, stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    FieldSet state{}, stage{}, saved{};
-    bool has_stage = false, has_saved = false;
-    double saved_time = 0.0;
-    int64_t saved_iteration = 0;
-    uint32_t saved_status = 0;
-    bool saved_tend_valid = true;
-    void* bc_value[TRM_BCV_COUNT][2] = {};
-    int bc_kind[TRM_BCV_COUNT][2] = {};
-    void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr, *d_lvl = nullptr;
-    void* d_rootf = nullptr;   // static root fraction per level [Nz] (root_distribution.jl:45-63)
-    std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
-    double dzf_bot = 0, dzf_top = 0, dzc_bot = 0, dzc_top = 0, Az = 1;
-    uint32_t* d_status = nullptr;
-    // time series input sources: whole series resident on the device, evaluated at the clock every step
-    struct Series {
-        bool is_bc = false;
-        int field = 0, var = 0, side = 0, indexing = 0;
-        std::vector<double> times;  // the time levels currently held, oldest first
-        void* d_values = nullptr;   // [cap][Nh]: a ring of time levels, level n of `times` in slot (head + n) % cap
-        long cap = 0, head = 0;
-        long pending_from = -1;     // first level (index into `times`) whose copy may still be in flight, or -1
-        size_t slot(int n) const { return (size_t)((head + n) % cap); }
-    };
-    std::vector<Series> series;
-    // trm_series_append: host values are staged through pinned memory and copied on a side stream under the running steps
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t copy_done = nullptr;     // the last appended levels have reached the device
-    hipEvent_t copy_order = nullptr;    // the context stream's work at the time levels were last released (trim)
-    bool copy_pending = false, order_recorded = false;
-    void* h_stage = nullptr;            // pinned staging buffer
-    size_t h_stage_cap = 0;
-    // ring grid (ColumnRingGrid, column_ring_grid.jl:37-59): column i <-> point ring_index[i] of the full grid
-    long ring_points = 0;
-    int32_t* d_ring_inv = nullptr;      // [ring_points] column of a grid point, -1 outside the mask
-    int32_t* d_ring_idx = nullptr;      // [Nh] grid point of a column
-    void* d_ring = nullptr;             // staging [rows][ring_points]
-    size_t ring_cap = 0;
-    void* bc_value_stage[TRM_BCV_COUNT][2] = {};  // Heun: the stage evaluates its boundary series at t + dt
-    void* d_top3 = nullptr;  // LandModel: [3][Nh] (T, sat, liq) of the top cell as left by the last fused step
-    bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)
-    bool top_escaped = false;  // a device pointer to T / sat / liq was handed out: never trust the copies again
-    bool tend_valid = true;    // the tendency fields hold what the reference would (false after a fused step that did not finalize)
-    // the stored (temperature, liquid_water_fraction) ARE the energy closure of the stored (internal_energy, saturation):
-    // true after a fused step / closure!, false after anything else wrote one of the four fields.  Lets the step derive
-    // them in registers instead of reading them (k_column<DERIVE>).
-    bool closure_consistent = false, closure_escaped = false, saved_closure_consistent = false;
-    void* d_zero = nullptr;  // [Nh] zeros: stands in for the value array of every unset boundary condition
-    double* d_reduce = nullptr;  // scratch for trm_reduce
-    size_t reduce_cap = 0;
-    void* d_io = nullptr;        // staging buffer of trm_upload / trm_download (host layout [rows][Nh])
-    size_t io_cap = 0;
-    double time = 0.0;
-    int64_t iteration = 0;
-    int opt_packed = 1;   // fp32: two columns per lane with packed math where the path allows it
-    int opt_async = 0, opt_kernel = TRM_KERNEL_FUSED, opt_write_kf = 1, opt_vwc_field = 0;
-    int opt_derive = 2;
-    int opt_steps_per_launch = 0;   // 0: chosen by the library (auto_steps_per_launch), 1: one launch per step, m > 1: up to m steps per launch
-    // Two halves of the columns (TRM_OPT_PIPELINE_PARTS): the per-step LandModel path runs the latency-bound 0-D surface
-    // processes of one half in the same launch as the soil columns of the other (k_land_euler).  Columns are independent.
-    int opt_pipeline = 2;           // 0: off, 1: whenever legal, 2: auto (column threshold)
-    int part = -1;                  // part the launch helpers currently address (-1: all columns)
-    long part_lo[2] = {0, 0}, part_n[2] = {0, 0};
-    // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;
-    // any call that changes what they are built from (boundary conditions, options, lazily allocated buffers) clears
-    // `args_valid` and the next launch rebuilds them.
-    // multi-device diagnostics: one RCCL communicator per context, collectives on a side stream (never on the step path)
-    ncclComm_t comm = nullptr;
-    int comm_rank = 0, comm_world = 1;
-    hipStream_t comm_stream = nullptr;
-    double* d_comm = nullptr;   // [2 * (Nz + 1) + 8] doubles: send | recv
-    // vegetation (trm_set_vegetation)
-    int veg_mode = TRM_VEGETATION_OFF;
-    trm_vegetation_params veg_params{};
-    // multi-step program with time series: device copies of the slot table and the per-step rows
-    void* d_series_table = nullptr;
-    void* d_series_rows = nullptr;
-    size_t series_rows_cap = 0;
-    // pinned staging for them: a ring, so that a launch never waits for the stream -- only for the copy that used the same
-    // staging buffer four launches ago
-    struct RowStage { void* h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
-    RowStage row_stage[4];
-    int row_stage_next = 0;
-    bool args_valid = false;
-    void* args = nullptr;   // LaunchArgs<NF>*, owned
-    void (*args_free)(void*) = nullptr;
-    std::string err;
-};
-
-namespace {
-
-thread_local std::string g_create_error;
-
+namespace trmh {
 int fail(trm_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->err = msg;
     else g_create_error = msg;
     return code;
 }
+}  // namespace trmh
 
-#define TRM_HIP(ctx, call)                                                                               \
-    do {                                                                                                 \
-        hipError_t e__ = (call);                                                                         \
-        if (e__ != hipSuccess)                                                                           \
-            return fail(ctx, TRM_EHIP, std::string(#call) + ": " + hipGetErrorString(e__));             \
-    } while (0)
-
-long field_rows(const trm_ctx* c, int field) {
-    if (field == TRM_FIELD_HYDRAULIC_CONDUCTIVITY) return c->Nz + 1;
-    if (field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING) return c->Nz;
-    if (field == TRM_FIELD_PLANT_AVAILABLE_WATER || field == TRM_FIELD_ROOT_FRACTION) return c->Nz;
-    return 1;
-}
-bool valid_field(int f) { return f >= 0 && f < TRM_FIELD_COUNT; }
-bool is_input_field(int f) {
-    return (f >= TRM_FIELD_AIR_TEMPERATURE && f <= TRM_FIELD_SURFACE_LONGWAVE_DOWN) || f == TRM_FIELD_ALBEDO || f == TRM_FIELD_EMISSIVITY ||
-           (f >= TRM_FIELD_CO2 && f <= TRM_FIELD_VEGETATION_GROUND_TEMPERATURE) || f == TRM_FIELD_STEM_AREA_INDEX;
-}
-bool is_3d(int field) {
-    return field <= TRM_FIELD_TEND_SATURATION_WATER_ICE || field == TRM_FIELD_VWC_FORCING || field == TRM_FIELD_PLANT_AVAILABLE_WATER ||
-           field == TRM_FIELD_ROOT_FRACTION;
-}
-// the 3-D vegetation fields exist only once trm_set_vegetation has run
-bool is_lazy_field(int field) { return field == TRM_FIELD_PLANT_AVAILABLE_WATER || field == TRM_FIELD_ROOT_FRACTION; }
-// elements of the device buffer of a field: [Nh][Nzp] for 3-D fields, [Nh] for 2-D fields
-size_t field_elems(const trm_ctx* c, int field) { return is_3d(field) ? (size_t)c->Nh * c->Nzp : (size_t)c->Nh; }
+namespace {
 
 // ---- grid: ColumnGrid (column_grid.jl:20-34) + Oceananigans' stretched-coordinate recipe --------------
 // thickness[0] is the surface layer.  All derived quantities are formed in NF.
@@ -375,17 +233,21 @@ template <class NF> View<NF> sub_view(const View<NF>& v, long lo, long n) {
     return s;
 }
 
-template <class NF> struct StageView { const NF *bcT_bot, *bcT_top; };
-template <class NF> StageView<NF> make_stage_view(const trm_ctx* c);
-template <class NF> struct LaunchArgs {
-    DevParams<NF> p;
-    View<NF> state, stage;
-    View<NF> part[2];   // the state's view restricted to the two pipeline parts
-    StageView<NF> w;
-};
-// columns the launch helpers currently address: all of them, or one pipeline part
-long ncols(const trm_ctx* c) { return c->part >= 0 ? c->part_n[c->part] : c->Nh; }
-long first_col(const trm_ctx* c) { return c->part >= 0 ? c->part_lo[c->part] : 0; }
+template <class NF> StageView<NF> make_stage_view(const trm_ctx* c) {
+    // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
+    StageView<NF> w{};
+    auto bc = [&](int side) {
+        void* q = c->bc_value_stage[TRM_BCV_TEMPERATURE][side] ? c->bc_value_stage[TRM_BCV_TEMPERATURE][side] : c->bc_value[TRM_BCV_TEMPERATURE][side];
+        return (const NF*)(q ? q : c->d_zero);
+    };
+    w.bcT_bot = bc(0);
+    w.bcT_top = bc(1);
+    return w;
+}
+
+}  // namespace
+
+namespace trmh {
 template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
     if (!c->args) {
         c->args = new LaunchArgs<NF>();
@@ -402,27 +264,8 @@ template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
     }
     return *a;
 }
-template <class NF> const View<NF>& cached_view(trm_ctx* c, const FieldSet& s) {
-    const LaunchArgs<NF>& a = launch_args<NF>(c);
-    if (&s == &c->stage) return a.stage;
-    return c->part >= 0 ? a.part[c->part] : a.state;
-}
-// the state's view as the step launches see it (one pipeline part, or everything)
-template <class NF> const View<NF>& state_view(trm_ctx* c) { return cached_view<NF>(c, c->state); }
-
-dim3 cell_grid(const trm_ctx* c, long /*rows*/ = 0) { return dim3((unsigned)(((size_t)c->Nh * c->Nzp + 255) / 256), 1, 1); }
-dim3 col_grid(const trm_ctx* c) { return dim3((unsigned)((ncols(c) + 255) / 256), 1, 1); }
-// lane = level kernels: one column per LPC lanes, 4 waves per workgroup
-dim3 wave_grid(const trm_ctx* c, int lpc) {
-    long waves = (ncols(c) + (64 / lpc) - 1) / (64 / lpc);
-    return dim3((unsigned)((waves + 3) / 4), 1, 1);
-}
-// addresses one part of the columns for the lifetime of the scope
-struct PartScope {
-    trm_ctx* c;
-    PartScope(trm_ctx* ctx, int q) : c(ctx) { c->part = q; }
-    ~PartScope() { c->part = -1; }
-};
+template const LaunchArgs<double>& launch_args<double>(trm_ctx*);
+template const LaunchArgs<float>& launch_args<float>(trm_ctx*);
 
 // Time interpolation indices of a series at time t -- Oceananigans' FieldTimeSeries indexing (Linear / Clamp /
 // Cyclical), restated; that package is not part of the reference tree (parity unpinned).
@@ -482,311 +325,49 @@ void series_time_indices(const std::vector<double>& times, int indexing, double 
         else if (t <= times[0]) { n1 = n2 = 0; f = 0.0; }
     }
 }
+}  // namespace trmh
 
-template <class NF> StageView<NF> make_stage_view(const trm_ctx* c) {
-    // Heun: the stage's temperature boundary values (a series evaluated at t + dt), else the state's
-    StageView<NF> w{};
-    auto bc = [&](int side) {
-        void* q = c->bc_value_stage[TRM_BCV_TEMPERATURE][side] ? c->bc_value_stage[TRM_BCV_TEMPERATURE][side] : c->bc_value[TRM_BCV_TEMPERATURE][side];
-        return (const NF*)(q ? q : c->d_zero);
-    };
-    w.bcT_bot = bc(0);
-    w.bcT_top = bc(1);
-    return w;
-}
+namespace {
 
 template <class NF> int upload_impl(trm_ctx* c, int field, const NF* host);
 
+// The step sequences of one precision.  The launches themselves are Unfused / Veg / ColumnLaunch / GenericLaunch / DeepLaunch /
+// LandLaunch / PackedLaunch (trm_host.hpp); the forwarders below keep their reference names in the sequences.
 template <class NF> struct Ops {
-    static bool richards(const trm_ctx* c) { return c->params.flow == TRM_FLOW_RICHARDS; }
-
-    // update_inputs!(state, clock) for the time series sources: evaluates every series at `time` into the input
-    // field / boundary value array of field set `s` (the Heun stage has its own copies)
-    // Levels appended by trm_series_append travel on the side stream; a step that reads one of them first makes the context
-    // stream wait for the copy (steps that stay within the older levels run under it).
-    static int await_levels(trm_ctx* c, trm_ctx::Series& sr, int last_level) {
-        if (sr.pending_from < 0 || last_level < sr.pending_from) return TRM_OK;
-        TRM_HIP(c, hipStreamWaitEvent(c->stream, c->copy_done, 0));
-        for (auto& o : c->series) o.pending_from = -1;     // (one event covers every copy issued so far)
-        return TRM_OK;
-    }
-    static int update_inputs(trm_ctx* c, const FieldSet& s, double time) {
-        if (c->series.empty()) return TRM_OK;
-        const bool stage = &s == &c->stage;
-        SeriesJobs<NF> jobs;
-        int nj = 0;
-        auto flush = [&]() -> int {
-            if (nj == 0) return TRM_OK;
-            hipLaunchKernelGGL(k_interp_series<NF>, dim3((unsigned)((ncols(c) + 255) / 256), (unsigned)nj), dim3(256), 0, c->stream, jobs, ncols(c));
-            TRM_HIP(c, hipGetLastError());
-            nj = 0;
-            return TRM_OK;
-        };
-        for (auto& sr : c->series) {
-            int n1, n2;
-            double f, g;
-            series_time_indices(sr.times, sr.indexing, time, n1, n2, f, g);
-            if (int rw = await_levels(c, sr, std::max(n1, n2))) return rw;
-            if (!sr.is_bc && stage && !c->has_stage) continue;   // (fused Heun: the stage's surface processes are never evaluated)
-            NF* dst;
-            if (sr.is_bc) {
-                void*& slot = stage ? c->bc_value_stage[sr.var][sr.side] : c->bc_value[sr.var][sr.side];
-                if (!slot) {
-                    TRM_HIP(c, hipMalloc(&slot, (size_t)c->Nh * sizeof(NF)));
-                    c->args_valid = false;
-                }
-                dst = (NF*)slot;
-            } else {
-                dst = (NF*)s.f[sr.field];
-            }
-            const NF* base = (const NF*)sr.d_values + first_col(c);   // (a pipeline part evaluates its own columns)
-            dst += first_col(c);
-            jobs.job[nj++] = SeriesJob<NF>{dst, base + sr.slot(n1) * c->Nh, base + sr.slot(n2) * c->Nh, f, g, sr.indexing == TRM_TIME_RASTER ? 1 : 0};
-            if (nj == 16) { int rc = flush(); if (rc) return rc; }
-        }
-        return flush();
-    }
-
-    // hydraulics specialisation of this context (trm_device.hpp: HYD_*)
-    static int hyd(const trm_ctx* c) {
-        if (c->params.swrc == TRM_SWRC_BROOKS_COREY && c->params.unsat_k == TRM_UNSATK_LINEAR) {
-            // the compile-time instance is lambda = 0.2 (-1/lambda = -5 exactly, Base's integer power); other lambda: generic
-            const PowSpec<NF> spec = make_pow_spec<NF>(NF(-1) / (NF)c->params.bc_lambda);
-            return (spec.kind == POW_INT && spec.n == -5) ? HYD_BC_LINEAR : HYD_GENERIC;
-        }
-        if (c->params.swrc == TRM_SWRC_VAN_GENUCHTEN && c->params.unsat_k == TRM_UNSATK_VAN_GENUCHTEN) {
-            // the compile-time instance is van Genuchten's n = 2 (every reference test and example); other n: generic
-            // (n = 2 exactly: -1/m = -2 {INT}, 1/n = (n-1)/n = 1/2 {HALVES, 1}, n/(n+1) = RN(2/3) {THIRDS, 2} in make_pow_spec)
-            if (c->params.vg_n == 2.0) return HYD_VG_N2;
-        }
-        return HYD_GENERIC;
-    }
-#define TRM_BY_HYD(c, CALL)                                   \
-    switch (hyd(c)) {                                         \
-        case HYD_BC_LINEAR: { constexpr int H = HYD_BC_LINEAR; CALL; } break; \
-        case HYD_VG_N2: { constexpr int H = HYD_VG_N2; CALL; } break;         \
-        default: { constexpr int H = HYD_GENERIC; CALL; } break;             \
-    }
-
-    static int hydraulics(trm_ctx* c, const FieldSet& s) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        TRM_BY_HYD(c, hipLaunchKernelGGL((k_hydraulics<NF, H>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p));
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    static int surface(trm_ctx* c, const FieldSet& s, bool from_state = false) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        if (from_state && c->top_valid && &s == &c->state) {
-            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
-            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
-        } else if (from_state) {
-            if (richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true, false>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
-            else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true, false>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
-        } else {
-            if (richards(c)) hipLaunchKernelGGL((k_surface<NF, true, HYD_GENERIC, false, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
-            else hipLaunchKernelGGL((k_surface<NF, false, HYD_GENERIC, false, false>), col_grid(c), dim3(256), 0, c->stream, v, p);
-        }
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    static bool coupled(const trm_ctx* c) { return c->veg_mode == TRM_VEGETATION_COUPLED; }
-    static int compute_auxiliary(trm_ctx* c, const FieldSet& s) {
-        int rc = hydraulics(c, s);
-        if (rc) return rc;
-        if (coupled(c)) rc = surface_veg<false, false>(c, s, 0.0);
-        else if (c->params.seb) rc = surface(c, s);
-        return rc;
-    }
-    static int compute_tendencies(trm_ctx* c, const FieldSet& s) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        if (richards(c)) hipLaunchKernelGGL((k_tendencies<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
-        else hipLaunchKernelGGL((k_tendencies<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
-        TRM_HIP(c, hipGetLastError());
-        if (coupled(c)) {   // surface hydrology (canopy water) and vegetation tendencies (land_model.jl:90-97)
-            hipLaunchKernelGGL((k_vegetation<NF, VEG_TEND>), col_grid(c), dim3(256), 0, c->stream, veg_view(c, s), veg_dev(c), NF(0), 1, 0);
-            TRM_HIP(c, hipGetLastError());
-        }
-        return TRM_OK;
-    }
-    static int reset_tendencies(trm_ctx* c, const FieldSet& s) {
-        for (int f : {TRM_FIELD_TEND_INTERNAL_ENERGY, TRM_FIELD_TEND_SATURATION_WATER_ICE, TRM_FIELD_TEND_SURFACE_EXCESS_WATER,
-                      TRM_FIELD_TEND_CARBON_VEGETATION, TRM_FIELD_TEND_VEGETATION_AREA_FRACTION, TRM_FIELD_TEND_CANOPY_WATER})
-            TRM_HIP(c, hipMemsetAsync(s.f[f], 0, field_elems(c, f) * sizeof(NF), c->stream));
-        return TRM_OK;
-    }
-    static int update_state(trm_ctx* c, const FieldSet& s, bool tendencies) {
-        int rc = reset_tendencies(c, s);
-        if (!rc) rc = compute_auxiliary(c, s);
-        if (!rc && tendencies) rc = compute_tendencies(c, s);
-        return rc;
-    }
-    static int explicit_step(trm_ctx* c, const FieldSet& s, double dt) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        if (richards(c)) hipLaunchKernelGGL((k_explicit_step<NF, true>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
-        else hipLaunchKernelGGL((k_explicit_step<NF, false>), cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p, (NF)dt);
-        TRM_HIP(c, hipGetLastError());
-        if (coupled(c)) {
-            hipLaunchKernelGGL((k_vegetation<NF, VEG_EXPLICIT>), col_grid(c), dim3(256), 0, c->stream, veg_view(c, s), veg_dev(c), (NF)dt, 1, 0);
-            TRM_HIP(c, hipGetLastError());
-        }
-        return TRM_OK;
-    }
-    // hydrology closure: adjust_saturation_profile! + compute_water_table! (+ saturation_to_pressure!)
-    template <bool PSI, bool ADJ, int H> static void launch_closure_hydrology(trm_ctx* c, View<NF> v, DevParams<NF> p) {
-        if (c->Nz <= 32) hipLaunchKernelGGL((k_closure_hydrology_wave<NF, PSI, H, ADJ, 32>), wave_grid(c, 32), dim3(256), 0, c->stream, v, p);
-        else if (c->Nz <= 64) hipLaunchKernelGGL((k_closure_hydrology_wave<NF, PSI, H, ADJ, 64>), wave_grid(c, 64), dim3(256), 0, c->stream, v, p);
-        else hipLaunchKernelGGL((k_closure_hydrology_seq<NF, PSI, H, ADJ>), col_grid(c), dim3(256), 0, c->stream, v, p);
-    }
-    static int closure_hydrology(trm_ctx* c, const FieldSet& s, bool with_psi, bool with_adjust = true) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        if (with_psi) {
-            TRM_BY_HYD(c, (launch_closure_hydrology<true, true, H>(c, v, p)));
-        } else if (with_adjust) {
-            launch_closure_hydrology<false, true, HYD_GENERIC>(c, v, p);
-        } else {
-            launch_closure_hydrology<false, false, HYD_GENERIC>(c, v, p);
-        }
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    static int closure(trm_ctx* c, const FieldSet& s) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        if (richards(c)) {
-            int rc = closure_hydrology(c, s, true);
-            if (rc) return rc;
-        }
-        hipLaunchKernelGGL(k_closure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    static int invclosure(trm_ctx* c, const FieldSet& s) {
-        const View<NF>& v = cached_view<NF>(c, s);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        if (richards(c)) {
-            hipLaunchKernelGGL(k_pressure_to_saturation<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
-            TRM_HIP(c, hipGetLastError());
-            int rc = closure_hydrology(c, s, false);
-            if (rc) return rc;
-        }
-        hipLaunchKernelGGL(k_invclosure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    static int initialize(trm_ctx* c) {
-        const View<NF>& v = cached_view<NF>(c, c->state);
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        if (richards(c)) {  // soil_hydrology_rre.jl:33-47
-            int rc = closure_hydrology(c, c->state, true);
-            if (!rc) rc = hydraulics(c, c->state);
-            if (rc) return rc;
-        } else {  // soil_hydrology.jl:113-117
-            int rc = hydraulics(c, c->state);
-            if (rc) return rc;
-            rc = closure_hydrology(c, c->state, false, false);  // compute_water_table! only
-            if (rc) return rc;
-        }
-        hipLaunchKernelGGL(k_invclosure_energy<NF>, cell_grid(c, c->Nz), dim3(256), 0, c->stream, v, p);  // soil_energy.jl:64-77
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-
-    // ---- fused step, column per (half-)wavefront ------------------------------------------------------
-    // the branch-free fused kernel covers Value on temperature and Flux on the prognostics; anything else is generic
-    static bool generic_bcs(const trm_ctx* c) {
-        bool generic = c->opt_vwc_field != 0;   // a per-cell vwc_forcing field is read by the generic instance only
-        for (int side = 0; side < 2; ++side) {
-            generic = generic || c->bc_kind[TRM_BCV_TEMPERATURE][side] == TRM_BC_GRADIENT;
-            for (int var : {TRM_BCV_SATURATION_WATER_ICE, TRM_BCV_LIQUID_WATER_FRACTION, TRM_BCV_PRESSURE_HEAD})
-                generic = generic || c->bc_kind[var][side] == TRM_BC_VALUE || c->bc_kind[var][side] == TRM_BC_GRADIENT;
-        }
-        return generic;
-    }
-    // ---- fused step, column per (half-)wavefront ------------------------------------------------------
-    // ---- vegetation (trm_vegetation.hpp) ---------------------------------------------------------------
-    static VegDev<NF> veg_dev(const trm_ctx* c) {
-        VegDev<NF> p;
-        const double* s = &c->veg_params.tau25;
-        NF* t = &p.tau25;
-        for (int n = 0; n < 40; ++n) t[n] = (NF)s[n];
-        p.eps_mw = (NF)c->params.eps_mw;
-        p.one_minus_eps_mw = NF(1) - p.eps_mw;
-        p.sqrt_eps = std::sqrt(std::numeric_limits<NF>::epsilon());
-        p.paw_span = p.field_capacity - p.wilting_point;
-        p.rpaw_span = NF(1) / p.paw_span;
-        p.ln_q10_tau = std::log(p.q10_tau); p.ln_q10_Kc = std::log(p.q10_Kc); p.ln_q10_Ko = std::log(p.q10_Ko);
-        p.ts_k1 = NF(2) * std::log(NF(1) / NF(0.99) - NF(1)) / (p.T_CO2_low - p.T_photos_low);     // photosynthesis.jl:165-188
-        p.ts_k2 = NF(0.5) * (p.T_CO2_low + p.T_photos_low);
-        p.ts_k3 = std::log(NF(0.99) / NF(0.01)) / (p.T_CO2_high - p.T_photos_high);
-        return p;
-    }
-    static VegView<NF> veg_view(const trm_ctx* c) { return veg_view(c, c->state); }
-    static VegView<NF> veg_view(const trm_ctx* c, const FieldSet& s) {
-        VegView<NF> v;
-        auto F = [&](int id) { return (NF*)s.f[id]; };
-        v.Nh = c->Nh;
-        v.C_veg = F(TRM_FIELD_CARBON_VEGETATION); v.nu = F(TRM_FIELD_VEGETATION_AREA_FRACTION);
-        v.G_C_veg = F(TRM_FIELD_TEND_CARBON_VEGETATION); v.G_nu = F(TRM_FIELD_TEND_VEGETATION_AREA_FRACTION);
-        v.LAI_b = F(TRM_FIELD_BALANCED_LEAF_AREA_INDEX); v.phen = F(TRM_FIELD_PHENOLOGY_FACTOR); v.LAI = F(TRM_FIELD_LEAF_AREA_INDEX);
-        v.gw_can = F(TRM_FIELD_CANOPY_WATER_CONDUCTANCE); v.lambda_c = F(TRM_FIELD_LEAF_TO_AIR_CO2_RATIO);
-        v.An = F(TRM_FIELD_NET_ASSIMILATION); v.Rd = F(TRM_FIELD_LEAF_RESPIRATION); v.GPP = F(TRM_FIELD_GROSS_PRIMARY_PRODUCTION);
-        v.Ra = F(TRM_FIELD_AUTOTROPHIC_RESPIRATION); v.NPP = F(TRM_FIELD_NET_PRIMARY_PRODUCTION);
-        v.Tair = F(TRM_FIELD_AIR_TEMPERATURE); v.pres = F(TRM_FIELD_AIR_PRESSURE); v.qair = F(TRM_FIELD_SPECIFIC_HUMIDITY);
-        v.swd = F(TRM_FIELD_SURFACE_SHORTWAVE_DOWN); v.CO2 = F(TRM_FIELD_CO2); v.smlf = F(TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR);
-        v.daily_Rd = F(TRM_FIELD_DAILY_LEAF_RESPIRATION);
-        v.Tground = F(TRM_FIELD_VEGETATION_GROUND_TEMPERATURE);
-        v.Tground_stride = 1;
-        const bool canopy = coupled(c);
-        auto G = [&](int id) { return canopy ? F(id) : (NF*)nullptr; };
-        v.w_can = G(TRM_FIELD_CANOPY_WATER); v.G_w_can = G(TRM_FIELD_TEND_CANOPY_WATER); v.I_can = G(TRM_FIELD_CANOPY_WATER_INTERCEPTION);
-        v.R_can = G(TRM_FIELD_CANOPY_WATER_REMOVAL); v.f_can = G(TRM_FIELD_SATURATION_CANOPY_WATER); v.rain_ground = G(TRM_FIELD_RAINFALL_GROUND);
-        v.E_can = G(TRM_FIELD_EVAPORATION_CANOPY); v.transp = G(TRM_FIELD_TRANSPIRATION); v.SAI = G(TRM_FIELD_STEM_AREA_INDEX);
-        v.paw = F(TRM_FIELD_PLANT_AVAILABLE_WATER);
-        v.rootf = (const NF*)c->d_rootf;   // static: one copy serves the stage as well
-        if (c->part >= 0 && &s == &c->state) {   // one pipeline part: columns [lo, lo + n)
-            const long lo = first_col(c);
-            v.Nh = ncols(c);
-            for (NF** q : {&v.C_veg, &v.nu, &v.G_C_veg, &v.G_nu, &v.LAI_b, &v.phen, &v.LAI, &v.gw_can, &v.lambda_c, &v.An, &v.Rd, &v.GPP, &v.Ra, &v.NPP,
-                           &v.w_can, &v.G_w_can, &v.I_can, &v.R_can, &v.f_can, &v.rain_ground, &v.E_can, &v.transp})
-                if (*q) *q += lo;
-            for (const NF** q : {&v.Tair, &v.pres, &v.qair, &v.swd, &v.CO2, &v.smlf, &v.daily_Rd, &v.Tground, &v.SAI})
-                if (*q) *q += lo * (q == &v.Tground ? v.Tground_stride : 1);
-            if (v.paw) v.paw += lo * c->Nzp;
-        }
-        return v;
-    }
-    // the 0-D part of the coupled LandModel's compute_auxiliary! (+ tendencies and explicit step of the 0-D prognostics)
+    using P = Policy<NF>;
+    using U = Unfused<NF>;
+    static bool richards(const trm_ctx* c) { return P::richards(c); }
+    static bool coupled(const trm_ctx* c) { return P::coupled(c); }
+    static int hyd(const trm_ctx* c) { return P::hyd(c); }
+    static bool generic_bcs(const trm_ctx* c) { return P::generic_bcs(c); }
+    static bool packed_path(trm_ctx* c) { return P::packed_path(c); }
+    static bool deep_columns(const trm_ctx* c) { return P::deep_columns(c); }
+    static int series_slot(const trm_ctx* c, const trm_ctx::Series& sr) { return P::series_slot(c, sr); }
+    static bool series_fit_program(const trm_ctx* c) { return P::series_fit_program(c); }
+    static VegDev<NF> veg_dev(const trm_ctx* c) { return P::veg_dev(c); }
+    static VegView<NF> veg_view(const trm_ctx* c) { return P::veg_view(c); }
+    static VegView<NF> veg_view(const trm_ctx* c, const FieldSet& s) { return P::veg_view(c, s); }
+    static int await_levels(trm_ctx* c, trm_ctx::Series& sr, int last_level) { return U::await_levels(c, sr, last_level); }
+    static int update_inputs(trm_ctx* c, const FieldSet& s, double time) { return U::update_inputs(c, s, time); }
+    static int hydraulics(trm_ctx* c, const FieldSet& s) { return U::hydraulics(c, s); }
+    static int surface(trm_ctx* c, const FieldSet& s, bool from_state = false) { return U::surface(c, s, from_state); }
+    static int compute_auxiliary(trm_ctx* c, const FieldSet& s) { return U::compute_auxiliary(c, s); }
+    static int compute_tendencies(trm_ctx* c, const FieldSet& s) { return U::compute_tendencies(c, s); }
+    static int reset_tendencies(trm_ctx* c, const FieldSet& s) { return U::reset_tendencies(c, s); }
+    static int update_state(trm_ctx* c, const FieldSet& s, bool tendencies) { return U::update_state(c, s, tendencies); }
+    static int explicit_step(trm_ctx* c, const FieldSet& s, double dt) { return U::explicit_step(c, s, dt); }
+    static int closure(trm_ctx* c, const FieldSet& s) { return U::closure(c, s); }
+    static int invclosure(trm_ctx* c, const FieldSet& s) { return U::invclosure(c, s); }
+    static int initialize(trm_ctx* c) { return U::initialize(c); }
+    static int average(trm_ctx* c, int field) { return U::average(c, field); }
     template <bool FROM_STATE, bool ADVANCE> static int surface_veg(trm_ctx* c, const FieldSet& s, double dt, bool store_paw = true) {
-        SurfaceVegArgs<NF> a{};
-        a.dt = (NF)dt;
-        a.richards = richards(c) ? 1 : 0;
-        a.from_state = FROM_STATE ? 1 : 0;
-        a.top_arrays = (FROM_STATE && c->top_valid && &s == &c->state) ? 1 : 0;
-        a.advance = ADVANCE ? 1 : 0;
-        a.store_paw = store_paw ? 1 : 0;
-        return surface_veg_launch(c, cached_view<NF>(c, s), veg_view(c, s), a);
+        return Veg<NF>::surface_veg(c, s, FROM_STATE, ADVANCE, dt, store_paw);
     }
-    static int surface_veg_launch(trm_ctx* c, const View<NF>& v, const VegView<NF>& vv, const SurfaceVegArgs<NF>& a) {
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        const VegDev<NF> vp = veg_dev(c);
-        const dim3 blocks((unsigned)((ncols(c) + 63) / 64));   // 64 columns per 256-thread workgroup
-        // (the kernel is bound by cold instruction fetch: the hydraulics of the top-face conductivity are compiled in)
-        if (c->Nzp == 32) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, 32, H>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a)); }
-        else if (c->Nzp == 64) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface_veg<NF, 64, H>), blocks, dim3(256), 0, c->stream, v, p, vv, vp, a)); }
-        else hipLaunchKernelGGL((k_surface_veg<NF, 0, HYD_GENERIC>), col_grid(c), dim3(256), 0, c->stream, v, p, vv, vp, a);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    template <int MODE> static int veg_launch(trm_ctx* c, double dt, int nsteps, int finalize) {
-        hipLaunchKernelGGL((k_vegetation<NF, MODE>), col_grid(c), dim3(256), 0, c->stream, veg_view(c), veg_dev(c), (NF)dt, nsteps, finalize);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
+    static int surface_veg_launch(trm_ctx* c, const View<NF>& v, const VegView<NF>& vv, const SurfaceVegArgs<NF>& a) { return Veg<NF>::surface_veg_launch(c, v, vv, a); }
+    template <int MODE> static int veg_launch(trm_ctx* c, double dt, int nsteps, int finalize) { return Veg<NF>::vegetation(c, c->state, MODE, dt, nsteps, finalize); }
+    static int plant_available_water(trm_ctx* c) { return Veg<NF>::plant_available_water(c, c->state, true); }
+    static int plant_available_water(trm_ctx* c, const FieldSet& s, bool store_paw) { return Veg<NF>::plant_available_water(c, s, store_paw); }
+
     // nsteps steps of the standalone VegetationModel; time series inputs are evaluated by the host between launches
     static int veg_step(trm_ctx* c, double dt, int nsteps, int finalize, bool heun) {
         int n = 0;
@@ -800,25 +381,6 @@ template <class NF> struct Ops {
             c->iteration += m;
             n += m;
         }
-        return TRM_OK;
-    }
-    static int plant_available_water(trm_ctx* c) { return plant_available_water(c, c->state, true); }
-    static int plant_available_water(trm_ctx* c, const FieldSet& s, bool store_paw) {
-        const DevParams<NF>& p = launch_args<NF>(c).p;
-        const NF *sat = (const NF*)s.f[TRM_FIELD_SATURATION_WATER_ICE], *liq = (const NF*)s.f[TRM_FIELD_LIQUID_WATER_FRACTION];
-        NF *paw = (NF*)s.f[TRM_FIELD_PLANT_AVAILABLE_WATER], *smlf = (NF*)s.f[TRM_FIELD_SOIL_MOISTURE_LIMITING_FACTOR];
-        const NF *rootf = (const NF*)c->d_rootf, *dzc = (const NF*)c->d_dzc, *rdzc = (const NF*)c->d_rdzc;
-        const dim3 blocks((unsigned)((c->Nh + 63) / 64));
-        if (c->Nzp == 32)
-            hipLaunchKernelGGL((k_plant_available_water_block<NF, 32>), blocks, dim3(256), 0, c->stream, sat, liq, rootf, dzc, rdzc, store_paw ? paw : nullptr, smlf,
-                               c->Nh, c->Nz, p.por, veg_dev(c));
-        else if (c->Nzp == 64)
-            hipLaunchKernelGGL((k_plant_available_water_block<NF, 64>), blocks, dim3(256), 0, c->stream, sat, liq, rootf, dzc, rdzc, store_paw ? paw : nullptr, smlf,
-                               c->Nh, c->Nz, p.por, veg_dev(c));
-        else
-            hipLaunchKernelGGL((k_plant_available_water<NF>), col_grid(c), dim3(256), 0, c->stream, sat, liq, (const NF*)c->state.f[TRM_FIELD_ROOT_FRACTION], paw, smlf,
-                               c->Nh, c->Nz, c->Nzp, p.por, veg_dev(c), dzc);
-        TRM_HIP(c, hipGetLastError());
         return TRM_OK;
     }
     // static root fractions: density at the cell centres x thickness, normalised over the column (root_distribution.jl:45-63)
@@ -840,126 +402,6 @@ template <class NF> struct Ops {
         for (int k = 0; k < c->Nz; ++k)
             for (long i = 0; i < c->Nh; ++i) host[(size_t)k * c->Nh + i] = R[k] / total;
         return upload_impl<NF>(c, TRM_FIELD_ROOT_FRACTION, host.data());
-    }
-
-    // ---- fused step, column per (half-)wavefront ------------------------------------------------------
-    static dim3 column_grid(const trm_ctx* c, int lpc) {
-        dim3 grid = wave_grid(c, lpc);
-        grid.x = (grid.x * 4 + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64);  // wave_grid counts 4-wave workgroups
-        return grid;
-    }
-    // k_step_wave: the generic boundary kinds, Euler
-    template <bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c, double dt, int finalize) {
-        const LaunchArgs<NF>& la = launch_args<NF>(c);
-        const View<NF>& v = state_view<NF>(c);
-        const DevParams<NF>& p = la.p;
-        const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
-        hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    // Deriving T and liq in registers saves 2 of 11 field accesses and costs ~40 instructions per cell.  Measured on MI355X
-    // (profiles/r03/exp4_ab_derive.log, interleaved medians on one box; fp64): 8 x N145 (HBM-resident) 215 vs 261 us, N145
-    // 25.1 vs 27.3 us with the reference-default hydraulics, 33.6 vs 35.1 (LandModel), 34.4 vs 35.6 (LandModel, van Genuchten);
-    // it loses on small grids (N72 heat-only: 7.1 vs 6.6 us, latency-bound) and for the packed fp32 kernel, which is not short of
-    // bytes (C5: liquid fraction alone 523 vs 500 us, both 562 vs 533).  Deriving the liquid fraction alone (mode 3: one read
-    // less, the temperature divide saved) sits between the two everywhere (8 x N145: 238 us) and is kept as an option only.
-    // AUTO (2): fp64 states beyond the Infinity Cache, or of >= 24 576 columns; fp32 states beyond the cache on the packed kernel:
-    // the liquid fraction alone (the numbers above for the packed kernel predate the store ordering of round 3; see below).
-    template <bool RICH> static int derive_now(const trm_ctx* c) {
-        // (the coupled vegetation reads T and liq of the whole column from memory every step)
-        if (!c->closure_consistent || c->closure_escaped || coupled(c) || c->opt_derive == 0) return DERIVE_NONE;
-        if (c->opt_derive == 1) return DERIVE_T_LIQ;
-        if (c->opt_derive == 3) return DERIVE_LIQ;
-        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
-        const bool beyond_cache = state_bytes > ((size_t)256 << 20);
-        const bool large = c->Nh >= 24576;
-        // fp32 on the packed kernel, HBM-resident: the liquid fraction alone (r3, re-measured on the final kernels,
-        // profiles/r03/exp21_derive_liq_fp32.log: C5 443.7 vs 457.9 us, C5-VG 472.5 vs 476.3; before the store ordering it lost)
-        if (std::is_same<NF, float>::value) return (beyond_cache && packed_path(const_cast<trm_ctx*>(c))) ? DERIVE_LIQ : DERIVE_NONE;
-        return (beyond_cache || large) ? DERIVE_T_LIQ : DERIVE_NONE;
-    }
-    // The per-column outputs of the column program through the workgroup's staging table (template parameter STAGED) or as direct 2-lane
-    // stores.  Measured (profiles/r03/exp20_staged_small_stores.log, same box, alternating): staged wins where the state streams
-    // from HBM (8 x N145: 201.7 vs 212.9 us, -5.3 %) and on the LandModel with its seven outputs (C4 33.7 vs 34.4), it loses
-    // where the step is launch- and latency-bound (C3 25.2 vs 24.7, N72 heat-only 7.3 vs 6.7): the barrier in front of the
-    // staged store.  TRM_STAGED_SMALL = 0 / 1 in the environment forces it (experiments).
-    // The per-column inputs of the column program through the scalar memory path: cache-resident states (see column_program).
-    // TRM_SCALAR_INPUTS = 0 / 1 in the environment forces it (experiments, tests).
-    template <bool RICH> static int scalar_inputs_now(const trm_ctx* c) {
-        static const int forced = [] { const char* e = std::getenv("TRM_SCALAR_INPUTS"); return e ? std::atoi(e) : -1; }();
-        if (forced >= 0) return forced != 0;
-        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
-        return state_bytes <= ((size_t)256 << 20) ? 1 : 0;
-    }
-    // The packed fp32 step does not gain (C5 472 vs 468 us, C5-VG 500 vs 487; exp20b): staging is off there unless forced.
-    template <bool RICH> static int staged_now(const trm_ctx* c, bool packed = false) {
-        static const int forced = [] { const char* e = std::getenv("TRM_STAGED_SMALL"); return e ? std::atoi(e) : -1; }();
-        if (forced >= 0) return forced != 0;
-        if (packed) return 0;
-        const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
-        const bool beyond_cache = state_bytes > ((size_t)256 << 20);
-        return (beyond_cache || (c->params.seb != 0 && c->Nh >= 24576)) ? 1 : 0;
-    }
-    // fp32: two columns per lane with packed math (trm_packed_f32.hpp) -- the reference-default hydraulics, and van
-    // Genuchten retention with Mualem conductivity
-    static bool packed_path(trm_ctx* c) {
-        if (!std::is_same<NF, float>::value || !c->opt_packed || generic_bcs(c)) return false;
-        if (hyd(c) == HYD_VG_N2) return true;
-        return hyd(c) == HYD_BC_LINEAR;
-    }
-    template <bool RICH, int LPC> static int launch_packed(trm_ctx* c, double dt, int finalize) {
-        if constexpr (std::is_same<NF, float>::value) {
-            const LaunchArgs<NF>& la = launch_args<NF>(c);
-            const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
-            const long pairs = (ncols(c) + 1) / 2;
-            const View<NF>& sv = state_view<NF>(c);
-            const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
-            dim3 pg((unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            const int derive = derive_now<RICH>(c);
-            const int staged = staged_now<RICH>(c, true);
-            const dim3 blk(TRM_STEP_BLOCK);
-#define TRM_LAUNCH_PK(HYDV)                                                                                                                        \
-    do {                                                                                                                                           \
-        if (derive == DERIVE_T_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_T_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
-        else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
-        else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_NONE>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);     \
-    } while (0)
-            if (hyd(c) == HYD_VG_N2) TRM_LAUNCH_PK(HYD_VG_N2);
-            else TRM_LAUNCH_PK(HYD_BC_LINEAR);
-#undef TRM_LAUNCH_PK
-            TRM_HIP(c, hipGetLastError());
-        }
-        return TRM_OK;
-    }
-    // k_column: the register-resident column programs (trm_column.hpp)
-    // slot of the multi-step program a series feeds, or -1 when the program cannot take it (the step then runs per launch)
-    static int series_slot(const trm_ctx* c, const trm_ctx::Series& sr) {
-        if (sr.is_bc) {
-            const int kind = c->bc_kind[sr.var][sr.side];
-            if (sr.var == TRM_BCV_TEMPERATURE && kind == TRM_BC_VALUE) return sr.side == TRM_TOP ? SLOT_T_TOP : SLOT_T_BOT;
-            if (sr.var == TRM_BCV_INTERNAL_ENERGY && kind == TRM_BC_FLUX && !(c->params.seb && sr.side == TRM_TOP)) return sr.side == TRM_TOP ? SLOT_FU_TOP : SLOT_FU_BOT;
-            if (sr.var == TRM_BCV_SATURATION_WATER_ICE && kind == TRM_BC_FLUX && richards(c) && !(c->params.seb && sr.side == TRM_TOP)) return sr.side == TRM_TOP ? SLOT_FS_TOP : SLOT_FS_BOT;
-            return -1;
-        }
-        if (!c->params.seb) return -1;     // (inputs nobody reads: leave them to update_inputs!)
-        switch (sr.field) {
-            case TRM_FIELD_AIR_TEMPERATURE: return SLOT_TAIR;
-            case TRM_FIELD_AIR_PRESSURE: return SLOT_PRES;
-            case TRM_FIELD_WINDSPEED: return SLOT_WIND;
-            case TRM_FIELD_SPECIFIC_HUMIDITY: return SLOT_QAIR;
-            case TRM_FIELD_RAINFALL: return SLOT_RAIN;
-            case TRM_FIELD_SURFACE_SHORTWAVE_DOWN: return SLOT_SWD;
-            case TRM_FIELD_SURFACE_LONGWAVE_DOWN: return SLOT_LWD;
-            case TRM_FIELD_ALBEDO: return c->params.prescribed_albedo ? SLOT_ALBEDO : -1;
-            case TRM_FIELD_EMISSIVITY: return c->params.prescribed_albedo ? SLOT_EMISSIVITY : -1;
-            default: return -1;
-        }
-    }
-    static bool series_fit_program(const trm_ctx* c) {
-        for (const auto& sr : c->series)
-            if (series_slot(c, sr) < 0) return false;
-        return true;
     }
     // slot table + [nsteps][nseries] rows for a multi-step launch that starts at the context clock
     static int upload_series_rows(trm_ctx* c, double dt, int nsteps) {
@@ -1024,100 +466,18 @@ template <class NF> struct Ops {
         st.pending = true;
         return TRM_OK;
     }
-    template <bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
-        const LaunchArgs<NF>& la = launch_args<NF>(c);
-        const View<NF>& v = state_view<NF>(c);
-        const DevParams<NF>& p = la.p;
-        ColumnArgs<NF> a;
-        a.dt = (NF)dt;
-        a.finalize = finalize;
-        a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
-        a.nsteps = nsteps;
-        a.bcT_bot_stage = la.w.bcT_bot;
-        a.bcT_top_stage = la.w.bcT_top;
-        a.series = (const SeriesTable<NF>*)c->d_series_table;
-        a.series_rows = (const SeriesRow*)c->d_series_rows;
-        a.nseries = (int)c->series.size();
-        a.stage_sat = a.stage_liq = a.stage_T = a.stage_S = nullptr;
-        if (PROG == PROG_HEUN && coupled(c)) {   // the stage's soil state is needed by the 0-D processes evaluated at the stage
-            a.stage_sat = (NF*)c->stage.f[TRM_FIELD_SATURATION_WATER_ICE];
-            a.stage_liq = (NF*)c->stage.f[TRM_FIELD_LIQUID_WATER_FRACTION];
-            a.stage_T = (NF*)c->stage.f[TRM_FIELD_TEMPERATURE];
-            a.stage_S = (NF*)c->stage.f[TRM_FIELD_SURFACE_EXCESS_WATER];
-        }
-        const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
-        const int derive = derive_now<RICH>(c);
-        if constexpr (PROG == PROG_MULTI) {
-            const bool series = !c->series.empty();
-            if (c->params.seb && series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, true>), grid, block, 0, c->stream, v, p, a);
-            else if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, false>), grid, block, 0, c->stream, v, p, a);
-            else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
-            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
-        } else if constexpr (PROG == PROG_EULER) {
-            // with the derivation (every large or HBM-resident fp64 state): how the per-column outputs leave / inputs arrive
-            if (derive == DERIVE_T_LIQ) {
-                if constexpr (!std::is_same<NF, double>::value) {
-                    // (fp32 off the packed kernel derives only on request: one instance)
-                    hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
-                } else {
-                    const int staged = staged_now<RICH>(c), scalar_in = scalar_inputs_now<RICH>(c);
-                    if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
-                    else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
-                    else if (scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
-                    else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, false>), grid, block, 0, c->stream, v, p, a);
-                }
-            }
-            else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
-            else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
-        } else {
-            hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);
-        }
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
     template <int PROG> static int column_program(trm_ctx* c, double dt, int finalize, int nsteps) {
-        int rc = TRM_OK;
-        const bool deep = c->Nz > 32;
-        if (richards(c)) {
-            TRM_BY_HYD(c, rc = deep ? (launch_column<true, H, 64, PROG>(c, dt, finalize, nsteps)) : (launch_column<true, H, 32, PROG>(c, dt, finalize, nsteps)));
-        } else {
-            TRM_BY_HYD(c, rc = deep ? (launch_column<false, H, 64, PROG>(c, dt, finalize, nsteps)) : (launch_column<false, H, 32, PROG>(c, dt, finalize, nsteps)));
-        }
-        return rc;
-    }
-    // columns of 65 ... 128 levels: two levels per lane, one column per wavefront (trm_column_deep.hpp)
-    static bool deep_columns(const trm_ctx* c) { return c->Nz > 64 && c->Nz <= 128; }
-    template <bool RICH, int H, int PROG = PROG_EULER, bool GENERIC = false> static int launch_deep(trm_ctx* c, double dt, int finalize, int nsteps = 1) {
-        const LaunchArgs<NF>& la = launch_args<NF>(c);
-        ColumnArgs<NF> a{};
-        a.dt = (NF)dt;
-        a.finalize = finalize;
-        a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
-        a.nsteps = nsteps;
-        a.bcT_bot_stage = la.w.bcT_bot;      // Heun: the stage's temperature boundary values (evaluated at t + dt)
-        a.bcT_top_stage = la.w.bcT_top;
-        const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
-        if constexpr (GENERIC) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
-        else if (derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
-        else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
+        return richards(c) ? ColumnLaunch<NF, true, PROG>::run(c, dt, finalize, nsteps) : ColumnLaunch<NF, false, PROG>::run(c, dt, finalize, nsteps);
     }
     // the resident multi-step program on deep columns (no surface energy balance, no series: see step())
-    static int deep_program(trm_ctx* c, double dt, int finalize, int nsteps) {
-        int rc = TRM_OK;
-        if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H, PROG_MULTI>(c, dt, finalize, nsteps))); }
-        else { TRM_BY_HYD(c, rc = (launch_deep<false, H, PROG_MULTI>(c, dt, finalize, nsteps))); }
-        return rc;
-    }
+    static int deep_program(trm_ctx* c, double dt, int finalize, int nsteps) { return DeepLaunch<NF>::run(c, PROG_MULTI, false, dt, finalize, nsteps); }
     // Heun of deep columns: the sequence of heun_step_fused with k_column_deep<PROG_HEUN> as the column program
     static int heun_step_deep(trm_ctx* c, double dt, int finalize) {
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
         if (!rc && c->params.seb) rc = surface(c, c->state, true);
         if (!rc) {
-            if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H, PROG_HEUN>(c, dt, finalize))); }
-            else { TRM_BY_HYD(c, rc = (launch_deep<false, H, PROG_HEUN>(c, dt, finalize))); }
+            rc = DeepLaunch<NF>::run(c, PROG_HEUN, false, dt, finalize, 1);
         }
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
@@ -1129,21 +489,14 @@ template <class NF> struct Ops {
     static int wave_step(trm_ctx* c, double dt, int finalize) {
         int rc = TRM_OK;
         if (deep_columns(c)) {
-            if (generic_bcs(c)) {
-                if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H, PROG_EULER, true>(c, dt, finalize))); }
-                else { TRM_BY_HYD(c, rc = (launch_deep<false, H, PROG_EULER, true>(c, dt, finalize))); }
-            } else if (richards(c)) { TRM_BY_HYD(c, rc = (launch_deep<true, H>(c, dt, finalize))); }
-            else { TRM_BY_HYD(c, rc = (launch_deep<false, H>(c, dt, finalize))); }
+            rc = DeepLaunch<NF>::run(c, PROG_EULER, generic_bcs(c), dt, finalize, 1);
             if (!rc) c->closure_consistent = true;
             return rc;
         }
-        const bool deep = c->Nz > 32;
         if (packed_path(c)) {
-            if (richards(c)) rc = deep ? launch_packed<true, 64>(c, dt, finalize) : launch_packed<true, 32>(c, dt, finalize);
-            else rc = deep ? launch_packed<false, 64>(c, dt, finalize) : launch_packed<false, 32>(c, dt, finalize);
+            rc = PackedLaunch::step(c, dt, finalize);
         } else if (generic_bcs(c)) {
-            if (richards(c)) { TRM_BY_HYD(c, rc = deep ? (launch_wave<true, H, 64>(c, dt, finalize)) : (launch_wave<true, H, 32>(c, dt, finalize))); }
-            else { TRM_BY_HYD(c, rc = deep ? (launch_wave<false, H, 64>(c, dt, finalize)) : (launch_wave<false, H, 32>(c, dt, finalize))); }
+            rc = GenericLaunch<NF>::step(c, dt, finalize);
         } else {
             rc = column_program<PROG_EULER>(c, dt, finalize, 1);
         }
@@ -1177,48 +530,7 @@ template <class NF> struct Ops {
         return c->opt_pipeline == 1;
     }
     // columns of part `qcol` step; the surface processes of part `qsurf` run beside them for ITS next column step
-    template <bool RICH, int H, int LPC> static int launch_land(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) {
-        const LaunchArgs<NF>& la = launch_args<NF>(c);
-        const View<NF>&vc = la.part[qcol], &vs = la.part[qsurf];
-        const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
-        const unsigned sblocks = (unsigned)((c->part_n[qsurf] + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK);
-        const dim3 block(TRM_STEP_BLOCK);
-        if constexpr (std::is_same<NF, float>::value) {
-            const long pairs = (c->part_n[qcol] + 1) / 2;
-            const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
-            const dim3 grid(sblocks + (unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            if (top_arrays) hipLaunchKernelGGL((k_land_pk<RICH, LPC, H, true>), grid, block, 0, c->stream, vc, la.p, (float)dt, finalize, wkf, vs, (int)sblocks);
-            else hipLaunchKernelGGL((k_land_pk<RICH, LPC, H, false>), grid, block, 0, c->stream, vc, la.p, (float)dt, finalize, wkf, vs, (int)sblocks);
-        } else {
-            ColumnArgs<NF> a{};
-            a.dt = (NF)dt;
-            a.finalize = finalize;
-            a.write_kf = wkf;
-            a.nsteps = 1;
-            a.bcT_bot_stage = la.w.bcT_bot;
-            a.bcT_top_stage = la.w.bcT_top;
-            const long waves = (c->part_n[qcol] + (64 / LPC) - 1) / (64 / LPC);
-            const dim3 grid(sblocks + (unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK));
-            const bool derive = derive_now<RICH>(c) == DERIVE_T_LIQ;
-#define TRM_LAND(D, T) hipLaunchKernelGGL((k_land_euler<NF, RICH, H, LPC, D, T>), grid, block, 0, c->stream, vc, la.p, a, vs, (int)sblocks)
-            if (derive) { if (top_arrays) TRM_LAND(DERIVE_T_LIQ, true); else TRM_LAND(DERIVE_T_LIQ, false); }
-            else { if (top_arrays) TRM_LAND(DERIVE_NONE, true); else TRM_LAND(DERIVE_NONE, false); }
-#undef TRM_LAND
-        }
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
-    static int land_launch(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) {
-        int rc = TRM_OK;
-        const bool deep = c->Nz > 32;
-        if constexpr (std::is_same<NF, float>::value) {
-            if (hyd(c) == HYD_VG_N2) rc = deep ? launch_land<true, HYD_VG_N2, 64>(c, qcol, qsurf, dt, finalize, top_arrays) : launch_land<true, HYD_VG_N2, 32>(c, qcol, qsurf, dt, finalize, top_arrays);
-            else rc = deep ? launch_land<true, HYD_BC_LINEAR, 64>(c, qcol, qsurf, dt, finalize, top_arrays) : launch_land<true, HYD_BC_LINEAR, 32>(c, qcol, qsurf, dt, finalize, top_arrays);
-        } else {
-            TRM_BY_HYD(c, rc = deep ? (launch_land<true, H, 64>(c, qcol, qsurf, dt, finalize, top_arrays)) : (launch_land<true, H, 32>(c, qcol, qsurf, dt, finalize, top_arrays)));
-        }
-        return rc;
-    }
+    static int land_launch(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) { return LandLaunch<NF>::run(c, qcol, qsurf, dt, finalize, top_arrays); }
     // `nsteps` >= 2 ForwardEuler steps of a bare-ground LandModel with constant inputs:
     //     surf(A, 0) | col(A, 0) + surf(B, 0) | col(B, 0) + surf(A, 1) | ... | col(A, N-1) + surf(B, N-1) | col(B, N-1)
     static int land_steps_interleaved(trm_ctx* c, double dt, int nsteps, int finalize) {
@@ -1326,13 +638,6 @@ template <class NF> struct Ops {
         }
         return TRM_OK;
     }
-    static int average(trm_ctx* c, int field) {
-        long n = (long)field_elems(c, field);
-        hipLaunchKernelGGL(k_average<NF>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream,
-                           (NF*)c->state.f[field], (const NF*)c->stage.f[field], n);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
-    }
     // Heun in ONE launch (TRM_KERNEL_FUSED, Nz <= 64, branch-free boundary kinds): both stages on the column in registers
     // (k_column<PROG_HEUN>), the stage never touches memory.  The stage's surface energy balance is not evaluated: its
     // fluxes would only enter through compute_z_bcs!, which the reference runs for the state alone (heun.jl:54-69).
@@ -1404,32 +709,17 @@ template <class NF> struct Ops {
         b.store_paw = 0;
         rc = surface_veg_launch(c, sv, vg, b);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_heun_average_0d<NF>), col_grid(c), dim3(256), 0, c->stream, vs, vg, (NF)dt, c->Nh);
-        TRM_HIP(c, hipGetLastError());
+        rc = Veg<NF>::heun_average_0d(c, vs, vg, dt);
+        if (rc) return rc;
         if (finalize) rc = surface_veg<true, false>(c, c->state, 0.0);
         return rc;
-    }
-    // Heun with the generic boundary kinds (Gradient, Value on liquid fraction / saturation / pressure head, per-cell
-    // vwc_forcing): k_heun_generic, one launch per step like k_column<PROG_HEUN>
-    template <bool RICH, int H, int LPC> static int launch_heun_generic(trm_ctx* c, double dt, int finalize) {
-        const LaunchArgs<NF>& la = launch_args<NF>(c);
-        ColumnArgs<NF> a{};
-        a.dt = (NF)dt;
-        a.finalize = finalize;
-        a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
-        a.nsteps = 1;
-        hipLaunchKernelGGL((k_heun_generic<NF, RICH, H, LPC>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, la.stage, a);
-        TRM_HIP(c, hipGetLastError());
-        return TRM_OK;
     }
     static int heun_step_generic_fused(trm_ctx* c, double dt, int finalize) {
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
         if (!rc && c->params.seb) rc = surface(c, c->state, true);
         if (rc) return rc;
-        const bool deep = c->Nz > 32;
-        if (richards(c)) { TRM_BY_HYD(c, rc = deep ? (launch_heun_generic<true, H, 64>(c, dt, finalize)) : (launch_heun_generic<true, H, 32>(c, dt, finalize))); }
-        else { TRM_BY_HYD(c, rc = deep ? (launch_heun_generic<false, H, 64>(c, dt, finalize)) : (launch_heun_generic<false, H, 32>(c, dt, finalize))); }
+        rc = GenericLaunch<NF>::heun(c, dt, finalize);
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
         c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;

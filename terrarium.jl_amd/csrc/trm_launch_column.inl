@@ -1,0 +1,67 @@
+// trm_launch_column.inl -- the launch of k_column<NF, RICH, ., ., ., PROG, ...> (trm_column.hpp) for one (precision, flow scheme,
+// program): included by the trm_launch_column_*.hip files, each of which instantiates its share of ColumnLaunch<NF, RICH, PROG>.
+#include "trm_host.hpp"
+
+namespace trmh {
+
+template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_column(trm_ctx* c, double dt, int finalize, int nsteps) {
+    using P = Policy<NF>;
+    const LaunchArgs<NF>& la = launch_args<NF>(c);
+    const View<NF>& v = state_view<NF>(c);
+    const DevParams<NF>& p = la.p;
+    ColumnArgs<NF> a;
+    a.dt = (NF)dt;
+    a.finalize = finalize;
+    a.write_kf = (c->opt_write_kf || finalize) ? 1 : 0;
+    a.nsteps = nsteps;
+    a.bcT_bot_stage = la.w.bcT_bot;
+    a.bcT_top_stage = la.w.bcT_top;
+    a.series = (const SeriesTable<NF>*)c->d_series_table;
+    a.series_rows = (const SeriesRow*)c->d_series_rows;
+    a.nseries = (int)c->series.size();
+    a.stage_sat = a.stage_liq = a.stage_T = a.stage_S = nullptr;
+    if (PROG == PROG_HEUN && P::coupled(c)) {   // the stage's soil state is needed by the 0-D processes evaluated at the stage
+        a.stage_sat = (NF*)c->stage.f[TRM_FIELD_SATURATION_WATER_ICE];
+        a.stage_liq = (NF*)c->stage.f[TRM_FIELD_LIQUID_WATER_FRACTION];
+        a.stage_T = (NF*)c->stage.f[TRM_FIELD_TEMPERATURE];
+        a.stage_S = (NF*)c->stage.f[TRM_FIELD_SURFACE_EXCESS_WATER];
+    }
+    const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
+    const int derive = P::template derive_now<RICH>(c);
+    if constexpr (PROG == PROG_MULTI) {
+        const bool series = !c->series.empty();
+        if (c->params.seb && series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, true>), grid, block, 0, c->stream, v, p, a);
+        else if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, false>), grid, block, 0, c->stream, v, p, a);
+        else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
+        else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
+    } else if constexpr (PROG == PROG_EULER) {
+        // with the derivation (every large or HBM-resident fp64 state): how the per-column outputs leave / inputs arrive
+        if (derive == DERIVE_T_LIQ) {
+            if constexpr (!std::is_same<NF, double>::value) {
+                // (fp32 off the packed kernel derives only on request: one instance)
+                hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+            } else {
+                const int staged = P::template staged_now<RICH>(c), scalar_in = P::template scalar_inputs_now<RICH>(c);
+                if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
+                else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
+                else if (scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
+                else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, false>), grid, block, 0, c->stream, v, p, a);
+            }
+        }
+        else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+        else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+    } else {
+        hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);
+    }
+    TRM_HIP(c, hipGetLastError());
+    return TRM_OK;
+}
+
+template <class NF, bool RICH, int PROG> int ColumnLaunch<NF, RICH, PROG>::run(trm_ctx* c, double dt, int finalize, int nsteps) {
+    int rc = TRM_OK;
+    const bool deep = c->Nz > 32;
+    TRM_BY_HYD(c, rc = deep ? (launch_column<NF, RICH, H, 64, PROG>(c, dt, finalize, nsteps)) : (launch_column<NF, RICH, H, 32, PROG>(c, dt, finalize, nsteps)));
+    return rc;
+}
+
+}  // namespace trmh

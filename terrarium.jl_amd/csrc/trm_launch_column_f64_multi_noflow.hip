@@ -1,0 +1,5 @@
+// trm_launch_column_f64_multi_noflow.hip -- k_column instantiations: double, PROG_MULTI (see trm_launch_column.inl)
+#include "trm_launch_column.inl"
+namespace trmh {
+template struct ColumnLaunch<double, false, PROG_MULTI>;
+}  // namespace trmh
