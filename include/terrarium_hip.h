@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 13
+#define TRM_ABI_VERSION 14
 
 typedef struct trm_ctx trm_ctx;
 
@@ -183,6 +183,11 @@ enum {
                                     /* 0: off; 1: whenever legal; 2 (default): the library's rule -- currently never: measured  */
                                     /* within +-2 % at 812 500 columns and +10 % at N145 (every launch carries ~4 us of fixed    */
                                     /* cost)                                                                         */
+    ,TRM_OPT_SINGLE_STEP_PROGRAM = 8 /* trm_step(ctx, dt, 1, .) of a bare-ground LandModel whose inputs change every step (a        */
+                                    /* coupled atmosphere: speedy_dry_land.jl:45-68): 1 runs the resident column program with the   */
+                                    /* surface processes inline for the single step -- ONE launch instead of the k_surface +        */
+                                    /* k_column pair; 0: the launch pair; 2 (default): the library's rule (small shards, where the  */
+                                    /* step is bound by launch latency: DESIGN 4.9)                                                  */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
@@ -331,6 +336,13 @@ int trm_bc_device_ptr(trm_ctx* ctx, int var, int side, void** dev);
 int trm_set_bc(trm_ctx* ctx, int bc_var, int side, int kind, const void* values, double scalar);
 /* update_inputs! (src/state_variables.jl:154-162): same as trm_upload on an input field. */
 int trm_set_forcing(trm_ctx* ctx, int input_field, const void* per_column);
+/* The same from DEVICE memory, stream-ordered: `dev_per_column` ([num_columns], context precision, on the context's device) is
+ * copied into the input field on the context stream without synchronising the host -- a coupled model on the same device hands
+ * over the next coupling interval's inputs between two asynchronous trm_step calls (speedy_dry_land.jl:45-68 does
+ * `set!(state.inputs.air_temperature, Tair)` per coupling step).  The source must stay valid until the copy has executed
+ * (trm_synchronize, or stream order on a shared stream: trm_set_stream).  Zero-copy alternative: write the field's own
+ * buffer (trm_field_device_ptr) on the context stream. */
+int trm_set_forcing_device(trm_ctx* ctx, int input_field, const void* dev_per_column);
 
 /* ---- time series input sources --------------------------------------------------------------------------
  * FieldTimeSeriesInputSource (src/input_output/input_sources.jl:142-171): update_inputs! sets the input
@@ -415,12 +427,39 @@ int trm_step(trm_ctx* ctx, double dt, int nsteps, int finalize);
  * registers; the stage never touches memory; every boundary kind), four for TRM_VEGETATION_COUPLED; ONE launch for 65 ... 128
  * levels with the branch-free boundary kinds as well; otherwise the reference-order kernels on a second copy of the state. */
 int trm_step_heun(trm_ctx* ctx, double dt, int nsteps, int finalize);
-/* As trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
+/* DIAGNOSTIC (benchmarks): as trm_step, bracketed by HIP events on the context stream: *ms = device time of the launches. */
 int trm_step_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);
 /* The same for trm_step_heun. */
 int trm_step_heun_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float* ms);
 
-/* Device-side checkpoint of the whole state (every field, the clock, the status word): trm_save_state copies it into
+/* ---- Heun with state-dependent forcings / boundary values (heun.jl:37-71 with forcings.jl:13-19, boundary_conditions.jl:25-28) --
+ * The reference evaluates a user's `forcing(i, j, k, grid, clock, fields)` / `getbc(..., clock, fields)` inside the tendency
+ * kernel at BOTH Heun stages: at the state (clock t) and at the stage (the predicted state, clock t + dt).  A closure cannot
+ * cross a C ABI; its values can, without leaving the device (see trm_field_device_ptr): the caller evaluates its function on
+ * the state's buffers into the state's boundary / input / vwc_forcing buffers, then
+ *     trm_heun_predict(ctx, dt)            -- heun.jl:41-52: update_state!(state), stage := state, explicit_step!(stage),
+ *                                             closure!(stage), tick!(stage.clock); series are evaluated at t + dt for the stage
+ *     (the caller evaluates its function on the STAGE's buffers -- trm_stage_field_device_ptr -- into the stage's boundary /
+ *      input / vwc_forcing buffers -- trm_stage_bc_device_ptr, trm_stage_field_device_ptr of the input --, on the context stream)
+ *     trm_heun_correct(ctx, dt, finalize)  -- heun.jl:54-71: update_state!(stage), average_tendencies!, explicit_step!(state),
+ *                                             closure!(state), tick!(clock) (+ compute_auxiliary! if `finalize`)
+ * The pair equals one trm_step_heun(ctx, dt, 1, finalize) bit for bit when the stage's values are the ones the library would
+ * have used itself.  It runs on the reference-order kernels (the stage lives in memory between the two calls by construction).
+ * A boundary condition or input whose stage buffer has been handed out keeps it; trm_step_heun refreshes such buffers from
+ * the state's values at every step, so mixing the two forms is safe. */
+int trm_heun_predict(trm_ctx* ctx, double dt);
+int trm_heun_correct(trm_ctx* ctx, double dt, int finalize);
+/* Device address of a field of the Heun STAGE (layout as trm_field_device_ptr): the predicted state after trm_heun_predict --
+ * to read --, or an input field / TRM_FIELD_VWC_FORCING of the stage -- to write before trm_heun_correct. */
+int trm_stage_field_device_ptr(trm_ctx* ctx, int field, void** dev, int64_t* pitch_elems);
+/* Device array [num_columns] of the STAGE's boundary values of (var, side) (allocated on first use as a copy of the state's) */
+int trm_stage_bc_device_ptr(trm_ctx* ctx, int var, int side, void** dev);
+
+/* ---- DIAGNOSTIC entry points (benchmarks, tests; not part of the reference interface) -----------------------------------
+ * trm_step_timed / trm_step_heun_timed (above) and the device-side one-slot snapshot below exist for bench.py and the A/B
+ * tools: a binder of the reference interface does not need them.  Restart files go through trm_download / trm_upload /
+ * trm_set_clock ("Restart").
+ * Device-side checkpoint of the whole state (every field, the clock, the status word): trm_save_state copies it into
  * a second set of buffers owned by the context, trm_restore_state copies it back.  One slot; no host traffic. */
 int trm_save_state(trm_ctx* ctx);
 int trm_restore_state(trm_ctx* ctx);
@@ -453,6 +492,24 @@ int trm_comm_destroy(trm_ctx* ctx);
 int trm_comm_info(const trm_ctx* ctx, int* rank, int* world_size);
 int trm_reduce_global(trm_ctx* ctx, int field, int op, double* out);
 int trm_status_global(trm_ctx* ctx, uint32_t* flags);
+/* ---- ONE host process (thread) driving n contexts, one per device -- the reference's host is one Julia process
+ * (column_grid.jl:32, model_integrator.jl:72-88).  trm_comm_init is a blocking collective: a single thread that holds every
+ * context would wait in the first call for ranks it has not reached yet.  The *_all forms take all contexts at once:
+ *   trm_comm_init_all     one RCCL communicator per context, created inside one ncclGroupStart / ncclGroupEnd; contexts must
+ *                         sit on distinct devices (RCCL refuses two ranks per device); rank = position in `ctxs`
+ *   trm_step_all          trm_step on every context without waiting in between (each on its own stream), then one wait for
+ *                         all of them unless the contexts are asynchronous (TRM_OPT_ASYNC); trm_synchronize_all waits
+ *   trm_reduce_global_all / trm_status_global_all
+ *                         what trm_reduce_global / trm_status_global give, for all contexts from one thread: the per-device
+ *                         partial results are combined by grouped RCCL all-reduces when the contexts carry communicators
+ *                         (trm_comm_init_all), and on the host otherwise (one process needs no wire for <= 2 (Nz + 1)
+ *                         doubles per device): same values, `out` written once. */
+int trm_comm_init_all(trm_ctx** ctxs, int n);
+int trm_step_all(trm_ctx** ctxs, int n, double dt, int nsteps, int finalize);
+int trm_step_heun_all(trm_ctx** ctxs, int n, double dt, int nsteps, int finalize);
+int trm_synchronize_all(trm_ctx** ctxs, int n);
+int trm_reduce_global_all(trm_ctx** ctxs, int n, int field, int op, double* out);
+int trm_status_global_all(trm_ctx** ctxs, int n, uint32_t* flags);
 
 int trm_set_option(trm_ctx* ctx, int option, int value);
 int trm_get_option(const trm_ctx* ctx, int option, int* value);

@@ -111,6 +111,10 @@ def _lib(omp=False):
         lib.trm_oracle_explicit_step.argtypes = [C.c_void_p, C.c_double]
         lib.trm_oracle_timestep.argtypes = [C.c_void_p, C.c_double, C.c_int]
         lib.trm_oracle_timestep_heun.argtypes = [C.c_void_p, C.c_double, C.c_int]
+        lib.trm_oracle_clone.restype = C.c_void_p
+        lib.trm_oracle_clone.argtypes = [C.c_void_p]
+        lib.trm_oracle_tick.argtypes = [C.c_void_p, C.c_double]
+        lib.trm_oracle_average_tendencies.argtypes = [C.c_void_p, C.c_void_p]
         lib.trm_oracle_run.argtypes = [C.c_void_p, C.c_double, C.c_long]
         lib.trm_oracle_steps.argtypes = [C.c_void_p, C.c_double, C.c_long]
         lib.trm_oracle_steps_blocked.argtypes = [C.c_void_p, C.c_double, C.c_long, C.c_long]
@@ -277,6 +281,38 @@ class Oracle:
     def seb_fluxes_only(self): self.lib.trm_oracle_seb_fluxes_only(self.h)
     def timestep(self, dt, finalize=True): self.lib.trm_oracle_timestep(self.h, float(dt), int(finalize))
     def timestep_heun(self, dt, finalize=True): self.lib.trm_oracle_timestep_heun(self.h, float(dt), int(finalize))
+
+    # Heun stepped by hand (heun.jl:37-71), for tests that evaluate a state-dependent function at the stage between the halves
+    def clone(self):
+        """`deepcopy(state)` (heun.jl:24): an independent oracle with the same fields, clock, boundary values and parameters"""
+        c = object.__new__(Oracle)
+        c.__dict__.update(lib=self.lib, dtype=self.dtype, Nh=self.Nh, thickness=self.thickness, Nz=self.Nz, params=self.params)
+        c.h = self.lib.trm_oracle_clone(self.h)
+        return c
+
+    def tick(self, dt): self.lib.trm_oracle_tick(self.h, float(dt))
+    def average_tendencies(self, stage): self.lib.trm_oracle_average_tendencies(self.h, stage.h)
+
+    def timestep_heun_by_hand(self, dt, finalize=True, at_state=None, at_stage=None):
+        """timestep!(integrator, ::Heun) with callbacks: `at_state(oracle)` before update_state!(state), `at_stage(stage)`
+        before update_state!(stage) (its clock has ticked) -- where the reference's tendency kernels would evaluate a
+        state-dependent forcing / boundary value."""
+        if at_state:
+            at_state(self)
+        self.update_state(True)
+        stage = self.clone()
+        stage.explicit_step(dt)
+        stage.closure()
+        stage.tick(dt)
+        if at_stage:
+            at_stage(stage)
+        stage.update_state(True)
+        self.average_tendencies(stage)
+        self.explicit_step(dt)
+        self.closure()
+        self.tick(dt)
+        if finalize:
+            self.compute_auxiliary()
     def run(self, dt, steps): self.lib.trm_oracle_run(self.h, float(dt), int(steps))
     def steps(self, dt, steps): self.lib.trm_oracle_steps(self.h, float(dt), int(steps))
     def steps_blocked(self, dt, steps, block=64): self.lib.trm_oracle_steps_blocked(self.h, float(dt), int(steps), int(block))

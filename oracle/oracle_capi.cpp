@@ -108,6 +108,19 @@ void trm_oracle_adjust_saturation_profile(OracleHandle* h) { DISPATCH(h, o->adju
 void trm_oracle_compute_water_table(OracleHandle* h) { DISPATCH(h, o->compute_water_table()); }
 void trm_oracle_timestep(OracleHandle* h, double dt, int finalize) { DISPATCH(h, o->timestep_euler(dt, finalize != 0)); }
 void trm_oracle_timestep_heun(OracleHandle* h, double dt, int finalize) { DISPATCH(h, o->timestep_heun(dt, finalize != 0)); }
+// Heun stepped BY HAND from the test harness (heun.jl:37-71), so that a test can evaluate a state-dependent forcing / boundary
+// value at the stage between the two halves: `stage = deepcopy(state)` (heun.jl:24, 45), tick!(clock), average_tendencies!
+OracleHandle* trm_oracle_clone(OracleHandle* h) {
+    OracleHandle* c = new OracleHandle{h->precision, nullptr, nullptr};
+    if (h->precision == 0) c->d = new Oracle<double>(*h->d);
+    else c->f = new Oracle<float>(*h->f);
+    return c;
+}
+void trm_oracle_tick(OracleHandle* h, double dt) { DISPATCH(h, o->tick(dt)); }
+void trm_oracle_average_tendencies(OracleHandle* h, OracleHandle* stage) {
+    if (h->precision == 0) h->d->average_tendencies(*stage->d);
+    else h->f->average_tendencies(*stage->f);
+}
 void trm_oracle_run(OracleHandle* h, double dt, long steps) { DISPATCH(h, o->run(dt, steps)); }
 // `steps` Euler steps without the trailing compute_auxiliary (timing leg)
 void trm_oracle_steps(OracleHandle* h, double dt, long steps) {

@@ -1195,14 +1195,8 @@ template <class NF> class Oracle {
         for (long s = 0; s < steps; ++s) timestep_euler(dt, false);
         compute_auxiliary();
     }
-    void timestep_heun(double dt, bool finalize) {  // heun.jl:37-71
-        update_state(true);
-        Oracle stage = *this;  // copyto!(stage, state)
-        stage.explicit_step(NF(dt));
-        stage.closure();
-        stage.tick(dt);
-        stage.update_state(true);
-        // average_tendencies! (heun.jl:27-35)
+    // average_tendencies! (heun.jl:27-35); the stage's status flags join the state's
+    void average_tendencies(const Oracle& stage) {
         for (size_t n = 0; n < G_U.size(); ++n) G_U[n] = (G_U[n] + stage.G_U[n]) / NF(2);
         if (richards()) {
             for (size_t n = 0; n < G_sat.size(); ++n) G_sat[n] = (G_sat[n] + stage.G_sat[n]) / NF(2);
@@ -1215,6 +1209,15 @@ template <class NF> class Oracle {
                 veg.G_nu[i] = (veg.G_nu[i] + stage.veg.G_nu[i]) / NF(2);
             }
         status |= stage.status;
+    }
+    void timestep_heun(double dt, bool finalize) {  // heun.jl:37-71
+        update_state(true);
+        Oracle stage = *this;  // copyto!(stage, state)
+        stage.explicit_step(NF(dt));
+        stage.closure();
+        stage.tick(dt);
+        stage.update_state(true);
+        average_tendencies(stage);
         explicit_step(NF(dt));
         closure();
         tick(dt);

@@ -30,7 +30,8 @@ from .integrator import (ForwardEuler, Heun, PrescribedSurfaceTemperature, Presc
                          GroundHeatFlux, GeothermalHeatFlux, InfiltrationFlux, ImpermeableBoundary, FreeDrainage,
                          merge_boundary_conditions, DeviceState, ModelIntegrator, FieldTimeSeries, StateFunction, InputSource, InputSources, initialize, initialize_integrator,
                          timestep, run, current_time, compute_auxiliary, compute_tendencies, closure, invclosure,
-                         update_state, default_dt, is_adaptive, iteration, time_step, reset, get_grid, znodes, zspacings)
+                         update_state, default_dt, is_adaptive, iteration, time_step, reset, get_grid, znodes, zspacings,
+                         checkpoint, restore, restart_fields, DeviceGroup)
 from ._capi import TerrariumHipError
 from .io import Hdf5File, RasterInputSource
 from .simulation import Simulation, Callback, IterationInterval, TimeInterval, SnapshotWriter, run_simulation

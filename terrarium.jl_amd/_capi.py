@@ -41,7 +41,7 @@ VEG_PARAM_NAMES = ("tau25 Kc25 Ko25 q10_tau q10_Kc q10_Ko alpha_leaf alpha_a alp
                    "gamma_v_min root_a root_b wilting_point field_capacity C_mass alpha_int canopy_k_ext w_can_max tau_w C_can").split()
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4,
-              derive_closure_fields=5, steps_per_launch=6, pipeline_parts=7)
+              derive_closure_fields=5, steps_per_launch=6, pipeline_parts=7, single_step_program=8)
 KERNEL = dict(fused=0, unfused=1)
 STATUS_NAN, STATUS_COMPOSITION = 1, 2
 TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE, TRM_ECOMM = range(7)
@@ -56,7 +56,9 @@ EXPORTS = (
     "trm_comm_unique_id trm_comm_init trm_comm_destroy trm_comm_info trm_reduce_global trm_status_global "
     "trm_default_vegetation_params trm_set_vegetation trm_compute_plant_available_water "
     "trm_series_append trm_series_trim_before trm_series_info trm_reset trm_download_rows trm_set_ring_grid trm_download_ring "
-    "trm_scatter_ring_device trm_upload_ring trm_gather_ring_device").split()
+    "trm_scatter_ring_device trm_upload_ring trm_gather_ring_device "
+    "trm_heun_predict trm_heun_correct trm_stage_field_device_ptr trm_stage_bc_device_ptr trm_set_forcing_device "
+    "trm_comm_init_all trm_step_all trm_step_heun_all trm_synchronize_all trm_reduce_global_all trm_status_global_all").split()
 TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2, raster=3)
 
 
@@ -175,6 +177,17 @@ def lib():
     L.trm_scatter_ring_device.argtypes = [vp, i32, i32, i32, dbl, vp]
     L.trm_upload_ring.argtypes = [vp, i32, vp]
     L.trm_gather_ring_device.argtypes = [vp, i32, vp]
+    L.trm_heun_predict.argtypes = [vp, dbl]
+    L.trm_heun_correct.argtypes = [vp, dbl, i32]
+    L.trm_stage_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64)]
+    L.trm_stage_bc_device_ptr.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.trm_set_forcing_device.argtypes = [vp, i32, vp]
+    L.trm_comm_init_all.argtypes = [C.POINTER(vp), i32]
+    L.trm_step_all.argtypes = [C.POINTER(vp), i32, dbl, i32, i32]
+    L.trm_step_heun_all.argtypes = [C.POINTER(vp), i32, dbl, i32, i32]
+    L.trm_synchronize_all.argtypes = [C.POINTER(vp), i32]
+    L.trm_reduce_global_all.argtypes = [C.POINTER(vp), i32, i32, i32, vp]
+    L.trm_status_global_all.argtypes = [C.POINTER(vp), i32, C.POINTER(C.c_uint32)]
     for name in EXPORTS:
         if name not in ("trm_last_error",):
             getattr(L, name).restype = i32

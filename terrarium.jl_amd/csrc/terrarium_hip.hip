@@ -185,7 +185,8 @@ template <class NF> View<NF> make_view(const trm_ctx* c, const FieldSet& s) {
     v.rdzf = (const NF*)c->d_rdzf;
     v.psiz = (const NF*)c->d_psiz;
     v.lvl = (const NF*)c->d_lvl;
-    v.Fvwc = c->opt_vwc_field ? (const NF*)c->state.f[TRM_FIELD_VWC_FORCING] : nullptr;   // static: shared by the Heun stage
+    // (static between the stages unless the caller evaluates a state-dependent forcing at the stage: trm_stage_field_device_ptr)
+    v.Fvwc = c->opt_vwc_field ? (const NF*)((&s == &c->stage && c->stage_vwc_own) ? c->stage.f[TRM_FIELD_VWC_FORCING] : c->state.f[TRM_FIELD_VWC_FORCING]) : nullptr;
     BcGeom<NF>& g = v.g;
     g.dzf_bot = (NF)c->dzf_bot;
     g.dzf_top = (NF)c->dzf_top;
@@ -329,6 +330,11 @@ void series_time_indices(const std::vector<double>& times, int indexing, double 
 
 namespace {
 
+// (measured: profiles/r04/coupling_exchange.log)
+#ifndef TRM_SINGLE_STEP_PROGRAM_MAX_COLUMNS
+#define TRM_SINGLE_STEP_PROGRAM_MAX_COLUMNS 0
+#endif
+
 template <class NF> int upload_impl(trm_ctx* c, int field, const NF* host);
 
 // The step sequences of one precision.  The launches themselves are Unfused / Veg / ColumnLaunch / GenericLaunch / DeepLaunch /
@@ -441,6 +447,8 @@ template <class NF> struct Ops {
                 tb.dst[slot] = (NF*)c->state.f[sr.field];
             }
             double t = c->time;
+            if (sr.trimmed && t < sr.trimmed_before)
+                return fail(c, TRM_EINVAL, "a windowed time series was asked for a time before the levels it still holds (trm_series_trim_before released them)");
             for (int s = 0; s < nsteps; ++s) {
                 int n1, n2;
                 double f, g;
@@ -466,6 +474,10 @@ template <class NF> struct Ops {
         st.pending = true;
         return TRM_OK;
     }
+    // the top-cell arrays (LandModel: T, sat, liq of the top cell, [Nh] each) can describe the state: they exist and no device
+    // pointer to T / sat / liq has been handed out.  Every "the next surface evaluation may read the arrays" decision goes
+    // through here -- a launch with TOP_ARRAYS on a context without them would read through a null pointer.
+    static bool tops_current(const trm_ctx* c) { return c->d_top3 != nullptr && tops_current(c); }
     template <int PROG> static int column_program(trm_ctx* c, double dt, int finalize, int nsteps) {
         return richards(c) ? ColumnLaunch<NF, true, PROG>::run(c, dt, finalize, nsteps) : ColumnLaunch<NF, false, PROG>::run(c, dt, finalize, nsteps);
     }
@@ -481,7 +493,7 @@ template <class NF> struct Ops {
         }
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
-        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+        c->top_valid = c->params.seb != 0 && !rc && tops_current(c);
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
     }
@@ -543,12 +555,12 @@ template <class NF> struct Ops {
         }
         for (int n = 0; n < nsteps && !rc; ++n) {
             const int fin = (finalize && n == nsteps - 1) ? 1 : 0;
-            const bool tops = (n == 0) ? top0 : !c->top_escaped;     // what a surface evaluation of an UNSTEPPED / stepped half reads
+            const bool tops = (n == 0) ? top0 : tops_current(c);     // what a surface evaluation of an UNSTEPPED / stepped half reads
             c->closure_consistent = (n == 0) ? cc0 : true;
             rc = land_launch(c, 0, 1, dt, fin, tops);
             if (rc) break;
             if (n < nsteps - 1) {
-                rc = land_launch(c, 1, 0, dt, 0, !c->top_escaped);   // (half A has just been stepped: its top arrays are current)
+                rc = land_launch(c, 1, 0, dt, 0, tops_current(c));   // (half A has just been stepped: its top arrays are current)
             } else {
                 PartScope scope(c, 1);
                 rc = wave_step(c, dt, fin);
@@ -558,7 +570,7 @@ template <class NF> struct Ops {
         }
         c->closure_consistent = !rc;
         c->tend_valid = finalize != 0;
-        c->top_valid = !rc && !c->top_escaped;
+        c->top_valid = !rc && tops_current(c);
         if (!rc && finalize) rc = surface(c, c->state, true);
         return rc;
     }
@@ -573,10 +585,20 @@ template <class NF> struct Ops {
         else if (c->params.seb) rc = surface(c, c->state, true);
         if (!rc) rc = wave_step(c, dt, fin);
         c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
-        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+        c->top_valid = c->params.seb != 0 && !rc && tops_current(c);
         if (!rc && fin && coupled(c)) rc = surface_veg<true, false>(c, c->state, 0.0);
         else if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
         return rc;
+    }
+    // TRM_OPT_SINGLE_STEP_PROGRAM: a bare-ground LandModel stepped ONE step per call (its inputs change every step: a coupled
+    // atmosphere) takes the resident column program with the surface processes inline -- one launch instead of the
+    // k_surface + k_column pair.  At N145 the pair wins by far (the inline surface balance runs on every lane of the column's
+    // half-wave: C4 103.9 vs 34.1 us); on a shard of a few thousand columns the step is bound by launch latency and
+    // the single launch wins.
+    static bool single_step_program(const trm_ctx* c) {
+        if (!c->params.seb || c->Nz > 64 || c->opt_single_step == 0) return false;
+        if (c->opt_single_step == 1) return true;
+        return c->Nh <= TRM_SINGLE_STEP_PROGRAM_MAX_COLUMNS;
     }
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
@@ -599,12 +621,12 @@ template <class NF> struct Ops {
                 c->tend_valid = true;
                 if (!rc) rc = unfused_step(c, dt, fin);
                 if (!rc) c->closure_consistent = true;   // closure! has just run
-            } else if (m > 1) {
+            } else if (m > 1 || (program_ok && single_step_program(c))) {
                 rc = c->series.empty() ? update_inputs(c, c->state, c->time) : upload_series_rows(c, dt, m);
                 if (!rc) rc = deep_columns(c) ? deep_program(c, dt, fin, m) : column_program<PROG_MULTI>(c, dt, fin, m);
                 if (!rc) c->closure_consistent = true;
                 c->tend_valid = fin != 0;
-                c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+                c->top_valid = c->params.seb != 0 && !rc && tops_current(c);
                 if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
             } else if (interleave_now(c, nsteps - n)) {
                 // every remaining step of the call in one go (the clock is ticked inside)
@@ -648,7 +670,7 @@ template <class NF> struct Ops {
         if (!rc) rc = column_program<PROG_HEUN>(c, dt, finalize, 1);
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
-        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+        c->top_valid = c->params.seb != 0 && !rc && tops_current(c);
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
     }
@@ -690,7 +712,7 @@ template <class NF> struct Ops {
         a.dt = (NF)dt;
         a.richards = richards(c) ? 1 : 0;
         a.from_state = 1;
-        a.top_arrays = (c->top_valid && !c->top_escaped) ? 1 : 0;
+        a.top_arrays = (c->top_valid && tops_current(c)) ? 1 : 0;
         a.advance = 3;
         a.store_paw = c->opt_write_kf != 0;
         a.st_w_can = vg.w_can; a.st_C_veg = vg.C_veg; a.st_nu = vg.nu; a.st_An = vg.An; a.st_Ts = sv.Ts;
@@ -699,7 +721,7 @@ template <class NF> struct Ops {
         if (rc) return rc;
         c->closure_consistent = true;
         c->tend_valid = finalize != 0;
-        c->top_valid = !c->top_escaped;
+        c->top_valid = tops_current(c);
         SurfaceVegArgs<NF> b{};
         b.dt = (NF)dt;
         b.richards = a.richards;
@@ -722,26 +744,37 @@ template <class NF> struct Ops {
         rc = GenericLaunch<NF>::heun(c, dt, finalize);
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
-        c->top_valid = c->params.seb != 0 && !rc && !c->top_escaped;
+        c->top_valid = c->params.seb != 0 && !rc && tops_current(c);
         if (!rc && finalize && c->params.seb) rc = surface(c, c->state, true);
         return rc;
     }
-    static int heun_step(trm_ctx* c, double dt, int finalize) {
-        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
-        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
-        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
-        if (c->opt_kernel == TRM_KERNEL_FUSED && deep_columns(c) && !generic_bcs(c) && !coupled(c)) return heun_step_deep(c, dt, finalize);
-        c->top_valid = false;
-        c->tend_valid = true;
-        c->closure_consistent = true;   // (ends with closure!)
+    // Stage buffers the caller of the two-call Heun has been handed (trm_stage_bc_device_ptr, the stage's vwc_forcing) hold
+    // what it wrote for ITS last stage.  Whenever the library forms a stage on its own they are the state's values again: the
+    // stage's predictor runs at the state's clock (heun.jl:47-50).
+    static int refresh_user_stage_buffers(trm_ctx* c) {
+        for (int a = 0; a < TRM_BCV_COUNT; ++a)
+            for (int b = 0; b < 2; ++b)
+                if (c->stage_bc_user[a][b] && c->bc_value_stage[a][b] && c->bc_value[a][b])
+                    TRM_HIP(c, hipMemcpyAsync(c->bc_value_stage[a][b], c->bc_value[a][b], (size_t)c->Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+        if (c->stage_vwc_own && c->stage.f[TRM_FIELD_VWC_FORCING])
+            TRM_HIP(c, hipMemcpyAsync(c->stage.f[TRM_FIELD_VWC_FORCING], c->state.f[TRM_FIELD_VWC_FORCING], field_elems(c, TRM_FIELD_VWC_FORCING) * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
+        return TRM_OK;
+    }
+    // heun.jl:41-52: the first half of timestep!(integrator, ::Heun) on the reference-order kernels
+    static int heun_predict(trm_ctx* c, double dt) {
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_state(c, c->state, true);
         if (!rc) rc = copy_state_to_stage(c);
+        if (!rc) rc = refresh_user_stage_buffers(c);
         if (!rc) rc = update_inputs(c, c->stage, c->time);   // the stage's clock is still t for its predictor step (heun.jl:47-50)
         if (!rc) rc = explicit_step(c, c->stage, dt);
         if (!rc) rc = closure(c, c->stage);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // the stage's clock has ticked (heun.jl:52)
-        if (!rc) rc = update_state(c, c->stage, true);
+        return rc;
+    }
+    // heun.jl:54-71: the second half
+    static int heun_correct(trm_ctx* c, double dt, int finalize) {
+        int rc = update_state(c, c->stage, true);
         if (!rc) rc = average(c, TRM_FIELD_TEND_INTERNAL_ENERGY);
         if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SATURATION_WATER_ICE);
         if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SURFACE_EXCESS_WATER);
@@ -751,6 +784,19 @@ template <class NF> struct Ops {
         if (!rc) rc = explicit_step(c, c->state, dt);
         if (!rc) rc = closure(c, c->state);
         if (!rc && finalize) rc = compute_auxiliary(c, c->state);
+        return rc;
+    }
+    static int heun_step(trm_ctx* c, double dt, int finalize) {
+        if (int rr = refresh_user_stage_buffers(c)) return rr;
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && deep_columns(c) && !generic_bcs(c) && !coupled(c)) return heun_step_deep(c, dt, finalize);
+        c->top_valid = false;
+        c->tend_valid = true;
+        c->closure_consistent = true;   // (ends with closure!)
+        int rc = heun_predict(c, dt);
+        if (!rc) rc = heun_correct(c, dt, finalize);
         return rc;
     }
 };
@@ -773,14 +819,37 @@ int finish(trm_ctx* c, int rc) {
 // interleave units: measured -3.7 ... -4.7 % on the HBM-resident fp64 step (8 x N145: 210.7 -> 200.9 us, 218.1 -> 209.9 on another
 // box), -3 % at C5, nothing on the cache-resident ones (profiles/r03/exp15*_skew.log).  TRM_FIELD_SKEW (bytes, a multiple of 256)
 // overrides it for experiments.
-size_t field_skew_bytes() {
-    static const size_t v = [] {
-        const char* e = std::getenv("TRM_FIELD_SKEW");
-        const size_t s = e ? (size_t)std::strtoull(e, nullptr, 10) : (size_t)16640;
-        return s - s % 256;
-    }();
-    return v;
+// Environment switches of experiments and tests are validated once; a value outside its range makes trm_create
+// fail with a message instead of silently selecting something else.
+bool parse_env_int(const char* name, long lo, long hi, long multiple_of, long& out, std::string& err) {
+    const char* e = std::getenv(name);
+    if (!e) return false;
+    char* end = nullptr;
+    const long v = std::strtol(e, &end, 10);
+    if (end == e || *end != 0 || v < lo || v > hi || (multiple_of > 1 && v % multiple_of != 0)) {
+        err = std::string(name) + "=" + e + ": expected an integer in [" + std::to_string(lo) + ", " + std::to_string(hi) + "]" +
+              (multiple_of > 1 ? " that is a multiple of " + std::to_string(multiple_of) : std::string());
+        return false;
+    }
+    out = v;
+    return true;
 }
+struct EnvSwitches {
+    long field_skew = 16640, derive_default = -1;
+    std::string error;
+    EnvSwitches() {
+        long v;
+        if (parse_env_int("TRM_FIELD_SKEW", 0, 1 << 20, 256, v, error)) field_skew = v;
+        if (error.empty() && parse_env_int("TRM_DERIVE_DEFAULT", 0, 3, 1, v, error)) derive_default = v;
+        if (error.empty() && parse_env_int("TRM_STAGED_SMALL", 0, 1, 1, v, error)) { /* read by Policy::staged_now */ }
+        if (error.empty() && parse_env_int("TRM_SCALAR_INPUTS", 0, 1, 1, v, error)) { /* read by Policy::scalar_inputs_now */ }
+    }
+};
+const EnvSwitches& env_switches() {
+    static const EnvSwitches e;
+    return e;
+}
+size_t field_skew_bytes() { return (size_t)env_switches().field_skew; }
 int alloc_fields(trm_ctx* c, FieldSet& s) {
     for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
         if (is_lazy_field(f) && c->veg_mode == TRM_VEGETATION_OFF) continue;
@@ -1133,6 +1202,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
@@ -1152,6 +1223,8 @@ Rccl* rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
     r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     return &r;
@@ -1178,6 +1251,10 @@ int comm_allreduce(trm_ctx* c, double* host, int n, ncclRedOp_t op) {
 // C ABI
 // ======================================================================================================
 extern "C" {
+
+#define TRM_ENTER(c)                                         \
+    if (!(c)) return TRM_EINVAL;                             \
+    TRM_HIP(c, hipSetDevice((c)->device));
 
 int trm_abi_version(void) { return TRM_ABI_VERSION; }
 
@@ -1220,6 +1297,7 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
             return fail(nullptr, TRM_EINVAL, "trm_create: one field (num_columns * level pitch * word size) must stay below 4 GiB per "
                                              "device (32-bit byte offsets in the step kernel); shard the columns over more contexts");
     }
+    if (!env_switches().error.empty()) return fail(nullptr, TRM_EINVAL, "trm_create: " + env_switches().error);
     trm_ctx* c = new trm_ctx();
     c->precision = g->precision;
     c->esize = g->precision == TRM_F64 ? 8 : 4;
@@ -1253,7 +1331,7 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     if (c->params.seb) hip(hipMalloc(&c->d_top3, 3 * (size_t)c->Nh * c->esize), "hipMalloc(top cells)");
     // (tests: TRM_DERIVE_DEFAULT = 1 makes small grids take the instances with the derivation, where the staged outputs and the
     // input paths are compiled in -- the value a context starts with for TRM_OPT_DERIVE_CLOSURE_FIELDS)
-    if (const char* e = std::getenv("TRM_DERIVE_DEFAULT")) c->opt_derive = std::atoi(e);
+    if (env_switches().derive_default >= 0) c->opt_derive = (int)env_switches().derive_default;
     if (rc == TRM_OK) hip(hipMemsetAsync(c->d_zero, 0, (size_t)c->Nh * c->esize, c->stream), "hipMemset(zero)");
     if (rc) return bail(rc);
     hip(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream), "hipMemset(status)");
@@ -1429,6 +1507,15 @@ int trm_set_forcing(trm_ctx* c, int input_field, const void* per_column) {
     return trm_upload(c, input_field, per_column);
 }
 
+int trm_set_forcing_device(trm_ctx* c, int input_field, const void* dev_per_column) {
+    TRM_ENTER(c);
+    if (!is_input_field(input_field) || !dev_per_column) return fail(c, TRM_EINVAL, "trm_set_forcing_device: not an input field / null pointer");
+    if (!c->state.f[input_field]) return fail(c, TRM_EINVAL, "trm_set_forcing_device: the field exists only after trm_set_vegetation");
+    // stream-ordered: behind the steps already enqueued, in front of the next one; the host does not wait
+    TRM_HIP(c, hipMemcpyAsync(c->state.f[input_field], dev_per_column, (size_t)c->Nh * c->esize, hipMemcpyDeviceToDevice, c->stream));
+    return TRM_OK;
+}
+
 namespace {
 int add_series(trm_ctx* c, trm_ctx::Series&& sr, int nt, const double* times, const void* values, const char* who) {
     if (nt < 1 || !times || !values) return fail(c, TRM_EINVAL, std::string(who) + ": nt >= 1, times and values are required");
@@ -1500,10 +1587,6 @@ int trm_clear_series(trm_ctx* c) {
     return TRM_OK;
 }
 
-#define TRM_ENTER(c)                                         \
-    if (!(c)) return TRM_EINVAL;                             \
-    TRM_HIP(c, hipSetDevice((c)->device));
-
 // ---- windowed time series ("device-side double-buffered forcing slabs") -------------------------------------
 namespace {
 trm_ctx::Series* find_series(trm_ctx* c, int is_bc, int id, int side) {
@@ -1562,6 +1645,7 @@ int trm_series_append(trm_ctx* c, int is_bc, int id, int side, int nt, const dou
     TRM_HIP(c, hipEventRecord(c->copy_done, c->copy_stream));
     c->copy_pending = true;
     if (sr->pending_from < 0) sr->pending_from = held;
+    sr->windowed = true;
     sr->times.insert(sr->times.end(), times, times + nt);
     return TRM_OK;
 }
@@ -1570,7 +1654,9 @@ int trm_series_trim_before(trm_ctx* c, double t) {
     if (!c) return TRM_EINVAL;
     bool released = false;
     for (auto& sr : c->series) {
-        if (sr.indexing == TRM_TIME_CYCLICAL) continue;
+        // only series that stream through a window (levels have been appended): a fully resident series that merely lives in
+        // the same context keeps its whole record, whatever the clock does later
+        if (sr.indexing == TRM_TIME_CYCLICAL || !sr.windowed) continue;
         // keep the node at or before t (the lower bracket of every later evaluation) and at least two levels
         long drop = 0;
         while ((long)sr.times.size() - drop > 2 && sr.times[(size_t)drop + 1] <= t) ++drop;
@@ -1578,6 +1664,8 @@ int trm_series_trim_before(trm_ctx* c, double t) {
             sr.times.erase(sr.times.begin(), sr.times.begin() + drop);
             sr.head = (sr.head + drop) % sr.cap;
             if (sr.pending_from >= 0) sr.pending_from = std::max<long>(0, sr.pending_from - drop);
+            sr.trimmed = true;
+            sr.trimmed_before = sr.times.front();
             released = true;
         }
     }
@@ -1826,6 +1914,81 @@ int trm_step_heun_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* 
     return TRM_OK;
 }
 
+// ---- Heun in two calls: the caller evaluates state-dependent forcings / boundary values at the stage in between ------------
+namespace {
+int ensure_stage(trm_ctx* c) {
+    int rc = alloc_fields(c, c->stage);
+    if (rc) return rc;
+    if (!c->has_stage) c->args_valid = false;
+    c->has_stage = true;
+    return TRM_OK;
+}
+}  // namespace
+
+int trm_heun_predict(trm_ctx* c, double dt) {
+    TRM_ENTER(c);
+    if (c->veg_mode == TRM_VEGETATION_STANDALONE) return fail(c, TRM_EUNSUPPORTED, "trm_heun_predict: the standalone VegetationModel has no state-dependent callbacks; use trm_step_heun");
+    if (int rc = ensure_stage(c)) return rc;
+    c->top_valid = false;
+    c->tend_valid = true;
+    c->closure_consistent = false;     // (the state is untouched so far; the flag is set again by trm_heun_correct)
+    const int rc = DISPATCH(c, heun_predict(c, dt));
+    if (rc) return rc;
+    c->heun_pending = true;
+    c->heun_dt = dt;
+    return finish(c, TRM_OK);
+}
+
+int trm_heun_correct(trm_ctx* c, double dt, int finalize) {
+    TRM_ENTER(c);
+    if (!c->heun_pending) return fail(c, TRM_EINVAL, "trm_heun_correct: call trm_heun_predict first");
+    if (dt != c->heun_dt) return fail(c, TRM_EINVAL, "trm_heun_correct: dt differs from the dt of trm_heun_predict");
+    c->heun_pending = false;
+    const int rc = DISPATCH(c, heun_correct(c, dt, finalize));
+    if (rc) return rc;
+    c->top_valid = false;
+    c->tend_valid = true;
+    c->closure_consistent = true;      // (ends with closure!)
+    c->time += dt;
+    c->iteration += 1;
+    return finish(c, TRM_OK);
+}
+
+int trm_stage_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems) {
+    TRM_ENTER(c);
+    if (!dev || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_stage_field_device_ptr: bad argument");
+    if (!c->state.f[field]) return fail(c, TRM_EINVAL, "trm_stage_field_device_ptr: the field exists only after trm_set_vegetation");
+    if (int rc = ensure_stage(c)) return rc;
+    if (field == TRM_FIELD_VWC_FORCING && !c->stage_vwc_own) {
+        if (!c->opt_vwc_field) return fail(c, TRM_EINVAL, "trm_stage_field_device_ptr: upload TRM_FIELD_VWC_FORCING (or set TRM_OPT_VWC_FORCING_FIELD) first");
+        TRM_HIP(c, hipMemcpyAsync(c->stage.f[field], c->state.f[field], field_elems(c, field) * c->esize, hipMemcpyDeviceToDevice, c->stream));
+        c->stage_vwc_own = true;
+        c->args_valid = false;
+    }
+    *dev = c->stage.f[field];
+    if (pitch_elems) *pitch_elems = is_3d(field) ? c->Nzp : 1;
+    return TRM_OK;
+}
+
+int trm_stage_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
+    TRM_ENTER(c);
+    if (!dev || var < 0 || var >= TRM_BCV_COUNT || (side != TRM_TOP && side != TRM_BOTTOM)) return fail(c, TRM_EINVAL, "trm_stage_bc_device_ptr: bad argument");
+    if (c->bc_kind[var][side] == TRM_BC_NOFLUX || !c->bc_value[var][side]) return fail(c, TRM_EINVAL, "trm_stage_bc_device_ptr: the condition carries no values (set it with trm_set_bc first)");
+    for (const auto& sr : c->series)
+        if (sr.is_bc && sr.var == var && sr.side == side) return fail(c, TRM_EINVAL, "trm_stage_bc_device_ptr: the boundary values are evaluated from a time series at both stages");
+    const size_t bytes = (size_t)c->Nh * c->esize;
+    if (!c->bc_value_stage[var][side]) {
+        TRM_HIP(c, hipMalloc(&c->bc_value_stage[var][side], bytes));
+        c->args_valid = false;
+    }
+    if (!c->stage_bc_user[var][side]) {
+        TRM_HIP(c, hipMemcpyAsync(c->bc_value_stage[var][side], c->bc_value[var][side], bytes, hipMemcpyDeviceToDevice, c->stream));
+        c->stage_bc_user[var][side] = true;
+    }
+    *dev = c->bc_value_stage[var][side];
+    return TRM_OK;
+}
+
 int trm_save_state(trm_ctx* c) {
     TRM_ENTER(c);
     {   // (allocates what is missing: everything the first time, the vegetation fields once they exist)
@@ -1981,30 +2144,92 @@ int trm_comm_info(const trm_ctx* c, int* rank, int* world) {
     return TRM_OK;
 }
 
+namespace {
+// What travels for one reduction: the local per-row results, for MIN / MAX next to a NaN flag that travels with the same
+// operator -- a NaN on any rank must reach every rank (Base.minimum / maximum), which RCCL's min / max do not promise.
+int reduce_rows(const trm_ctx* c, int field, int op) { return op == TRM_REDUCE_VOLUME_INTEGRAL_Z ? 1 : (int)field_rows(c, field); }
+int pack_reduce(int op, int rows, const double* local, std::vector<double>& buf) {
+    if (op == TRM_REDUCE_MIN || op == TRM_REDUCE_MAX) {
+        const double sentinel = op == TRM_REDUCE_MIN ? HUGE_VAL : -HUGE_VAL, yes = op == TRM_REDUCE_MIN ? -1.0 : 1.0;
+        buf.assign((size_t)2 * rows, 0.0);
+        for (int r = 0; r < rows; ++r) {
+            const bool nan = local[r] != local[r];
+            buf[r] = nan ? sentinel : local[r];
+            buf[rows + r] = nan ? yes : 0.0;
+        }
+        return 2 * rows;
+    }
+    buf.assign(local, local + rows);
+    return rows;
+}
+ncclRedOp_t reduce_operator(int op) { return op == TRM_REDUCE_MIN ? ncclMin : ((op == TRM_REDUCE_MAX || op == TRM_REDUCE_HASNAN) ? ncclMax : ncclSum); }
+void unpack_reduce(int op, int rows, const std::vector<double>& buf, double* out) {
+    if (op == TRM_REDUCE_MIN || op == TRM_REDUCE_MAX) {
+        for (int r = 0; r < rows; ++r) out[r] = buf[rows + r] != 0.0 ? std::nan("") : buf[r];
+        return;
+    }
+    for (int r = 0; r < rows; ++r) out[r] = buf[r];
+}
+// the all-reduce of the packed form on the HOST, ranks folded in order (one process: no wire needed)
+void fold_packed(int op, int n, std::vector<double>& acc, const std::vector<double>& x) {
+    for (int j = 0; j < n; ++j) {
+        if (op == TRM_REDUCE_MIN) acc[j] = std::min(acc[j], x[j]);
+        else if (op == TRM_REDUCE_MAX || op == TRM_REDUCE_HASNAN) acc[j] = std::max(acc[j], x[j]);
+        else acc[j] += x[j];
+    }
+}
+bool all_have_comm(trm_ctx** ctxs, int n) {
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]->comm || ctxs[i]->comm_world != n || ctxs[i]->comm_rank != i) return false;
+    return true;
+}
+// n all-reduces of `count` doubles, one per context, issued from ONE thread inside a group (RCCL would otherwise block in the
+// first one waiting for ranks this thread has not reached yet)
+int grouped_allreduce(trm_ctx** ctxs, int n, std::vector<std::vector<double>>& bufs, int count, ncclRedOp_t op) {
+    Rccl* r = rccl();
+    for (int i = 0; i < n; ++i) {
+        trm_ctx* c = ctxs[i];
+        TRM_HIP(c, hipSetDevice(c->device));
+        TRM_HIP(c, hipMemcpyAsync(c->d_comm, bufs[i].data(), (size_t)count * sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
+    }
+    TRM_NCCL(ctxs[0], r->GroupStart());
+    for (int i = 0; i < n; ++i) {
+        trm_ctx* c = ctxs[i];
+        const ncclResult_t e = r->AllReduce(c->d_comm, c->d_comm + count, (size_t)count, ncclDouble, op, c->comm, c->comm_stream);
+        if (e != ncclSuccess) {
+            (void)r->GroupEnd();
+            return fail(c, TRM_ECOMM, std::string("ncclAllReduce: ") + r->GetErrorString(e));
+        }
+    }
+    TRM_NCCL(ctxs[0], r->GroupEnd());
+    for (int i = 0; i < n; ++i) {
+        trm_ctx* c = ctxs[i];
+        TRM_HIP(c, hipSetDevice(c->device));
+        TRM_HIP(c, hipMemcpyAsync(bufs[i].data(), c->d_comm + count, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+        TRM_HIP(c, hipStreamSynchronize(c->comm_stream));
+    }
+    return TRM_OK;
+}
+int check_ctx_list(trm_ctx** ctxs, int n, const char* who) {
+    if (!ctxs || n < 1) return fail(nullptr, TRM_EINVAL, std::string(who) + ": need at least one context");
+    for (int i = 0; i < n; ++i)
+        if (!ctxs[i]) return fail(nullptr, TRM_EINVAL, std::string(who) + ": null context in the list");
+    for (int i = 1; i < n; ++i)
+        if (ctxs[i]->Nz != ctxs[0]->Nz) return fail(ctxs[0], TRM_EINVAL, std::string(who) + ": the contexts are shards of one grid: same number of levels expected");
+    return TRM_OK;
+}
+}  // namespace
+
 int trm_reduce_global(trm_ctx* c, int field, int op, double* out) {
     int rc = trm_reduce(c, field, op, out);     // this device's columns (synchronous)
     if (rc) return rc;
     if (!c->comm) return fail(c, TRM_EINVAL, "trm_reduce_global: call trm_comm_init first");
-    const int rows = op == TRM_REDUCE_VOLUME_INTEGRAL_Z ? 1 : (int)field_rows(c, field);
-    std::vector<double> buf((size_t)2 * rows);
-    if (op == TRM_REDUCE_MIN || op == TRM_REDUCE_MAX) {
-        // a NaN on any rank must reach every rank (Base.minimum / maximum): RCCL's min / max do not promise that,
-        // so the values travel NaN-free next to a flag that travels with the same operator
-        const double sentinel = op == TRM_REDUCE_MIN ? HUGE_VAL : -HUGE_VAL, yes = op == TRM_REDUCE_MIN ? -1.0 : 1.0;
-        for (int r = 0; r < rows; ++r) {
-            const bool nan = out[r] != out[r];
-            buf[r] = nan ? sentinel : out[r];
-            buf[rows + r] = nan ? yes : 0.0;
-        }
-        rc = comm_allreduce(c, buf.data(), 2 * rows, op == TRM_REDUCE_MIN ? ncclMin : ncclMax);
-        if (rc) return rc;
-        for (int r = 0; r < rows; ++r) out[r] = buf[rows + r] != 0.0 ? std::nan("") : buf[r];
-        return TRM_OK;
-    }
-    for (int r = 0; r < rows; ++r) buf[r] = out[r];
-    rc = comm_allreduce(c, buf.data(), rows, op == TRM_REDUCE_HASNAN ? ncclMax : ncclSum);
+    const int rows = reduce_rows(c, field, op);
+    std::vector<double> buf;
+    const int count = pack_reduce(op, rows, out, buf);
+    rc = comm_allreduce(c, buf.data(), count, reduce_operator(op));
     if (rc) return rc;
-    for (int r = 0; r < rows; ++r) out[r] = buf[r];
+    unpack_reduce(op, rows, buf, out);
     return TRM_OK;
 }
 
@@ -2020,6 +2245,128 @@ int trm_status_global(trm_ctx* c, uint32_t* flags) {
     if (rc) return rc;
     *flags = 0;
     for (int b = 0; b < 8; ++b) *flags |= bits[b] != 0.0 ? (1u << b) : 0u;
+    return TRM_OK;
+}
+
+// ---- one host thread, n contexts ("1 process x 8 HIP devices") ---------------------------------------------
+int trm_comm_init_all(trm_ctx** ctxs, int n) {
+    if (int rc = check_ctx_list(ctxs, n, "trm_comm_init_all")) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (ctxs[i]->comm) return fail(ctxs[i], TRM_EINVAL, "trm_comm_init_all: the context already has a communicator");
+        for (int j = 0; j < i; ++j)
+            if (ctxs[j]->device == ctxs[i]->device)
+                return fail(ctxs[i], TRM_EINVAL, "trm_comm_init_all: two contexts on one device (RCCL takes one rank per device; without communicators "
+                                                 "trm_reduce_global_all / trm_status_global_all combine the shards on the host)");
+    }
+    Rccl* r = rccl();
+    if (!r->error.empty()) return fail(ctxs[0], TRM_ECOMM, r->error);
+    ncclUniqueId id;
+    TRM_NCCL(ctxs[0], r->GetUniqueId(&id));
+    TRM_NCCL(ctxs[0], r->GroupStart());
+    for (int i = 0; i < n; ++i) {
+        trm_ctx* c = ctxs[i];
+        ncclResult_t e = ncclSuccess;
+        if (hipSetDevice(c->device) != hipSuccess) e = ncclUnhandledCudaError;
+        if (e == ncclSuccess) e = r->CommInitRank(&c->comm, n, id, i);
+        if (e != ncclSuccess) {
+            (void)r->GroupEnd();
+            for (int j = 0; j <= i; ++j) ctxs[j]->comm = nullptr;
+            return fail(c, TRM_ECOMM, std::string("ncclCommInitRank (grouped): ") + r->GetErrorString(e));
+        }
+    }
+    {
+        const ncclResult_t e = r->GroupEnd();
+        if (e != ncclSuccess) {
+            for (int j = 0; j < n; ++j) ctxs[j]->comm = nullptr;
+            return fail(ctxs[0], TRM_ECOMM, std::string("ncclGroupEnd: ") + r->GetErrorString(e));
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        trm_ctx* c = ctxs[i];
+        c->comm_rank = i;
+        c->comm_world = n;
+        TRM_HIP(c, hipSetDevice(c->device));
+        TRM_HIP(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        TRM_HIP(c, hipMalloc((void**)&c->d_comm, (size_t)(4 * (c->Nz + 1) + 16) * sizeof(double)));
+    }
+    return TRM_OK;
+}
+
+namespace {
+int step_all(trm_ctx** ctxs, int n, const char* who, int (*step)(trm_ctx*, double, int, int), double dt, int nsteps, int finalize) {
+    if (int rc = check_ctx_list(ctxs, n, who)) return rc;
+    // every context is stepped without waiting for it (each on its own stream, each device running its shard), then ONE wait
+    // per context -- unless the caller drives them asynchronously anyway
+    std::vector<int> async((size_t)n);
+    int rc = TRM_OK;
+    for (int i = 0; i < n && !rc; ++i) {
+        async[(size_t)i] = ctxs[i]->opt_async;
+        ctxs[i]->opt_async = 1;
+        rc = step(ctxs[i], dt, nsteps, finalize);
+        ctxs[i]->opt_async = async[(size_t)i];
+    }
+    for (int i = 0; i < n; ++i) {
+        if (async[(size_t)i]) continue;
+        const int rs = trm_synchronize(ctxs[i]);      // (also after a failure: nothing is left running behind the caller's back)
+        if (!rc) rc = rs;
+    }
+    return rc;
+}
+}  // namespace
+int trm_step_all(trm_ctx** ctxs, int n, double dt, int nsteps, int finalize) {
+    return step_all(ctxs, n, "trm_step_all", trm_step, dt, nsteps, finalize);
+}
+int trm_step_heun_all(trm_ctx** ctxs, int n, double dt, int nsteps, int finalize) {
+    return step_all(ctxs, n, "trm_step_heun_all", trm_step_heun, dt, nsteps, finalize);
+}
+int trm_synchronize_all(trm_ctx** ctxs, int n) {
+    if (int rc = check_ctx_list(ctxs, n, "trm_synchronize_all")) return rc;
+    int rc = TRM_OK;
+    for (int i = 0; i < n; ++i) {
+        const int rs = trm_synchronize(ctxs[i]);
+        if (!rc) rc = rs;
+    }
+    return rc;
+}
+
+int trm_reduce_global_all(trm_ctx** ctxs, int n, int field, int op, double* out) {
+    if (int rc = check_ctx_list(ctxs, n, "trm_reduce_global_all")) return rc;
+    if (!out || !valid_field(field)) return fail(ctxs[0], TRM_EINVAL, "trm_reduce_global_all: bad argument");
+    const int rows = reduce_rows(ctxs[0], field, op);
+    std::vector<std::vector<double>> bufs((size_t)n);
+    std::vector<double> local((size_t)field_rows(ctxs[0], field) + 1);
+    int count = 0;
+    for (int i = 0; i < n; ++i) {
+        int rc = trm_reduce(ctxs[i], field, op, local.data());       // this device's columns
+        if (rc) return rc;
+        count = pack_reduce(op, rows, local.data(), bufs[(size_t)i]);
+    }
+    if (n > 1 && all_have_comm(ctxs, n)) {
+        if (int rc = grouped_allreduce(ctxs, n, bufs, count, reduce_operator(op))) return rc;
+    } else {
+        for (int i = 1; i < n; ++i) fold_packed(op, count, bufs[0], bufs[(size_t)i]);
+    }
+    unpack_reduce(op, rows, bufs[0], out);
+    return TRM_OK;
+}
+
+int trm_status_global_all(trm_ctx** ctxs, int n, uint32_t* flags) {
+    if (int rc = check_ctx_list(ctxs, n, "trm_status_global_all")) return rc;
+    if (!flags) return TRM_EINVAL;
+    std::vector<std::vector<double>> bufs((size_t)n, std::vector<double>(8));
+    for (int i = 0; i < n; ++i) {
+        uint32_t local = 0;
+        int rc = trm_status(ctxs[i], &local);
+        if (rc) return rc;
+        for (int b = 0; b < 8; ++b) bufs[(size_t)i][(size_t)b] = (double)((local >> b) & 1u);
+    }
+    if (n > 1 && all_have_comm(ctxs, n)) {
+        if (int rc = grouped_allreduce(ctxs, n, bufs, 8, ncclMax)) return rc;
+    } else {
+        for (int i = 1; i < n; ++i) fold_packed(TRM_REDUCE_MAX, 8, bufs[0], bufs[(size_t)i]);
+    }
+    *flags = 0;
+    for (int b = 0; b < 8; ++b) *flags |= bufs[0][(size_t)b] != 0.0 ? (1u << b) : 0u;
     return TRM_OK;
 }
 
@@ -2055,6 +2402,10 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             if (value < 0 || value > 2) break;
             c->opt_pipeline = value;
             return TRM_OK;
+        case TRM_OPT_SINGLE_STEP_PROGRAM:
+            if (value < 0 || value > 2) break;
+            c->opt_single_step = value;
+            return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -2070,6 +2421,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_DERIVE_CLOSURE_FIELDS: *value = c->opt_derive; return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
+        case TRM_OPT_SINGLE_STEP_PROGRAM: *value = c->opt_single_step; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

@@ -55,6 +55,9 @@ struct trm_ctx {
         void* d_values = nullptr;   // [cap][Nh]: a ring of time levels, level n of `times` in slot (head + n) % cap
         long cap = 0, head = 0;
         long pending_from = -1;     // first level (index into `times`) whose copy may still be in flight, or -1
+        bool windowed = false;      // levels have been appended (trm_series_append): trm_series_trim_before may release its head
+        bool trimmed = false;       // ... and has: evaluations before `trimmed_before` would need levels that are gone
+        double trimmed_before = 0.0;
         size_t slot(int n) const { return (size_t)((head + n) % cap); }
     };
     std::vector<Series> series;
@@ -72,6 +75,11 @@ struct trm_ctx {
     void* d_ring = nullptr;             // staging [rows][ring_points]
     size_t ring_cap = 0;
     void* bc_value_stage[TRM_BCV_COUNT][2] = {};  // Heun: the stage evaluates its boundary series at t + dt
+    // the two-call Heun (trm_heun_predict / trm_heun_correct): stage buffers the caller writes between the two calls
+    bool stage_bc_user[TRM_BCV_COUNT][2] = {};    // handed out by trm_stage_bc_device_ptr
+    bool stage_vwc_own = false;                   // the stage reads its own per-cell vwc_forcing (else the state's)
+    bool heun_pending = false;                    // trm_heun_predict has run, trm_heun_correct has not
+    double heun_dt = 0.0;
     void* d_top3 = nullptr;  // LandModel: [3][Nh] (T, sat, liq) of the top cell as left by the last fused step
     bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)
     bool top_escaped = false;  // a device pointer to T / sat / liq was handed out: never trust the copies again
@@ -94,6 +102,7 @@ struct trm_ctx {
     // Two halves of the columns (TRM_OPT_PIPELINE_PARTS): the per-step LandModel path runs the latency-bound 0-D surface
     // processes of one half in the same launch as the soil columns of the other (k_land_euler).  Columns are independent.
     int opt_pipeline = 2;           // 0: off, 1: whenever legal, 2: auto (column threshold)
+    int opt_single_step = 2;        // TRM_OPT_SINGLE_STEP_PROGRAM: 0 off, 1 whenever legal, 2 the library's rule
     int part = -1;                  // part the launch helpers currently address (-1: all columns)
     long part_lo[2] = {0, 0}, part_n[2] = {0, 0};
     // Launch arguments (DevParams, View of the state / the stage, StageView) are built once and reused by every launch;

@@ -9,6 +9,7 @@ template <int H, int LPC> static int launch_land(trm_ctx* c, int qcol, int qsurf
     constexpr bool RICH = true;
     const LaunchArgs<NF>& la = launch_args<NF>(c);
     const View<NF>&vc = la.part[qcol], &vs = la.part[qsurf];
+    if (top_arrays && !vs.top_T) return fail(c, TRM_EINVAL, "LandModel launch: the top-cell arrays were requested on a context that has none");
     const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
     const unsigned sblocks = (unsigned)((c->part_n[qsurf] + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK);
     const dim3 block(TRM_STEP_BLOCK);

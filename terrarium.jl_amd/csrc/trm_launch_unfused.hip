@@ -30,6 +30,9 @@ template <class NF> int Unfused<NF>::update_inputs(trm_ctx* c, const FieldSet& s
     for (auto& sr : c->series) {
         int n1, n2;
         double f, g;
+        if (sr.trimmed && time < sr.trimmed_before)
+            return fail(c, TRM_EINVAL, "a windowed time series was asked for a time before the levels it still holds (trm_series_trim_before released them): "
+                                       "re-create the series from the record's head before stepping from an earlier clock");
         series_time_indices(sr.times, sr.indexing, time, n1, n2, f, g);
         if (int rw = await_levels(c, sr, std::max(n1, n2))) return rw;
         if (!sr.is_bc && stage && !c->has_stage) continue;   // (fused Heun: the stage's surface processes are never evaluated)
@@ -61,7 +64,7 @@ template <class NF> int Unfused<NF>::hydraulics(trm_ctx* c, const FieldSet& s) {
 template <class NF> int Unfused<NF>::surface(trm_ctx* c, const FieldSet& s, bool from_state) {
     const View<NF>& v = cached_view<NF>(c, s);
     const DevParams<NF>& p = launch_args<NF>(c).p;
-    if (from_state && c->top_valid && &s == &c->state) {
+    if (from_state && c->top_valid && c->d_top3 && &s == &c->state) {   // (the top-cell arrays: only where they exist)
         if (Policy<NF>::richards(c)) { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, true, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
         else { TRM_BY_HYD(c, hipLaunchKernelGGL((k_surface<NF, false, H, true, true>), col_grid(c), dim3(256), 0, c->stream, v, p)); }
     } else if (from_state) {

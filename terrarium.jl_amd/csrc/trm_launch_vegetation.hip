@@ -11,12 +11,13 @@ template <class NF> int Veg<NF>::surface_veg(trm_ctx* c, const FieldSet& s, bool
     a.dt = (NF)dt;
     a.richards = Policy<NF>::richards(c) ? 1 : 0;
     a.from_state = from_state ? 1 : 0;
-    a.top_arrays = (from_state && c->top_valid && &s == &c->state) ? 1 : 0;
+    a.top_arrays = (from_state && c->top_valid && c->d_top3 && &s == &c->state) ? 1 : 0;
     a.advance = advance ? 1 : 0;
     a.store_paw = store_paw ? 1 : 0;
     return surface_veg_launch(c, cached_view<NF>(c, s), Policy<NF>::veg_view(c, s), a);
 }
 template <class NF> int Veg<NF>::surface_veg_launch(trm_ctx* c, const View<NF>& v, const VegView<NF>& vv, const SurfaceVegArgs<NF>& a) {
+    if (a.top_arrays && !v.top_T) return fail(c, TRM_EINVAL, "k_surface_veg: the top-cell arrays were requested on a context that has none");
     const DevParams<NF>& p = launch_args<NF>(c).p;
     const VegDev<NF> vp = Policy<NF>::veg_dev(c);
     const dim3 blocks((unsigned)((ncols(c) + 63) / 64));   // 64 columns per 256-thread workgroup

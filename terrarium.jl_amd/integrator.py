@@ -395,6 +395,34 @@ class DeviceState:
         self._check(self._lib.trm_step_heun_timed(self._ctx, float(dt), int(nsteps), int(finalize), C.byref(ms)), "trm_step_heun_timed")
         return float(ms.value)
 
+    # -- Heun in two calls (state-dependent forcings / boundary values evaluated at the stage in between) ------------------
+    def heun_predict(self, dt):
+        """heun.jl:41-52: update_state!(state), stage := state, explicit_step!(stage), closure!(stage) (trm_heun_predict)."""
+        self._check(self._lib.trm_heun_predict(self._ctx, float(dt)), "trm_heun_predict")
+
+    def heun_correct(self, dt, finalize=True):
+        """heun.jl:54-71: update_state!(stage), average_tendencies!, explicit_step!(state), closure!(state) (trm_heun_correct)."""
+        self._check(self._lib.trm_heun_correct(self._ctx, float(dt), int(finalize)), "trm_heun_correct")
+
+    def stage_device_array(self, name) -> "DeviceArray":
+        """The device buffer of a field of the Heun STAGE (layout as `device_array`; trm_stage_field_device_ptr)."""
+        ptr, pitch = C.c_void_p(), C.c_int64()
+        self._check(self._lib.trm_stage_field_device_ptr(self._ctx, _capi.FIELD[name], C.byref(ptr), C.byref(pitch)), "trm_stage_field_device_ptr")
+        shape = (self.grid.Nh,) if self.rows(name) == 1 else (self.grid.Nh, int(pitch.value))
+        return DeviceArray(ptr.value, shape, self.dtype, self)
+
+    def stage_bc_device_array(self, var, side) -> "DeviceArray":
+        """The device array `[num_columns]` of the STAGE's boundary values (trm_stage_bc_device_ptr)."""
+        ptr = C.c_void_p()
+        self._check(self._lib.trm_stage_bc_device_ptr(self._ctx, _capi.BC_VAR[var], _capi.SIDE[side], C.byref(ptr)), "trm_stage_bc_device_ptr")
+        return DeviceArray(ptr.value, (self.grid.Nh,), self.dtype, self)
+
+    def set_forcing_device(self, name, device_ptr):
+        """An input field from DEVICE memory `[num_columns]`, stream-ordered, the host does not wait (trm_set_forcing_device)."""
+        if name == "ground_temperature":
+            name = "vegetation_ground_temperature"
+        self._check(self._lib.trm_set_forcing_device(self._ctx, _capi.FIELD[name], C.c_void_p(int(device_ptr))), "trm_set_forcing_device")
+
     def clock(self):
         t, it = C.c_double(), C.c_int64()
         self._check(self._lib.trm_clock(self._ctx, C.byref(t), C.byref(it)), "trm_clock")
@@ -470,7 +498,9 @@ class StateFunction:
       clock           `.time`, `.iteration`
     and returns a tensor (or number) that broadcasts to the target: `[num_columns, Nz]` for `vwc_forcing`, `[num_columns]`
     for a boundary value or an input.  Evaluation and the step share one stream, so nothing waits on the host.
-    ForwardEuler only: Heun's second stage would need the function at the stage's state, inside the fused launch."""
+    Under Heun the function is evaluated twice per step, as the reference does (heun.jl:37-71): at the state with the clock at
+    t, and at the STAGE -- `fields` are then the predicted state's buffers -- with the clock at t + dt, between the library's
+    trm_heun_predict and trm_heun_correct."""
 
     def __init__(self, func, parameters=None):
         self.func = func
@@ -485,15 +515,17 @@ class _Clock:
 class _DeviceFields:
     """`fields` of a StateFunction: attribute access -> torch view of the field's device buffer (cached)."""
 
-    def __init__(self, state, torch):
+    def __init__(self, state, torch, stage=False):
         object.__setattr__(self, "_state", state)
         object.__setattr__(self, "_torch", torch)
         object.__setattr__(self, "_views", {})
+        object.__setattr__(self, "_stage", stage)      # the Heun stage's buffers instead of the state's
 
     def __getattr__(self, name):
         if name not in self._views:
             field, row0, rows = self._state._alias(name)      # (e.g. ground_temperature = the top row of temperature)
-            t = self._torch.as_tensor(self._state.device_array(field), device=f"cuda:{int(self._state.grid.device)}")
+            arr = self._state.stage_device_array(field) if self._stage else self._state.device_array(field)
+            t = self._torch.as_tensor(arr, device=f"cuda:{int(self._state.grid.device)}")
             if t.dim() == 2:
                 t = t[:, row0] if (field != name and rows == 1) else t[:, row0:row0 + rows]
             self._views[name] = t
@@ -558,8 +590,6 @@ class ModelIntegrator:
         self._sf = []
         if not fns:
             return
-        if isinstance(self.timestepper, Heun):
-            raise NotImplementedError("a StateFunction needs the stage's state at Heun's second stage: use ForwardEuler")
         import torch  # device memory / stream plumbing of the host mirror
         st = self.state
         dev = f"cuda:{int(st.grid.device)}"
@@ -578,18 +608,47 @@ class ModelIntegrator:
             else:
                 st.set("vwc_forcing", np.zeros((st.grid.Nz, st.grid.Nh), dtype=st.dtype))
                 dest = self._sf_fields.vwc_forcing
-            self._sf.append((fn, dest))
+            self._sf.append((fn, dest, target))
+        self._sf_stage = None      # the stage's destinations (Heun), bound at the first Heun step
+
+    def _bind_stage_functions(self):
+        """The Heun stage's `fields` and the stage's copies of the targets (trm_stage_*_device_ptr)."""
+        import torch
+        st = self.state
+        dev = f"cuda:{int(st.grid.device)}"
+        self._sf_stage_fields = _DeviceFields(st, torch, stage=True)
+        self._sf_stage = []
+        for fn, _, target in self._sf:
+            if target[0] == "bc":
+                dest = torch.as_tensor(st.stage_bc_device_array(target[1], target[2]), device=dev)
+            elif target[0] == "input":
+                dest = getattr(self._sf_stage_fields, target[1])
+            else:
+                dest = self._sf_stage_fields.vwc_forcing
+            self._sf_stage.append((fn, dest))
+
+    def _evaluate(self, pairs, fields, clock):
+        import torch
+        with torch.cuda.stream(self._sf_stream):
+            for fn, dest in pairs:
+                out = fn.func(fields, clock, fn.parameters)
+                dest.copy_(torch.as_tensor(out, device=dest.device, dtype=dest.dtype).expand_as(dest))
 
     def _apply_state_functions(self, t):
         if not self._sf:
             return False
-        import torch
-        clock = _Clock(t, self.state.clock()[1])
-        with torch.cuda.stream(self._sf_stream):
-            for fn, dest in self._sf:
-                out = fn.func(self._sf_fields, clock, fn.parameters)
-                dest.copy_(torch.as_tensor(out, device=dest.device, dtype=dest.dtype).expand_as(dest))
+        self._evaluate([(fn, dest) for fn, dest, _ in self._sf], self._sf_fields, _Clock(t, self.state.clock()[1]))
         return True
+
+    def _heun_step_with_state_functions(self, dt, finalize):
+        """One Heun step with the functions evaluated at both stages (heun.jl:37-71): the state's values have been written by
+        _apply_time_dependent; predict, evaluate at the stage (clock t + dt), correct."""
+        if self._sf_stage is None:
+            self._bind_stage_functions()
+        t, it = self.state.clock()
+        self.state.heun_predict(dt)
+        self._evaluate(self._sf_stage, self._sf_stage_fields, _Clock(t + dt, it))
+        self.state.heun_correct(dt, finalize)
 
     # -- windowed series: a record streamed through a fixed device window ------------------------------------------------
     def _windowed(self):
@@ -622,9 +681,29 @@ class ModelIntegrator:
                 ok = min(ok, k)
         return ok
 
+    def _seek_windows(self, t):
+        """Moves the device windows forward until they hold the bracket of time `t` (a restart into a fresh integrator, whose
+        windows start at the head of their records)."""
+        for target, fts in self._windowed():
+            while True:
+                info = self.state.series_info(target)
+                nxt = self._next_level[id(fts)]
+                if info["t_last"] > t or nxt >= fts.times.size:
+                    break
+                self.state.series_trim_before(min(t, info["t_last"]))
+                info = self.state.series_info(target)
+                hi = min(nxt + max(1, fts.window - info["levels"]), fts.times.size)
+                self.state.series_append(target, fts.times[nxt:hi], np.asarray(fts.values[nxt:hi]))
+                self._next_level[id(fts)] = hi
+
     def _step(self, dt, nsteps, finalize, heun=None):
         """`nsteps` steps in as few library calls as the device windows of the time series allow (one, without windows)."""
         heun = isinstance(self.timestepper, Heun) if heun is None else heun
+        if heun and self._sf:
+            assert nsteps == 1, "state-dependent functions are evaluated before every step"
+            if self._windowed():
+                self._feed(self.state.clock()[0], dt, 1)
+            return self._heun_step_with_state_functions(dt, finalize)
         stepper = self.state.step_heun if heun else self.state.step
         if not self._windowed():
             return stepper(dt, nsteps, finalize=finalize)
@@ -764,6 +843,112 @@ def compute_tendencies(state: DeviceState, model=None): state.compute_tendencies
 def closure(state: DeviceState, model=None): state.closure()
 def invclosure(state: DeviceState, model=None): state.invclosure()
 def update_state(integ: ModelIntegrator, compute_tendencies=True): integ.state.update_state(compute_tendencies)
+
+
+# ---- restart ("download/upload of all prognostic buffers + clock is sufficient for restart";
+# docs/src/running/time_stepping.md:97-139 saves and reloads the state of a simulation) ------------------------------------------
+# The restart set: every prognostic variable, the closure variables that belong to them (stored, not recomputed: a restart
+# continues bit for bit), the water table, and -- with vegetation -- the net assimilation the stomatal conductance carries from
+# the previous evaluation (vegetation_carbon.jl:88-92).  Everything else is recomputed by the next step (auxiliaries) or is the
+# caller's (inputs, boundary values, series).
+RESTART_FIELDS_SOIL = ("internal_energy", "temperature", "liquid_water_fraction", "saturation_water_ice")
+RESTART_FIELDS_RICHARDS = ("pressure_head", "surface_excess_water", "water_table")
+RESTART_FIELDS_LAND = ("skin_temperature",)
+RESTART_FIELDS_VEGETATION = ("carbon_vegetation", "vegetation_area_fraction", "net_assimilation")
+RESTART_FIELDS_CANOPY = ("canopy_water",)
+
+
+def restart_fields(integ: ModelIntegrator):
+    st = integ.state
+    mode = getattr(st, "vegetation_mode", "off")
+    if mode == "standalone":
+        return list(RESTART_FIELDS_VEGETATION)
+    names = list(RESTART_FIELDS_SOIL)
+    if st.params.flow == _capi.FLOW["richards"]:
+        names += RESTART_FIELDS_RICHARDS
+    if st.params.seb:
+        names += RESTART_FIELDS_LAND
+    if mode == "coupled":
+        names += RESTART_FIELDS_VEGETATION + RESTART_FIELDS_CANOPY
+    return names
+
+
+def checkpoint(integ: ModelIntegrator) -> dict:
+    """The restart set of an integrator as host arrays (trm_download) + the clock + the status word."""
+    st = integ.state
+    t, it = st.clock()
+    return dict(time=t, iteration=it, status=st.status(), dtype=str(np.dtype(st.dtype)), Nh=st.grid.Nh, Nz=st.grid.Nz,
+                fields={name: st.get(name) for name in restart_fields(integ)})
+
+
+def restore(integ: ModelIntegrator, ckpt: dict) -> ModelIntegrator:
+    """Continues from `checkpoint(...)` in THIS integrator -- typically a fresh one (a new process, another device): the
+    fields are uploaded (trm_upload), the clock is set (trm_set_clock), windowed series are moved forward to the clock.
+    Initialise the integrator as for a cold start first (boundary conditions, inputs, series); its initial state is replaced."""
+    st = integ.state
+    if (ckpt["Nh"], ckpt["Nz"], ckpt["dtype"]) != (st.grid.Nh, st.grid.Nz, str(np.dtype(st.dtype))):
+        raise ValueError("the checkpoint belongs to another grid / precision")
+    missing = [n for n in restart_fields(integ) if n not in ckpt["fields"]]
+    if missing:
+        raise ValueError(f"the checkpoint lacks {missing}")
+    for name in restart_fields(integ):
+        st.set(name, ckpt["fields"][name])
+    st.set_clock(ckpt["time"], ckpt["iteration"])
+    integ._seek_windows(ckpt["time"])
+    st.update_inputs()      # the inputs as update_inputs! leaves them at the restored clock
+    return integ
+
+
+# ---- one host process, several devices (SURVEY 5 / 8(e): "1 process x 8 HIP devices") ---------------------------------------
+class DeviceGroup:
+    """The shards of one grid, one `DeviceState` per device, driven from ONE host thread -- the reference's host is one Julia
+    process (column_grid.jl:32, model_integrator.jl:72-88).  `step` enqueues the steps on every device without waiting in
+    between and waits once (trm_step_all); global diagnostics combine the shards inside the library (trm_reduce_global_all /
+    trm_status_global_all: grouped RCCL all-reduces once `comm_init` has run, a host fold otherwise)."""
+
+    def __init__(self, states):
+        self.states = list(states)
+        self._lib = _capi.lib()
+        self._arr = (C.c_void_p * len(self.states))(*[s._ctx for s in self.states])
+
+    def __len__(self):
+        return len(self.states)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            for s in self.states:
+                msg = self._lib.trm_last_error(s._ctx)
+                if msg:
+                    break
+            err = _capi.TerrariumHipError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+            err.code = rc
+            raise err
+
+    def comm_init(self):
+        """One RCCL communicator per context inside one group (trm_comm_init_all); the contexts must sit on distinct devices."""
+        self._check(self._lib.trm_comm_init_all(self._arr, len(self)), "trm_comm_init_all")
+
+    def step(self, dt, nsteps=1, finalize=True, heun=False):
+        fn = self._lib.trm_step_heun_all if heun else self._lib.trm_step_all
+        self._check(fn(self._arr, len(self), float(dt), int(nsteps), int(finalize)), "trm_step_all")
+
+    def synchronize(self):
+        self._check(self._lib.trm_synchronize_all(self._arr, len(self)), "trm_synchronize_all")
+
+    def reduce_global(self, name, op) -> np.ndarray:
+        rows = 1 if op == "volume_integral_z" else self.states[0].rows(name)
+        out = np.zeros(rows, dtype=np.float64)
+        self._check(self._lib.trm_reduce_global_all(self._arr, len(self), _capi.FIELD[name], _capi.REDUCE[op], out.ctypes.data), "trm_reduce_global_all")
+        return out
+
+    def status_global(self) -> int:
+        f = C.c_uint32()
+        self._check(self._lib.trm_status_global_all(self._arr, len(self), C.byref(f)), "trm_status_global_all")
+        return int(f.value)
+
+    def gather(self, name) -> np.ndarray:
+        """The field on the whole grid: the shards' columns side by side."""
+        return np.concatenate([np.atleast_2d(s.get(name)) for s in self.states], axis=-1)
 
 
 # ---- the small interface functions the reference exports (src/timesteppers/*.jl, model_integrator.jl:39-66, grids) ----------

@@ -125,13 +125,17 @@ class Simulation:
     def _events(self):
         return [(cb.schedule, cb.func) for cb in self.callbacks.values()] + [(w.schedule, w) for w in self.output_writers.values()]
 
-    def _fire(self, initial=False):
+    def _fire(self, initial=False, time_only=False):
+        """`time_only`: the clock was moved onto an event time WITHOUT a step (the sliver case of `run`): the iteration has not
+        advanced, so schedules that depend on the iteration alone have already fired for it and must not fire twice."""
         t, it = self.integrator.state.clock()
         for schedule, func in self._events():
             if initial:
                 if isinstance(schedule, TimeInterval):
                     schedule.first, schedule.actuations = t, 0
                 func(self)           # Oceananigans evaluates every callback / writer once at initialisation
+            elif time_only and not isinstance(schedule, TimeInterval):
+                continue
             elif schedule.actuates(t, it):
                 func(self)
 
@@ -158,7 +162,7 @@ class Simulation:
                 # The device clock accumulates dt step by step: with a dt that is not exactly representable it can land a few
                 # ulp short of the target.  Oceananigans' `minimum_relative_step` treats that as reached: no sliver step.
                 integ.state.set_clock(t_next, it)
-                self._fire()
+                self._fire(time_only=True)
                 continue
             if n >= 1:
                 if host_dependent:      # functions of time are evaluated on the host before every step

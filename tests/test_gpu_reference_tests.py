@@ -398,6 +398,24 @@ def test_simulation_driver_with_callbacks_and_ring_output(tmp_path, stepper):
         assert np.array_equal(grid.gather(f["ground_temperature"][k]), snap[-1]), k
 
 
+def test_simulation_schedules_of_both_kinds_with_a_step_that_is_not_representable():
+    """dt = 0.1 accumulates to a few ulp short of the TimeInterval targets: the driver moves the clock onto the target without a
+    step (Oceananigans' minimum_relative_step) -- and an IterationInterval callback / writer must not fire a second time for the
+    same iteration when it does."""
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=8), 5)
+    integ = trm.initialize(trm.SoilModel(grid), trm.ForwardEuler(dt=0.1), initializers=dict(temperature=1.0, saturation_water_ice=0.5))
+    sim = trm.Simulation(integ, dt=0.1, stop_time=0.9)
+    by_iteration, by_time = [], []
+    sim.add_callback(lambda s: by_iteration.append(s.iteration), trm.IterationInterval(1), name="every step")
+    sim.add_callback(lambda s: by_time.append((s.iteration, s.time)), trm.TimeInterval(0.3), name="every 0.3 s")
+    sim.output_writers["snap"] = trm.SnapshotWriter(["temperature"], trm.IterationInterval(3))
+    trm.run_simulation(sim)
+    assert sim.iteration == 9 and sim.time == 0.9
+    assert by_iteration == list(range(10)), by_iteration                   # once per iteration, the initial call included
+    assert [it for it, _ in by_time] == [0, 3, 6, 9] and [t for _, t in by_time] == [0.0, 0.3, 0.6, 0.9]
+    assert sim.output_writers["snap"].iterations == [0, 3, 6, 9]
+
+
 # model_integrator.jl:96-109 + state_variables.jl:102-120: initialize!(integrator) begins with reset!(state) -- every
 # prognostic, auxiliary and tendency field back to zero -- so a re-initialised run repeats a fresh one exactly
 @pytest.mark.parametrize("stepper", [trm.ForwardEuler, trm.Heun])

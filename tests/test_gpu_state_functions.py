@@ -26,8 +26,24 @@ def columns(n):
     return rng.uniform(-1.0, 1.0, n)
 
 
-def test_relaxation_forcing_of_the_water_content_follows_the_state():
-    """vwc_forcing = -(sat - target) * rate per cell: a nudging term, the textbook state-dependent Forcing"""
+def stepper_of(name, dt):
+    return trm.Heun(dt=dt) if name == "heun" else trm.ForwardEuler(dt=dt)
+
+
+def oracle_step(o, heun, dt, finalize, evaluate):
+    """One step of the oracle with `evaluate(oracle)` where the reference's tendency kernels would evaluate the user's function:
+    at the state, and under Heun at the stage as well (heun.jl:37-71: its clock has ticked)."""
+    if heun:
+        o.timestep_heun_by_hand(dt, finalize, at_state=evaluate, at_stage=evaluate)
+    else:
+        evaluate(o)
+        o.timestep(dt, finalize)
+
+
+@pytest.mark.parametrize("stepper", ["euler", "heun"])
+def test_relaxation_forcing_of_the_water_content_follows_the_state(stepper):
+    """vwc_forcing = -(sat - target) * rate per cell: a nudging term, the textbook state-dependent Forcing.  Under Heun the
+    function is evaluated at both stages (the stage's own per-cell forcing buffer: trm_stage_field_device_ptr)."""
     Nz, Nh, dt = 24, 130, 60.0
     u = columns(Nh)
     grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
@@ -37,7 +53,7 @@ def test_relaxation_forcing_of_the_water_content_follows_the_state():
     model = trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq(), vwc_forcing=F)))
     T_init = (3.0 + 2.0 * u)[None, :] - 0.05 * zc[:, None]
     sat = np.clip(np.minimum(1.0, 0.8 - 0.05 * zc)[:, None] * (1.0 + 0.1 * u)[None, :], 0.05, 1.0)
-    integ = trm.initialize(model, trm.ForwardEuler(dt=dt), boundary_conditions=trm.PrescribedSurfaceTemperature("Ts", 5.0 + u),
+    integ = trm.initialize(model, stepper_of(stepper, dt), boundary_conditions=trm.PrescribedSurfaceTemperature("Ts", 5.0 + u),
                            initializers=dict(temperature=T_init, saturation_water_ice=sat))
     o = oracle_like(integ)
     o.set("temperature", T_init)
@@ -46,26 +62,27 @@ def test_relaxation_forcing_of_the_water_content_follows_the_state():
     o.initialize()
     trm.run(integ, steps=25)
     for n in range(25):
-        o.set("vwc_forcing", (o.get("saturation_water_ice") - par["target"]) * (-par["rate"]))
-        o.timestep(dt, n == 24)
+        oracle_step(o, stepper == "heun", dt, n == 24, lambda q: q.set("vwc_forcing", (q.get("saturation_water_ice") - par["target"]) * (-par["rate"])))
     assert integ.state.clock() == (25 * dt, 25) and integ.state.status() == 0
     for name in ("saturation_water_ice", "internal_energy", "temperature", "pressure_head", "liquid_water_fraction"):
         assert np.array_equal(integ.state.get(name), o.get(name)), name
     # the forcing did something: without it the column mean stays where the fluxes put it
-    plain = trm.initialize(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq()))), trm.ForwardEuler(dt=dt),
+    plain = trm.initialize(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq()))), stepper_of(stepper, dt),
                            boundary_conditions=trm.PrescribedSurfaceTemperature("Ts", 5.0 + u), initializers=dict(temperature=T_init, saturation_water_ice=sat))
     trm.run(plain, steps=25)
     assert np.max(np.abs(plain.state.saturation_water_ice - integ.state.saturation_water_ice)) > 1e-4
 
 
-def test_boundary_value_that_reads_the_top_cell():
-    """top temperature value = 0.5 (T_top + 10): a boundary condition in discrete form reading `fields`; timestep! and run!"""
+@pytest.mark.parametrize("stepper", ["euler", "heun"])
+def test_boundary_value_that_reads_the_top_cell(stepper):
+    """top temperature value = 0.5 (T_top + 10): a boundary condition in discrete form reading `fields`; timestep! and run!
+    Under Heun the stage's boundary values are its own array (trm_stage_bc_device_ptr), evaluated from the stage's temperature."""
     Nz, Nh, dt = 16, 77, 300.0
     u = columns(Nh)
     grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
     bc = trm.PrescribedSurfaceTemperature("Ts", trm.StateFunction(lambda f, clock, p: 0.5 * (f.temperature[:, -1] + 10.0)))
     T_init = (2.0 + 4.0 * u)[None, :] * np.ones((Nz, 1))
-    integ = trm.initialize(trm.SoilModel(grid), trm.ForwardEuler(dt=dt), boundary_conditions=bc, initializers=dict(temperature=T_init, saturation_water_ice=0.8))
+    integ = trm.initialize(trm.SoilModel(grid), stepper_of(stepper, dt), boundary_conditions=bc, initializers=dict(temperature=T_init, saturation_water_ice=0.8))
     o = oracle_like(integ)
     o.set("temperature", T_init)
     o.set("saturation_water_ice", 0.8)
@@ -73,16 +90,17 @@ def test_boundary_value_that_reads_the_top_cell():
     trm.timestep(integ)
     trm.run(integ, steps=11)
     for n in range(12):
-        o.set_bc("temperature", "top", "value", 0.5 * (o.get("temperature")[-1] + 10.0))
-        o.timestep(dt, True)
+        oracle_step(o, stepper == "heun", dt, True, lambda q: q.set_bc("temperature", "top", "value", 0.5 * (q.get("temperature")[-1] + 10.0)))
     for name in ("internal_energy", "temperature", "liquid_water_fraction"):
         assert np.array_equal(integ.state.get(name), o.get(name)), name
     assert np.all(integ.state.temperature[-1] != T_init[-1])
 
 
-def test_atmospheric_input_that_follows_the_skin_temperature():
+@pytest.mark.parametrize("stepper", ["euler", "heun"])
+def test_atmospheric_input_that_follows_the_skin_temperature(stepper):
     """LandModel input air_temperature = skin temperature + 2 K: an input source driven by the land state (the coupling
-    direction of speedy_dry_land.jl:45-66, here as a function of `fields`); the clock reaches the function"""
+    direction of speedy_dry_land.jl:45-66, here as a function of `fields`); the clock reaches the function -- under Heun twice
+    per step: (t, n) at the state and (t + dt, n) at the stage"""
     Nz, Nh, dt = 20, 90, 60.0
     u = columns(Nh)
     grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
@@ -99,7 +117,7 @@ def test_atmospheric_input_that_follows_the_skin_temperature():
     sat = np.clip(np.minimum(1.0, 0.8 - 0.05 * zc)[:, None] * (1.0 + 0.05 * u)[None, :], 0.05, 1.0)
     other = dict(air_pressure=101325.0, windspeed=1.0 + 2.0 * np.abs(u), specific_humidity=2.0e-3, surface_shortwave_down=300.0 + 100.0 * u,
                  surface_longwave_down=300.0, rainfall=1.0e-8 * (u > 0))
-    integ = trm.initialize(land, trm.ForwardEuler(dt=dt), initializers=dict(temperature=T_init, saturation_water_ice=sat),
+    integ = trm.initialize(land, stepper_of(stepper, dt), initializers=dict(temperature=T_init, saturation_water_ice=sat),
                            inputs=dict(air_temperature=trm.StateFunction(air), **other))
     o = oracle_like(integ, land=True)
     o.set("temperature", T_init)
@@ -111,19 +129,50 @@ def test_atmospheric_input_that_follows_the_skin_temperature():
     assert np.array_equal(integ.state.skin_temperature, o.get("skin_temperature"))
     trm.run(integ, steps=15)
     for n in range(15):
-        o.set("air_temperature", np.ravel(o.get("skin_temperature")) + 2.0)
-        o.timestep(dt, n == 14)
-    assert seen == [(n * dt, n) for n in range(15)]
+        oracle_step(o, stepper == "heun", dt, n == 14, lambda q: q.set("air_temperature", np.ravel(q.get("skin_temperature")) + 2.0))
+    if stepper == "heun":
+        assert seen == [x for n in range(15) for x in ((n * dt, n), (n * dt + dt, n))]
+    else:
+        assert seen == [(n * dt, n) for n in range(15)]
     for name in ("skin_temperature", "internal_energy", "saturation_water_ice", "ground_heat_flux", "sensible_heat_flux"):
         a, b = integ.state.get(name), o.get(name)
         assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-10, name
 
 
-def test_heun_refuses_a_state_function():
-    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=8), 4)
-    bc = trm.PrescribedSurfaceTemperature("Ts", trm.StateFunction(lambda f, clock, p: f.temperature[:, -1]))
-    with pytest.raises(NotImplementedError):
-        trm.initialize(trm.SoilModel(grid), trm.Heun(dt=10.0), boundary_conditions=bc)
+def test_two_call_heun_equals_the_one_call_when_nothing_is_changed_at_the_stage():
+    """trm_heun_predict + trm_heun_correct = trm_step_heun bit for bit (every Heun path: the fused one-launch programs and the
+    reference-order kernels), with a constant top boundary value, a bottom flux and a boundary series evaluated at t and t + dt;
+    a stage boundary array that has been handed out is refreshed from the state's by the one-call form; misuse is refused."""
+    import workloads as W
+    lat, lon = W.synthetic_columns(150)
+    for config, Nz in (("richards", 24), ("land", 40), ("heat", 100)):
+        w = W.make_workload(config, lat, lon, Nz)
+        a, b, c = W.setup_device(w), W.setup_device(w), W.setup_device(w)
+        tt = np.array([0.0, 400.0, 900.0, 2000.0])
+        for d in (a, b, c):
+            d.set_bc("internal_energy", "bottom", "flux", 0.05 + 0.01 * w["u"])
+            if config != "land":
+                d.set_bc_series("temperature", "top", "value", tt, w["T0"][None, :] + np.sin(tt / 300.0)[:, None])
+        c.set_option("step_kernel", "unfused")
+        b.stage_bc_device_array("internal_energy", "bottom")        # (handed out, never written: must not disturb anything)
+        for n in range(6):
+            a.step_heun(w["dt"], 1, finalize=(n == 5))
+            b.heun_predict(w["dt"])
+            b.heun_correct(w["dt"], finalize=(n == 5))
+            c.step_heun(w["dt"], 1, finalize=(n == 5))
+        assert a.clock() == b.clock() == c.clock()
+        for name in W.compared_fields(w):
+            assert np.array_equal(a.get(name), b.get(name), equal_nan=True), (config, name)
+            assert np.array_equal(a.get(name), c.get(name), equal_nan=True), (config, name)
+        assert a.status() == b.status() == c.status()
+        b.step_heun(w["dt"], 2)          # the one-call form after the two-call form: the stage array follows the state's again
+        a.step_heun(w["dt"], 2)
+        assert np.array_equal(a.get("internal_energy"), b.get("internal_energy"))
+    with pytest.raises(trm.TerrariumHipError, match="trm_heun_predict first"):
+        a.heun_correct(w["dt"])
+    a.heun_predict(w["dt"])
+    with pytest.raises(trm.TerrariumHipError, match="dt differs"):
+        a.heun_correct(2 * w["dt"])
 
 
 def test_library_loaded_before_torch_shares_one_hip_runtime():

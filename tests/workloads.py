@@ -71,6 +71,15 @@ def make_workload(config, lat, lon, Nz, dtype=np.float64, hydraulics="default", 
     return w
 
 
+def shard_workload(w, lo, hi):
+    """Columns [lo, hi) of a workload: the block one device owns (parallel.shard_range)."""
+    s = dict(w, Nh=hi - lo, lat=w["lat"][lo:hi], lon=w["lon"][lo:hi], T0=w["T0"][lo:hi], u=w["u"][lo:hi], dx=w.get("dx", 1.0 / w["Nh"]))
+    s["fields"] = {k: (v[..., lo:hi] if np.ndim(v) else v) for k, v in w["fields"].items()}
+    s["bcs"] = {k: (kind, v[lo:hi] if np.ndim(v) else v) for k, (kind, v) in w["bcs"].items()}
+    s["inputs"] = {k: (v[lo:hi] if np.ndim(v) else v) for k, v in w["inputs"].items()}
+    return s
+
+
 FIELDS_3D = ("internal_energy", "temperature", "liquid_water_fraction")
 FIELDS_RICHARDS = ("saturation_water_ice", "pressure_head", "hydraulic_conductivity", "surface_excess_water",
                    "water_table")
@@ -122,6 +131,8 @@ def setup_device(w, device=0, steps_per_launch=1):
     for k, v in w["params"].items():
         setattr(p, k, v)
     grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(w["thickness"])), w["Nh"], dtype=w["dtype"], device=device)
+    if "dx" in w:
+        grid.dx = w["dx"]       # a shard keeps the x spacing of the global grid (dx enters the flux boundary terms as Az / V)
     d = trm.DeviceState(grid, p)
     d.set_option("steps_per_launch", steps_per_launch)
     if w.get("vegetation"):     # LandModel(grid; soil, vegetation = VegetationCarbon()) with the default canopy schemes
