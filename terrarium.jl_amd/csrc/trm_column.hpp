@@ -33,6 +33,9 @@ struct LaneInfo { int lane, k; bool is_bot, is_top, act; unsigned long long m_ac
 template <class NF> struct ColumnBC {
     NF bTb, bTt;            // temperature boundary values (used when the Value condition is set)
     NF flux_U, flux_S;      // compute_z_bcs! term of this lane's cell (flux * Az / V, signed; 0 in the interior)
+    // whether any flux condition feeds flux_U / flux_S (wave-uniform): without one the term is +0 in every lane and the
+    // tendencies, which are never -0.0 (`0 + ...`), are left alone instead of receiving `+ 0`
+    bool has_U = true, has_S = true;
 };
 template <class NF> struct Tendency { NF gU, gS, Kf_lo, Kc; };
 
@@ -55,28 +58,44 @@ template <class NF> TRM_DEV NF liquid_fraction_wave(const DevParams<NF>& p, NF U
     if (no_lane_divides(thawed, frozen, Lth > Limits<NF>::eps())) return thawed ? NF(1) : NF(-0.0);
     return thawed ? NF(1) : boolmul(U >= nLth, NF(1) - safediv(U, nLth));
 }
-template <class NF> TRM_DEV void energy_closure_wave(const DevParams<NF>& p, NF U, NF sat, NF& liq, NF& T, uint32_t& viol) {
+// CHECK: 0 = no composition check (the caller ignores it: a state whose bounds were flagged by the launch that produced it),
+// 1 = the full check of volumetric_fractions (soil_volume.jl:26-28), 2 = the saturation has been through the repair of this
+// step and is in [0, 1] or NaN by construction (adjust_saturation_profile!: every cell above 1 / below 0 is levelled, the top
+// overflows, the bottom is clamped), so `0 <= sat <= 1` is `sat == sat`.  In the common path the liquid fraction is 1 or -0.0:
+// inside the bounds; the path that divides checks it.  Same flags as the full check, 1 compare instead of 4.
+// Returns the volumetric fractions it formed (the tendencies that follow need the same ones).
+template <class NF, int CHECK = 1> TRM_DEV Frac<NF> energy_closure_wave(const DevParams<NF>& p, NF U, NF sat, NF& liq, NF& T, uint32_t& viol) {
     const NF Lth = p.L * sat * p.por;
     const NF nLth = -Lth;
     const bool thawed = U >= NF(0), frozen = U < nLth;
+    bool ok;
     if (no_lane_divides(thawed, frozen, Lth > Limits<NF>::eps())) {
         liq = thawed ? NF(1) : NF(-0.0);
+        ok = CHECK == 2 ? sat == sat : (NF(0) <= sat && sat <= NF(1));
     } else {
+        TRM_PHASE("rare+ phase-change divide");
         liq = thawed ? NF(1) : boolmul(U >= nLth, NF(1) - safediv(U, nLth));
+        ok = (NF(0) <= sat && sat <= NF(1)) && (NF(0) <= liq && liq <= NF(1));
+        TRM_PHASE("rare-");
     }
-    const NF C = heat_capacity(p, fractions(p, sat, liq, viol));
+    if (CHECK != 0) viol |= ok ? 0u : 2u;
+    const Frac<NF> f = fractions_unchecked(p, sat, liq);
+    const NF C = heat_capacity(p, f);
     const NF num = frozen ? (U + Lth) : U;
     const NF quo = div_nr(num, C);
     T = (frozen || thawed) ? quo : NF(0);
+    return f;
 }
 
 // compute_auxiliary! + compute_tendencies! of the column in registers, WITHOUT the compute_z_bcs! terms.
+// `pre`: the volumetric fractions of (c.sat, c.liq) when the closure that produced the cell has just formed them (same operands,
+// same operations: same bits), else null.
 template <class NF, bool RICHARDS, int HYD, int LPC>
 TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p, const LevelGeom<NF>& L, const LaneInfo& ln,
-                                       const Cell<NF>& c, NF bTb, NF bTt, bool need_kc, uint32_t& viol) {
+                                       const Cell<NF>& c, NF bTb, NF bTt, bool need_kc, uint32_t& viol, const Frac<NF>* pre = nullptr) {
     const bool is_bot = ln.is_bot, is_top = ln.is_top;
-    uint32_t viol_old = 0;   // (composition bounds of an incoming state were flagged by the launch / program step that produced it)
-    const Frac<NF> f = fractions(p, c.sat, c.liq, viol_old);
+    // (composition bounds of an incoming state were flagged by the launch / program step that produced it)
+    const Frac<NF> f = pre ? *pre : fractions_unchecked(p, c.sat, c.liq);
     const NF kap = conductivity(p, f);
     const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD, false>(p, c.liq, f) : NF(0);
     // neighbours by DPP shifts (executed by all lanes, never inside a divergent select)
@@ -84,8 +103,10 @@ TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p
     // temperature halos: every condition that is not set costs one wave-uniform branch, every condition that is set is
     // computed by all lanes and kept by the edge lane
     NF T_ext_b = c.T, T_ext_t = c.T;
-    if (v.bc.kind[2][0] == 1) T_ext_b = c.T + div_const(c.T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
-    if (v.bc.kind[2][1] == 1) T_ext_t = c.T + div_const(bTt - c.T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
+    // (div_const_nsz: a zero gradient's sign reaches T_ext only when T itself is a zero, then the face flux q_T as a signed zero,
+    // and `0 + (-(dq * rdz))` below gives +0 whatever its sign -- or a non-zero neighbour flux absorbs it)
+    if (v.bc.kind[2][0] == 1) T_ext_b = c.T + div_const_nsz(c.T - bTb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
+    if (v.bc.kind[2][1] == 1) T_ext_t = c.T + div_const_nsz(bTt - c.T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
     const NF T_m = is_bot ? T_ext_b : T_sh;
     const NF T_h = T_ext_t;
     // liquid fraction / saturation / pressure head carry the default condition (halo = edge cell): the halo cell's
@@ -112,7 +133,10 @@ TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p
     if (RICHARDS) {  // Darcy fluxes (soil_hydrology_rre.jl:95-131)
         const NF Kf_lo = t.Kf_lo;
         const NF Kf_up = shfl_up1<NF, LPC>(Kf_lo), Kf_dn = shfl_dn1<NF, LPC>(Kf_lo), psi_sh = shfl_up1<NF, LPC>(c.psi);
-        const NF Kf_m = is_bot ? NF(0) : Kf_up;   // halo face below: never written (0)
+        // The halo face below the bottom cell (never written: 0) would be selected by a NEGATIVE head gradient only; with the
+        // default condition the bottom lane's gradient is (psi - psi) * rdz = +0 or NaN, never negative: its value is never
+        // taken, and the select that put the 0 there is gone (the lane receives its neighbour column's top face instead).
+        const NF Kf_m = Kf_up;
         const NF Kf_p = is_top ? Kc : Kf_dn;      // face Nz repeats the top cell's value
         const NF psi_m = is_bot ? c.psi : psi_sh;
         const NF g_lo = (c.psi - psi_m) * L.rdzf_lo;
@@ -125,7 +149,7 @@ TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p
         const NF qW_t = -jl_min(Kc, NF(0)) * zero_or_nan;
         const NF qW_hi = is_top ? qW_t : qW_sh;
         const NF dtheta = -((qW_hi - qW_lo) * L.rdzc) + NF(0) + p.vwc_forcing;
-        t.gS = NF(0) + div_const(dtheta, p.por, p.rpor);
+        t.gS = NF(0) + div_const_nsz(dtheta, p.por, p.rpor);       // (`0 + q`: +0 for a zero quotient of either sign)
     }
     return t;
 }
@@ -136,14 +160,14 @@ TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p
 template <class NF, bool RICHARDS, int LPC>
 TRM_DEV NF column_advance(const View<NF>& v, const LevelGeom<NF>& L, const LaneInfo& ln, int Nz, const ColumnBC<NF>& bc,
                           NF U0, NF sat0, NF& gU, NF& gS, NF dt, Cell<NF>& n, NF& z0, bool& bad) {
-    gU += bc.flux_U;
+    if (bc.has_U) gU += bc.flux_U;
     n.U = U0 + gU * dt;
     if (!RICHARDS) bad = bad || (ln.act && is_nan(n.U));
     n.sat = sat0;
     z0 = NF(0);
     NF over = NF(0);
     if (RICHARDS) {
-        gS += bc.flux_S;
+        if (bc.has_S) gS += bc.flux_S;
         NF snew = sat0 + gS * dt;
         bad = bad || (ln.act && __builtin_isunordered(n.U, snew));   // either one NaN: one compare
         over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.m_act, ln.is_bot, ln.is_top, L);
@@ -153,10 +177,12 @@ TRM_DEV NF column_advance(const View<NF>& v, const LevelGeom<NF>& L, const LaneI
     return over;
 }
 
+// (n.sat comes out of column_advance: under Richards it has been through the repair)
 template <class NF, bool RICHARDS, int HYD>
-TRM_DEV void column_closure(const DevParams<NF>& p, const LevelGeom<NF>& L, NF z0, Cell<NF>& n, uint32_t& viol) {
-    energy_closure_wave(p, n.U, n.sat, n.liq, n.T, viol);
-    n.psi = RICHARDS ? pressure_head<NF, HYD>(p, n.sat, L.zC, L.psiz, z0) : NF(0);
+TRM_DEV Frac<NF> column_closure(const DevParams<NF>& p, const LevelGeom<NF>& L, NF z0, Cell<NF>& n, uint32_t& viol) {
+    const Frac<NF> f = energy_closure_wave<NF, RICHARDS ? 2 : 1>(p, n.U, n.sat, n.liq, n.T, viol);
+    n.psi = RICHARDS ? pressure_head<NF, HYD, true>(p, n.sat, L.zC, L.psiz, z0) : NF(0);
+    return f;
 }
 
 // LandModel inside the program (PROG_MULTI): the 0-D surface processes of the column, evaluated by its top lane from
@@ -223,37 +249,45 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     static_assert(!SEB_INLINE || PROG == PROG_MULTI, "the in-kernel surface energy balance belongs to the multi-step program");
     static_assert(!SERIES || PROG == PROG_MULTI, "in-kernel time series belong to the multi-step program");
     constexpr int CPW = 64 / LPC;
+    TRM_PHASE("addressing");
     LaneInfo ln;
     ln.lane = threadIdx.x & 63;
-    const int wave = (int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    // (the wave index and everything that follows from it alone lives on the scalar unit)
+    const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6));
     ln.k = ln.lane % LPC;
     const int sub = ln.lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
-    ln.is_bot = ln.k == 0;
-    ln.is_top = ln.k == Nz - 1;
+    // which lanes hold the bottom / top cell, a real cell, the wave's second column: wave-uniform masks, no lane-wise compare
+    const bool upper = CPW == 2 && lane_in(0xffffffff00000000ull);
+    ln.is_bot = lane_in(level_lanes<LPC>(0));
+    ln.is_top = lane_in(level_lanes<LPC>(Nz - 1));
     const LevelGeom<NF> L = level_geom(v, ln.k);
     const NF dt = a.dt;
     const int finalize = a.finalize, write_kf = a.write_kf;
     const bool need_kc = RICHARDS || write_kf;
 
-    const int i = wave * CPW + sub;
-    const bool colok = i < Nh;
-    ln.act = colok && ln.k < Nz;
-    ln.m_act = wave_ballot(colok) & wave_ballot(ln.k < Nz);
-    const int ii = colok ? i : Nh - 1;
+    const int col_first = wave * CPW;                              // (uniform) first column of the wave
+    const int i = col_first + sub;
+    const unsigned long long m_col = CPW == 1 ? (col_first < Nh ? ~0ull : 0ull)
+                                              : ((col_first < Nh ? 0x00000000ffffffffull : 0ull) | (col_first + 1 < Nh ? 0xffffffff00000000ull : 0ull));
+    ln.m_act = m_col & levels_below<LPC>(Nz);
+    ln.act = lane_in(ln.m_act);
+    const int ii = i < Nh ? i : Nh - 1;
     const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);
     uint32_t viol = 0;
     bool bad = false;
 
     // ---- the column comes in: 5 (3 with DERIVE) coalesced reads -------------------------------------------------------
+    TRM_PHASE("loads+derive");
     Cell<NF> c;
     c.U = ldg(v.U, cb0);
     c.sat = ldg(v.sat, cb0);
     c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
+    Frac<NF> f_in{};          // the incoming cell's volumetric fractions, when the derivation has formed them
     if (DERIVE == DERIVE_T_LIQ) {
         uint32_t viol_in = 0;
-        energy_closure_wave(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat, c.liq, c.T, viol_in);   // (its scalars die right here)
+        f_in = energy_closure_wave<NF, 0>(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat, c.liq, c.T, viol_in);   // (its scalars die right here)
     } else if (DERIVE == DERIVE_LIQ) {
         // the liquid fraction alone: one compare and, for waves with a cell in phase change, the ballot-guarded divide;
         // temperature -- the expensive half of the closure (composition, heat capacity, a full divide) -- is read
@@ -264,6 +298,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         c.liq = ldg(v.liq, cb0);
     }
     // ---- boundary inputs of the column --------------------------------------------------------------------------------
+    TRM_PHASE_FENCE("inputs", c.U, c.sat, c.psi, c.T, c.liq);
     const bool seb = p.seb != 0;
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
     ColumnBC<NF> bc;
@@ -271,32 +306,36 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     // scalar memory path (sld): one s_load per column of the wave, selected per half-wave -- where the state is cache-resident
     // (SCALAR_IN, chosen per launch; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
     // 8 x N145 200.8 -> 208.0: from HBM the scalar cache's 64-byte lines for 16 useful bytes cost more than the vector path).
-    const int col_w0 = __builtin_amdgcn_readfirstlane(wave * CPW);
-    const int jc0 = col_w0 < Nh ? col_w0 : Nh - 1, jc1 = col_w0 + 1 < Nh ? col_w0 + 1 : Nh - 1;
+    const int jc0 = col_first < Nh ? col_first : Nh - 1, jc1 = col_first + 1 < Nh ? col_first + 1 : Nh - 1;
     auto col_ld = [&](const NF* ptr) -> NF {
         if (!SCALAR_IN) return ldg(ptr, ib0);
         const NF x0 = sld(ptr, jc0);
         if (CPW == 1) return x0;
         const NF x1 = sld(ptr, jc1);
-        return sub ? x1 : x0;
+        return upper ? x1 : x0;
     };
     bc.bTb = vTb ? col_ld(bcval(v, 2, 0)) : NF(0);
     bc.bTt = vTt ? col_ld(bcval(v, 2, 1)) : NF(0);
-    {   // flux conditions: edge terms, 0 unless a condition is set; kept by the edge lanes
-        NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
-        if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(col_ld(bcval(v, 0, 0)), v.g);
-        if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(col_ld(bcval(v, 1, 0)), v.g);
-        if (!SEB_INLINE) {
-            // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before
-            // this launch.  Top terms enter with a minus sign.
-            if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(col_ld(seb ? v.ghf : bcval(v, 0, 1)), v.g);
-            if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
-                const NF fS = col_ld(seb ? v.infil : bcval(v, 1, 1));
-                eS_t = -flux_term_top(seb ? -fS : fS, v.g);
-            }
+    {   // flux conditions: a term for the edge lane of every condition that is SET (wave-uniform branches), nothing otherwise.
+        // (flux_term_*_nsz: the term is added to a tendency that is never -0.0, so the sign of a zero term is immaterial)
+        NF fU = NF(0), fS = NF(0);
+        const bool bU = v.bc.kind[0][0] == 2, bS = RICHARDS && v.bc.kind[1][0] == 2;
+        const bool tU = !SEB_INLINE && (seb || v.bc.kind[0][1] == 2), tS = RICHARDS && !SEB_INLINE && (seb || v.bc.kind[1][1] == 2);
+        if (bU) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 0, 0)), v.g); fU = ln.is_bot ? e : fU; }
+        if (bS) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 1, 0)), v.g); fS = ln.is_bot ? e : fS; }
+        // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this launch.
+        // Top terms enter with a minus sign.
+        if (tU) { const NF e = -flux_term_top_nsz(col_ld(seb ? v.ghf : bcval(v, 0, 1)), v.g); fU = ln.is_top ? e : fU; }
+        if (tS) {
+            const NF x = col_ld(seb ? v.infil : bcval(v, 1, 1));
+            const NF e = -flux_term_top_nsz(seb ? -x : x, v.g);
+            fS = ln.is_top ? e : fS;
         }
-        bc.flux_U = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
-        bc.flux_S = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
+        bc.flux_U = fU;
+        bc.flux_S = fS;
+        // (the multi-step program may receive its terms later: from a series, from the inline surface energy balance)
+        bc.has_U = PROG == PROG_MULTI || bU || tU;
+        bc.has_S = PROG == PROG_MULTI || bS || tS;
     }
     // surface_excess_water (and LandModel's surface state) is owned by the column's top lane.  The one-step programs
     // touch it in one short top-lane block at the end; the multi-step program carries it in a register.
@@ -324,14 +363,15 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     NF gU_out = NF(0), gS_out = NF(0), GS_out = NF(0), z0 = NF(0);
 
     NF over = NF(0), over_stage = NF(0);   // (top lane) overflow of the column into surface_excess_water
+    Frac<NF> f_new{};                      // volumetric fractions of the new state (its closure forms them)
     if (PROG == PROG_HEUN) {
         // stage 1: tendencies at the state, Euler predictor (with the state's boundary fluxes) and its closures
-        t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
+        t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol, DERIVE == DERIVE_T_LIQ ? &f_in : nullptr);
         const NF G1U = t.gU, G1S = t.gS;
         NF gU = G1U, gS = G1S, z0s;
         Cell<NF> s;
         over_stage = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, s, z0s, bad);
-        column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0s, s, viol);
+        const Frac<NF> f_stage = column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0s, s, viol);
         if (a.stage_T && ln.act) {   // (wave-uniform: the stage leaves the registers only for the coupled vegetation)
             const unsigned cb = block_local(cb0);
             stg(a.stage_sat, cb, s.sat);
@@ -341,13 +381,13 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
         const NF bTb2 = vTb ? col_ld(a.bcT_bot_stage) : NF(0), bTt2 = vTt ? col_ld(a.bcT_top_stage) : NF(0);
         uint32_t viol_stage = 0;
-        const Tendency<NF> t2 = column_tendencies<NF, RICHARDS, HYD, LPC>(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), L, ln, s, bTb2, bTt2, RICHARDS, viol_stage);
+        const Tendency<NF> t2 = column_tendencies<NF, RICHARDS, HYD, LPC>(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), L, ln, s, bTb2, bTt2, RICHARDS, viol_stage, &f_stage);
         viol |= viol_stage;
         // average_tendencies! (heun.jl:27-35), then the step of the STATE with its own boundary fluxes
         gU = (G1U + t2.gU) / NF(2);
         gS = RICHARDS ? (G1S + t2.gS) / NF(2) : NF(0);
         over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
-        column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
+        f_new = column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
         gU_out = gU; gS_out = gS;
     } else {
         const int nsteps = PROG == PROG_MULTI ? a.nsteps : 1;
@@ -394,7 +434,8 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             if (SEB_INLINE) {
                 // compute_auxiliary! of the surface processes from the top cell in registers (k_surface<FROM_STATE>)
                 uint32_t viol_s = 0;
-                const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, c.liq, fractions(p, c.sat, c.liq, viol_s));
+                (void)viol_s;
+                const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, c.liq, step > 0 ? f_new : fractions_unchecked(p, c.sat, c.liq));
                 const NF Ts_in = sf.out.Ts;
                 surface_processes(p, sf.in, Ts_in, c.T, c.sat, c.liq, Kf_top, S, RICHARDS, v.g.dzc_top, sf.out);
                 if (ln.is_top) {
@@ -411,8 +452,12 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
                 }
                 sf.out.Ts = sf.out.Ts + NF(0) * dt;   // zero-tendency prognostic skin_temperature
             }
-            t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol);
+            TRM_PHASE_FENCE("tendencies", c.U, c.sat, c.psi, c.T, c.liq, bc.bTb, bc.bTt, bc.flux_U, bc.flux_S, S_in, Ts_in);
+            // (the cell's fractions: from the derivation at entry, from the previous step's closure inside the multi-step loop)
+            const Frac<NF>* pre = (PROG == PROG_MULTI && step > 0) ? &f_new : (DERIVE == DERIVE_T_LIQ ? &f_in : nullptr);
+            t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol, pre);
             NF gU = t.gU, gS = t.gS;
+            TRM_PHASE_FENCE("advance", gU, gS, t.Kf_lo, t.Kc);
             over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
             if (PROG == PROG_MULTI && RICHARDS) {   // surface_excess_water carried in the top lane's register
                 GS_out = NF(0) + jl_min(NF(0), S);
@@ -420,16 +465,18 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             }
             // (second half of the step: parameters fetched afresh instead of being kept in SGPRs across the first half --
             // the kernel is short of scalar registers, and what does not fit is parked in VGPR lanes at a VALU move each)
-            column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
+            TRM_PHASE_FENCE("closure", n.U, n.sat, z0, over, gU, gS);
+            f_new = column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0, n, viol);
             gU_out = gU; gS_out = gS;
         }
     }
+    TRM_PHASE_FENCE("outputs", n.U, n.sat, n.T, n.liq, n.psi);
 
     // ---- hydraulic_conductivity of the state: K(state the last tendencies saw), K(new state) when finalizing -----------
     NF Kf_out = t.Kf_lo, Kf_out_top = t.Kc;
     if (finalize && write_kf) {
         const DevParams<NF>& p = kernarg_reload<DevParams<NF>>(off_p);
-        const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(p, n.liq, fractions(p, n.sat, n.liq, viol));
+        const NF Kc_new = conductivity_hydraulic<NF, HYD, false>(p, n.liq, f_new);     // (the closure has checked this composition)
         const NF Kc_new_m = shfl_up1<NF, LPC>(Kc_new);
         const NF Kmin_new = jl_min(Kc_new, Kc_new_m);
         Kf_out = (ln.is_bot || ln.is_top) ? Kc_new : Kmin_new;
@@ -449,10 +496,11 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             }
             S = (S + GS_out * dt) + over;
         }
-        Ts_new = Ts_in + NF(0) * dt;   // zero-tendency prognostic skin_temperature
+        if (seb) Ts_new = Ts_in + NF(0) * dt;   // zero-tendency prognostic skin_temperature
         asm volatile("" : "+v"(S), "+v"(GS_out), "+v"(Ts_new), "+v"(S_stage_out));
     }
     // ---- the column goes out: 6 coalesced stores ---------------------------------------------------------------------------
+    TRM_PHASE_FENCE("stores", Kf_out, Kf_out_top, S, GS_out, Ts_new);
     if (ln.act) {
         const View<NF>& v = kernarg_reload<View<NF>>(0);
         const unsigned cb = block_local(cb0), ib = block_local(ib0);
@@ -487,6 +535,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
                 st[SMALL_TS * cpb + cib] = SEB_INLINE ? sf.out.Ts : Ts_new;
             }
         } else if (ln.is_top) {
+            const unsigned ib = block_local(ib0);     // (in THIS block: see block_local -- else every store below pays a 64-bit address add)
             if (write_kf) stg(v.Kf_top, ib, Kf_out_top);
             if (RICHARDS) {
 #ifndef TRM_DIAG_NO_2D_STORES
@@ -519,6 +568,9 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
 template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
+#ifdef TRM_COLUMN_NUM_SGPR
+    __attribute__((amdgpu_num_sgpr(TRM_COLUMN_NUM_SGPR)))
+#endif
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
     column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES, STAGED, SCALAR_IN>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
 }

@@ -10,6 +10,27 @@
 
 #define TRM_DEV __device__ __forceinline__
 #define TRM_HD __host__ __device__ __forceinline__
+// Phase markers for the per-phase instruction budget (profiles/tools/isa_phases.py).  With -DTRM_PHASE_MARKERS every marker
+// leaves a comment line in the device assembly AND makes the values that are live at the boundary opaque to the optimiser
+// (an empty volatile asm with "+v" operands), so that no arithmetic crosses it: the instructions between two comment lines are
+// the phase's.  The marker build is a measuring instrument -- its schedule differs from the shipped kernel's, its instruction
+// counts per phase are the shipped kernel's up to what the optimiser shares ACROSS phases (reported next to the shipped
+// total).  Without the flag the markers vanish.
+#ifdef TRM_PHASE_MARKERS
+#define TRM_PHASE(name) asm volatile("; TRM_PHASE " name)
+namespace trm {
+template <class T> __device__ __forceinline__ void phase_opaque(T& x) { asm volatile("" : "+v"(x)); }
+template <class... T> __device__ __forceinline__ void phase_fence_values(T&... x) { (phase_opaque(x), ...); }
+}
+#define TRM_PHASE_FENCE(name, ...)                 \
+    do {                                           \
+        ::trm::phase_fence_values(__VA_ARGS__);    \
+        asm volatile("; TRM_PHASE " name);         \
+    } while (0)
+#else
+#define TRM_PHASE(name) ((void)0)
+#define TRM_PHASE_FENCE(name, ...) ((void)0)
+#endif
 
 namespace trm {
 
@@ -84,6 +105,15 @@ template <class NF> TRM_HD NF div_const(NF a, NF b, NF rb) {
     NF r = fma_(-q, b, a);
     NF q2 = fma_(r, rb, q);
     return (q == NF(0)) ? q : q2;  // keeps the sign of a zero quotient
+}
+// div_const without the select that keeps the sign of a ZERO quotient: identical to div_const for every a except a == -0.0,
+// where it gives +0.0 (q = -0, r = fma(+0, b, -0) = +0, q2 = fma(+0, rb, -0) = +0).  Used where that sign provably cannot
+// reach a result: the quotient is added to a value that is never -0.0 (x + (+-0) = x), or the numerator cannot be -0.0.  Each
+// call site says which.  (An underflowing quotient, a != 0, reproduces itself: q2 = RN(a * rb) = q.)  Saves 3 of 6 instructions.
+template <class NF> TRM_HD NF div_const_nsz(NF a, NF b, NF rb) {
+    const NF q = a * rb;
+    const NF r = fma_(-q, b, a);
+    return fma_(r, rb, q);
 }
 // n / d for VARIABLE operands in fp64 without the scaling steps of the full IEEE sequence.  The compiler expands `/` to
 // v_div_scale x2, v_rcp, two Newton steps on the reciprocal, q = n * y, the residual fma, v_div_fmas, v_div_fixup.
@@ -272,6 +302,14 @@ template <class NF> TRM_HD NF pow_int_m5(NF x) {
     const NF l4 = fma_(x2, x2, -x4) + err;
     // n = 1: combine
     err = fma_(rx, l4, x4 * ynlo);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Base's `isfinite(x) && isfinite(err) ? muladd(x, y, err) : x * y`: an overflowing power (r below ~1e-62) is the rare case,
+    // decided per wave from two ballots -- two compares and the fma instead of two compares, the fma, a product and a select
+    const NF full = fma_(x4, rx, err);
+    const unsigned long long all_finite = wave_ballot(is_finite(x4)) & wave_ballot(is_finite(err));
+    if (all_finite == wave_ballot(true)) return full;
+    rare_path();
+#endif
     return (is_finite(x4) && is_finite(err)) ? fma_(x4, rx, err) : x4 * rx;
 }
 
@@ -346,6 +384,16 @@ template <class NF> TRM_DEV Frac<NF> fractions(const DevParams<NF>& p, NF sat, N
     viol |= ok ? 0u : 2u;
     Frac<NF> f;
     NF wi = sat * p.por;
+    f.water = wi * liq;
+    f.ice = wi * (NF(1) - liq);
+    f.air = (NF(1) - sat) * p.por;
+    return f;
+}
+// the same without the bounds check (the caller flags the composition itself: column programs, where most of the check is
+// known to hold by construction)
+template <class NF> TRM_DEV Frac<NF> fractions_unchecked(const DevParams<NF>& p, NF sat, NF liq) {
+    Frac<NF> f;
+    const NF wi = sat * p.por;
     f.water = wi * liq;
     f.ice = wi * (NF(1) - liq);
     f.air = (NF(1) - sat) * p.por;
@@ -453,14 +501,16 @@ template <class NF> TRM_DEV void energy_invclosure(const DevParams<NF>& p, NF T,
 }
 
 // FreezeCurves.jl 0.9 SWRCs (restated): psi_m(theta; theta_sat = por)
-template <class NF, bool M5 = false> TRM_DEV NF swrc_psi_bc(const DevParams<NF>& p, NF theta) {
-    NF r = div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
+// NSZ: the caller guarantees theta is not -0.0 (a saturation that has been through the repair is +0.0 at least: `s + 0`, the
+// bottom clamp max(s, +0)), so the numerator theta - theta_res cannot be -0.0 and the quotient's zero needs no sign fix
+template <class NF, bool M5 = false, bool NSZ = false> TRM_DEV NF swrc_psi_bc(const DevParams<NF>& p, NF theta) {
+    NF r = NSZ ? div_const_nsz(theta - p.theta_res, p.theta_span, p.rtheta_span) : div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
     NF v = -p.bc_psi_s * (M5 ? pow_int_m5(r) : jl_pow(r, p.bc_neg_inv_lambda));
     return (theta < p.por) ? v : -p.bc_psi_s;
 }
-template <class NF, bool N2 = false> TRM_DEV NF swrc_psi_vg(const DevParams<NF>& p, NF theta) {
+template <class NF, bool N2 = false, bool NSZ = false> TRM_DEV NF swrc_psi_vg(const DevParams<NF>& p, NF theta) {
     if (theta < p.por) {
-        NF r = div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
+        NF r = NSZ ? div_const_nsz(theta - p.theta_res, p.theta_span, p.rtheta_span) : div_const(theta - p.theta_res, p.theta_span, p.rtheta_span);
         if (N2) {   // r^(-2) = (1 / r)^2 (pow_int, n = -2), then the square root
             const NF rr = div_nr(NF(1), r);
             return p.neg_inv_alpha * sqrt_(rr * rr - NF(1));
@@ -469,10 +519,10 @@ template <class NF, bool N2 = false> TRM_DEV NF swrc_psi_vg(const DevParams<NF>&
     }
     return NF(0);
 }
-template <class NF, int HYD> TRM_DEV NF swrc_psi(const DevParams<NF>& p, NF theta) {
-    if (HYD == HYD_BC_LINEAR) return swrc_psi_bc<NF, true>(p, theta);
-    if (HYD == HYD_VG_N2) return swrc_psi_vg<NF, true>(p, theta);
-    return p.swrc == 1 ? swrc_psi_vg(p, theta) : swrc_psi_bc(p, theta);
+template <class NF, int HYD, bool NSZ = false> TRM_DEV NF swrc_psi(const DevParams<NF>& p, NF theta) {
+    if (HYD == HYD_BC_LINEAR) return swrc_psi_bc<NF, true, NSZ>(p, theta);
+    if (HYD == HYD_VG_N2) return swrc_psi_vg<NF, true, NSZ>(p, theta);
+    return p.swrc == 1 ? swrc_psi_vg<NF, false, NSZ>(p, theta) : swrc_psi_bc<NF, false, NSZ>(p, theta);
 }
 template <class NF> TRM_DEV NF swrc_theta(const DevParams<NF>& p, NF psi, NF theta_sat) {
     if (p.swrc == 1) {
@@ -485,8 +535,8 @@ template <class NF> TRM_DEV NF swrc_theta(const DevParams<NF>& p, NF psi, NF the
 }
 // saturation_to_pressure! (soil_hydraulic_closures.jl:102-129): psi = (psi_h + psi_m) + psi_z,
 // psi_z = z - z_ref is a per-level constant formed on the host.
-template <class NF, int HYD> TRM_DEV NF pressure_head(const DevParams<NF>& p, NF sat, NF z, NF psiz, NF z0) {
-    NF psim = swrc_psi<NF, HYD>(p, sat * p.por);
+template <class NF, int HYD, bool SAT_REPAIRED = false> TRM_DEV NF pressure_head(const DevParams<NF>& p, NF sat, NF z, NF psiz, NF z0) {
+    NF psim = swrc_psi<NF, HYD, SAT_REPAIRED>(p, sat * p.por);
     NF psih = jl_max(NF(0), z0 - z);
     return psih + psim + psiz;
 }
@@ -639,5 +689,8 @@ template <class NF> TRM_DEV NF halo_bottom(int kind, const NF* val, long i, NF c
 // compute_z_bcs!: flux * Az / V of a boundary cell
 template <class NF> TRM_DEV NF flux_term_top(NF flux, const BcGeom<NF>& g) { return div_const(flux * g.Az, g.V_top, g.rV_top); }
 template <class NF> TRM_DEV NF flux_term_bottom(NF flux, const BcGeom<NF>& g) { return div_const(flux * g.Az, g.V_bot, g.rV_bot); }
+// (for terms that are ADDED to a tendency that is never -0.0: see div_const_nsz)
+template <class NF> TRM_DEV NF flux_term_top_nsz(NF flux, const BcGeom<NF>& g) { return div_const_nsz(flux * g.Az, g.V_top, g.rV_top); }
+template <class NF> TRM_DEV NF flux_term_bottom_nsz(NF flux, const BcGeom<NF>& g) { return div_const_nsz(flux * g.Az, g.V_bot, g.rV_bot); }
 
 }  // namespace trm

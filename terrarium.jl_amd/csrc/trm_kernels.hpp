@@ -358,6 +358,32 @@ template <int LPC> TRM_DEV unsigned long long group_mask(int lane) {
     return (lane & 32) ? 0xffffffff00000000ull : 0x00000000ffffffffull;
 }
 
+// A wave-uniform 64-bit lane mask as a per-lane predicate WITHOUT a vector compare: selects and exec masks take the scalar
+// register pair as it is.  "Which lanes hold the bottom / top cell, a real cell, the second column of the wave" are functions of
+// launch constants -- formed on the scalar unit (the lane-wise compares they replace were 1 vector instruction each).
+TRM_DEV bool lane_in(unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); }
+// the lanes of level k of every column of the wave (LPC lanes per column)
+template <int LPC> TRM_DEV unsigned long long level_lanes(int k) {
+    const unsigned long long one = 1ull << k;
+    return LPC == 64 ? one : (one | (one << 32));
+}
+// the lanes of levels 0 .. n - 1 of every column of the wave
+template <int LPC> TRM_DEV unsigned long long levels_below(int n) {
+    if (LPC == 64) return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const unsigned long long m = n >= 32 ? 0xffffffffull : ((1ull << n) - 1ull);
+    return m | (m << 32);
+}
+// value of lane `src` (a lane index, per lane) -- ds_bpermute without HIP's own lane arithmetic (__shfl recomputes the lane id
+// with two v_mbcnt)
+TRM_DEV double lane_read(double x, int src_lane) {
+    union { double d; int w[2]; } u;
+    u.d = x;
+    u.w[0] = __builtin_amdgcn_ds_bpermute(src_lane << 2, u.w[0]);
+    u.w[1] = __builtin_amdgcn_ds_bpermute(src_lane << 2, u.w[1]);
+    return u.d;
+}
+TRM_DEV float lane_read(float x, int src_lane) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, x))); }
+
 // per-lane grid constants of level k (fixed for the whole kernel: lane <-> level)
 // Global accesses with a 32-bit BYTE offset: `scalar base + zero-extended vector offset` is the one form the
 // backend maps onto global_load/store's saddr addressing, so a cell's ~30 accesses share a single offset
@@ -429,6 +455,7 @@ TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, unsigne
     // (idempotent, and absorbed by a later non-zero addend), so apply it once up front
     snew = is_bot ? snew : snew + NF(0);
     if (any_bad != 0ull) {
+        TRM_PHASE("rare+ repair");
         // thickness of the cells above / below, from the neighbouring lanes' level records (wave-uniform branch: every lane
         // executes the shifts; the edge lanes, which would receive the next column's value, keep their own as
         // neighbour_dz() does -- no loads in this rare path, so nothing of it is ever pending in the common one)
@@ -479,6 +506,7 @@ TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, unsigne
             if (is_bot) snew = snew - pend;
         }
     }
+    TRM_PHASE("rare-");
     // surface overflow joins surface_excess_water (top lane); bottom clamp (bottom lane)
     const NF e_top = is_top ? jl_max(snew - NF(1), NF(0)) : NF(0);
     snew = snew - e_top;
@@ -487,11 +515,22 @@ TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, unsigne
 }
 // compute_water_table! (soil_hydrology.jl:170-175, kernel_utils.jl:7-16): lower face of the first
 // unsaturated cell from the bottom, the surface if there is none.
+// The search runs on the SCALAR unit: one ballot, the first set bit of each column's half of it (s_ff1), the source lane of
+// the lookup selected per half-wave -- the lane-wise form (the ballot masked per lane, 64-bit ffs in vector registers) was ~20
+// vector instructions.
 template <class NF, int LPC> TRM_DEV NF water_table(NF sat, unsigned long long m_act, int lane, const LevelGeom<NF>& L) {
-    const unsigned long long unsat = wave_ballot(sat < NF(1)) & m_act & group_mask<LPC>(lane);
-    const int first = unsat ? (__ffsll((long long)unsat) - 1) % LPC : -1;
-    const NF z_first = shfl_from<NF, LPC>(L.zFlo, first >= 0 ? first : 0);
-    return first >= 0 ? z_first : L.zF_top;
+    const unsigned long long unsat = wave_ballot(sat < NF(1)) & m_act;
+    if (LPC == 64) {
+        const int src = unsat ? __builtin_ctzll(unsat) : 0;                       // (uniform)
+        const NF z_first = lane_read(L.zFlo, src);
+        return unsat ? z_first : L.zF_top;
+    }
+    const unsigned lo = (unsigned)unsat, hi = (unsigned)(unsat >> 32);
+    const int src_lo = lo ? __builtin_ctz(lo) : 0, src_hi = 32 + (hi ? __builtin_ctz(hi) : 0);    // (uniform: one per column)
+    const bool upper = lane_in(0xffffffff00000000ull);
+    const NF z_first = lane_read(L.zFlo, upper ? src_hi : src_lo);
+    const unsigned long long found = (lo ? 0x00000000ffffffffull : 0ull) | (hi ? 0xffffffff00000000ull : 0ull);
+    return lane_in(found) ? z_first : L.zF_top;
 }
 
 // hydrology closure! with lane = level (Nz <= 64): grid = ceil(Nh / (64 / LPC)) waves

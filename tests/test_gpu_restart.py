@@ -29,13 +29,23 @@ def coupled_integrator(n, stepper, dt=0.5, N=20, seed=5):
     return trm.initialize(land_with_vegetation(grid), stepper(dt=dt), initializers=inits, inputs=inputs)
 
 
+@pytest.mark.parametrize("finalized", [True, False])
 @pytest.mark.parametrize("stepper", [trm.ForwardEuler, trm.Heun])
-def test_restart_of_the_vegetation_coupled_land_model_into_a_fresh_context(stepper):
+def test_restart_of_the_vegetation_coupled_land_model_into_a_fresh_context(stepper, finalized):
+    """`finalized`: the first leg ends as run! does, with compute_auxiliary! (model_integrator.jl:85-86) -- one more evaluation of
+    the surface energy balance and of the net assimilation the next step's stomatal conductance reads, in the reference as
+    here -- so the uninterrupted run is run(12); run(8) in ONE context.  Not finalized (the driver's inner loop): 12 + 8 steps
+    across the restart equal 20 steps in one call."""
     n = 150
     whole = coupled_integrator(n, stepper)
-    trm.run(whole, steps=20)
     first = coupled_integrator(n, stepper)
-    trm.run(first, steps=12)
+    if finalized:
+        trm.run(whole, steps=12)
+        trm.run(whole, steps=8)
+        trm.run(first, steps=12)
+    else:
+        trm.run(whole, steps=20)
+        first._step(first.timestepper.dt, 12, finalize=False)
     ckpt = pickle.loads(pickle.dumps(trm.checkpoint(first)))          # (what a restart file holds: plain arrays and numbers)
     assert set(ckpt["fields"]) == {"internal_energy", "temperature", "liquid_water_fraction", "saturation_water_ice", "pressure_head",
                                    "surface_excess_water", "water_table", "skin_temperature", "carbon_vegetation", "vegetation_area_fraction",
