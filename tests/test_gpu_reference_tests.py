@@ -412,7 +412,7 @@ def test_simulation_schedules_of_both_kinds_with_a_step_that_is_not_representabl
     trm.run_simulation(sim)
     assert sim.iteration == 9 and sim.time == 0.9
     assert by_iteration == list(range(10)), by_iteration                   # once per iteration, the initial call included
-    assert [it for it, _ in by_time] == [0, 3, 6, 9] and [t for _, t in by_time] == [0.0, 0.3, 0.6, 0.9]
+    assert [it for it, _ in by_time] == [0, 3, 6, 9] and [t for _, t in by_time] == pytest.approx([0.0, 0.3, 0.6, 0.9], abs=1e-12)
     assert sim.output_writers["snap"].iterations == [0, 3, 6, 9]
 
 
