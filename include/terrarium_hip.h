@@ -386,6 +386,11 @@ int trm_update_inputs(trm_ctx* ctx);
  * are bit-identical to the all-resident series as long as the window covers [t, t + dt] of every step taken (FieldTimeSeries
  * `InMemory(chunk)` backends play this role on the reference side).  TRM_TIME_CYCLICAL series cannot be windowed. */
 int trm_series_append(trm_ctx* ctx, int is_bc, int id, int side, int nt, const double* times, const void* values);
+/* Declares a series as WINDOWED (trm_series_append does the same implicitly): only windowed series are touched by
+ * trm_series_trim_before -- a fully resident series that lives in the same context keeps its whole record -- and a windowed
+ * series refuses (TRM_EINVAL) an evaluation at a time before the levels it still holds instead of extrapolating from its trimmed
+ * head.  `levels` > the levels held reserves ring capacity for that many (0: leave the capacity as it is). */
+int trm_series_window(trm_ctx* ctx, int is_bc, int id, int side, int levels);
 int trm_series_trim_before(trm_ctx* ctx, double t);
 int trm_series_info(const trm_ctx* ctx, int is_bc, int id, int side, int64_t* levels_held, int64_t* capacity, double* t_first, double* t_last);
 

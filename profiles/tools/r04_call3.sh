@@ -14,6 +14,7 @@ for round in 1 2 3; do
     run 300 $AB c4 $B: --steps 50 >> $L 2>&1
     run 300 $AB c2 $B: >> $L 2>&1
     run 300 $AB c3vg $B: >> $L 2>&1
+    run 300 $AB c5 $B: --steps 30 --reps 5 >> $L 2>&1
   done
 done
 unset TRM_LIBRARY
@@ -28,7 +29,7 @@ for line in open("gpurun_out/r04_exp1_valu_cut.log"):
 for wl, r in rows.items():
     print(wl, {k: v for k, v in r.items()}, "new/r3", round(sum(r["new"]) / sum(r["r3"]), 3), "sg90/r3", round(sum(r["sg90"]) / sum(r["r3"]), 3))
 PY
-for wl in c3 c3x8 c4; do
+for wl in c3 c3x8 c4 c5; do
   bash profiles/tools/pmc_count.sh r3 $wl $PWD/build/variants/libtrm_r3.so || exit 1
   bash profiles/tools/pmc_count.sh new $wl || exit 1
 done

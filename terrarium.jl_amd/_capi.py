@@ -58,7 +58,7 @@ EXPORTS = (
     "trm_series_append trm_series_trim_before trm_series_info trm_reset trm_download_rows trm_set_ring_grid trm_download_ring "
     "trm_scatter_ring_device trm_upload_ring trm_gather_ring_device "
     "trm_heun_predict trm_heun_correct trm_stage_field_device_ptr trm_stage_bc_device_ptr trm_set_forcing_device "
-    "trm_comm_init_all trm_step_all trm_step_heun_all trm_synchronize_all trm_reduce_global_all trm_status_global_all").split()
+    "trm_series_window trm_comm_init_all trm_step_all trm_step_heun_all trm_synchronize_all trm_reduce_global_all trm_status_global_all").split()
 TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2, raster=3)
 
 
@@ -169,6 +169,7 @@ def lib():
     L.trm_status_global.argtypes = [vp, C.POINTER(C.c_uint32)]
     L.trm_series_append.argtypes = [vp, i32, i32, i32, i32, vp, vp]
     L.trm_series_trim_before.argtypes = [vp, dbl]
+    L.trm_series_window.argtypes = [vp, i32, i32, i32, i32]
     L.trm_series_info.argtypes = [vp, i32, i32, i32, C.POINTER(i64), C.POINTER(i64), C.POINTER(dbl), C.POINTER(dbl)]
     L.trm_reset.argtypes = [vp]
     L.trm_download_rows.argtypes = [vp, i32, i32, i32, vp]

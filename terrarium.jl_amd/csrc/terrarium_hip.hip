@@ -1650,6 +1650,31 @@ int trm_series_append(trm_ctx* c, int is_bc, int id, int side, int nt, const dou
     return TRM_OK;
 }
 
+int trm_series_window(trm_ctx* c, int is_bc, int id, int side, int levels) {
+    TRM_ENTER(c);
+    trm_ctx::Series* sr = find_series(c, is_bc, id, side);
+    if (!sr) return fail(c, TRM_EINVAL, "trm_series_window: no such series (create it with trm_set_forcing_series / trm_set_bc_series first)");
+    if (sr->indexing == TRM_TIME_CYCLICAL) return fail(c, TRM_EINVAL, "trm_series_window: a cyclical series is periodic over its whole record and cannot be windowed");
+    if (levels < 0) return fail(c, TRM_EINVAL, "trm_series_window: levels < 0");
+    sr->windowed = true;
+    const long held = (long)sr->times.size();
+    if (levels > sr->cap) {      // reserve: the levels held are laid out from slot 0 of the larger ring
+        const size_t row = (size_t)c->Nh * c->esize;
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        if (int rs = sync_copies(c)) return rs;
+        void* grown = nullptr;
+        TRM_HIP(c, hipMalloc(&grown, (size_t)levels * row));
+        for (long n = 0; n < held; ++n)
+            TRM_HIP(c, hipMemcpyAsync((char*)grown + (size_t)n * row, (char*)sr->d_values + sr->slot((int)n) * row, row, hipMemcpyDeviceToDevice, c->stream));
+        TRM_HIP(c, hipStreamSynchronize(c->stream));
+        TRM_HIP(c, hipFree(sr->d_values));
+        sr->d_values = grown;
+        sr->cap = levels;
+        sr->head = 0;
+    }
+    return TRM_OK;
+}
+
 int trm_series_trim_before(trm_ctx* c, double t) {
     if (!c) return TRM_EINVAL;
     bool released = false;

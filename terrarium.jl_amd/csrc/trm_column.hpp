@@ -306,12 +306,12 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     // scalar memory path (sld): one s_load per column of the wave, selected per half-wave -- where the state is cache-resident
     // (SCALAR_IN, chosen per launch; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
     // 8 x N145 200.8 -> 208.0: from HBM the scalar cache's 64-byte lines for 16 useful bytes cost more than the vector path).
-    const int jc0 = col_first < Nh ? col_first : Nh - 1, jc1 = col_first + 1 < Nh ? col_first + 1 : Nh - 1;
+    const unsigned jo0 = (unsigned)(col_first < Nh ? col_first : Nh - 1) * (unsigned)sizeof(NF), jo1 = (unsigned)(col_first + 1 < Nh ? col_first + 1 : Nh - 1) * (unsigned)sizeof(NF);
     auto col_ld = [&](const NF* ptr) -> NF {
         if (!SCALAR_IN) return ldg(ptr, ib0);
-        const NF x0 = sld(ptr, jc0);
+        const NF x0 = sld_off<NF>(ptr, jo0);
         if (CPW == 1) return x0;
-        const NF x1 = sld(ptr, jc1);
+        const NF x1 = sld_off<NF>(ptr, jo1);
         return upper ? x1 : x0;
     };
     bc.bTb = vTb ? col_ld(bcval(v, 2, 0)) : NF(0);

@@ -400,6 +400,14 @@ template <class NF> TRM_DEV NF sld(const NF* base, int idx_uniform) {
     typedef const NF __attribute__((address_space(4))) * cptr;
     return ((cptr)(uintptr_t)base)[idx_uniform];
 }
+// The same with a wave-uniform 32-bit BYTE offset: the backend then uses the scalar load's own register offset
+// (`s_load_dwordx2 sdst, sbase, soffset`) instead of forming a 64-bit address per load on the scalar ALU (4 instructions per
+// load: ~100 of the 260 scalar instructions per wave of the packed fp32 LandModel step).  T may be a pair (one wider load).
+template <class T> TRM_DEV T sld_off(const void* base, unsigned byte_off_uniform) {
+    typedef const char __attribute__((address_space(4))) * bptr;
+    typedef const T __attribute__((address_space(4))) * cptr;
+    return *(cptr)((bptr)(uintptr_t)base + byte_off_uniform);
+}
 template <class NF> TRM_DEV void stg(NF* base, unsigned byte_off, NF x) {
     *reinterpret_cast<NF*>(reinterpret_cast<char*>(base) + byte_off) = x;
 }

@@ -43,7 +43,22 @@ TRM_DEV v2f div_const2(v2f a, float b, float rb) {
     return sel(eq(q, splat(0.0f)), q, q2);
 }
 
+// div_const_nsz (trm_device.hpp) on both components: no select for the sign of a zero quotient -- where it cannot matter
+TRM_DEV v2f div_const2_nsz(v2f a, float b, float rb) {
+    const v2f q = a * rb;
+    const v2f r = fma2(-q, splat(b), a);
+    return fma2(r, splat(rb), q);
+}
+
 struct Frac2 { v2f water, ice, air; };
+TRM_DEV Frac2 fractions2_unchecked(const DevParams<float>& p, v2f sat, v2f liq) {
+    Frac2 f;
+    const v2f wi = sat * p.por;
+    f.water = wi * liq;
+    f.ice = wi * (splat(1.0f) - liq);
+    f.air = (splat(1.0f) - sat) * p.por;
+    return f;
+}
 TRM_DEV Frac2 fractions2(const DevParams<float>& p, v2f sat, v2f liq, uint32_t& viol) {
     // (bit 1: component x out of bounds, bit 2: component y -- folded into the status flag by the caller, for the
     // components that are real cells only: the copy a tail lane carries is not repaired and may be out of bounds)
@@ -91,8 +106,10 @@ TRM_DEV v2f liquid_fraction2(const DevParams<float>& p, v2f U, v2f sat) {
     const v2f bm = v2f{(U.x >= nLth.x) ? x.x : copysign_(0.0f, x.x), (U.y >= nLth.y) ? x.y : copysign_(0.0f, x.y)};
     return sel(thawed, splat(1.0f), bm);
 }
-// energy_closure (trm_device.hpp) on both components
-TRM_DEV void energy_closure2(const DevParams<float>& p, v2f U, v2f sat, v2f& liq, v2f& T, uint32_t& viol) {
+// energy_closure (trm_device.hpp) on both components; CHECK as energy_closure_wave (trm_column.hpp): 0 none, 1 full, 2 the
+// saturation comes out of this step's repair (in [0, 1] or NaN by construction: `sat == sat` is the whole check in the common
+// path, where the liquid fraction is 1 or -0.0).  Returns the volumetric fractions it formed.
+template <int CHECK = 1> TRM_DEV Frac2 energy_closure2(const DevParams<float>& p, v2f U, v2f sat, v2f& liq, v2f& T, uint32_t& viol) {
     const v2f Lth = sat * p.L * p.por;   // (p.L * sat) * por: multiplication by the scalar commutes bit for bit
     const v2f nLth = -Lth;
     // liq = (U >= 0) ? 1 : boolmul(U >= -Lth, 1 - safediv(U, -Lth))
@@ -101,20 +118,29 @@ TRM_DEV void energy_closure2(const DevParams<float>& p, v2f U, v2f sat, v2f& liq
     const float eps = Limits<float>::eps();
     const M2 thawed = ge(U, splat(0.0f)), frozen0 = lt(U, nLth);
     const bool needx = !thawed.x && !(frozen0.x && Lth.x > eps), needy = !thawed.y && !(frozen0.y && Lth.y > eps);
+    bool okx, oky;
     if (wave_ballot(needx || needy) == 0ull) {
         liq = sel(thawed, splat(1.0f), splat(-0.0f));
+        okx = CHECK == 2 ? sat.x == sat.x : (0.0f <= sat.x && sat.x <= 1.0f);
+        oky = CHECK == 2 ? sat.y == sat.y : (0.0f <= sat.y && sat.y <= 1.0f);
     } else {
         const v2f den = nLth + eps;
         const v2f sd = v2f{(nLth.x == 0.0f) ? Limits<float>::inf() : div_nr(U.x, den.x), (nLth.y == 0.0f) ? Limits<float>::inf() : div_nr(U.y, den.y)};
         const v2f x = splat(1.0f) - sd;
         const v2f bm = v2f{(U.x >= nLth.x) ? x.x : copysign_(0.0f, x.x), (U.y >= nLth.y) ? x.y : copysign_(0.0f, x.y)};
         liq = sel(thawed, splat(1.0f), bm);
+        okx = (0.0f <= sat.x && sat.x <= 1.0f) && (0.0f <= liq.x && liq.x <= 1.0f);
+        oky = (0.0f <= sat.y && sat.y <= 1.0f) && (0.0f <= liq.y && liq.y <= 1.0f);
     }
-    const v2f C = heat_capacity2(p, fractions2(p, sat, liq, viol));
+    // (bit 1: component x out of bounds, bit 2: component y -- see fractions2)
+    if (CHECK != 0) viol |= (okx ? 0u : 2u) | (oky ? 0u : 4u);
+    const Frac2 f = fractions2_unchecked(p, sat, liq);
+    const v2f C = heat_capacity2(p, f);
     const M2 frozen = lt(U, nLth);
     const v2f num = sel(frozen, U + Lth, U);
     const v2f quo = div2(num, C);
     T = sel(frozen || ge(U, splat(0.0f)), quo, splat(0.0f));
+    return f;
 }
 // pow_int_m5 (trm_device.hpp) on both components
 TRM_DEV v2f pow_int_m5_2(v2f x) {
@@ -128,13 +154,19 @@ TRM_DEV v2f pow_int_m5_2(v2f x) {
     const v2f x4 = x2 * x2;
     const v2f l4 = fma2(x2, x2, -x4) + err;
     err = fma2(rx, l4, x4 * ynlo);
-    const v2f a = fma2(x4, rx, err), b = x4 * rx;
+    const v2f a = fma2(x4, rx, err);
+    // (an overflowing power is the rare case, decided per wave: see pow_int_m5)
+    const unsigned long long all_finite = wave_ballot(is_finite(x4.x)) & wave_ballot(is_finite(err.x)) & wave_ballot(is_finite(x4.y)) & wave_ballot(is_finite(err.y));
+    if (all_finite == wave_ballot(true)) return a;
+    rare_path();
+    const v2f b = x4 * rx;
     return v2f{(is_finite(x4.x) && is_finite(err.x)) ? a.x : b.x, (is_finite(x4.y) && is_finite(err.y)) ? a.y : b.y};
 }
 // pressure_head<float, HYD_BC_LINEAR> on both components (z0: per-component water table)
+// (sat has been through the repair: never -0.0, see swrc_psi_bc's NSZ)
 TRM_DEV v2f pressure_head2(const DevParams<float>& p, v2f sat, float z, float psiz, v2f z0) {
     const v2f theta = sat * p.por;
-    const v2f r = div_const2(theta - p.theta_res, p.theta_span, p.rtheta_span);
+    const v2f r = div_const2_nsz(theta - p.theta_res, p.theta_span, p.rtheta_span);
     const v2f v = pow_int_m5_2(r) * (-p.bc_psi_s);
     const v2f psim = sel(lt(theta, splat(p.por)), v, splat(-p.bc_psi_s));
     const v2f psih = max2(splat(0.0f), z0 - z);
@@ -150,7 +182,7 @@ template <int HYD> TRM_DEV v2f conductivity_hydraulic2(const DevParams<float>& p
 }
 template <int HYD> TRM_DEV v2f pressure_head_hyd2(const DevParams<float>& p, v2f sat, float z, float psiz, v2f z0) {
     if (HYD == HYD_BC_LINEAR) return pressure_head2(p, sat, z, psiz, z0);
-    return v2f{pressure_head<float, HYD_VG_N2>(p, sat.x, z, psiz, z0.x), pressure_head<float, HYD_VG_N2>(p, sat.y, z, psiz, z0.y)};
+    return v2f{pressure_head<float, HYD_VG_N2, true>(p, sat.x, z, psiz, z0.x), pressure_head<float, HYD_VG_N2, true>(p, sat.y, z, psiz, z0.y)};
 }
 // upwind_conductivity on both components
 TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(lt(g, splat(0.0f)), Kdn, Kup)); }
@@ -171,15 +203,23 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     typedef float NF;
     constexpr int CPW = 64 / LPC;   // column PAIRS per wave
     const int lane = threadIdx.x & 63;
-    const int wave = (int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    // (the wave index and what follows from it alone on the scalar unit; lane predicates from wave-uniform masks: lane_in)
+    const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6));
     const int k = lane % LPC, sub = lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
-    const bool is_bot = k == 0, is_top = k == Nz - 1;
+    const bool upper = CPW == 2 && lane_in(0xffffffff00000000ull);
+    const bool is_bot = lane_in(level_lanes<LPC>(0)), is_top = lane_in(level_lanes<LPC>(Nz - 1));
     const LevelGeom<NF> L = level_geom(v, k);
     const bool need_kc = RICHARDS || write_kf;
 
-    const int i0 = (wave * CPW + sub) * 2, i1 = i0 + 1;
-    const bool act0 = i0 < Nh && k < Nz, act1 = i1 < Nh && k < Nz;
+    const int pair_w0 = wave * CPW * 2;                  // (uniform) first column of the wave
+    const int i0 = pair_w0 + sub * 2, i1 = i0 + 1;
+    // columns pair_w0 + {0, 1} live in the lower half-wave (or the whole wave), + {2, 3} in the upper one
+    const unsigned long long half_lo = CPW == 1 ? ~0ull : 0x00000000ffffffffull, half_hi = CPW == 1 ? 0ull : 0xffffffff00000000ull;
+    const unsigned long long m_lev = levels_below<LPC>(Nz);
+    const unsigned long long m_act0 = ((pair_w0 < Nh ? half_lo : 0ull) | (pair_w0 + 2 < Nh ? half_hi : 0ull)) & m_lev;
+    const unsigned long long m_act1 = ((pair_w0 + 1 < Nh ? half_lo : 0ull) | (pair_w0 + 3 < Nh ? half_hi : 0ull)) & m_lev;
+    const bool act0 = lane_in(m_act0), act1 = lane_in(m_act1);
     const int j0 = i0 < Nh ? i0 : Nh - 1, j1 = i1 < Nh ? i1 : Nh - 1;
     const unsigned kk = (unsigned)(k < Nz ? k : Nz - 1);
     const unsigned ib0 = (unsigned)j0 * 4u, ib1 = (unsigned)j1 * 4u;
@@ -189,14 +229,14 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     // half-wave) from s_loads, selected per half-wave, instead of two vector loads per input in which every lane of a column reads
     // the same address (profiles/r03/exp27: C5 450.4 -> 447.0 us, a 12 696-column shard 15.3 -> 15.0).
     staged &= 1;
-    const int pair_w0 = __builtin_amdgcn_readfirstlane(wave * CPW) * 2;
-    auto clampi = [&](int i) { return i < Nh ? i : Nh - 1; };
-    const int q0 = clampi(pair_w0), q1 = clampi(pair_w0 + 1), q2 = clampi(pair_w0 + 2), q3 = clampi(pair_w0 + 3);
+    // (byte offsets in scalar registers: the loads use them as they are, no 64-bit address per load -- sld_off)
+    auto clampo = [&](int i) { return (unsigned)(i < Nh ? i : Nh - 1) * 4u; };
+    const unsigned q0 = clampo(pair_w0), q1 = clampo(pair_w0 + 1), q2 = clampo(pair_w0 + 2), q3 = clampo(pair_w0 + 3);
     auto col_ld2 = [&](const float* ptr) -> v2f {
-        const float a0 = sld(ptr, q0), a1 = sld(ptr, q1);
+        const float a0 = sld_off<float>(ptr, q0), a1 = sld_off<float>(ptr, q1);
         if (CPW == 1) return v2f{a0, a1};
-        const float a2 = sld(ptr, q2), a3 = sld(ptr, q3);
-        return v2f{sub ? a2 : a0, sub ? a3 : a1};
+        const float a2 = sld_off<float>(ptr, q2), a3 = sld_off<float>(ptr, q3);
+        return v2f{upper ? a2 : a0, upper ? a3 : a1};
     };
 
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
@@ -204,14 +244,14 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     v2f T, liq;
     if (DERIVE == DERIVE_T_LIQ) {      // both re-derived from (U, sat): two field reads less (k_column: DERIVE_T_LIQ)
         uint32_t viol_in = 0;
-        energy_closure2(kernarg_reload<DevParams<float>>(off_p), U, sat, liq, T, viol_in);
+        (void)energy_closure2<0>(kernarg_reload<DevParams<float>>(off_p), U, sat, liq, T, viol_in);
     } else {
         T = ld2(v.T, cb0, cb1);
         liq = DERIVE == DERIVE_LIQ ? liquid_fraction2(kernarg_reload<DevParams<float>>(off_p), U, sat) : ld2(v.liq, cb0, cb1);
     }
 
-    uint32_t viol_old = 0;   // (bounds of the incoming state were flagged by the launch that produced it)
-    const Frac2 f = fractions2(p, sat, liq, viol_old);
+    // (bounds of the incoming state were flagged by the launch that produced it)
+    const Frac2 f = fractions2_unchecked(p, sat, liq);
     const v2f kap = conductivity2(p, f);
     const v2f Kc = need_kc ? conductivity_hydraulic2<HYD>(p, liq, f) : splat(0.0f);
 
@@ -222,11 +262,11 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     v2f T_ext_b = T, T_ext_t = T;
     if (vTb) {
         const v2f b = col_ld2(bcval(v, 2, 0));
-        T_ext_b = T + div_const2(T - b, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);
+        T_ext_b = T + div_const2_nsz(T - b, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);      // (nsz: see column_tendencies)
     }
     if (vTt) {
         const v2f b = col_ld2(bcval(v, 2, 1));
-        T_ext_t = T + div_const2(b - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
+        T_ext_t = T + div_const2_nsz(b - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
     }
     const v2f T_m = sel(is_bot, T_ext_b, T_sh);
     const v2f T_h = T_ext_t;
@@ -235,22 +275,15 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const v2f kap_m = sel(is_bot, kap_halo, kap_sh);
     const v2f kap_h = kap_halo;
     const bool seb = p.seb != 0;
-    {
-        const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
-        v2f eU_b = splat(0.0f), eU_t = splat(0.0f);
-        if (fUb) eU_b = div_const2(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
-        if (fUt) eU_t = -div_const2(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top);
-        flux_U = sel(is_bot, eU_b, sel(is_top, eU_t, splat(0.0f)));
-        if (RICHARDS) {
-            const bool fSb = v.bc.kind[1][0] == 2, fSt = seb || v.bc.kind[1][1] == 2;
-            v2f eS_b = splat(0.0f), eS_t = splat(0.0f);
-            if (fSb) eS_b = div_const2(col_ld2(bcval(v, 1, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
-            if (fSt) {
-                const v2f fS = col_ld2(seb ? v.infil : bcval(v, 1, 1));
-                eS_t = -div_const2((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top);
-            }
-            flux_S = sel(is_bot, eS_b, sel(is_top, eS_t, splat(0.0f)));
-        }
+    // flux conditions: a term for the edge lane of every condition that is SET, nothing otherwise (column_program, trm_column.hpp)
+    const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
+    const bool fSb = RICHARDS && v.bc.kind[1][0] == 2, fSt = RICHARDS && (seb || v.bc.kind[1][1] == 2);
+    if (fUb) flux_U = sel(is_bot, div_const2_nsz(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_U);
+    if (fUt) flux_U = sel(is_top, -div_const2_nsz(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top), flux_U);
+    if (fSb) flux_S = sel(is_bot, div_const2_nsz(col_ld2(bcval(v, 1, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_S);
+    if (fSt) {
+        const v2f fS = col_ld2(seb ? v.infil : bcval(v, 1, 1));
+        flux_S = sel(is_top, -div_const2_nsz((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top), flux_S);
     }
     // surface_excess_water and the skin temperature of the two columns: READ HERE, with the other inputs.  Vector memory retires in
     // order, loads and stores through the one counter: a load issued behind a store holds the whole wave until that store has
@@ -271,7 +304,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     }
     if (RICHARDS) {
         const v2f Kf_up = up2(Kf_lo), Kf_dn = dn2(Kf_lo), psi_sh = up2(psi);
-        const v2f Kf_m = sel(is_bot, splat(0.0f), Kf_up);
+        const v2f Kf_m = Kf_up;      // (the bottom lane's gradient is never negative: see column_tendencies)
         const v2f Kf_p = sel(is_top, Kc, Kf_dn);
         const v2f psi_m = sel(is_bot, psi, psi_sh);
         const v2f g_lo = (psi - psi_m) * L.rdzf_lo;
@@ -282,10 +315,10 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         const v2f qW_t = -min2(Kc, splat(0.0f)) * zero_or_nan;
         const v2f qW_hi = sel(is_top, qW_t, qW_sh);
         const v2f dtheta = -((qW_hi - qW_lo) * L.rdzc) + splat(0.0f) + p.vwc_forcing;
-        gS = splat(0.0f) + div_const2(dtheta, p.por, p.rpor);
+        gS = splat(0.0f) + div_const2_nsz(dtheta, p.por, p.rpor);
     }
-    gU += flux_U;
-    if (RICHARDS) gS += flux_S;
+    if (fUb || fUt) gU += flux_U;
+    if (fSb || fSt) gS += flux_S;
     // ---- explicit Euler update
     const v2f Unew = U + gU * dt;
     bool bad = (act0 && is_nan(Unew.x)) || (act1 && is_nan(Unew.y));
@@ -294,7 +327,6 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         snew = sat + gS * dt;
         bad = bad || (act0 && is_nan(snew.x)) || (act1 && is_nan(snew.y));
         float sx = snew.x, sy = snew.y;
-        const unsigned long long m_lev = wave_ballot(k < Nz), m_act0 = wave_ballot(i0 < Nh) & m_lev, m_act1 = wave_ballot(i1 < Nh) & m_lev;
         const float over0 = repair_saturation<NF, LPC>(v, sx, k, Nz, m_act0, is_bot, is_top, L);
         const float over1 = repair_saturation<NF, LPC>(v, sy, k, Nz, m_act1, is_bot, is_top, L);
         snew = v2f{sx, sy};
@@ -306,11 +338,11 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     // ---- closures
     v2f ln, Tn;
     const DevParams<float>& p2 = kernarg_reload<DevParams<float>>(off_p);   // (second half of the step: see kernarg_reload)
-    energy_closure2(p2, Unew, snew, ln, Tn, viol);
+    const Frac2 f_new = energy_closure2<RICHARDS ? 2 : 1>(p2, Unew, snew, ln, Tn, viol);
     const v2f psin = RICHARDS ? pressure_head_hyd2<HYD>(p2, snew, L.zC, L.psiz, z0) : splat(0.0f);
     v2f Kf_out = Kf_lo, Kf_out_top = Kc;
     if (finalize && write_kf) {
-        const v2f Kc_new = conductivity_hydraulic2<HYD>(p, ln, fractions2(p, snew, ln, viol));
+        const v2f Kc_new = conductivity_hydraulic2<HYD>(p, ln, f_new);      // (the closure has checked this composition)
         const v2f Kmin_new = min2(Kc_new, up2(Kc_new));
         Kf_out = sel(is_bot || is_top, Kc_new, Kmin_new);
         Kf_out_top = Kc_new;
@@ -357,7 +389,8 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         }
     };
     // every loaded value has been consumed before the first store is issued (nothing is waited for behind the stores)
-    v2f Ts_new = Ts_in + splat(0.0f) * dt;     // zero-tendency prognostic skin_temperature
+    v2f Ts_new = splat(0.0f);
+    if (seb) Ts_new = Ts_in + splat(0.0f) * dt;     // zero-tendency prognostic skin_temperature
     asm volatile("" : "+v"(Ts_new), "+v"(S_out), "+v"(GS_top));
     const int cib0 = ((int)(threadIdx.x >> 6) * CPW + sub) * 2;
     store(act0, cib0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x, S_out.x, GS_top.x, z0.x, Ts_new.x);

@@ -337,6 +337,11 @@ class DeviceState:
         t, v, _ = self._series_args(times, values, "linear")
         self._check(self._lib.trm_series_append(self._ctx, is_bc, sid, side, t.size, t.ctypes.data, v.ctypes.data), "trm_series_append")
 
+    def series_window(self, target, levels=0):
+        """Declares a series as windowed: trimmed by `series_trim_before`, strict about times before its head (trm_series_window)."""
+        is_bc, sid, side = self._series_id(target)
+        self._check(self._lib.trm_series_window(self._ctx, is_bc, sid, side, int(levels)), "trm_series_window")
+
     def series_trim_before(self, t):
         """Releases the time levels no evaluation at a time >= t can touch (trm_series_trim_before)."""
         self._check(self._lib.trm_series_trim_before(self._ctx, float(t)), "trm_series_trim_before")
@@ -785,6 +790,8 @@ def initialize_integrator(integ: ModelIntegrator):
             value.attach_boundary(st, var, side, kind)     # a named input variable as boundary value (soil_heat_global_era5.jl:31-44)
         elif isinstance(value, FieldTimeSeries):
             st.set_bc_series(var, side, kind, *head(value), value.time_indexing)
+            if value.window:
+                st.series_window((var, side), value.window)
         elif not isinstance(value, StateFunction):
             st.set_bc(var, side, kind, value(0.0) if callable(value) else value)
     for name, value in integ.inputs.items():
@@ -793,6 +800,8 @@ def initialize_integrator(integ: ModelIntegrator):
             value.attach(st)      # static raster: set once; time-indexed: device-resident series (ext/TerrariumRastersExt)
         elif isinstance(value, FieldTimeSeries):
             st.set_forcing_series(name, *head(value), value.time_indexing)
+            if value.window:
+                st.series_window(name, value.window)
         elif not isinstance(value, StateFunction):
             st.set_forcing(name, value(0.0) if callable(value) else value)
     integ._bind_state_functions()

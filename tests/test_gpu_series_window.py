@@ -49,6 +49,7 @@ def test_200_levels_through_a_16_level_window(config, dtype, mode):
     for target, rule, vals in series:
         attach(a, target, rule, vals, nt)
         attach(b, target, rule, vals, W_LEVELS)
+        b.series_window(target, W_LEVELS)          # (a resident series is never trimmed: the window is declared)
         nxt[target] = W_LEVELS
     step = (lambda d, n, fin: d.step_heun(w["dt"], n, finalize=fin)) if mode == "heun" else (lambda d, n, fin: d.step(w["dt"], n, finalize=fin))
     step(a, steps, True)
@@ -124,6 +125,17 @@ def test_append_argument_errors_and_growth():
     d.update_inputs()
     d.series_trim_before(650.0)
     assert d.series_info(("temperature", "top"))["levels"] == 2 and d.series_info(("temperature", "top"))["t_first"] == 600.0
+    # a fully resident series in the same context keeps its record, and the windowed one refuses a clock before its head
+    d.set_forcing_series("air_temperature", t, v, "linear")
+    d.series_trim_before(650.0)
+    assert d.series_info("air_temperature")["levels"] == 4
+    d.set_clock(100.0, 0)
+    with pytest.raises(trm.TerrariumHipError, match="before the levels it still holds"):
+        d.update_inputs()
+    with pytest.raises(trm.TerrariumHipError, match="before the levels it still holds"):
+        d.step(w["dt"], 1)
+    d.set_clock(650.0, 0)
+    d.step(w["dt"], 1)
     d.set_bc_series("internal_energy", "bottom", "flux", t, v, "cyclical")
     with pytest.raises(trm.TerrariumHipError):
         d.series_append(("internal_energy", "bottom"), t + 400.0, v)   # cyclical series cannot be windowed
