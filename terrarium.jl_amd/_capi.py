@@ -121,6 +121,18 @@ def lib():
             "(or __graft_entry__.build()).  There is no CPU fallback.")
     _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
+    if "TRM_LIBRARY" in os.environ:
+        # an older build of the library in an A/B experiment (profiles/tools): entry points it lacks bind to a stub that fails when
+        # CALLED; the shipped library must export every one of EXPORTS (__graft_entry__.build() checks)
+        def _missing(name):
+            def stub(*args):
+                raise TerrariumHipError(f"{LIB_PATH} (TRM_LIBRARY) does not export {name}")
+            return stub
+        for name in EXPORTS:
+            try:
+                getattr(L, name)
+            except AttributeError:
+                setattr(L, name, _missing(name))
     vp, i32, i64, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_double
     L.trm_abi_version.restype = i32
     L.trm_default_params.argtypes = [C.POINTER(TrmParams)]

@@ -489,7 +489,7 @@ template <class NF> struct Ops {
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
         if (!rc && c->params.seb) rc = surface(c, c->state, true);
         if (!rc) {
-            rc = DeepLaunch<NF>::run(c, PROG_HEUN, false, dt, finalize, 1);
+            rc = DeepLaunch<NF>::run(c, PROG_HEUN, generic_bcs(c), dt, finalize, 1);
         }
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
@@ -604,7 +604,7 @@ template <class NF> struct Ops {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
         // deeper takes the reference-order kernels
-        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || (deep_columns(c) && !coupled(c)));
+        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c));
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
         // (columns of 65 ... 128 levels: contexts without the surface energy balance and without series)
@@ -717,7 +717,7 @@ template <class NF> struct Ops {
         a.store_paw = c->opt_write_kf != 0;
         a.st_w_can = vg.w_can; a.st_C_veg = vg.C_veg; a.st_nu = vg.nu; a.st_An = vg.An; a.st_Ts = sv.Ts;
         rc = surface_veg_launch(c, v0, vs, a);
-        if (!rc) rc = column_program<PROG_HEUN>(c, dt, finalize, 1);
+        if (!rc) rc = deep_columns(c) ? DeepLaunch<NF>::run(c, PROG_HEUN, false, dt, finalize, 1) : column_program<PROG_HEUN>(c, dt, finalize, 1);
         if (rc) return rc;
         c->closure_consistent = true;
         c->tend_valid = finalize != 0;
@@ -789,9 +789,9 @@ template <class NF> struct Ops {
     static int heun_step(trm_ctx* c, double dt, int finalize) {
         if (int rr = refresh_user_stage_buffers(c)) return rr;
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
-        if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c)) && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
-        if (c->opt_kernel == TRM_KERNEL_FUSED && deep_columns(c) && !generic_bcs(c) && !coupled(c)) return heun_step_deep(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && deep_columns(c) && !coupled(c)) return heun_step_deep(c, dt, finalize);      // (every boundary kind)
         c->top_valid = false;
         c->tend_valid = true;
         c->closure_consistent = true;   // (ends with closure!)

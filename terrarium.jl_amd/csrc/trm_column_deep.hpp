@@ -6,8 +6,9 @@
 // per field, the k - 1 neighbour of a is the previous lane's b (one DPP shift), of b the lane's own a (free); likewise
 // upwards.  Ballots come in pairs (a cells, b cells).  Every operation is the one k_column<PROG_EULER> / the reference-order
 // kernels perform on the cell, in the same order: results are bit-identical (tests/test_gpu_deep_columns.py).
-// Scope: ForwardEuler (every boundary kind: GENERIC), Heun (both stages in registers, one launch) and the multi-step program with
-// the branch-free kinds, with the derivation of T / liq; the coupled vegetation and Nz > 128 keep the reference-order kernels.
+// Scope: ForwardEuler and Heun (both stages in registers, one launch) with every boundary kind (GENERIC), the multi-step program
+// with the branch-free kinds, the derivation of T / liq, and the soil half of the vegetation-coupled LandModel (Heun stores what
+// the 0-D processes need of the stage); Nz > 128 keeps the reference-order kernels.
 #pragma once
 #include "trm_column.hpp"
 
@@ -145,13 +146,18 @@ template <class NF> TRM_DEV NF level_word(const View<NF>& v, unsigned rec, int w
 // per step, the sequence of column_program<PROG_HEUN> (trm_column.hpp) cell by cell.
 // GENERIC: every boundary kind (Value / Gradient on temperature, liquid fraction, saturation, pressure head) and the per-cell
 // vwc_forcing field, with the halo formulas of column_tendencies_generic (trm_column.hpp) on the edge cells.
+// `vs_arg`: the Heun stage's view -- its boundary kinds and values (series evaluated at t + dt, arrays the caller of the two-call
+// Heun wrote) are what the stage's tendencies see with GENERIC (k_heun_generic, trm_column.hpp); unused otherwise.
 template <class NF, bool RICHARDS, int HYD, bool DERIVE = false, int PROG = PROG_EULER, bool GENERIC = false>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_per_eu(TRM_DEEP_WAVES, 8)))
-    k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
-    static_assert(!GENERIC || PROG == PROG_EULER, "generic boundary kinds on deep columns: ForwardEuler");
+    k_column_deep(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a, View<NF> vs_arg) {
+    static_assert(!GENERIC || PROG != PROG_MULTI, "generic boundary kinds on deep columns: one step per launch");
     // PROG_MULTI: a.nsteps ForwardEuler steps on the resident column (contexts without the surface energy balance and without
     // time series: constants between the steps), fields written once per launch -- column_program<PROG_MULTI>'s loop.
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+    constexpr unsigned off_a = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(ColumnArgs<NF>));
+    constexpr unsigned off_vs = round_up_to(off_a + (unsigned)sizeof(ColumnArgs<NF>), (unsigned)alignof(View<NF>));
+    (void)off_vs;
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
     DeepLane ln;
@@ -372,10 +378,23 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         NF z0s;
         over_stage = advance(gU, gS, flux_U, flux_S, Us, ss, z0s);
         closure(Us, ss, z0s, ls, Ts, ps);
-        // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
-        const NF bTb2 = vTb ? ldg(a.bcT_bot_stage, ib_late) : NF(0), bTt2 = vTt ? ldg(a.bcT_top_stage, ib_late) : NF(0);
+        if (a.stage_T) {   // (wave-uniform: the vegetation-coupled LandModel evaluates its 0-D processes AT the stage: k_column<PROG_HEUN>)
+            auto stage_cell = [&](bool act, unsigned cb_, NF s_, NF l_, NF t_) {
+                if (!act) return;
+                const unsigned cb = block_local(cb_);
+                stg(a.stage_sat, cb, s_);
+                stg(a.stage_liq, cb, l_);
+                stg(a.stage_T, cb, t_);
+            };
+            const unsigned sa = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)ln.ka) * (unsigned)sizeof(NF);
+            stage_cell(ln.act_a, sa, ss.a, ls.a, Ts.a);
+            stage_cell(ln.act_b, sa + (unsigned)sizeof(NF), ss.b, ls.b, Ts.b);
+        }
+        // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59); with GENERIC every
+        // boundary kind and value of the stage's view
+        const NF bTb2 = (!GENERIC && vTb) ? ldg(a.bcT_bot_stage, ib_late) : NF(0), bTt2 = (!GENERIC && vTt) ? ldg(a.bcT_top_stage, ib_late) : NF(0);
         uint32_t vs_a = 0, vs_b = 0;
-        const Tend t2 = tendencies(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), Ts, ls, ss, ps, bTb2, bTt2, RICHARDS, vs_a, vs_b);
+        const Tend t2 = tendencies(kernarg_reload<View<NF>>(GENERIC ? off_vs : 0u), kernarg_reload<DevParams<NF>>(off_p), Ts, ls, ss, ps, bTb2, bTt2, RICHARDS, vs_a, vs_b);
         viol_a |= vs_a; viol_b |= vs_b;
         // average_tendencies! (heun.jl:27-35), then the step of the STATE with its own boundary fluxes
         gU = Two<NF>{(G1U.a + t2.gU.a) / NF(2), (G1U.b + t2.gU.b) / NF(2)};
@@ -417,7 +436,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         Kf_out_top = ln.top_a ? Kn.a : Kn.b;
     }
     // surface_excess_water after the step, formed before the first store (column_program)
-    NF S = NF(0), GS = NF(0);
+    NF S = NF(0), GS = NF(0), S_stage = NF(0);
     if (RICHARDS && PROG == PROG_MULTI) {
         S = S_multi;
         GS = GS_multi;
@@ -425,7 +444,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         S = S_in;
         GS = NF(0) + jl_min(NF(0), S);
         if (PROG == PROG_HEUN) {
-            const NF S_stage = (S + GS * dt) + over_stage;
+            S_stage = (S + GS * dt) + over_stage;
             GS = (GS + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
         }
         S = (S + GS * dt) + over;
@@ -456,6 +475,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
             stg(vo.S, ib, S);
             stg(vo.wt, ib, z0);
             if (finalize) stg(vo.G_S, ib, GS);
+            if (PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage);
         }
         if (seb) {
             stg(vo.top_T, ib, Tt);

@@ -14,10 +14,16 @@ template <class NF, bool RICH, int H, int PROG, bool GENERIC> static int launch_
     a.nsteps = nsteps;
     a.bcT_bot_stage = la.w.bcT_bot;      // Heun: the stage's temperature boundary values (evaluated at t + dt)
     a.bcT_top_stage = la.w.bcT_top;
+    if (PROG == PROG_HEUN && Policy<NF>::coupled(c)) {   // the stage's soil state is needed by the 0-D processes evaluated at the stage
+        a.stage_sat = (NF*)c->stage.f[TRM_FIELD_SATURATION_WATER_ICE];
+        a.stage_liq = (NF*)c->stage.f[TRM_FIELD_LIQUID_WATER_FRACTION];
+        a.stage_T = (NF*)c->stage.f[TRM_FIELD_TEMPERATURE];
+        a.stage_S = (NF*)c->stage.f[TRM_FIELD_SURFACE_EXCESS_WATER];
+    }
     const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
-    if constexpr (GENERIC) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
-    else if (Policy<NF>::template derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
-    else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a);
+    if constexpr (GENERIC) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG, true>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a, la.stage);
+    else if (Policy<NF>::template derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a, la.stage);
+    else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a, la.stage);
     TRM_HIP(c, hipGetLastError());
     return TRM_OK;
 }
@@ -29,8 +35,9 @@ template <class NF, int PROG, bool GENERIC> static int deep_by_flow(trm_ctx* c, 
 }
 template <class NF> int DeepLaunch<NF>::run(trm_ctx* c, int prog, bool generic, double dt, int finalize, int nsteps) {
     if (generic) {
-        if (prog != PROG_EULER) return fail(c, TRM_EINVAL, "k_column_deep: the generic boundary kinds run under ForwardEuler only");
-        return deep_by_flow<NF, PROG_EULER, true>(c, dt, finalize, nsteps);
+        if (prog == PROG_EULER) return deep_by_flow<NF, PROG_EULER, true>(c, dt, finalize, nsteps);
+        if (prog == PROG_HEUN) return deep_by_flow<NF, PROG_HEUN, true>(c, dt, finalize, nsteps);
+        return fail(c, TRM_EINVAL, "k_column_deep: the generic boundary kinds run one step per launch");
     }
     switch (prog) {
         case PROG_EULER: return deep_by_flow<NF, PROG_EULER, false>(c, dt, finalize, nsteps);

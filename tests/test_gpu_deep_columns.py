@@ -180,3 +180,77 @@ def test_deep_columns_multistep_program_equals_per_step_launches_bitwise(config,
     a.synchronize(); b.synchronize()
     ta, tb = a.step_timed(w["dt"], 40, finalize=False), b.step_timed(w["dt"], 40, finalize=False)
     assert ta < 0.8 * tb, (ta, tb)
+
+
+# heun.jl:37-71 with EVERY boundary kind on deep columns (the reference's FreeDrainage() -- soil_model_bcs.jl:40 -- on its own
+# UniformSpacing(N = 100) grid, soil_hydrology_tests.jl:93-123): k_column_deep<PROG_HEUN, GENERIC>, one launch per step, the stage's
+# boundary values from the stage's view (series evaluated at t + dt) -- bit for bit the staged reference-order Heun and the oracle
+@pytest.mark.parametrize("config,dtype,Nz,Nh", [("richards", np.float64, 100, 83), ("richards", np.float64, 127, 11), ("heat", np.float64, 80, 20),
+                                                 ("richards", np.float32, 66, 40), ("land", np.float64, 96, 30)])
+def test_deep_columns_heun_with_generic_boundary_kinds_runs_fused(config, dtype, Nz, Nh):
+    lat, lon = small_columns(Nh)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype)
+    rng = np.random.default_rng(9)
+    if config == "heat":
+        w["bcs"][("temperature", "bottom")] = ("gradient", 0.01)
+        w["bcs"][("liquid_water_fraction", "top")] = ("gradient", 0.1)
+    else:
+        w["bcs"].update({("temperature", "bottom"): ("value", w["T0"] - 1.0), ("internal_energy", "bottom"): ("flux", np.full(Nh, 0.05)),
+                         ("pressure_head", "bottom"): ("gradient", 0.0), ("liquid_water_fraction", "top"): ("gradient", 0.1)})   # FreeDrainage()
+        if config == "richards":
+            w["bcs"][("saturation_water_ice", "top")] = ("flux", -1.0e-8 * rng.random(Nh))
+            w["bcs"][("pressure_head", "top")] = ("value", np.full(Nh, -0.3))
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("step_kernel", "unfused")
+    o = W.setup_oracle(w) if (dtype == np.float64 and config != "land") else None
+    times = w["dt"] * np.arange(0, 16)
+    if config != "land":      # a time-dependent bottom temperature value / gradient: the stage takes it at t + dt
+        kind = "gradient" if config == "heat" else "value"
+        vals = np.stack([(0.01 if config == "heat" else w["T0"] - 1.0) + 0.002 * (t / w["dt"]) * np.ones(Nh) for t in times])
+        for d in (a, b) + ((o,) if o is not None else ()):
+            d.set_bc_series("temperature", "bottom", kind, times, vals)
+    if config != "heat":
+        zc = a.z_centers()
+        F = (-2.0e-7 * np.exp(zc / 0.5)[:, None] * (1.0 + 0.5 * np.cos(np.arange(Nh)))[None, :]).astype(dtype)
+        for d in (a, b) + ((o,) if o is not None else ()):
+            d.set("vwc_forcing", F)
+    nsteps = 12
+    for d in (a, b):
+        d.step_heun(w["dt"], 1, finalize=False)
+        d.step_heun(w["dt"], nsteps - 2, finalize=False)
+        d.step_heun(w["dt"], 1, finalize=True)
+    names = W.compared_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else [])
+    for n in names:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status() and a.clock() == b.clock()
+    if o is not None:
+        for k in range(nsteps):
+            o.timestep_heun(w["dt"], True)
+        for n in W.compared_fields(w):
+            assert np.array_equal(a.get(n), o.get(n)), n
+    ta, tb = a.step_heun_timed(w["dt"], 10, finalize=False), b.step_heun_timed(w["dt"], 10, finalize=False)
+    assert ta < 0.5 * tb, (ta, tb)          # one launch per step against the staged sequence
+
+
+# LandModel(vegetation = VegetationCarbon) on deep columns (land_model.jl:79-97): the soil half of every step is k_column_deep, the
+# 0-D half the per-column form of k_surface_veg; Heun stores what the 0-D processes need of the stage -- bit for bit the
+# reference-order kernels, ForwardEuler and Heun, fp64 and fp32
+@pytest.mark.parametrize("heun", [False, True])
+@pytest.mark.parametrize("dtype,Nz,Nh", [(np.float64, 100, 70), (np.float64, 65, 33), (np.float32, 128, 40)])
+def test_vegetation_coupled_land_model_on_deep_columns_runs_fused(dtype, Nz, Nh, heun):
+    lat, lon = small_columns(Nh)
+    w = W.make_workload("landveg", lat, lon, Nz, dtype=dtype, hydraulics="vg")
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("step_kernel", "unfused")
+    step = (lambda d, n, fin: d.step_heun(w["dt"], n, finalize=fin)) if heun else (lambda d, n, fin: d.step(w["dt"], n, finalize=fin))
+    for d in (a, b):
+        step(d, 1, False)
+        step(d, 10, False)
+        step(d, 1, True)
+    names = W.compared_fields(w) + ["tend_internal_energy", "tend_saturation_water_ice", "tend_canopy_water", "tend_carbon_vegetation"]
+    for n in names:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status() and a.clock() == b.clock()
+    timed = (lambda d: d.step_heun_timed(w["dt"], 10, finalize=False)) if heun else (lambda d: d.step_timed(w["dt"], 10, finalize=False))
+    ta, tb = timed(a), timed(b)
+    assert ta < 0.7 * tb, (ta, tb)
