@@ -71,7 +71,7 @@ template <class NF, int CHECK = 1> TRM_DEV Frac<NF> energy_closure_wave(const De
     bool ok;
     if (no_lane_divides(thawed, frozen, Lth > Limits<NF>::eps())) {
         liq = thawed ? NF(1) : NF(-0.0);
-        ok = CHECK == 2 ? sat == sat : (NF(0) <= sat && sat <= NF(1));
+        ok = (CHECK == 2 && TRM_CUT_CHECK) ? sat == sat : (TRM_CUT_CHECK ? (NF(0) <= sat && sat <= NF(1)) : ((NF(0) <= sat && sat <= NF(1)) && (NF(0) <= liq && liq <= NF(1))));
     } else {
         TRM_PHASE("rare+ phase-change divide");
         liq = thawed ? NF(1) : boolmul(U >= nLth, NF(1) - safediv(U, nLth));
@@ -95,7 +95,7 @@ TRM_DEV Tendency<NF> column_tendencies(const View<NF>& v, const DevParams<NF>& p
                                        const Cell<NF>& c, NF bTb, NF bTt, bool need_kc, uint32_t& viol, const Frac<NF>* pre = nullptr) {
     const bool is_bot = ln.is_bot, is_top = ln.is_top;
     // (composition bounds of an incoming state were flagged by the launch / program step that produced it)
-    const Frac<NF> f = pre ? *pre : fractions_unchecked(p, c.sat, c.liq);
+    const Frac<NF> f = (pre && TRM_CUT_FRAC) ? *pre : fractions_unchecked(p, c.sat, c.liq);
     const NF kap = conductivity(p, f);
     const NF Kc = need_kc ? conductivity_hydraulic<NF, HYD, false>(p, c.liq, f) : NF(0);
     // neighbours by DPP shifts (executed by all lanes, never inside a divergent select)
@@ -252,6 +252,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     TRM_PHASE("addressing");
     LaneInfo ln;
     ln.lane = threadIdx.x & 63;
+#if TRM_CUT_MASKS
     // (the wave index and everything that follows from it alone lives on the scalar unit)
     const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6));
     ln.k = ln.lane % LPC;
@@ -273,6 +274,25 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     ln.m_act = m_col & levels_below<LPC>(Nz);
     ln.act = lane_in(ln.m_act);
     const int ii = i < Nh ? i : Nh - 1;
+#else      // (A/B builds: round 3's lane-wise form)
+    const int wave = (int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    ln.k = ln.lane % LPC;
+    const int sub = ln.lane / LPC;
+    const int Nz = v.Nz, Nh = (int)v.Nh;
+    const bool upper = sub != 0;
+    ln.is_bot = ln.k == 0;
+    ln.is_top = ln.k == Nz - 1;
+    const LevelGeom<NF> L = level_geom(v, ln.k);
+    const NF dt = a.dt;
+    const int finalize = a.finalize, write_kf = a.write_kf;
+    const bool need_kc = RICHARDS || write_kf;
+    const int i = wave * CPW + sub;
+    const bool colok = i < Nh;
+    ln.act = colok && ln.k < Nz;
+    ln.m_act = wave_ballot(colok) & wave_ballot(ln.k < Nz);
+    const int ii = colok ? i : Nh - 1;
+    const int col_first = __builtin_amdgcn_readfirstlane(wave * CPW);
+#endif
     const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);
     uint32_t viol = 0;
@@ -321,6 +341,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         NF fU = NF(0), fS = NF(0);
         const bool bU = v.bc.kind[0][0] == 2, bS = RICHARDS && v.bc.kind[1][0] == 2;
         const bool tU = !SEB_INLINE && (seb || v.bc.kind[0][1] == 2), tS = RICHARDS && !SEB_INLINE && (seb || v.bc.kind[1][1] == 2);
+#if TRM_CUT_FLUX
         if (bU) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 0, 0)), v.g); fU = ln.is_bot ? e : fU; }
         if (bS) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 1, 0)), v.g); fS = ln.is_bot ? e : fS; }
         // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this launch.
@@ -331,11 +352,23 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             const NF e = -flux_term_top_nsz(seb ? -x : x, v.g);
             fS = ln.is_top ? e : fS;
         }
+#endif
+#if !TRM_CUT_FLUX
+        {   // (A/B builds: the round-3 form -- both edge terms always formed, two selects per variable)
+            NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
+            if (bU) eU_b = flux_term_bottom(col_ld(bcval(v, 0, 0)), v.g);
+            if (bS) eS_b = flux_term_bottom(col_ld(bcval(v, 1, 0)), v.g);
+            if (tU) eU_t = -flux_term_top(col_ld(seb ? v.ghf : bcval(v, 0, 1)), v.g);
+            if (tS) { const NF x = col_ld(seb ? v.infil : bcval(v, 1, 1)); eS_t = -flux_term_top(seb ? -x : x, v.g); }
+            fU = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
+            fS = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
+        }
+#endif
         bc.flux_U = fU;
         bc.flux_S = fS;
         // (the multi-step program may receive its terms later: from a series, from the inline surface energy balance)
-        bc.has_U = PROG == PROG_MULTI || bU || tU;
-        bc.has_S = PROG == PROG_MULTI || bS || tS;
+        bc.has_U = !TRM_CUT_FLUX || PROG == PROG_MULTI || bU || tU;
+        bc.has_S = !TRM_CUT_FLUX || PROG == PROG_MULTI || bS || tS;
     }
     // surface_excess_water (and LandModel's surface state) is owned by the column's top lane.  The one-step programs
     // touch it in one short top-lane block at the end; the multi-step program carries it in a register.

@@ -32,6 +32,32 @@ template <class... T> __device__ __forceinline__ void phase_fence_values(T&... x
 #define TRM_PHASE_FENCE(name, ...) ((void)0)
 #endif
 
+// Round-4 instruction cuts, individually switchable for same-box A/B builds (profiles/tools/r04_exp2.sh): 1 = on (default)
+#ifndef TRM_CUT_MASKS      // lane predicates / active masks from wave-uniform scalar masks instead of lane-wise compares
+#define TRM_CUT_MASKS 1
+#endif
+#ifndef TRM_CUT_WT         // water table search on the scalar unit
+#define TRM_CUT_WT 1
+#endif
+#ifndef TRM_CUT_NSZ        // divides by launch constants without the sign-of-zero select where it cannot matter
+#define TRM_CUT_NSZ 1
+#endif
+#ifndef TRM_CUT_FLUX       // flux boundary terms: a select per condition that is set
+#define TRM_CUT_FLUX 1
+#endif
+#ifndef TRM_CUT_CHECK      // composition check of the closure reduced to what is not known by construction
+#define TRM_CUT_CHECK 1
+#endif
+#ifndef TRM_CUT_POWRARE    // the non-finite case of the compensated power as a wave-uniform rare branch
+#define TRM_CUT_POWRARE 1
+#endif
+#ifndef TRM_CUT_FRAC       // volumetric fractions shared between a closure and the tendencies that follow it
+#define TRM_CUT_FRAC 1
+#endif
+#ifndef TRM_CUT_SOFF       // scalar loads with a register byte offset instead of a 64-bit address each
+#define TRM_CUT_SOFF 1
+#endif
+
 namespace trm {
 
 // ---------------------------------------------------------------------------
@@ -111,6 +137,9 @@ template <class NF> TRM_HD NF div_const(NF a, NF b, NF rb) {
 // reach a result: the quotient is added to a value that is never -0.0 (x + (+-0) = x), or the numerator cannot be -0.0.  Each
 // call site says which.  (An underflowing quotient, a != 0, reproduces itself: q2 = RN(a * rb) = q.)  Saves 3 of 6 instructions.
 template <class NF> TRM_HD NF div_const_nsz(NF a, NF b, NF rb) {
+#if !TRM_CUT_NSZ
+    return div_const(a, b, rb);
+#endif
     const NF q = a * rb;
     const NF r = fma_(-q, b, a);
     return fma_(r, rb, q);
@@ -302,7 +331,7 @@ template <class NF> TRM_HD NF pow_int_m5(NF x) {
     const NF l4 = fma_(x2, x2, -x4) + err;
     // n = 1: combine
     err = fma_(rx, l4, x4 * ynlo);
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && TRM_CUT_POWRARE
     // Base's `isfinite(x) && isfinite(err) ? muladd(x, y, err) : x * y`: an overflowing power (r below ~1e-62) is the rare case,
     // decided per wave from two ballots -- two compares and the fma instead of two compares, the fma, a product and a select
     const NF full = fma_(x4, rx, err);

@@ -404,6 +404,9 @@ template <class NF> TRM_DEV NF sld(const NF* base, int idx_uniform) {
 // (`s_load_dwordx2 sdst, sbase, soffset`) instead of forming a 64-bit address per load on the scalar ALU (4 instructions per
 // load: ~100 of the 260 scalar instructions per wave of the packed fp32 LandModel step).  T may be a pair (one wider load).
 template <class T> TRM_DEV T sld_off(const void* base, unsigned byte_off_uniform) {
+#if !TRM_CUT_SOFF
+    return sld((const T*)base, (int)(byte_off_uniform / (unsigned)sizeof(T)));
+#endif
     typedef const char __attribute__((address_space(4))) * bptr;
     typedef const T __attribute__((address_space(4))) * cptr;
     return *(cptr)((bptr)(uintptr_t)base + byte_off_uniform);
@@ -527,6 +530,14 @@ TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, unsigne
 // the lookup selected per half-wave -- the lane-wise form (the ballot masked per lane, 64-bit ffs in vector registers) was ~20
 // vector instructions.
 template <class NF, int LPC> TRM_DEV NF water_table(NF sat, unsigned long long m_act, int lane, const LevelGeom<NF>& L) {
+#if !TRM_CUT_WT
+    {
+        const unsigned long long unsat_l = wave_ballot(sat < NF(1)) & m_act & group_mask<LPC>(lane);
+        const int first = unsat_l ? (__ffsll((long long)unsat_l) - 1) % LPC : -1;
+        const NF z_first = shfl_from<NF, LPC>(L.zFlo, first >= 0 ? first : 0);
+        return first >= 0 ? z_first : L.zF_top;
+    }
+#endif
     const unsigned long long unsat = wave_ballot(sat < NF(1)) & m_act;
     if (LPC == 64) {
         const int src = unsat ? __builtin_ctzll(unsat) : 0;                       // (uniform)

@@ -45,6 +45,9 @@ TRM_DEV v2f div_const2(v2f a, float b, float rb) {
 
 // div_const_nsz (trm_device.hpp) on both components: no select for the sign of a zero quotient -- where it cannot matter
 TRM_DEV v2f div_const2_nsz(v2f a, float b, float rb) {
+#if !TRM_CUT_NSZ
+    return div_const2(a, b, rb);
+#endif
     const v2f q = a * rb;
     const v2f r = fma2(-q, splat(b), a);
     return fma2(r, splat(rb), q);
@@ -121,8 +124,9 @@ template <int CHECK = 1> TRM_DEV Frac2 energy_closure2(const DevParams<float>& p
     bool okx, oky;
     if (wave_ballot(needx || needy) == 0ull) {
         liq = sel(thawed, splat(1.0f), splat(-0.0f));
-        okx = CHECK == 2 ? sat.x == sat.x : (0.0f <= sat.x && sat.x <= 1.0f);
-        oky = CHECK == 2 ? sat.y == sat.y : (0.0f <= sat.y && sat.y <= 1.0f);
+        okx = (CHECK == 2 && TRM_CUT_CHECK) ? sat.x == sat.x : (0.0f <= sat.x && sat.x <= 1.0f);
+        oky = (CHECK == 2 && TRM_CUT_CHECK) ? sat.y == sat.y : (0.0f <= sat.y && sat.y <= 1.0f);
+        if (!TRM_CUT_CHECK) { okx = okx && (0.0f <= liq.x && liq.x <= 1.0f); oky = oky && (0.0f <= liq.y && liq.y <= 1.0f); }
     } else {
         const v2f den = nLth + eps;
         const v2f sd = v2f{(nLth.x == 0.0f) ? Limits<float>::inf() : div_nr(U.x, den.x), (nLth.y == 0.0f) ? Limits<float>::inf() : div_nr(U.y, den.y)};
@@ -155,10 +159,12 @@ TRM_DEV v2f pow_int_m5_2(v2f x) {
     const v2f l4 = fma2(x2, x2, -x4) + err;
     err = fma2(rx, l4, x4 * ynlo);
     const v2f a = fma2(x4, rx, err);
+#if TRM_CUT_POWRARE
     // (an overflowing power is the rare case, decided per wave: see pow_int_m5)
     const unsigned long long all_finite = wave_ballot(is_finite(x4.x)) & wave_ballot(is_finite(err.x)) & wave_ballot(is_finite(x4.y)) & wave_ballot(is_finite(err.y));
     if (all_finite == wave_ballot(true)) return a;
     rare_path();
+#endif
     const v2f b = x4 * rx;
     return v2f{(is_finite(x4.x) && is_finite(err.x)) ? a.x : b.x, (is_finite(x4.y) && is_finite(err.y)) ? a.y : b.y};
 }
@@ -204,6 +210,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     constexpr int CPW = 64 / LPC;   // column PAIRS per wave
     const int lane = threadIdx.x & 63;
     // (the wave index and what follows from it alone on the scalar unit; lane predicates from wave-uniform masks: lane_in)
+#if TRM_CUT_MASKS
     const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6));
     const int k = lane % LPC, sub = lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
@@ -221,6 +228,20 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const unsigned long long m_act1 = ((pair_w0 + 1 < Nh ? half_lo : 0ull) | (pair_w0 + 3 < Nh ? half_hi : 0ull)) & m_lev;
     const bool act0 = lane_in(m_act0), act1 = lane_in(m_act1);
     const int j0 = i0 < Nh ? i0 : Nh - 1, j1 = i1 < Nh ? i1 : Nh - 1;
+#else      // (A/B builds: round 3's lane-wise form)
+    const int wave = (int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int k = lane % LPC, sub = lane / LPC;
+    const int Nz = v.Nz, Nh = (int)v.Nh;
+    const bool upper = sub != 0;
+    const bool is_bot = k == 0, is_top = k == Nz - 1;
+    const LevelGeom<NF> L = level_geom(v, k);
+    const bool need_kc = RICHARDS || write_kf;
+    const int i0 = (wave * CPW + sub) * 2, i1 = i0 + 1;
+    const bool act0 = i0 < Nh && k < Nz, act1 = i1 < Nh && k < Nz;
+    const int j0 = i0 < Nh ? i0 : Nh - 1, j1 = i1 < Nh ? i1 : Nh - 1;
+    const int pair_w0 = __builtin_amdgcn_readfirstlane(wave * CPW) * 2;
+    const unsigned long long m_lev = wave_ballot(k < Nz), m_act0 = wave_ballot(i0 < Nh) & m_lev, m_act1 = wave_ballot(i1 < Nh) & m_lev;
+#endif
     const unsigned kk = (unsigned)(k < Nz ? k : Nz - 1);
     const unsigned ib0 = (unsigned)j0 * 4u, ib1 = (unsigned)j1 * 4u;
     const unsigned cb0 = ((unsigned)j0 * (unsigned)v.Nzp + kk) * 4u, cb1 = ((unsigned)j1 * (unsigned)v.Nzp + kk) * 4u;
