@@ -226,6 +226,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-resident", action="store_true", help="skip the HBM-resident companion measurements (c3x8, c5)")
+    ap.add_argument("--no-single-process", action="store_true", help="skip the leg in which ONE host thread drives one context per device (trm_step_all)")
     ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling companion (BASELINE config 4: N145 sharded over the ranks)")
     ap.add_argument("--multistep", type=int, default=50, help="also time the resident-column multi-step kernel with this many steps per launch (temporal blocking; reported separately)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -379,6 +380,14 @@ def main():
     if world > 1 and not hung and not args.no_strong and args.workload == "c3" and args.scaling == "weak":
         out["strong"] = strong_leg(W, parallel, args, world, rank, local_rank, configure, sync, barrier, reduce_max, reduce_sum)
 
+    if not hung and not args.no_single_process and args.workload == "c3" and args.scaling == "weak" and args.kernel == "fused" and not heun:
+        # ONE host thread driving one context per device (the reference's host is one Julia process): rank 0 alone, the other
+        # ranks idle at the barrier below
+        if rank == 0:
+            out["single_process"] = single_process_leg(W, parallel, args, list(range(world)) if world > 1 else [local_rank, local_rank], torch)
+        if world > 1:
+            dist.barrier()
+
     single = rank == 0 and n_gpus == 1
     if single and args.multistep > 1 and args.kernel == "fused" and not heun and not args.series and args.steps_per_launch == 1:
         out["multistep"] = multistep_leg(W, w, desc, config, Nz, Nh, wordsize, args, sync, local_rank)
@@ -434,6 +443,74 @@ def strong_leg(W, parallel, args, world, rank, device, configure, sync, barrier,
         res[key] = {"steps_per_launch": spl, "steps": steps, "us_per_step": m["ms_per_step"] * 1e3, "us_per_step_min": m["ms_per_step_min"] * 1e3,
                     "kernel_us_per_step": m["kernel_us_per_step"], "column_steps_per_s": total * steps / m["wall_s"], "repeats": m["repeats"],
                     "status_flags": int(parallel.global_status(st))}
+    return res
+
+
+def single_process_leg(W, parallel, args, devices, torch):
+    """SURVEY 5 / 8(e) "1 process x 8 HIP devices": ONE host thread, one asynchronous context per entry of `devices` (each a full
+    N145 C3 shard: weak scaling), stepped with trm_step_all -- the launches dealt to the devices in turn, one wait at the end --,
+    per-step launches and the library's default (the resident program); global diagnostics through trm_status_global_all (grouped
+    RCCL all-reduces when every context has a device of its own, a host fold otherwise).  On a one-GPU box the driver's default
+    run exercises the same path with two contexts on the one device (they time-slice it: the numbers say nothing about scaling)."""
+    import threading
+    import terrarium_jl_amd as trm
+    w, desc, config, Nz, dt_name = build_workload(W, parallel, "c3", 1, 0, "weak")
+    n, distinct = len(devices), len(set(devices)) == len(devices)
+    res = {"contexts": n, "devices": len(set(devices)), "columns_per_context": w["Nh"], "host_threads": 1,
+           "note": "one host thread, trm_step_all: launches dealt to the contexts in turn, one wait at the end"
+                   + ("" if distinct and n > 1 else "; the contexts share ONE device here (time-sliced): a functional run of the path, not a scaling number")}
+    steps, reps = min(args.steps, 100), min(args.repeats, 5)
+
+    def sync_all():
+        for d in set(devices):
+            torch.cuda.synchronize(d)
+
+    for key, spl in (("per_step", 1), ("library_default", 0)):
+        states = [W.setup_device(w, device=d) for d in devices]
+        for s in states:
+            s.set_option("steps_per_launch", spl)
+            s.set_option("pipeline_parts", 0)
+            s.set_option("asynchronous", 1)
+        group = trm.DeviceGroup(states)
+        group.step(w["dt"], 10, finalize=False)
+        group.synchronize()
+        for s in states:
+            s.save_state()
+        walls = []
+        for _ in range(reps):
+            for s in states:
+                s.restore_state()
+            group.synchronize()
+            sync_all()
+            t0 = time.perf_counter()
+            group.step(w["dt"], steps, finalize=False)
+            group.synchronize()
+            walls.append(time.perf_counter() - t0)
+        wall = float(np.median(walls))
+        res[key] = {"steps_per_launch": spl, "steps": steps, "repeats": reps, "us_per_step": wall / steps * 1e6, "us_per_step_min": min(walls) / steps * 1e6,
+                    "column_steps_per_s": n * w["Nh"] * steps / wall}
+        if key == "library_default":
+            # global diagnostics from the one thread; the RCCL set-up in a watchdog (a hung collective is reported, not waited for)
+            box = {}
+
+            def diagnostics():
+                try:
+                    if distinct and n > 1:
+                        group.comm_init()
+                    box["status"] = group.status_global()
+                    box["rccl_ranks"] = states[0].comm_world()
+                    box["max_T"] = float(np.max(group.reduce_global("temperature", "max")))
+                except Exception as e:   # noqa: BLE001 -- diagnostic leg
+                    box["error"] = f"{type(e).__name__}: {e}"
+
+            th = threading.Thread(target=diagnostics, daemon=True)
+            th.start()
+            th.join(90.0)
+            res["global_diagnostics"] = {"timeout": True} if th.is_alive() else dict(box, path="grouped RCCL all-reduce" if (distinct and n > 1 and "error" not in box) else "host fold (no communicator: one device)")
+            if th.is_alive():
+                return res          # (the contexts are left to the process exit)
+        for s in states:
+            s.close()
     return res
 
 

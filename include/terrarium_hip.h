@@ -167,7 +167,9 @@ enum {
                                     /* less, bit-identical results.  0: never; 1: whenever legal; 2 (default): for fp64 states  */
                                     /* beyond the 256 MiB Infinity Cache or of >= 24 576 columns, and the liquid fraction alone */
                                     /* for fp32 states beyond the cache on the packed kernel: where it was measured to win      */
-                                    /* (DESIGN 4.1, 4.3); 3: the liquid fraction alone (one read less)                          */
+                                    /* (DESIGN 4.1, 4.3); 3: the liquid fraction alone (one read less); 4: the liquid fraction   */
+                                    /* and, on the packed fp32 step with Richards, the pressure head from the stored saturation */
+                                    /* and water table (two reads less; elsewhere as 3)                                          */
     TRM_OPT_STEPS_PER_LAUNCH = 6,   /* trm_step keeps every column in registers for up to m steps per launch and writes the */
                                     /* fields once per launch (temporal blocking of run!'s loop, model_integrator.jl:72-88;  */
                                     /* bit-identical to m = 1).  0 (default): the library chooses -- 50 wherever the program  */
@@ -188,6 +190,14 @@ enum {
                                     /* surface processes inline for the single step -- ONE launch instead of the k_surface +        */
                                     /* k_column pair; 0: the launch pair; 2 (default): the library's rule (small shards, where the  */
                                     /* step is bound by launch latency: DESIGN 4.9)                                                  */
+};
+/* DIAGNOSTIC, read-only (trm_get_option): which fast paths the NEXT step will take -- what the library tracks about its own
+ * buffers.  Tests pin them (a wrong value costs speed, never correctness, so nothing else would notice). */
+enum {
+    TRM_INFO_TOP_ARRAYS_CURRENT = 100, /* 1: the LandModel's next surface evaluation reads the compact top-cell arrays the last   */
+                                       /* fused step wrote (coalesced) instead of gathering one word per column from the fields   */
+    TRM_INFO_CLOSURE_CONSISTENT = 101  /* 1: the stored temperature / liquid fraction are the closure of the stored state, so a  */
+                                       /* step may re-derive them in registers (TRM_OPT_DERIVE_CLOSURE_FIELDS)                   */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

@@ -477,7 +477,7 @@ template <class NF> struct Ops {
     // the top-cell arrays (LandModel: T, sat, liq of the top cell, [Nh] each) can describe the state: they exist and no device
     // pointer to T / sat / liq has been handed out.  Every "the next surface evaluation may read the arrays" decision goes
     // through here -- a launch with TOP_ARRAYS on a context without them would read through a null pointer.
-    static bool tops_current(const trm_ctx* c) { return c->d_top3 != nullptr && tops_current(c); }
+    static bool tops_current(const trm_ctx* c) { return c->d_top3 != nullptr && !c->top_escaped; }
     template <int PROG> static int column_program(trm_ctx* c, double dt, int finalize, int nsteps) {
         return richards(c) ? ColumnLaunch<NF, true, PROG>::run(c, dt, finalize, nsteps) : ColumnLaunch<NF, false, PROG>::run(c, dt, finalize, nsteps);
     }
@@ -840,7 +840,7 @@ struct EnvSwitches {
     EnvSwitches() {
         long v;
         if (parse_env_int("TRM_FIELD_SKEW", 0, 1 << 20, 256, v, error)) field_skew = v;
-        if (error.empty() && parse_env_int("TRM_DERIVE_DEFAULT", 0, 3, 1, v, error)) derive_default = v;
+        if (error.empty() && parse_env_int("TRM_DERIVE_DEFAULT", 0, 4, 1, v, error)) derive_default = v;
         if (error.empty() && parse_env_int("TRM_STAGED_SMALL", 0, 1, 1, v, error)) { /* read by Policy::staged_now */ }
         if (error.empty() && parse_env_int("TRM_SCALAR_INPUTS", 0, 1, 1, v, error)) { /* read by Policy::scalar_inputs_now */ }
     }
@@ -1418,7 +1418,7 @@ int trm_upload(trm_ctx* c, int field, const void* host) {
                                    "(root_distribution.jl:45-63): set them with trm_set_vegetation");
     TRM_HIP(c, hipSetDevice(c->device));
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
-    if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_consistent = false;
+    if (field <= TRM_FIELD_PRESSURE_HEAD || field == TRM_FIELD_WATER_TABLE) c->closure_consistent = false;   // (U, sat, T, liq, psi, water table)
     if (!rc && field == TRM_FIELD_VWC_FORCING) {
         c->opt_vwc_field = 1;
         c->args_valid = false;
@@ -1452,7 +1452,7 @@ int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems
     // the caller may write the state behind the library's back from now on: stop trusting the top-cell copies
     if (field == TRM_FIELD_TEMPERATURE || field == TRM_FIELD_SATURATION_WATER_ICE || field == TRM_FIELD_LIQUID_WATER_FRACTION)
         c->top_escaped = true;
-    if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_escaped = true;   // U, sat, T, liq may change behind the library's back
+    if (field <= TRM_FIELD_PRESSURE_HEAD || field == TRM_FIELD_WATER_TABLE) c->closure_escaped = true;   // U, sat, T, liq, psi, the water table may change behind the library's back
     c->top_valid = false;
     return TRM_OK;
 }
@@ -1794,7 +1794,7 @@ static int gather_ring(trm_ctx* c, int field, const void* full, bool device, con
     if (int rc = ring_args_ok(c, field, 0, (int)field_rows(c, field), full, who)) return rc;
     if (field == TRM_FIELD_ROOT_FRACTION) return fail(c, TRM_EINVAL, std::string(who) + ": root_fraction is derived from the root distribution parameters");
     int rc = c->precision == TRM_F64 ? gather_ring_impl<double>(c, field, full, device) : gather_ring_impl<float>(c, field, full, device);
-    if (field <= TRM_FIELD_LIQUID_WATER_FRACTION) c->closure_consistent = false;
+    if (field <= TRM_FIELD_PRESSURE_HEAD || field == TRM_FIELD_WATER_TABLE) c->closure_consistent = false;
     if (!rc && field == TRM_FIELD_VWC_FORCING) { c->opt_vwc_field = 1; c->args_valid = false; }
     c->top_valid = false;
     if (!rc && is_tendency(field)) c->tend_valid = true;
@@ -2324,12 +2324,24 @@ int step_all(trm_ctx** ctxs, int n, const char* who, int (*step)(trm_ctx*, doubl
     // per context -- unless the caller drives them asynchronously anyway
     std::vector<int> async((size_t)n);
     int rc = TRM_OK;
-    for (int i = 0; i < n && !rc; ++i) {
+    // The steps are dealt to the devices launch by launch -- every context receives the steps of ONE of its launches (1, or up to
+    // 50 with the resident program) before the next context is visited -- so that all devices start at once instead of device
+    // d waiting for the host to have enqueued all nsteps launches of devices 0 .. d - 1.  Same results as one call per context
+    // (a call of m steps equals m calls of one step, bit for bit).
+    int chunk = 50;
+    for (int i = 0; i < n; ++i) {
         async[(size_t)i] = ctxs[i]->opt_async;
         ctxs[i]->opt_async = 1;
-        rc = step(ctxs[i], dt, nsteps, finalize);
-        ctxs[i]->opt_async = async[(size_t)i];
+        chunk = std::min(chunk, ctxs[i]->opt_steps_per_launch > 0 ? ctxs[i]->opt_steps_per_launch : 50);
     }
+    for (int done = 0; done < nsteps && !rc; done += chunk) {
+        const int m = std::min(chunk, nsteps - done);
+        const int fin = (finalize && done + m == nsteps) ? 1 : 0;
+        for (int i = 0; i < n && !rc; ++i) rc = step(ctxs[i], dt, m, fin);
+    }
+    if (nsteps == 0 && finalize)
+        for (int i = 0; i < n && !rc; ++i) rc = step(ctxs[i], dt, 0, finalize);
+    for (int i = 0; i < n; ++i) ctxs[i]->opt_async = async[(size_t)i];
     for (int i = 0; i < n; ++i) {
         if (async[(size_t)i]) continue;
         const int rs = trm_synchronize(ctxs[i]);      // (also after a failure: nothing is left running behind the caller's back)
@@ -2416,7 +2428,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
         case TRM_OPT_VWC_FORCING_FIELD: c->opt_vwc_field = value != 0; return TRM_OK;
         case TRM_OPT_PACKED_F32: c->opt_packed = value != 0; return TRM_OK;
         case TRM_OPT_DERIVE_CLOSURE_FIELDS:
-            if (value < 0 || value > 3) break;
+            if (value < 0 || value > 4) break;
             c->opt_derive = value;
             return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH:
@@ -2447,6 +2459,8 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
         case TRM_OPT_SINGLE_STEP_PROGRAM: *value = c->opt_single_step; return TRM_OK;
+        case TRM_INFO_TOP_ARRAYS_CURRENT: *value = c->top_valid ? 1 : 0; return TRM_OK;
+        case TRM_INFO_CLOSURE_CONSISTENT: *value = (c->closure_consistent && !c->closure_escaped) ? 1 : 0; return TRM_OK;
         default: return TRM_EINVAL;
     }
 }

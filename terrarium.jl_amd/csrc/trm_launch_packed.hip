@@ -21,6 +21,7 @@ template <bool RICH, int LPC> static int launch_packed(trm_ctx* c, double dt, in
     do {                                                                                                                                           \
         if (derive == DERIVE_T_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_T_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
         else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
+        else if (derive == DERIVE_LIQ_PSI) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ_PSI>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
         else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_NONE>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);     \
     } while (0)
     if (P::hyd(c) == HYD_VG_N2) TRM_LAUNCH_PK(HYD_VG_N2);

@@ -261,14 +261,22 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     };
 
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
-    const v2f psi = RICHARDS ? ld2(v.psi, cb0, cb1) : splat(0.0f);
+    v2f psi = splat(0.0f);
+    if (RICHARDS && DERIVE == DERIVE_LIQ_PSI) {
+        // saturation_to_pressure! of the stored state, from the stored saturation and the stored water table (what the step that
+        // wrote the field evaluated: same function, same operands, same bits) instead of a fourth field read
+        const v2f z0_in = col_ld2(v.wt);
+        psi = pressure_head_hyd2<HYD>(kernarg_reload<DevParams<float>>(off_p), sat, L.zC, L.psiz, z0_in);
+    } else if (RICHARDS) {
+        psi = ld2(v.psi, cb0, cb1);
+    }
     v2f T, liq;
     if (DERIVE == DERIVE_T_LIQ) {      // both re-derived from (U, sat): two field reads less (k_column: DERIVE_T_LIQ)
         uint32_t viol_in = 0;
         (void)energy_closure2<0>(kernarg_reload<DevParams<float>>(off_p), U, sat, liq, T, viol_in);
     } else {
         T = ld2(v.T, cb0, cb1);
-        liq = DERIVE == DERIVE_LIQ ? liquid_fraction2(kernarg_reload<DevParams<float>>(off_p), U, sat) : ld2(v.liq, cb0, cb1);
+        liq = (DERIVE == DERIVE_LIQ || DERIVE == DERIVE_LIQ_PSI) ? liquid_fraction2(kernarg_reload<DevParams<float>>(off_p), U, sat) : ld2(v.liq, cb0, cb1);
     }
 
     // (bounds of the incoming state were flagged by the launch that produced it)

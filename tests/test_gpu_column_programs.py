@@ -341,3 +341,31 @@ def test_staged_per_column_outputs_forced_on_small_grids():
                           "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert " passed" in out.stdout and "failed" not in out.stdout, out.stdout[-500:]
+
+
+def test_fast_path_bookkeeping_is_what_the_steps_leave_behind():
+    """What the library tracks about its own buffers decides which kernel instance the NEXT step takes: the LandModel's surface
+    evaluation reads the compact top-cell arrays only while they describe the state, T / liq are re-derived in registers only
+    while the stored ones are the closure of the stored state.  A wrong flag costs speed, never correctness -- round 4 shipped a
+    build for an hour in which the first one was stuck at 0 (C4 +7 %, C5 +17 %) with every parity test green -- so it is pinned."""
+    lat, lon = small_columns(300)
+    w = W.make_workload("land", lat, lon, 32)
+    for steps_per_launch in (1, 0):
+        d = W.setup_device(w, steps_per_launch=steps_per_launch)
+        assert d.get_option("info_top_arrays_current") == 0 and d.get_option("info_closure_consistent") == 0     # the user's initial state
+        d.step(w["dt"], 1, finalize=False)
+        assert d.get_option("info_top_arrays_current") == 1 and d.get_option("info_closure_consistent") == 1
+        d.step(w["dt"], 7, finalize=True)
+        assert d.get_option("info_top_arrays_current") == 1 and d.get_option("info_closure_consistent") == 1
+        d.step_heun(w["dt"], 2, finalize=False)
+        assert d.get_option("info_top_arrays_current") == 1
+        d.set("temperature", d.get("temperature"))                 # an upload: the library no longer knows
+        assert d.get_option("info_top_arrays_current") == 0 and d.get_option("info_closure_consistent") == 0
+        d.step(w["dt"], 1, finalize=False)
+        assert d.get_option("info_top_arrays_current") == 1
+        d.device_array("temperature")                              # a device pointer to T has escaped: never trust the copies again
+        d.step(w["dt"], 1, finalize=False)
+        assert d.get_option("info_top_arrays_current") == 0 and d.get_option("info_closure_consistent") == 0
+    s = W.setup_device(W.make_workload("richards", lat, lon, 32))
+    s.step(w["dt"], 2, finalize=False)
+    assert s.get_option("info_top_arrays_current") == 0 and s.get_option("info_closure_consistent") == 1       # (a SoilModel has no top arrays)
