@@ -32,7 +32,10 @@ template <class... T> __device__ __forceinline__ void phase_fence_values(T&... x
 #define TRM_PHASE_FENCE(name, ...) ((void)0)
 #endif
 
-// Round-4 instruction cuts, individually switchable for same-box A/B builds (profiles/tools/r04_exp2.sh): 1 = on (default)
+// Round-4 instruction cuts, individually switchable for same-box A/B builds (profiles/tools/r04_exp2.sh, r04_exp3.sh).  Measured
+// (profiles/r04/exp3_instruction_cuts.log): together they take 27 ... 40 vector instructions per wave out of the step
+// kernels and move the step time by 0 ... -2 %; the two that put a NEW wave-uniform branch into the hot path (FLUX, POWRARE) cost
+// the HBM-resident step +4 % and are off; the others are on.
 #ifndef TRM_CUT_MASKS      // lane predicates / active masks from wave-uniform scalar masks instead of lane-wise compares
 #define TRM_CUT_MASKS 1
 #endif
@@ -42,14 +45,14 @@ template <class... T> __device__ __forceinline__ void phase_fence_values(T&... x
 #ifndef TRM_CUT_NSZ        // divides by launch constants without the sign-of-zero select where it cannot matter
 #define TRM_CUT_NSZ 1
 #endif
-#ifndef TRM_CUT_FLUX       // flux boundary terms: a select per condition that is set
-#define TRM_CUT_FLUX 1
+#ifndef TRM_CUT_FLUX       // flux boundary terms: a select per condition that is set (branches around the terms: OFF, see above)
+#define TRM_CUT_FLUX 0
 #endif
 #ifndef TRM_CUT_CHECK      // composition check of the closure reduced to what is not known by construction
 #define TRM_CUT_CHECK 1
 #endif
-#ifndef TRM_CUT_POWRARE    // the non-finite case of the compensated power as a wave-uniform rare branch
-#define TRM_CUT_POWRARE 1
+#ifndef TRM_CUT_POWRARE    // the non-finite case of the compensated power as a wave-uniform rare branch (OFF, see above)
+#define TRM_CUT_POWRARE 0
 #endif
 #ifndef TRM_CUT_FRAC       // volumetric fractions shared between a closure and the tendencies that follow it
 #define TRM_CUT_FRAC 1

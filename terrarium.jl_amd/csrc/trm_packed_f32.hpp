@@ -307,6 +307,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     // flux conditions: a term for the edge lane of every condition that is SET, nothing otherwise (column_program, trm_column.hpp)
     const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
     const bool fSb = RICHARDS && v.bc.kind[1][0] == 2, fSt = RICHARDS && (seb || v.bc.kind[1][1] == 2);
+#if TRM_CUT_FLUX
     if (fUb) flux_U = sel(is_bot, div_const2_nsz(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_U);
     if (fUt) flux_U = sel(is_top, -div_const2_nsz(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top), flux_U);
     if (fSb) flux_S = sel(is_bot, div_const2_nsz(col_ld2(bcval(v, 1, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_S);
@@ -314,6 +315,22 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         const v2f fS = col_ld2(seb ? v.infil : bcval(v, 1, 1));
         flux_S = sel(is_top, -div_const2_nsz((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top), flux_S);
     }
+#else
+    {   // both edge terms always formed, two selects per variable (the form measured faster: no select inside the branches)
+        v2f eU_b = splat(0.0f), eU_t = splat(0.0f), eS_b = splat(0.0f), eS_t = splat(0.0f);
+        if (fUb) eU_b = div_const2_nsz(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
+        if (fUt) eU_t = -div_const2_nsz(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top);
+        flux_U = sel(is_bot, eU_b, sel(is_top, eU_t, splat(0.0f)));
+        if (RICHARDS) {
+            if (fSb) eS_b = div_const2_nsz(col_ld2(bcval(v, 1, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
+            if (fSt) {
+                const v2f fS = col_ld2(seb ? v.infil : bcval(v, 1, 1));
+                eS_t = -div_const2_nsz((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top);
+            }
+            flux_S = sel(is_bot, eS_b, sel(is_top, eS_t, splat(0.0f)));
+        }
+    }
+#endif
     // surface_excess_water and the skin temperature of the two columns: READ HERE, with the other inputs.  Vector memory retires in
     // order, loads and stores through the one counter: a load issued behind a store holds the whole wave until that store has
     // been acknowledged by memory (the top-lane block used to do that three times per wave).
@@ -346,8 +363,13 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         const v2f dtheta = -((qW_hi - qW_lo) * L.rdzc) + splat(0.0f) + p.vwc_forcing;
         gS = splat(0.0f) + div_const2_nsz(dtheta, p.por, p.rpor);
     }
+#if TRM_CUT_FLUX
     if (fUb || fUt) gU += flux_U;
     if (fSb || fSt) gS += flux_S;
+#else
+    gU += flux_U;
+    if (RICHARDS) gS += flux_S;
+#endif
     // ---- explicit Euler update
     const v2f Unew = U + gU * dt;
     bool bad = (act0 && is_nan(Unew.x)) || (act1 && is_nan(Unew.y));

@@ -572,6 +572,31 @@ def test_packed_fp32_equals_scalar_bitwise(config, Nz, Nh, hydraulics):
     assert a.status() == b.status() and a.clock() == b.clock()
 
 
+@pytest.mark.parametrize("hydraulics", ["default", "vg"])
+@pytest.mark.parametrize("config,Nz,Nh", [("richards", 32, 130), ("land", 64, 77), ("land", 20, 33)])
+def test_packed_fp32_with_the_pressure_head_derived_equals_the_stored_one_bitwise(config, Nz, Nh, hydraulics):
+    """TRM_OPT_DERIVE_CLOSURE_FIELDS = 4: the packed fp32 step re-derives the liquid fraction AND the pressure head (from the stored
+    saturation and water table) instead of reading them -- the same function of the same operands the previous step stored, so the
+    same bits; an upload of the pressure head / the water table / the saturation makes the next step read the fields again."""
+    lat, lon = small_columns(Nh)
+    w = W.make_workload(config, lat, lon, Nz, dtype=np.float32, hydraulics=hydraulics)
+    a, b = W.setup_device(w), W.setup_device(w)
+    a.set_option("derive_closure_fields", 4)
+    b.set_option("derive_closure_fields", 0)
+    for d in (a, b):
+        d.step(w["dt"], 1, False)
+        d.step(w["dt"], 9, False)
+    psi = b.get("pressure_head")
+    psi[2] += 0.125                                   # a user edit of the closure field: the step after it must READ it
+    for d in (a, b):
+        d.set("pressure_head", psi)
+        d.step(w["dt"], 1, False)
+        d.step(w["dt"], 6, True)
+    for n in W.compared_fields(w):
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status() and a.clock() == b.clock()
+
+
 def test_external_stream_and_async_option():
     """trm_set_stream (a torch / HIP stream owned by the caller) + TRM_OPT_ASYNC: the launches are only enqueued, the
     caller synchronises; results equal the synchronous run on the context's own stream."""
