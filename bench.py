@@ -44,7 +44,7 @@ import numpy as np
 STABLE_STEPS = {"heat": 10 ** 9, "richards": 150, "land": 50, "landveg": 50}
 MAX_WARMUP = 40      # warm-up steps executed before the timed stretches (config.warmup_executed reports the count)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 # bytes the reference's unfused passes stream per cell and step (count of arrays each kernel reads / writes)
 REFERENCE_ORDER_BYTES_PER_CELL_STEP = {"heat": 140, "richards": 300, "land": 300, "landveg": 300}
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collects the round's profile on the GPU box (run through gpurun from the repo root):
-#   bash profiles/collect.sh r03 <commit>
+#   bash profiles/collect.sh r04 <commit>
 # Per workload, in this order:
 #   1. PMC counters in separate rocprofv3 --pmc passes (never combined with a trace) -> pmc_summary_<wl>_fused.json, copied
 #      into profiles/<round>/ ON THE BOX so that the bench runs below read the traffic of THIS kernel build;
@@ -8,9 +8,11 @@
 #      --no-cpu-baseline` -> kernel_stats_<wl>.csv: the dominant kernel's average is one row, one launch size;
 #   3. the bench line of the same command without the profiler -> bench_<wl>.json.
 # Output: gpurun_out/prof_<round>/ (scratch); copy kernel_stats_* / pmc_summary_* / bench_*.json into profiles/<round>/.
-ROUND=${1:-r03}
+ROUND=${1:-r04}
 COMMIT=${2:-unknown}
-run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+# A step that fails for ANY reason (a timeout, an abort or a fault under the profiler: rc 134 / 139, a Python error) ends the collection:
+# no GPU work follows a faulted step, and no summary is made of partial counters.
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -ne 0 ]; then echo "FAILED ($rc): $*"; ls -t $OUT/*.err 2>/dev/null | head -1 | xargs -r tail -5; exit 1; fi; return 0; }
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$ROUND
 rm -rf $OUT; mkdir -p $OUT $GRAFT_REPO_ROOT/profiles/$ROUND

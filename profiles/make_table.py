@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Markdown table of DESIGN.md section 5 from the committed profile of a round:  python profiles/make_table.py r03
+"""Markdown table of DESIGN.md section 5 from the committed profile of a round:  python profiles/make_table.py r04
 Every number is read from profiles/<round>/: bench_<wl>.json (the bench line of `bench.py --workload <wl> --no-hbm-resident
 --multistep 0 --no-cpu-baseline`), kernel_stats_<wl>.csv (rocprofv3 --kernel-trace --stats of the same command: one launch size
 per file) and pmc_summary_<wl>_fused.json (rocprofv3 --pmc passes)."""
@@ -9,7 +9,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 d = os.path.join(ROOT, rnd)
 NAMES = {"c3": "**C3** N145 × 32, heat + Richards, fp64 — headline", "c3x8": "C3 physics on 8 × N145 (HBM-resident, 0.93 GB of state)",
          "c5": "C5 812 500 × 64 LandModel fp32 (packed)", "c4": "C4 N145 LandModel, default hydraulics", "c4vg": "C4 LandModel, van Genuchten",

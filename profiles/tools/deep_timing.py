@@ -41,6 +41,44 @@ for config in ("heat", "richards"):
             ts.append(step(w["dt"], 50, finalize=False) * 1e3 / 50)
         out[f"{config}_Nz100_{name}"] = {"us_per_step": round(float(np.median(ts)), 2), "status": d.status()}
         d.close()
+# round 4: the coverage holes closed -- Heun with the generic boundary kinds (FreeDrainage: soil_model_bcs.jl:40) on Nz = 100, the
+# vegetation-coupled LandModel on Nz = 100, columns of 129 ... 256 levels (four levels per lane) -- each against the reference-order kernels
+def timed(d, step, dt, n=20):
+    d.save_state()
+    ts = []
+    for _ in range(5):
+        d.restore_state()
+        step(dt, n, finalize=False)
+        d.restore_state()
+        ts.append(step(dt, n, finalize=False) * 1e3 / n)
+    return round(float(np.median(ts)), 2)
+w = W.make_workload("richards", lat, lon, 100)
+w["bcs"][("pressure_head", "bottom")] = ("gradient", 0.0)
+for kernel in ("fused", "unfused"):
+    d = W.setup_device(w)
+    d.set_option("step_kernel", kernel)
+    d.step_heun(w["dt"], 5, finalize=False)
+    out[f"richards_Nz100_free_drainage_heun_{kernel}"] = {"us_per_step": timed(d, d.step_heun_timed, w["dt"]), "status": d.status()}
+    d.close()
+ncol = min(lat.size, 14017)
+wv = W.make_workload("landveg", lat[:ncol], lon[:ncol], 100, hydraulics="vg")
+for heun in (False, True):
+    for kernel in ("fused", "unfused"):
+        d = W.setup_device(wv)
+        d.set_option("step_kernel", kernel)
+        (d.step_heun if heun else d.step)(wv["dt"], 5, finalize=False)
+        out[f"landveg_Nz100_{'heun' if heun else 'euler'}_{kernel}"] = {"columns": ncol, "us_per_step": timed(d, d.step_heun_timed if heun else d.step_timed, wv["dt"]), "status": d.status()}
+        d.close()
+for config in ("heat", "richards"):
+    for Nz in (160, 256):
+        w = W.make_workload(config, lat[:ncol], lon[:ncol], Nz)
+        for heun in (False, True):
+            for kernel in ("fused", "unfused"):
+                d = W.setup_device(w)
+                d.set_option("step_kernel", kernel)
+                (d.step_heun if heun else d.step)(w["dt"], 5, finalize=False)
+                out[f"{config}_Nz{Nz}_{'heun' if heun else 'euler'}_{kernel}"] = {"columns": ncol, "us_per_step": timed(d, d.step_heun_timed if heun else d.step_timed, w["dt"]), "status": d.status()}
+                d.close()
 for config in ("heat", "richards"):
     out[f"{config}_per_cell_ratio_100_vs_64"] = round(out[f"{config}_Nz100_fused"]["ps_per_cell"] / out[f"{config}_Nz64_fused"]["ps_per_cell"], 3)
 print(json.dumps(out))

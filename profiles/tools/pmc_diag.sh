@@ -1,6 +1,6 @@
 # Diagnostic counter passes for the dominant step kernel of a workload (wave allocation stalls, wave / VMEM levels, L1-L2 request
 # latencies, L2-fabric stalls):   bash profiles/tools/pmc_diag.sh c3x8 [c5 ...]      -> gpurun_out/pmc_diag_<wl>.json
-run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return 0; }
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -ne 0 ]; then echo "FAILED ($rc): $*"; exit 1; fi; return 0; }
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/pmc_diag; rm -rf $OUT; mkdir -p $OUT; cd $R
 for wl in "$@"; do

@@ -348,6 +348,7 @@ template <class NF> struct Ops {
     static bool generic_bcs(const trm_ctx* c) { return P::generic_bcs(c); }
     static bool packed_path(trm_ctx* c) { return P::packed_path(c); }
     static bool deep_columns(const trm_ctx* c) { return P::deep_columns(c); }
+    static bool wide_columns(const trm_ctx* c) { return P::wide_columns(c); }
     static int series_slot(const trm_ctx* c, const trm_ctx::Series& sr) { return P::series_slot(c, sr); }
     static bool series_fit_program(const trm_ctx* c) { return P::series_fit_program(c); }
     static VegDev<NF> veg_dev(const trm_ctx* c) { return P::veg_dev(c); }
@@ -489,7 +490,7 @@ template <class NF> struct Ops {
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
         if (!rc && c->params.seb) rc = surface(c, c->state, true);
         if (!rc) {
-            rc = DeepLaunch<NF>::run(c, PROG_HEUN, generic_bcs(c), dt, finalize, 1);
+            rc = wide_columns(c) ? WideLaunch<NF>::run(c, PROG_HEUN, generic_bcs(c), dt, finalize) : DeepLaunch<NF>::run(c, PROG_HEUN, generic_bcs(c), dt, finalize, 1);
         }
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
@@ -500,6 +501,11 @@ template <class NF> struct Ops {
     // one fused ForwardEuler step (the state's surface processes have run)
     static int wave_step(trm_ctx* c, double dt, int finalize) {
         int rc = TRM_OK;
+        if (wide_columns(c)) {
+            rc = WideLaunch<NF>::run(c, PROG_EULER, generic_bcs(c), dt, finalize);
+            if (!rc) c->closure_consistent = true;
+            return rc;
+        }
         if (deep_columns(c)) {
             rc = DeepLaunch<NF>::run(c, PROG_EULER, generic_bcs(c), dt, finalize, 1);
             if (!rc) c->closure_consistent = true;
@@ -604,7 +610,9 @@ template <class NF> struct Ops {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
         // deeper takes the reference-order kernels
-        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c));
+        // the fused kernels map one soil level to one lane (two for 65 ... 128 levels, four for 129 ... 256 -- the latter without the
+        // coupled vegetation); anything deeper takes the reference-order kernels
+        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c) || (wide_columns(c) && !coupled(c)));
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
         // (columns of 65 ... 128 levels: contexts without the surface energy balance and without series)
@@ -791,7 +799,7 @@ template <class NF> struct Ops {
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c)) && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
-        if (c->opt_kernel == TRM_KERNEL_FUSED && deep_columns(c) && !coupled(c)) return heun_step_deep(c, dt, finalize);      // (every boundary kind)
+        if (c->opt_kernel == TRM_KERNEL_FUSED && (deep_columns(c) || wide_columns(c)) && !coupled(c)) return heun_step_deep(c, dt, finalize);      // (every boundary kind)
         c->top_valid = false;
         c->tend_valid = true;
         c->closure_consistent = true;   // (ends with closure!)

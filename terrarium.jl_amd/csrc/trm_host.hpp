@@ -288,6 +288,8 @@ template <class NF> struct Policy {
     }
     // columns of 65 ... 128 levels: two levels per lane, one column per wavefront (trm_column_deep.hpp)
     static bool deep_columns(const trm_ctx* c) { return c->Nz > 64 && c->Nz <= 128; }
+    // columns of 129 ... 256 levels: four levels per lane (trm_column_wide.hpp)
+    static bool wide_columns(const trm_ctx* c) { return c->Nz > 128 && c->Nz <= 256; }
     // slot of the multi-step program a series feeds, or -1 when the program cannot take it (the step then runs per launch)
     static int series_slot(const trm_ctx* c, const trm_ctx::Series& sr) {
         if (sr.is_bc) {
@@ -410,6 +412,8 @@ template <class NF> struct GenericLaunch {
 };
 // columns of 65 ... 128 levels: k_column_deep (trm_launch_deep_f64.hip / _f32.hip)
 template <class NF> struct DeepLaunch { static int run(trm_ctx* c, int prog, bool generic, double dt, int finalize, int nsteps); };
+// columns of 129 ... 256 levels, four levels per lane: k_column_wide (trm_launch_wide_f64.hip / _f32.hip)
+template <class NF> struct WideLaunch { static int run(trm_ctx* c, int prog, bool generic, double dt, int finalize); };
 // interleaved LandModel launches: k_land_euler (fp64, trm_launch_land.hip) / k_land_pk (fp32, trm_launch_packed.hip)
 template <class NF> struct LandLaunch { static int run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays); };
 template <> int LandLaunch<double>::run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays);

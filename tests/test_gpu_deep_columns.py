@@ -254,3 +254,87 @@ def test_vegetation_coupled_land_model_on_deep_columns_runs_fused(dtype, Nz, Nh,
     timed = (lambda d: d.step_heun_timed(w["dt"], 10, finalize=False)) if heun else (lambda d: d.step_timed(w["dt"], 10, finalize=False))
     ta, tb = timed(a), timed(b)
     assert ta < 0.7 * tb, (ta, tb)
+
+
+# Columns of 129 ... 256 levels: four levels per lane (csrc/trm_column_wide.hpp), ForwardEuler and Heun in one launch per step, the
+# branch-free and the generic boundary kinds -- bit for bit the reference-order kernels and the oracle; ragged level counts (the top
+# lane partly filled, an odd number of levels), ragged column counts, fp64 and fp32
+WIDE_CASES = [("heat", "default", np.float64, 129, 21), ("richards", "default", np.float64, 200, 37), ("richards", "default", np.float64, 256, 9),
+              ("richards", "vg", np.float64, 131, 12), ("land", "default", np.float64, 160, 17), ("richards", "default", np.float32, 254, 15),
+              ("land", "vg", np.float32, 130, 10)]
+
+
+@pytest.mark.parametrize("heun", [False, True])
+@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("config,hydraulics,dtype,Nz,Nh", WIDE_CASES)
+def test_wide_columns_run_fused_and_equal_the_reference_order_kernels_bitwise(config, hydraulics, dtype, Nz, Nh, generic, heun):
+    lat, lon = small_columns(Nh)
+    w = W.make_workload(config, lat, lon, Nz, dtype=dtype, hydraulics=hydraulics)
+    rng = np.random.default_rng(13)
+    if generic:
+        w["bcs"][("liquid_water_fraction", "top")] = ("gradient", 0.1)
+        if config == "heat":
+            w["bcs"][("temperature", "bottom")] = ("gradient", 0.01)
+        else:
+            w["bcs"].update({("temperature", "bottom"): ("value", w["T0"] - 1.0), ("pressure_head", "bottom"): ("gradient", 0.0)})     # FreeDrainage()
+            if config == "richards":
+                w["bcs"][("pressure_head", "top")] = ("value", np.full(Nh, -0.3))
+    else:
+        w["bcs"][("internal_energy", "bottom")] = ("flux", np.full(Nh, 0.05))
+        if config == "richards":
+            w["bcs"][("saturation_water_ice", "top")] = ("flux", -2.0e-7 * rng.random(Nh))
+    a, b = W.setup_device(w), W.setup_device(w)
+    b.set_option("step_kernel", "unfused")
+    o = W.setup_oracle(w) if (dtype == np.float64 and hydraulics == "default" and config != "land") else None
+    if config != "land" and not (generic and config == "heat"):      # a time-dependent boundary temperature: the Heun stage takes it at t + dt
+        times = w["dt"] * np.arange(0, 20)
+        side = "bottom" if generic else "top"
+        vals = np.stack([w["T0"] + (-1.0 if generic else 10.0 * np.sin(2 * np.pi * t / 86400.0 - lon)) + 0.01 * t / w["dt"] for t in times])
+        for d in (a, b) + ((o,) if o is not None else ()):
+            d.set_bc_series("temperature", side, "value", times, vals)
+    nsteps = 14
+    step = (lambda d, n, fin: d.step_heun(w["dt"], n, finalize=fin)) if heun else (lambda d, n, fin: d.step(w["dt"], n, finalize=fin))
+    for d in (a, b):
+        step(d, 1, False)
+        step(d, nsteps - 2, False)
+        step(d, 1, True)
+    names = W.compared_fields(w) + ["tend_internal_energy"] + (["tend_saturation_water_ice", "tend_surface_excess_water"] if config != "heat" else [])
+    for n in names:
+        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
+    assert a.status() == b.status() and a.clock() == b.clock()
+    if o is not None:
+        for k in range(nsteps):
+            (o.timestep_heun if heun else o.timestep)(w["dt"], True)
+        for n in W.compared_fields(w):
+            assert np.array_equal(a.get(n), o.get(n)), n
+    timed = (lambda d: d.step_heun_timed(w["dt"], 10, finalize=False)) if heun else (lambda d: d.step_timed(w["dt"], 10, finalize=False))
+    ta, tb = timed(a), timed(b)
+    assert ta < 0.6 * tb, (ta, tb)          # one launch per step against the reference-order sequence
+
+
+def test_saturation_repair_inside_the_wide_fused_step():
+    """The lane-serial repair passes with four levels per lane: strong infiltration into a nearly saturated 200-level column with
+    saturated pockets -- oversaturation travels up through lanes and slots, the top overflows (soil_hydrology.jl:185-219)."""
+    import oracle
+    grid = trm.ColumnGrid(trm.UniformSpacing(dz=0.05, N=200), 11)
+    rng = np.random.default_rng(4)
+    sat = np.clip(0.97 + 0.02 * rng.normal(size=(200, 11)), 0.0, 1.0)
+    sat[-1] = 0.999
+    sat[77:83, ::2] = 1.0
+    sat[150:153, 1::3] = 1.0
+    integ = trm.initialize(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq()))),
+                           trm.ForwardEuler(dt=30.0), boundary_conditions=trm.InfiltrationFlux(-5.0e-5),
+                           initializers=dict(temperature=3.0, saturation_water_ice=sat))
+    st = integ.state
+    st.set_option("steps_per_launch", 1)
+    o = oracle.Oracle(11, grid.thickness, oracle.default_params(flow=1))
+    o.set("temperature", 3.0); o.set("saturation_water_ice", sat)
+    o.set_bc("saturation_water_ice", "top", "flux", -5.0e-5)
+    o.initialize()
+    trm.run(integ, steps=25)
+    o.run(30.0, 25)
+    assert np.any(st.surface_excess_water > 0)
+    s = st.saturation_water_ice
+    assert s.min() >= 0.0 and s.max() <= 1.0
+    for n in ("saturation_water_ice", "surface_excess_water", "water_table", "pressure_head", "internal_energy", "temperature", "hydraulic_conductivity"):
+        assert np.array_equal(st.get(n), o.get(n)), n
