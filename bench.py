@@ -384,7 +384,8 @@ def main():
         # ONE host thread driving one context per device (the reference's host is one Julia process): rank 0 alone, the other
         # ranks idle at the barrier below
         if rank == 0:
-            out["single_process"] = single_process_leg(W, parallel, args, list(range(world)) if world > 1 else [local_rank, local_rank], torch)
+            ndev = torch.cuda.device_count()      # (a rehearsal with several ranks on one GPU: the contexts share it)
+            out["single_process"] = single_process_leg(W, parallel, args, [d % ndev for d in range(world)] if world > 1 else [local_rank, local_rank], torch)
         if world > 1:
             dist.barrier()
 
