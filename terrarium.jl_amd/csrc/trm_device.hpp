@@ -22,10 +22,11 @@ namespace trm {
 template <class T> __device__ __forceinline__ void phase_opaque(T& x) { asm volatile("" : "+v"(x)); }
 template <class... T> __device__ __forceinline__ void phase_fence_values(T&... x) { (phase_opaque(x), ...); }
 }
+// (the comment FIRST: volatile asms keep their order, so everything that depends on a fenced value follows the comment line)
 #define TRM_PHASE_FENCE(name, ...)                 \
     do {                                           \
-        ::trm::phase_fence_values(__VA_ARGS__);    \
         asm volatile("; TRM_PHASE " name);         \
+        ::trm::phase_fence_values(__VA_ARGS__);    \
     } while (0)
 #else
 #define TRM_PHASE(name) ((void)0)

@@ -208,6 +208,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     using namespace pk;
     typedef float NF;
     constexpr int CPW = 64 / LPC;   // column PAIRS per wave
+    TRM_PHASE("addressing");
     const int lane = threadIdx.x & 63;
     // (the wave index and what follows from it alone on the scalar unit; lane predicates from wave-uniform masks: lane_in)
 #if TRM_CUT_MASKS
@@ -260,6 +261,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         return v2f{upper ? a2 : a0, upper ? a3 : a1};
     };
 
+    TRM_PHASE("loads+derive");
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
     v2f psi = splat(0.0f);
     if (RICHARDS && DERIVE == DERIVE_LIQ_PSI) {
@@ -279,13 +281,15 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         liq = (DERIVE == DERIVE_LIQ || DERIVE == DERIVE_LIQ_PSI) ? liquid_fraction2(kernarg_reload<DevParams<float>>(off_p), U, sat) : ld2(v.liq, cb0, cb1);
     }
 
+    TRM_PHASE_FENCE("cell properties", T, liq, psi);
     // (bounds of the incoming state were flagged by the launch that produced it)
     const Frac2 f = fractions2_unchecked(p, sat, liq);
     const v2f kap = conductivity2(p, f);
     const v2f Kc = need_kc ? conductivity_hydraulic2<HYD>(p, liq, f) : splat(0.0f);
 
-    const v2f T_sh = up2(T), kap_sh = up2(kap);
+    v2f T_sh = up2(T), kap_sh = up2(kap);
     v2f flux_U = splat(0.0f), flux_S = splat(0.0f);
+    TRM_PHASE_FENCE("inputs", T_sh, kap_sh);
     // ---- boundary conditions: one wave-uniform branch per condition that is not set (k_step_wave, GENERIC_BC = false)
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
     v2f T_ext_b = T, T_ext_t = T;
@@ -297,12 +301,12 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         const v2f b = col_ld2(bcval(v, 2, 1));
         T_ext_t = T + div_const2_nsz(b - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
     }
-    const v2f T_m = sel(is_bot, T_ext_b, T_sh);
-    const v2f T_h = T_ext_t;
+    v2f T_m = sel(is_bot, T_ext_b, T_sh);
+    v2f T_h = T_ext_t;
     v2f kap_halo = kap;
     if (!RICHARDS && p.halo_policy != 1) kap_halo = conductivity2(p, fractions2(p, splat(0.0f), liq, viol));
-    const v2f kap_m = sel(is_bot, kap_halo, kap_sh);
-    const v2f kap_h = kap_halo;
+    v2f kap_m = sel(is_bot, kap_halo, kap_sh);
+    v2f kap_h = kap_halo;
     const bool seb = p.seb != 0;
     // flux conditions: a term for the edge lane of every condition that is SET, nothing otherwise (column_program, trm_column.hpp)
     const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
@@ -336,6 +340,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     // been acknowledged by memory (the top-lane block used to do that three times per wave).
     const v2f S_in = RICHARDS ? col_ld2(v.S) : splat(0.0f);
     const v2f Ts_in = seb ? col_ld2(v.Ts) : splat(0.0f);
+    TRM_PHASE_FENCE("tendencies", flux_U, flux_S, T_m, T_h, kap_m, kap_h, psi);
     // ---- heat
     const v2f qT_lo = -((kap + kap_m) * 0.5f) * ((T - T_m) * L.rdzf_lo);
     const v2f qT_sh = dn2(qT_lo);
@@ -370,6 +375,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     gU += flux_U;
     if (RICHARDS) gS += flux_S;
 #endif
+    TRM_PHASE_FENCE("advance", gU, gS, Kf_lo);
     // ---- explicit Euler update
     const v2f Unew = U + gU * dt;
     bool bad = (act0 && is_nan(Unew.x)) || (act1 && is_nan(Unew.y));
@@ -386,11 +392,13 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         GS_top = v2f{0.0f + jl_min(0.0f, S_in.x), 0.0f + jl_min(0.0f, S_in.y)};
         S_out = v2f{(S_in.x + GS_top.x * dt) + over0, (S_in.y + GS_top.y * dt) + over1};
     }
+    TRM_PHASE_FENCE("closure", snew, z0, S_out, GS_top);
     // ---- closures
     v2f ln, Tn;
     const DevParams<float>& p2 = kernarg_reload<DevParams<float>>(off_p);   // (second half of the step: see kernarg_reload)
     const Frac2 f_new = energy_closure2<RICHARDS ? 2 : 1>(p2, Unew, snew, ln, Tn, viol);
     const v2f psin = RICHARDS ? pressure_head_hyd2<HYD>(p2, snew, L.zC, L.psiz, z0) : splat(0.0f);
+    TRM_PHASE_FENCE("outputs", ln, Tn);
     v2f Kf_out = Kf_lo, Kf_out_top = Kc;
     if (finalize && write_kf) {
         const v2f Kc_new = conductivity_hydraulic2<HYD>(p, ln, f_new);      // (the closure has checked this composition)
@@ -443,6 +451,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     v2f Ts_new = splat(0.0f);
     if (seb) Ts_new = Ts_in + splat(0.0f) * dt;     // zero-tendency prognostic skin_temperature
     asm volatile("" : "+v"(Ts_new), "+v"(S_out), "+v"(GS_top));
+    TRM_PHASE("stores");
     const int cib0 = ((int)(threadIdx.x >> 6) * CPW + sub) * 2;
     store(act0, cib0, cb0, ib0, Unew.x, Tn.x, ln.x, snew.x, psin.x, Kf_out.x, Kf_out_top.x, gU.x, gS.x, S_out.x, GS_top.x, z0.x, Ts_new.x);
     store(act1, cib0 + 1, cb1, ib1, Unew.y, Tn.y, ln.y, snew.y, psin.y, Kf_out.y, Kf_out_top.y, gU.y, gS.y, S_out.y, GS_top.y, z0.y, Ts_new.y);
