@@ -848,7 +848,7 @@ struct EnvSwitches {
     EnvSwitches() {
         long v;
         if (parse_env_int("TRM_FIELD_SKEW", 0, 1 << 20, 256, v, error)) field_skew = v;
-        if (error.empty() && parse_env_int("TRM_DERIVE_DEFAULT", 0, 4, 1, v, error)) derive_default = v;
+        if (error.empty() && parse_env_int("TRM_DERIVE_DEFAULT", 0, 5, 1, v, error)) derive_default = v;
         if (error.empty() && parse_env_int("TRM_STAGED_SMALL", 0, 1, 1, v, error)) { /* read by Policy::staged_now */ }
         if (error.empty() && parse_env_int("TRM_SCALAR_INPUTS", 0, 1, 1, v, error)) { /* read by Policy::scalar_inputs_now */ }
     }
@@ -2436,7 +2436,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
         case TRM_OPT_VWC_FORCING_FIELD: c->opt_vwc_field = value != 0; return TRM_OK;
         case TRM_OPT_PACKED_F32: c->opt_packed = value != 0; return TRM_OK;
         case TRM_OPT_DERIVE_CLOSURE_FIELDS:
-            if (value < 0 || value > 4) break;
+            if (value < 0 || value > 5) break;
             c->opt_derive = value;
             return TRM_OK;
         case TRM_OPT_STEPS_PER_LAUNCH:

@@ -303,9 +303,10 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     Cell<NF> c;
     c.U = ldg(v.U, cb0);
     c.sat = ldg(v.sat, cb0);
-    c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
+    constexpr bool DERIVE_TL = DERIVE == DERIVE_T_LIQ || DERIVE == DERIVE_ALL;
+    c.psi = (RICHARDS && DERIVE != DERIVE_ALL) ? ldg(v.psi, cb0) : NF(0);
     Frac<NF> f_in{};          // the incoming cell's volumetric fractions, when the derivation has formed them
-    if (DERIVE == DERIVE_T_LIQ) {
+    if (DERIVE_TL) {
         uint32_t viol_in = 0;
         f_in = energy_closure_wave<NF, 0>(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat, c.liq, c.T, viol_in);   // (its scalars die right here)
     } else if (DERIVE == DERIVE_LIQ) {
@@ -334,6 +335,11 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         const NF x1 = sld_off<NF>(ptr, jo1);
         return upper ? x1 : x0;
     };
+    if (RICHARDS && DERIVE == DERIVE_ALL) {
+        // saturation_to_pressure! of the stored state from the stored saturation and the stored water table: what the launch that
+        // wrote the field evaluated (column_closure: same function, same operands, same bits) instead of a third field read
+        c.psi = pressure_head<NF, HYD>(kernarg_reload<DevParams<NF>>(off_p), c.sat, L.zC, L.psiz, col_ld(v.wt));
+    }
     bc.bTb = vTb ? col_ld(bcval(v, 2, 0)) : NF(0);
     bc.bTt = vTt ? col_ld(bcval(v, 2, 1)) : NF(0);
     {   // flux conditions: a term for the edge lane of every condition that is SET (wave-uniform branches), nothing otherwise.
@@ -400,7 +406,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     Frac<NF> f_new{};                      // volumetric fractions of the new state (its closure forms them)
     if (PROG == PROG_HEUN) {
         // stage 1: tendencies at the state, Euler predictor (with the state's boundary fluxes) and its closures
-        t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol, DERIVE == DERIVE_T_LIQ ? &f_in : nullptr);
+        t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol, DERIVE_TL ? &f_in : nullptr);
         const NF G1U = t.gU, G1S = t.gS;
         NF gU = G1U, gS = G1S, z0s;
         Cell<NF> s;
@@ -488,7 +494,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             }
             TRM_PHASE_FENCE("tendencies", c.U, c.sat, c.psi, c.T, c.liq, bc.bTb, bc.bTt, bc.flux_U, bc.flux_S, S_in, Ts_in);
             // (the cell's fractions: from the derivation at entry, from the previous step's closure inside the multi-step loop)
-            const Frac<NF>* pre = (PROG == PROG_MULTI && step > 0) ? &f_new : (DERIVE == DERIVE_T_LIQ ? &f_in : nullptr);
+            const Frac<NF>* pre = (PROG == PROG_MULTI && step > 0) ? &f_new : (DERIVE_TL ? &f_in : nullptr);
             t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol, pre);
             NF gU = t.gU, gS = t.gS;
             TRM_PHASE_FENCE("advance", gU, gS, t.Kf_lo, t.Kc);

@@ -248,6 +248,7 @@ template <class NF> struct Policy {
         if (!c->closure_consistent || c->closure_escaped || coupled(c) || c->opt_derive == 0) return DERIVE_NONE;
         if (c->opt_derive == 1) return DERIVE_T_LIQ;
         if (c->opt_derive == 3) return DERIVE_LIQ;
+        if (c->opt_derive == 5) return (std::is_same<NF, double>::value && RICH) ? DERIVE_ALL : DERIVE_T_LIQ;   // (experiment: psi derived as well)
         if (c->opt_derive == 4) return (std::is_same<NF, float>::value && RICH && packed_path(const_cast<trm_ctx*>(c))) ? DERIVE_LIQ_PSI : DERIVE_LIQ;
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
         const bool beyond_cache = state_bytes > ((size_t)256 << 20);

@@ -63,7 +63,8 @@ template <class NF> struct View {
 };
 // which closure fields of the incoming state a fused step re-derives from (U, sat) instead of reading (TRM_OPT_DERIVE_CLOSURE_FIELDS)
 enum { DERIVE_NONE = 0, DERIVE_T_LIQ = 1, DERIVE_LIQ = 2,
-       DERIVE_LIQ_PSI = 3 };   // (packed fp32 step only) the liquid fraction AND the pressure head: psi = psi(sat, water table), two reads less
+       DERIVE_LIQ_PSI = 3,     // (packed fp32 step only) the liquid fraction AND the pressure head: psi = psi(sat, water table), two reads less
+       DERIVE_ALL = 4 };       // (fp64 column program, Richards) T, liq AND psi: the step reads U and sat alone
 enum { SMALL_KF_TOP = 0, SMALL_S, SMALL_WT, SMALL_G_S, SMALL_TOP_T, SMALL_TOP_SAT, SMALL_TOP_LIQ, SMALL_TS, SMALL_COUNT };
 template <class NF> inline void fill_small_table(View<NF>& v) {
     v.small[SMALL_KF_TOP] = v.Kf_top; v.small[SMALL_S] = v.S; v.small[SMALL_WT] = v.wt; v.small[SMALL_G_S] = v.G_S;

@@ -48,6 +48,14 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
                 else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, false>), grid, block, 0, c->stream, v, p, a);
             }
         }
+        else if (derive == DERIVE_ALL) {
+            if constexpr (std::is_same<NF, double>::value && RICH) {
+                const int staged = P::template staged_now<RICH>(c), scalar_in = P::template scalar_inputs_now<RICH>(c);
+                if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
+                else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
+                else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
+            }
+        }
         else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
         else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
     } else {
