@@ -338,6 +338,8 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     if (RICHARDS && DERIVE == DERIVE_ALL) {
         // saturation_to_pressure! of the stored state from the stored saturation and the stored water table: what the launch that
         // wrote the field evaluated (column_closure: same function, same operands, same bits) instead of a third field read
+        // (re-deriving the water table as well -- a ballot of the stored saturation and a scalar search instead of the per-column
+        // load -- is slower still: profiles/r04/exp5b)
         c.psi = pressure_head<NF, HYD>(kernarg_reload<DevParams<NF>>(off_p), c.sat, L.zC, L.psiz, col_ld(v.wt));
     }
     bc.bTb = vTb ? col_ld(bcval(v, 2, 0)) : NF(0);
