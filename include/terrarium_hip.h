@@ -190,14 +190,20 @@ enum {
                                     /* surface processes inline for the single step -- ONE launch instead of the k_surface +        */
                                     /* k_column pair; 0: the launch pair; 2 (default): the library's rule (small shards, where the  */
                                     /* step is bound by launch latency: DESIGN 4.9)                                                  */
+    ,TRM_OPT_BC_SIGNATURE = 9       /* 1 (default): a per-step ForwardEuler launch whose boundary kinds match one of the signatures    */
+                                    /* compiled into the library (none; prescribed surface temperature; that + a bottom heat flux;    */
+                                    /* the LandModel wiring) takes the program with the kinds as compile-time constants (-3 ... -5 %, */
+                                    /* DESIGN 4.3); 0: always the program that reads the kinds at run time (same results; A/B, tests)  */
 };
 /* DIAGNOSTIC, read-only (trm_get_option): which fast paths the NEXT step will take -- what the library tracks about its own
  * buffers.  Tests pin them (a wrong value costs speed, never correctness, so nothing else would notice). */
 enum {
     TRM_INFO_TOP_ARRAYS_CURRENT = 100, /* 1: the LandModel's next surface evaluation reads the compact top-cell arrays the last   */
                                        /* fused step wrote (coalesced) instead of gathering one word per column from the fields   */
-    TRM_INFO_CLOSURE_CONSISTENT = 101  /* 1: the stored temperature / liquid fraction are the closure of the stored state, so a  */
+    TRM_INFO_CLOSURE_CONSISTENT = 101,  /* 1: the stored temperature / liquid fraction are the closure of the stored state, so a  */
                                        /* step may re-derive them in registers (TRM_OPT_DERIVE_CLOSURE_FIELDS)                   */
+    TRM_INFO_BC_SIGNATURE = 102        /* the boundary-condition signature of the context's current kinds (BCSIG bits: 1 / 2 Value on  */
+                                       /* temperature bottom / top, 4 / 8 Flux on energy / saturation bottom, 16 / 32 top, 64 LandModel) */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

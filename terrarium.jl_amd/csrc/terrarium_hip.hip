@@ -2451,6 +2451,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             if (value < 0 || value > 2) break;
             c->opt_single_step = value;
             return TRM_OK;
+        case TRM_OPT_BC_SIGNATURE: c->opt_bc_signature = value != 0; return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -2467,6 +2468,8 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_STEPS_PER_LAUNCH: *value = c->opt_steps_per_launch; return TRM_OK;
         case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
         case TRM_OPT_SINGLE_STEP_PROGRAM: *value = c->opt_single_step; return TRM_OK;
+        case TRM_OPT_BC_SIGNATURE: *value = c->opt_bc_signature; return TRM_OK;
+        case TRM_INFO_BC_SIGNATURE: *value = trmh::bc_signature_of(c); return TRM_OK;
         case TRM_INFO_TOP_ARRAYS_CURRENT: *value = c->top_valid ? 1 : 0; return TRM_OK;
         case TRM_INFO_CLOSURE_CONSISTENT: *value = (c->closure_consistent && !c->closure_escaped) ? 1 : 0; return TRM_OK;
         default: return TRM_EINVAL;

@@ -240,7 +240,7 @@ template <class NF> struct ColumnArgs {
 // those that run the program.
 // STAGED / SCALAR_IN: how the per-column outputs leave and the per-column inputs arrive (see below) -- compile-time: as
 // wave-uniform run-time branches they cost the field loads their back-to-back issue (profiles/r03/exp28: 8 x N145 +7 %).
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true>
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME>
 TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, const ColumnArgs<NF>& a, unsigned block) {
     // (kernarg layout: the arguments in order, each at its natural alignment)
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
@@ -320,8 +320,10 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     }
     // ---- boundary inputs of the column --------------------------------------------------------------------------------
     TRM_PHASE_FENCE("inputs", c.U, c.sat, c.psi, c.T, c.liq);
-    const bool seb = p.seb != 0;
-    const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
+    // (BCSIG >= 0: the launcher has matched the context's kinds against the signature -- constants from here on)
+    constexpr bool SIG = BCSIG >= 0;
+    const bool seb = SIG ? (BCSIG & BCSIG_LAND) != 0 : p.seb != 0;
+    const bool vTb = SIG ? (BCSIG & BCSIG_T_BOT) != 0 : v.bc.kind[2][0] == 1, vTt = SIG ? (BCSIG & BCSIG_T_TOP) != 0 : v.bc.kind[2][1] == 1;
     ColumnBC<NF> bc;
     // The per-column inputs (boundary values, LandModel's ground heat flux / infiltration, the 0-D fields) come through the
     // scalar memory path (sld): one s_load per column of the wave, selected per half-wave -- where the state is cache-resident
@@ -347,8 +349,9 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     {   // flux conditions: a term for the edge lane of every condition that is SET (wave-uniform branches), nothing otherwise.
         // (flux_term_*_nsz: the term is added to a tendency that is never -0.0, so the sign of a zero term is immaterial)
         NF fU = NF(0), fS = NF(0);
-        const bool bU = v.bc.kind[0][0] == 2, bS = RICHARDS && v.bc.kind[1][0] == 2;
-        const bool tU = !SEB_INLINE && (seb || v.bc.kind[0][1] == 2), tS = RICHARDS && !SEB_INLINE && (seb || v.bc.kind[1][1] == 2);
+        const bool bU = SIG ? (BCSIG & BCSIG_FU_BOT) != 0 : v.bc.kind[0][0] == 2, bS = RICHARDS && (SIG ? (BCSIG & BCSIG_FS_BOT) != 0 : v.bc.kind[1][0] == 2);
+        const bool tU = !SEB_INLINE && (seb || (SIG ? (BCSIG & BCSIG_FU_TOP) != 0 : v.bc.kind[0][1] == 2));
+        const bool tS = RICHARDS && !SEB_INLINE && (seb || (SIG ? (BCSIG & BCSIG_FS_TOP) != 0 : v.bc.kind[1][1] == 2));
 #if TRM_CUT_FLUX
         if (bU) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 0, 0)), v.g); fU = ln.is_bot ? e : fU; }
         if (bS) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 1, 0)), v.g); fS = ln.is_bot ? e : fS; }
@@ -607,14 +610,14 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     if (viol && ln.act) atomicOr(v_arg.status, viol);
 }
 
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true>
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     __attribute__((amdgpu_waves_per_eu(PROG == PROG_EULER ? (HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5) : (PROG == PROG_HEUN ? 5 : (HYD == HYD_BC_LINEAR ? 4 : 3)), 8)))
 #ifdef TRM_COLUMN_NUM_SGPR
     __attribute__((amdgpu_num_sgpr(TRM_COLUMN_NUM_SGPR)))
 #endif
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
-    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES, STAGED, SCALAR_IN>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES, STAGED, SCALAR_IN, BCSIG>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
 }
 
 // ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the

@@ -102,6 +102,7 @@ struct trm_ctx {
     // Two halves of the columns (TRM_OPT_PIPELINE_PARTS): the per-step LandModel path runs the latency-bound 0-D surface
     // processes of one half in the same launch as the soil columns of the other (k_land_euler).  Columns are independent.
     int opt_pipeline = 2;           // 0: off, 1: whenever legal, 2: auto (column threshold)
+    int opt_bc_signature = 1;       // TRM_OPT_BC_SIGNATURE: 1 the program with the boundary kinds compiled in where one matches
     int opt_single_step = 2;        // TRM_OPT_SINGLE_STEP_PROGRAM: 0 off, 1 whenever legal, 2 the library's rule
     int part = -1;                  // part the launch helpers currently address (-1: all columns)
     long part_lo[2] = {0, 0}, part_n[2] = {0, 0};
@@ -371,6 +372,14 @@ template <class NF> struct Policy {
         return v;
     }
 };
+// the context's boundary kinds as a BCSIG signature (trm_kernels.hpp); meaningful where the branch-free kinds hold (Policy::generic_bcs)
+inline int bc_signature_of(const trm_ctx* c) {
+    const bool rich = c->params.flow == TRM_FLOW_RICHARDS;
+    int sig = (c->bc_kind[TRM_BCV_TEMPERATURE][0] == TRM_BC_VALUE ? BCSIG_T_BOT : 0) | (c->bc_kind[TRM_BCV_TEMPERATURE][1] == TRM_BC_VALUE ? BCSIG_T_TOP : 0) |
+              (c->bc_kind[TRM_BCV_INTERNAL_ENERGY][0] == TRM_BC_FLUX ? BCSIG_FU_BOT : 0) | ((rich && c->bc_kind[TRM_BCV_SATURATION_WATER_ICE][0] == TRM_BC_FLUX) ? BCSIG_FS_BOT : 0);
+    if (c->params.seb) return sig | BCSIG_LAND;      // (the LandModel's wiring owns the top flux conditions: land_model.jl:56-61)
+    return sig | (c->bc_kind[TRM_BCV_INTERNAL_ENERGY][1] == TRM_BC_FLUX ? BCSIG_FU_TOP : 0) | ((rich && c->bc_kind[TRM_BCV_SATURATION_WATER_ICE][1] == TRM_BC_FLUX) ? BCSIG_FS_TOP : 0);
+}
 #define TRM_BY_HYD(c, CALL)                                   \
     switch (::trmh::Policy<NF>::hyd(c)) {                     \
         case HYD_BC_LINEAR: { constexpr int H = HYD_BC_LINEAR; CALL; } break; \
@@ -406,6 +415,11 @@ template <class NF> struct Veg {
 };
 // the register-resident column programs k_column (trm_launch_column*.hip: one file per precision x program)
 template <class NF, bool RICH, int PROG> struct ColumnLaunch { static int run(trm_ctx* c, double dt, int finalize, int nsteps); };
+// the ForwardEuler program with the derivation of T / liq and the boundary-condition signature compiled in (BCSIG, trm_kernels.hpp):
+// one explicit instantiation per signature in the trm_launch_column_sig_*.hip files; `supported` lists them.
+template <class NF, bool RICH, int SIG> struct ColumnSigLaunch {
+    static void run(trm_ctx* c, const View<NF>& v, const DevParams<NF>& p, const ColumnArgs<NF>& a, dim3 grid, dim3 block, int lpc, int staged, int scalar_in);
+};
 // generic boundary kinds: k_step_wave (Euler) and k_heun_generic (trm_launch_generic*.hip)
 template <class NF> struct GenericLaunch {
     static int step(trm_ctx* c, double dt, int finalize);

@@ -61,6 +61,15 @@ template <class NF> struct View {
     // G_S, top_T, top_sat, top_liq, Ts -- the same pointers as above, as a table a lane can index
     NF* small[8];
 };
+// The boundary-condition SIGNATURE of a launch as a compile-time constant (template parameter BCSIG of the per-step column programs;
+// -1 = read the kinds at run time).  The kinds are wave-uniform run-time values, each one a scalar compare and a branch around a
+// conditional load in front of the column's arithmetic; compiled in they cost the Euler program 3 ... 5 % of its time
+// (profiles/r04/exp6_diag_bc_signature.log).  The launchers instantiate the signatures of the reference's examples and models.
+enum { BCSIG_RUNTIME = -1,
+       BCSIG_T_BOT = 1, BCSIG_T_TOP = 2,      // Value on temperature, bottom / top
+       BCSIG_FU_BOT = 4, BCSIG_FS_BOT = 8,    // Flux on internal energy / saturation, bottom
+       BCSIG_FU_TOP = 16, BCSIG_FS_TOP = 32,  // Flux on internal energy / saturation, top
+       BCSIG_LAND = 64 };                     // LandModel: ground heat flux and infiltration wired to the top (land_model.jl:56-61)
 // which closure fields of the incoming state a fused step re-derives from (U, sat) instead of reading (TRM_OPT_DERIVE_CLOSURE_FIELDS)
 enum { DERIVE_NONE = 0, DERIVE_T_LIQ = 1, DERIVE_LIQ = 2,
        DERIVE_LIQ_PSI = 3,     // (packed fp32 step only) the liquid fraction AND the pressure head: psi = psi(sat, water table), two reads less

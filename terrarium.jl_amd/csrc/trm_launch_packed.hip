@@ -17,9 +17,13 @@ template <bool RICH, int LPC> static int launch_packed(trm_ctx* c, double dt, in
     const int derive = P::derive_now<RICH>(c);
     const int staged = P::staged_now<RICH>(c, true);
     const dim3 blk(TRM_STEP_BLOCK);
+    // (the boundary kinds compiled in for the signatures that have an instance: TRM_OPT_BC_SIGNATURE, trm_kernels.hpp BCSIG)
+    const int sig = c->opt_bc_signature ? bc_signature_of(c) : -1;
 #define TRM_LAUNCH_PK(HYDV)                                                                                                                        \
     do {                                                                                                                                           \
         if (derive == DERIVE_T_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_T_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
+        else if (derive == DERIVE_LIQ && RICH && sig == BCSIG_LAND) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ, RICH ? BCSIG_LAND : BCSIG_RUNTIME>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
+        else if (derive == DERIVE_LIQ && RICH && sig == BCSIG_T_TOP) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ, RICH ? BCSIG_T_TOP : BCSIG_RUNTIME>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
         else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
         else if (derive == DERIVE_LIQ_PSI) hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_LIQ_PSI>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged); \
         else hipLaunchKernelGGL((k_step_pk<RICH, LPC, HYDV, DERIVE_NONE>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged);     \

@@ -200,7 +200,7 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // per step -- the packed kernel is not short of bytes -- and is not offered.)
 // DERIVE_LIQ: the incoming liquid fraction is re-derived from (U, sat) instead of being read (legal when the stored fields
 // are the closure of the stored state, trm_ctx::closure_consistent): one of the five field reads less.
-template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE>
+template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE, int BCSIG = BCSIG_RUNTIME>
 TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p_arg, float dt, int finalize, int write_kf, unsigned block, int staged = 0) {
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
@@ -291,7 +291,8 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     v2f flux_U = splat(0.0f), flux_S = splat(0.0f);
     TRM_PHASE_FENCE("inputs", T_sh, kap_sh);
     // ---- boundary conditions: one wave-uniform branch per condition that is not set (k_step_wave, GENERIC_BC = false)
-    const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
+    constexpr bool SIG = BCSIG >= 0;      // (the boundary kinds as compile-time constants: BCSIG, trm_kernels.hpp)
+    const bool vTb = SIG ? (BCSIG & BCSIG_T_BOT) != 0 : v.bc.kind[2][0] == 1, vTt = SIG ? (BCSIG & BCSIG_T_TOP) != 0 : v.bc.kind[2][1] == 1;
     v2f T_ext_b = T, T_ext_t = T;
     if (vTb) {
         const v2f b = col_ld2(bcval(v, 2, 0));
@@ -307,10 +308,10 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     if (!RICHARDS && p.halo_policy != 1) kap_halo = conductivity2(p, fractions2(p, splat(0.0f), liq, viol));
     v2f kap_m = sel(is_bot, kap_halo, kap_sh);
     v2f kap_h = kap_halo;
-    const bool seb = p.seb != 0;
+    const bool seb = SIG ? (BCSIG & BCSIG_LAND) != 0 : p.seb != 0;
     // flux conditions: a term for the edge lane of every condition that is SET, nothing otherwise (column_program, trm_column.hpp)
-    const bool fUb = v.bc.kind[0][0] == 2, fUt = seb || v.bc.kind[0][1] == 2;
-    const bool fSb = RICHARDS && v.bc.kind[1][0] == 2, fSt = RICHARDS && (seb || v.bc.kind[1][1] == 2);
+    const bool fUb = SIG ? (BCSIG & BCSIG_FU_BOT) != 0 : v.bc.kind[0][0] == 2, fUt = seb || (SIG ? (BCSIG & BCSIG_FU_TOP) != 0 : v.bc.kind[0][1] == 2);
+    const bool fSb = RICHARDS && (SIG ? (BCSIG & BCSIG_FS_BOT) != 0 : v.bc.kind[1][0] == 2), fSt = RICHARDS && (seb || (SIG ? (BCSIG & BCSIG_FS_TOP) != 0 : v.bc.kind[1][1] == 2));
 #if TRM_CUT_FLUX
     if (fUb) flux_U = sel(is_bot, div_const2_nsz(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_U);
     if (fUt) flux_U = sel(is_top, -div_const2_nsz(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top), flux_U);
@@ -465,9 +466,9 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u);
     if (flags) atomicOr(v.status, flags);
 }
-template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE>
+template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE, int BCSIG = BCSIG_RUNTIME>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf, int staged) {
-    step_pk_program<RICHARDS, LPC, HYD, DERIVE>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x), staged);
+    step_pk_program<RICHARDS, LPC, HYD, DERIVE, BCSIG>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x), staged);
 }
 // LandModel in fp32: the packed column step of one half of the columns beside the surface processes of the other half in one
 // launch (k_land_euler, trm_column.hpp).  (View, DevParams) first: step_pk_program re-reads them from the kernarg segment.

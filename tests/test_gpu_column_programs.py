@@ -322,6 +322,63 @@ def test_divide_sequences_fp32():
     assert np.array_equal(Kc[0], K_expected[0]) and np.array_equal(Kc[-1], K_expected[-1])
 
 
+SIGNATURES = [("heat", {}, 2), ("heat", {("internal_energy", "bottom"): ("flux", 0.05)}, 6), ("richards", {}, 2),
+              ("richards", {("internal_energy", "bottom"): ("flux", 0.05)}, 6), ("richards", "closed", 0), ("land", {}, 64),
+              ("land", {("internal_energy", "bottom"): ("flux", 0.05)}, 68), ("richards", {("saturation_water_ice", "top"): ("flux", -2.0e-7)}, 34)]
+
+
+@pytest.mark.parametrize("hydraulics,Nz", [("default", 32), ("vg", 50)])
+@pytest.mark.parametrize("config,extra,signature", SIGNATURES)
+def test_programs_with_the_boundary_signature_compiled_in_equal_the_runtime_program_bitwise(config, extra, signature, hydraulics, Nz):
+    """TRM_OPT_BC_SIGNATURE (BCSIG of k_column): the deriving ForwardEuler program with the boundary kinds as compile-time constants --
+    no conditions, a prescribed surface temperature, that + a bottom heat flux, the LandModel wiring -- against the same program reading
+    the kinds at run time and against the reference-order kernels; signatures without an instance (68, 34) take the run-time program."""
+    lat, lon = small_columns(333)
+    w = W.make_workload(config, lat, lon, Nz, hydraulics=hydraulics)
+    if extra == "closed":
+        w["bcs"].clear()
+    else:
+        for key, (kind, value) in extra.items():
+            w["bcs"][key] = (kind, np.full(lat.size, value))
+    sig, run, ref = W.setup_device(w), W.setup_device(w), W.setup_device(w)
+    assert sig.get_option("bc_signature") == 1 and sig.get_option("info_bc_signature") == signature
+    run.set_option("bc_signature", 0)
+    ref.set_option("step_kernel", "unfused")
+    for d in (sig, run, ref):
+        d.set_option("derive_closure_fields", 1)
+        d.step(w["dt"], 1, finalize=False)
+        d.step(w["dt"], 17, finalize=False)
+        d.step(w["dt"], 1, finalize=True)
+    for n in all_fields(w) + ["tend_internal_energy"]:
+        a = ref.get(n)
+        assert np.array_equal(sig.get(n), a, equal_nan=True), n
+        assert np.array_equal(run.get(n), a, equal_nan=True), n
+    assert sig.status() == run.status() == ref.status()
+
+
+@pytest.mark.parametrize("hydraulics,Nz", [("default", 64), ("vg", 30)])
+@pytest.mark.parametrize("config,signature", [("land", 64), ("richards", 2)])
+def test_packed_fp32_step_with_the_boundary_signature_compiled_in(config, signature, hydraulics, Nz):
+    """k_step_pk<..., DERIVE_LIQ, BCSIG>: the packed fp32 step of an HBM-resident state (the liquid fraction derived) with the LandModel
+    wiring / the prescribed surface temperature compiled in, against the run-time kinds and the reference-order kernels."""
+    lat, lon = small_columns(251)
+    w = W.make_workload(config, lat, lon, Nz, dtype=np.float32, hydraulics=hydraulics)
+    sig, run, ref = W.setup_device(w), W.setup_device(w), W.setup_device(w)
+    assert sig.get_option("packed_f32") == 1 and sig.get_option("info_bc_signature") == signature
+    run.set_option("bc_signature", 0)
+    ref.set_option("step_kernel", "unfused")
+    for d in (sig, run, ref):
+        d.set_option("derive_closure_fields", 3)
+        d.step(w["dt"], 1, finalize=False)
+        d.step(w["dt"], 11, finalize=False)
+        d.step(w["dt"], 1, finalize=True)
+    for n in all_fields(w) + ["tend_internal_energy"]:
+        a = ref.get(n)
+        assert np.array_equal(sig.get(n), a, equal_nan=True), n
+        assert np.array_equal(run.get(n), a, equal_nan=True), n
+    assert sig.status() == run.status() == ref.status()
+
+
 def test_staged_per_column_outputs_forced_on_small_grids():
     """The column programs store their per-column outputs either directly or through the workgroup's staging table
     (template parameter STAGED of the deriving instances; the library stages HBM-resident fp64 states and large LandModels).  TRM_STAGED_SMALL=1 forces the
