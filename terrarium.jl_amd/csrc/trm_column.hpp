@@ -305,6 +305,55 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     c.sat = ldg(v.sat, cb0);
     constexpr bool DERIVE_TL = DERIVE == DERIVE_T_LIQ || DERIVE == DERIVE_ALL;
     c.psi = (RICHARDS && DERIVE != DERIVE_ALL) ? ldg(v.psi, cb0) : NF(0);
+    // (BCSIG >= 0: the launcher has matched the context's kinds against the signature -- constants from here on)
+    constexpr bool SIG = BCSIG >= 0;
+    const bool seb = SIG ? (BCSIG & BCSIG_LAND) != 0 : p.seb != 0;
+    const bool vTb = SIG ? (BCSIG & BCSIG_T_BOT) != 0 : v.bc.kind[2][0] == 1, vTt = SIG ? (BCSIG & BCSIG_T_TOP) != 0 : v.bc.kind[2][1] == 1;
+    const bool bU = SIG ? (BCSIG & BCSIG_FU_BOT) != 0 : v.bc.kind[0][0] == 2, bS = RICHARDS && (SIG ? (BCSIG & BCSIG_FS_BOT) != 0 : v.bc.kind[1][0] == 2);
+    const bool tU = !SEB_INLINE && (seb || (SIG ? (BCSIG & BCSIG_FU_TOP) != 0 : v.bc.kind[0][1] == 2));
+    const bool tS = RICHARDS && !SEB_INLINE && (seb || (SIG ? (BCSIG & BCSIG_FS_TOP) != 0 : v.bc.kind[1][1] == 2));
+    // The per-column inputs (boundary values, LandModel's ground heat flux / infiltration, the 0-D fields) come through the
+    // scalar memory path (sld): one s_load per column of the wave, selected per half-wave -- where the state is cache-resident
+    // (SCALAR_IN, chosen per launch; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
+    // 8 x N145 200.8 -> 208.0: from HBM the scalar cache's 64-byte lines for 16 useful bytes cost more than the vector path).
+    const unsigned jo0 = (unsigned)(col_first < Nh ? col_first : Nh - 1) * (unsigned)sizeof(NF), jo1 = (unsigned)(col_first + 1 < Nh ? col_first + 1 : Nh - 1) * (unsigned)sizeof(NF);
+    auto col_ld = [&](const NF* ptr) -> NF {
+        if (!SCALAR_IN) return ldg(ptr, ib0);
+        const NF x0 = sld_off<NF>(ptr, jo0);
+        if (CPW == 1) return x0;
+        const NF x1 = sld_off<NF>(ptr, jo1);
+        return upper ? x1 : x0;
+    };
+    // ALL of them are requested HERE, behind the field loads and in front of the derivation: the derivation waits for U and sat and
+    // branches (the phase-change divide), and a load issued behind it starts its trip to memory only then -- a second full memory
+    // latency in every wave's life (round 4: in the round-3 order the boundary values of the HBM-resident step were requested ~110
+    // instructions after the fields).  surface_excess_water and the skin temperature likewise: vector memory retires in order, loads and
+    // stores through the one counter, so a load issued behind the field stores would hold the wave until its stores were acknowledged.
+    NF in_Tb = NF(0), in_Tt = NF(0), in_Ub = NF(0), in_Sb = NF(0), in_Ut = NF(0), in_St = NF(0), in_wt = NF(0), in_Tb2 = NF(0), in_Tt2 = NF(0);
+    NF S_in = NF(0), Ts_in = NF(0), S_stage_out = NF(0);
+    auto request_inputs = [&] {
+        if (vTb) in_Tb = col_ld(bcval(v, 2, 0));
+        if (vTt) in_Tt = col_ld(bcval(v, 2, 1));
+        if (bU) in_Ub = col_ld(bcval(v, 0, 0));
+        if (bS) in_Sb = col_ld(bcval(v, 1, 0));
+        // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this launch
+        if (tU) in_Ut = col_ld(seb ? v.ghf : bcval(v, 0, 1));
+        if (tS) in_St = col_ld(seb ? v.infil : bcval(v, 1, 1));
+        if (RICHARDS && DERIVE == DERIVE_ALL) in_wt = col_ld(v.wt);
+        if (PROG == PROG_HEUN) {      // the stage's temperature boundary values, taken at t + dt (heun.jl:52-59)
+            if (vTb) in_Tb2 = col_ld(a.bcT_bot_stage);
+            if (vTt) in_Tt2 = col_ld(a.bcT_top_stage);
+        }
+        if (PROG != PROG_MULTI) {
+            if (RICHARDS) S_in = col_ld(v.S);
+            if (seb) Ts_in = col_ld(v.Ts);
+        }
+    };
+    // ... on the VECTOR path only.  Scalar loads return out of order, so every use of one waits for ALL of them (lgkmcnt(0)): requested
+    // early, the per-column values -- from L2 or beyond -- hold up the parameter reloads of the derivation, which hit the scalar cache
+    // (profiles/r04/exp8: early / late on one box, 8 x N145 [vector path] 0.981 / 0.997 of round 3's time, C3 [scalar path] 0.960 / 0.929).
+    constexpr bool EARLY = TRM_EARLY_INPUTS && !SCALAR_IN;
+    if (EARLY) request_inputs();
     Frac<NF> f_in{};          // the incoming cell's volumetric fractions, when the derivation has formed them
     if (DERIVE_TL) {
         uint32_t viol_in = 0;
@@ -320,58 +369,35 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     }
     // ---- boundary inputs of the column --------------------------------------------------------------------------------
     TRM_PHASE_FENCE("inputs", c.U, c.sat, c.psi, c.T, c.liq);
-    // (BCSIG >= 0: the launcher has matched the context's kinds against the signature -- constants from here on)
-    constexpr bool SIG = BCSIG >= 0;
-    const bool seb = SIG ? (BCSIG & BCSIG_LAND) != 0 : p.seb != 0;
-    const bool vTb = SIG ? (BCSIG & BCSIG_T_BOT) != 0 : v.bc.kind[2][0] == 1, vTt = SIG ? (BCSIG & BCSIG_T_TOP) != 0 : v.bc.kind[2][1] == 1;
+    if (!EARLY) request_inputs();
     ColumnBC<NF> bc;
-    // The per-column inputs (boundary values, LandModel's ground heat flux / infiltration, the 0-D fields) come through the
-    // scalar memory path (sld): one s_load per column of the wave, selected per half-wave -- where the state is cache-resident
-    // (SCALAR_IN, chosen per launch; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
-    // 8 x N145 200.8 -> 208.0: from HBM the scalar cache's 64-byte lines for 16 useful bytes cost more than the vector path).
-    const unsigned jo0 = (unsigned)(col_first < Nh ? col_first : Nh - 1) * (unsigned)sizeof(NF), jo1 = (unsigned)(col_first + 1 < Nh ? col_first + 1 : Nh - 1) * (unsigned)sizeof(NF);
-    auto col_ld = [&](const NF* ptr) -> NF {
-        if (!SCALAR_IN) return ldg(ptr, ib0);
-        const NF x0 = sld_off<NF>(ptr, jo0);
-        if (CPW == 1) return x0;
-        const NF x1 = sld_off<NF>(ptr, jo1);
-        return upper ? x1 : x0;
-    };
     if (RICHARDS && DERIVE == DERIVE_ALL) {
         // saturation_to_pressure! of the stored state from the stored saturation and the stored water table: what the launch that
         // wrote the field evaluated (column_closure: same function, same operands, same bits) instead of a third field read
         // (re-deriving the water table as well -- a ballot of the stored saturation and a scalar search instead of the per-column
         // load -- is slower still: profiles/r04/exp5b)
-        c.psi = pressure_head<NF, HYD>(kernarg_reload<DevParams<NF>>(off_p), c.sat, L.zC, L.psiz, col_ld(v.wt));
+        c.psi = pressure_head<NF, HYD>(kernarg_reload<DevParams<NF>>(off_p), c.sat, L.zC, L.psiz, in_wt);
     }
-    bc.bTb = vTb ? col_ld(bcval(v, 2, 0)) : NF(0);
-    bc.bTt = vTt ? col_ld(bcval(v, 2, 1)) : NF(0);
+    bc.bTb = in_Tb;
+    bc.bTt = in_Tt;
     {   // flux conditions: a term for the edge lane of every condition that is SET (wave-uniform branches), nothing otherwise.
         // (flux_term_*_nsz: the term is added to a tendency that is never -0.0, so the sign of a zero term is immaterial)
-        NF fU = NF(0), fS = NF(0);
-        const bool bU = SIG ? (BCSIG & BCSIG_FU_BOT) != 0 : v.bc.kind[0][0] == 2, bS = RICHARDS && (SIG ? (BCSIG & BCSIG_FS_BOT) != 0 : v.bc.kind[1][0] == 2);
-        const bool tU = !SEB_INLINE && (seb || (SIG ? (BCSIG & BCSIG_FU_TOP) != 0 : v.bc.kind[0][1] == 2));
-        const bool tS = RICHARDS && !SEB_INLINE && (seb || (SIG ? (BCSIG & BCSIG_FS_TOP) != 0 : v.bc.kind[1][1] == 2));
-#if TRM_CUT_FLUX
-        if (bU) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 0, 0)), v.g); fU = ln.is_bot ? e : fU; }
-        if (bS) { const NF e = flux_term_bottom_nsz(col_ld(bcval(v, 1, 0)), v.g); fS = ln.is_bot ? e : fS; }
-        // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this launch.
         // Top terms enter with a minus sign.
-        if (tU) { const NF e = -flux_term_top_nsz(col_ld(seb ? v.ghf : bcval(v, 0, 1)), v.g); fU = ln.is_top ? e : fU; }
-        if (tS) {
-            const NF x = col_ld(seb ? v.infil : bcval(v, 1, 1));
-            const NF e = -flux_term_top_nsz(seb ? -x : x, v.g);
-            fS = ln.is_top ? e : fS;
-        }
+        NF fU = NF(0), fS = NF(0);
+#if TRM_CUT_FLUX
+        if (bU) { const NF e = flux_term_bottom_nsz(in_Ub, v.g); fU = ln.is_bot ? e : fU; }
+        if (bS) { const NF e = flux_term_bottom_nsz(in_Sb, v.g); fS = ln.is_bot ? e : fS; }
+        if (tU) { const NF e = -flux_term_top_nsz(in_Ut, v.g); fU = ln.is_top ? e : fU; }
+        if (tS) { const NF e = -flux_term_top_nsz(seb ? -in_St : in_St, v.g); fS = ln.is_top ? e : fS; }
 #endif
 #if !TRM_CUT_FLUX
         {   // both edge terms always formed, two selects per variable: the form measured faster (no select inside the branches,
             // no branch around the `+ flux` of column_advance)
             NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
-            if (bU) eU_b = flux_term_bottom_nsz(col_ld(bcval(v, 0, 0)), v.g);
-            if (bS) eS_b = flux_term_bottom_nsz(col_ld(bcval(v, 1, 0)), v.g);
-            if (tU) eU_t = -flux_term_top_nsz(col_ld(seb ? v.ghf : bcval(v, 0, 1)), v.g);
-            if (tS) { const NF x = col_ld(seb ? v.infil : bcval(v, 1, 1)); eS_t = -flux_term_top_nsz(seb ? -x : x, v.g); }
+            if (bU) eU_b = flux_term_bottom_nsz(in_Ub, v.g);
+            if (bS) eS_b = flux_term_bottom_nsz(in_Sb, v.g);
+            if (tU) eU_t = -flux_term_top_nsz(in_Ut, v.g);
+            if (tS) eS_t = -flux_term_top_nsz(seb ? -in_St : in_St, v.g);
             fU = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
             fS = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
         }
@@ -381,16 +407,6 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         // (the multi-step program may receive its terms later: from a series, from the inline surface energy balance)
         bc.has_U = !TRM_CUT_FLUX || PROG == PROG_MULTI || bU || tU;
         bc.has_S = !TRM_CUT_FLUX || PROG == PROG_MULTI || bS || tS;
-    }
-    // surface_excess_water (and LandModel's surface state) is owned by the column's top lane.  The one-step programs
-    // touch it in one short top-lane block at the end; the multi-step program carries it in a register.
-    // Both are READ HERE, with the other inputs of the column: vector memory retires in order, loads and stores through the one
-    // counter, so a load issued behind the field stores would hold the whole wave until every one of its stores had been
-    // acknowledged -- the wave's last act before it frees its slot.
-    NF S_in = NF(0), Ts_in = NF(0), S_stage_out = NF(0);
-    if (PROG != PROG_MULTI) {
-        if (RICHARDS) S_in = col_ld(v.S);
-        if (seb) Ts_in = col_ld(v.Ts);
     }
     NF S = NF(0);
     SurfaceRegs<NF> sf;
@@ -424,7 +440,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             stg(a.stage_T, cb, s.T);
         }
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59)
-        const NF bTb2 = vTb ? col_ld(a.bcT_bot_stage) : NF(0), bTt2 = vTt ? col_ld(a.bcT_top_stage) : NF(0);
+        const NF bTb2 = in_Tb2, bTt2 = in_Tt2;
         uint32_t viol_stage = 0;
         const Tendency<NF> t2 = column_tendencies<NF, RICHARDS, HYD, LPC>(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), L, ln, s, bTb2, bTt2, RICHARDS, viol_stage, &f_stage);
         viol |= viol_stage;

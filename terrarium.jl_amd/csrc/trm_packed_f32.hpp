@@ -264,11 +264,38 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     TRM_PHASE("loads+derive");
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
     v2f psi = splat(0.0f);
+    // ---- the per-column inputs
+    constexpr bool SIG = BCSIG >= 0;      // (the boundary kinds as compile-time constants: BCSIG, trm_kernels.hpp)
+    const bool vTb = SIG ? (BCSIG & BCSIG_T_BOT) != 0 : v.bc.kind[2][0] == 1, vTt = SIG ? (BCSIG & BCSIG_T_TOP) != 0 : v.bc.kind[2][1] == 1;
+    const bool seb = SIG ? (BCSIG & BCSIG_LAND) != 0 : p.seb != 0;
+    // flux conditions: a term for the edge lane of every condition that is SET, nothing otherwise (column_program, trm_column.hpp)
+    const bool fUb = SIG ? (BCSIG & BCSIG_FU_BOT) != 0 : v.bc.kind[0][0] == 2, fUt = seb || (SIG ? (BCSIG & BCSIG_FU_TOP) != 0 : v.bc.kind[0][1] == 2);
+    const bool fSb = RICHARDS && (SIG ? (BCSIG & BCSIG_FS_BOT) != 0 : v.bc.kind[1][0] == 2), fSt = RICHARDS && (seb || (SIG ? (BCSIG & BCSIG_FS_TOP) != 0 : v.bc.kind[1][1] == 2));
+    v2f in_Tb = splat(0.0f), in_Tt = splat(0.0f), in_Ub = splat(0.0f), in_Ut = splat(0.0f), in_Sb = splat(0.0f), in_St = splat(0.0f), in_wt = splat(0.0f);
+    v2f S_in = splat(0.0f), Ts_in = splat(0.0f);
+    auto request_inputs = [&] {
+        if (vTb) in_Tb = col_ld2(bcval(v, 2, 0));
+        if (vTt) in_Tt = col_ld2(bcval(v, 2, 1));
+        if (fUb) in_Ub = col_ld2(bcval(v, 0, 0));
+        if (fUt) in_Ut = col_ld2(seb ? v.ghf : bcval(v, 0, 1));
+        if (fSb) in_Sb = col_ld2(bcval(v, 1, 0));
+        if (fSt) in_St = col_ld2(seb ? v.infil : bcval(v, 1, 1));
+        if (RICHARDS && DERIVE == DERIVE_LIQ_PSI) in_wt = col_ld2(v.wt);
+        // surface_excess_water and the skin temperature of the two columns: with the other inputs.  Vector memory retires in order,
+        // loads and stores through the one counter: a load issued behind a store holds the whole wave until that store has been
+        // acknowledged by memory (the top-lane block used to do that three times per wave).
+        if (RICHARDS) S_in = col_ld2(v.S);
+        if (seb) Ts_in = col_ld2(v.Ts);
+    };
+    // (they travel through the scalar path, whose loads return out of order: requested in front of the derivation they hold up its
+    // parameter reloads -- C5 +4 %, profiles/r04/exp8 -- so the request stays behind it; k_column's vector path requests early)
+    constexpr bool EARLY = false;
+    if (EARLY) request_inputs();
     if (RICHARDS && DERIVE == DERIVE_LIQ_PSI) {
         // saturation_to_pressure! of the stored state, from the stored saturation and the stored water table (what the step that
         // wrote the field evaluated: same function, same operands, same bits) instead of a fourth field read
-        const v2f z0_in = col_ld2(v.wt);
-        psi = pressure_head_hyd2<HYD>(kernarg_reload<DevParams<float>>(off_p), sat, L.zC, L.psiz, z0_in);
+        if (!EARLY) in_wt = col_ld2(v.wt);
+        psi = pressure_head_hyd2<HYD>(kernarg_reload<DevParams<float>>(off_p), sat, L.zC, L.psiz, in_wt);
     } else if (RICHARDS) {
         psi = ld2(v.psi, cb0, cb1);
     }
@@ -290,57 +317,35 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     v2f T_sh = up2(T), kap_sh = up2(kap);
     v2f flux_U = splat(0.0f), flux_S = splat(0.0f);
     TRM_PHASE_FENCE("inputs", T_sh, kap_sh);
+    if (!EARLY) request_inputs();
     // ---- boundary conditions: one wave-uniform branch per condition that is not set (k_step_wave, GENERIC_BC = false)
-    constexpr bool SIG = BCSIG >= 0;      // (the boundary kinds as compile-time constants: BCSIG, trm_kernels.hpp)
-    const bool vTb = SIG ? (BCSIG & BCSIG_T_BOT) != 0 : v.bc.kind[2][0] == 1, vTt = SIG ? (BCSIG & BCSIG_T_TOP) != 0 : v.bc.kind[2][1] == 1;
     v2f T_ext_b = T, T_ext_t = T;
-    if (vTb) {
-        const v2f b = col_ld2(bcval(v, 2, 0));
-        T_ext_b = T + div_const2_nsz(T - b, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);      // (nsz: see column_tendencies)
-    }
-    if (vTt) {
-        const v2f b = col_ld2(bcval(v, 2, 1));
-        T_ext_t = T + div_const2_nsz(b - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
-    }
+    if (vTb) T_ext_b = T + div_const2_nsz(T - in_Tb, v.g.hdzf_bot, v.g.rhdzf_bot) * (-v.g.dzf_bot);      // (nsz: see column_tendencies)
+    if (vTt) T_ext_t = T + div_const2_nsz(in_Tt - T, v.g.hdzf_top, v.g.rhdzf_top) * v.g.dzf_top;
     v2f T_m = sel(is_bot, T_ext_b, T_sh);
     v2f T_h = T_ext_t;
     v2f kap_halo = kap;
     if (!RICHARDS && p.halo_policy != 1) kap_halo = conductivity2(p, fractions2(p, splat(0.0f), liq, viol));
     v2f kap_m = sel(is_bot, kap_halo, kap_sh);
     v2f kap_h = kap_halo;
-    const bool seb = SIG ? (BCSIG & BCSIG_LAND) != 0 : p.seb != 0;
-    // flux conditions: a term for the edge lane of every condition that is SET, nothing otherwise (column_program, trm_column.hpp)
-    const bool fUb = SIG ? (BCSIG & BCSIG_FU_BOT) != 0 : v.bc.kind[0][0] == 2, fUt = seb || (SIG ? (BCSIG & BCSIG_FU_TOP) != 0 : v.bc.kind[0][1] == 2);
-    const bool fSb = RICHARDS && (SIG ? (BCSIG & BCSIG_FS_BOT) != 0 : v.bc.kind[1][0] == 2), fSt = RICHARDS && (seb || (SIG ? (BCSIG & BCSIG_FS_TOP) != 0 : v.bc.kind[1][1] == 2));
 #if TRM_CUT_FLUX
-    if (fUb) flux_U = sel(is_bot, div_const2_nsz(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_U);
-    if (fUt) flux_U = sel(is_top, -div_const2_nsz(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top), flux_U);
-    if (fSb) flux_S = sel(is_bot, div_const2_nsz(col_ld2(bcval(v, 1, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_S);
-    if (fSt) {
-        const v2f fS = col_ld2(seb ? v.infil : bcval(v, 1, 1));
-        flux_S = sel(is_top, -div_const2_nsz((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top), flux_S);
-    }
+    if (fUb) flux_U = sel(is_bot, div_const2_nsz(in_Ub * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_U);
+    if (fUt) flux_U = sel(is_top, -div_const2_nsz(in_Ut * v.g.Az, v.g.V_top, v.g.rV_top), flux_U);
+    if (fSb) flux_S = sel(is_bot, div_const2_nsz(in_Sb * v.g.Az, v.g.V_bot, v.g.rV_bot), flux_S);
+    if (fSt) flux_S = sel(is_top, -div_const2_nsz((seb ? -in_St : in_St) * v.g.Az, v.g.V_top, v.g.rV_top), flux_S);
 #else
     {   // both edge terms always formed, two selects per variable (the form measured faster: no select inside the branches)
         v2f eU_b = splat(0.0f), eU_t = splat(0.0f), eS_b = splat(0.0f), eS_t = splat(0.0f);
-        if (fUb) eU_b = div_const2_nsz(col_ld2(bcval(v, 0, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
-        if (fUt) eU_t = -div_const2_nsz(col_ld2(seb ? v.ghf : bcval(v, 0, 1)) * v.g.Az, v.g.V_top, v.g.rV_top);
+        if (fUb) eU_b = div_const2_nsz(in_Ub * v.g.Az, v.g.V_bot, v.g.rV_bot);
+        if (fUt) eU_t = -div_const2_nsz(in_Ut * v.g.Az, v.g.V_top, v.g.rV_top);
         flux_U = sel(is_bot, eU_b, sel(is_top, eU_t, splat(0.0f)));
         if (RICHARDS) {
-            if (fSb) eS_b = div_const2_nsz(col_ld2(bcval(v, 1, 0)) * v.g.Az, v.g.V_bot, v.g.rV_bot);
-            if (fSt) {
-                const v2f fS = col_ld2(seb ? v.infil : bcval(v, 1, 1));
-                eS_t = -div_const2_nsz((seb ? -fS : fS) * v.g.Az, v.g.V_top, v.g.rV_top);
-            }
+            if (fSb) eS_b = div_const2_nsz(in_Sb * v.g.Az, v.g.V_bot, v.g.rV_bot);
+            if (fSt) eS_t = -div_const2_nsz((seb ? -in_St : in_St) * v.g.Az, v.g.V_top, v.g.rV_top);
             flux_S = sel(is_bot, eS_b, sel(is_top, eS_t, splat(0.0f)));
         }
     }
 #endif
-    // surface_excess_water and the skin temperature of the two columns: READ HERE, with the other inputs.  Vector memory retires in
-    // order, loads and stores through the one counter: a load issued behind a store holds the whole wave until that store has
-    // been acknowledged by memory (the top-lane block used to do that three times per wave).
-    const v2f S_in = RICHARDS ? col_ld2(v.S) : splat(0.0f);
-    const v2f Ts_in = seb ? col_ld2(v.Ts) : splat(0.0f);
     TRM_PHASE_FENCE("tendencies", flux_U, flux_S, T_m, T_h, kap_m, kap_h, psi);
     // ---- heat
     const v2f qT_lo = -((kap + kap_m) * 0.5f) * ((T - T_m) * L.rdzf_lo);
