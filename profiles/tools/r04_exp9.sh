@@ -1,0 +1,30 @@
+# round 4, experiment 9: the store phase with every base pointer fetched in one batch of scalar loads and every store in the
+# scalar-base form (k_column: TRM_STORE_POINTERS_UPFRONT; k_step_pk: block_local in every storing block) against the previous commit's
+# build (build/variants/lib_prev.so); one process per sample, alternating, three rounds.  First the tests of the files the change touches.
+run() { local limit=$1; shift; timeout -k 10 $limit "$@"; local rc=$?; if [ $rc -ne 0 ]; then echo "FAILED ($rc): $*"; tail -30 gpurun_out/r04_exp9_tests.log; exit 1; fi; return 0; }
+run 1000 python -m pytest tests/test_gpu_column_programs.py tests/test_gpu_parity.py -m gpu -q -x -W ignore::DeprecationWarning > gpurun_out/r04_exp9_tests.log 2>&1; tail -3 gpurun_out/r04_exp9_tests.log
+L=gpurun_out/r04_exp9_store_pointers.log; : > $L
+AB="python profiles/tools/ab_options.py"
+for round in 1 2 3; do
+  for B in prev new; do
+    case $B in new) unset TRM_LIBRARY;; *) export TRM_LIBRARY=$PWD/build/variants/lib_$B.so;; esac
+    run 300 $AB c3x8 $B: --steps 60 --reps 5 >> $L 2>&1
+    run 300 $AB c3 $B: --reps 7 >> $L 2>&1
+    run 300 $AB c4 $B: --steps 50 --reps 7 >> $L 2>&1
+    run 300 $AB c4vg $B: --steps 50 --reps 7 >> $L 2>&1
+    run 300 $AB c5 $B: --steps 30 --reps 5 >> $L 2>&1
+  done
+done
+unset TRM_LIBRARY
+python - <<'PY'
+import json
+rows = {}
+for line in open("gpurun_out/r04_exp9_store_pointers.log"):
+    if line.startswith("{"):
+        d = json.loads(line)
+        for k, v in d["us_per_step"].items():
+            rows.setdefault(d["workload"], {}).setdefault(k, []).append(v["median"])
+for wl, r in rows.items():
+    base = sum(r["prev"]) / len(r["prev"])
+    print(wl, " ".join(f"{k}={sum(v)/len(v):.2f}({sum(v)/len(v)/base:.3f})" for k, v in r.items()), {k: v for k, v in r.items()})
+PY

@@ -564,16 +564,24 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     TRM_PHASE_FENCE("stores", Kf_out, Kf_out_top, S, GS_out, Ts_new);
     if (ln.act) {
         const View<NF>& v = kernarg_reload<View<NF>>(0);
+#if TRM_STORE_POINTERS_UPFRONT
+        // every base pointer the store phase may need in ONE batch of scalar loads: fetched where they are used -- inside the
+        // finalize / write_kf / top-lane branches -- each is a scalar load and a wait of its own in front of its store
+        NF* const pGU = v.G_U; NF* const pGS3 = v.G_sat; NF* const pKf = v.Kf; NF* const pKft = v.Kf_top; NF* const pS = v.S; NF* const pwt = v.wt;
+        asm volatile("" : : "s"(pGU), "s"(pGS3), "s"(pKf), "s"(pKft), "s"(pS), "s"(pwt));
+#else
+        NF* const pGU = v.G_U; NF* const pGS3 = v.G_sat; NF* const pKf = v.Kf;
+#endif
         const unsigned cb = block_local(cb0), ib = block_local(ib0);
         stg(v.U, cb, n.U);
         stg(v.T, cb, n.T);
         stg(v.liq, cb, n.liq);
         if (RICHARDS) { stg(v.sat, cb, n.sat); stg(v.psi, cb, n.psi); }
         if (finalize) {   // state.tendencies as the reference leaves them after its last step
-            stg(v.G_U, cb, gU_out);
-            if (RICHARDS) stg(v.G_sat, cb, gS_out);
+            stg(pGU, block_local(cb0), gU_out);
+            if (RICHARDS) stg(pGS3, block_local(cb0), gS_out);
         }
-        if (write_kf) stg(v.Kf, cb, Kf_out);
+        if (write_kf) stg(pKf, block_local(cb0), Kf_out);
         if (ln.is_top && RICHARDS && PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage_out);
         if (ln.is_top && STAGED) {
             // The per-column outputs (up to eight 8-byte values: top face of K, surface excess water, water table, its tendency,
@@ -597,11 +605,18 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             }
         } else if (ln.is_top) {
             const unsigned ib = block_local(ib0);     // (in THIS block: see block_local -- else every store below pays a 64-bit address add)
+#if TRM_STORE_POINTERS_UPFRONT
+            if (write_kf) stg(pKft, block_local(ib0), Kf_out_top);
+            if (RICHARDS) {
+                stg(pS, block_local(ib0), S);
+                stg(pwt, block_local(ib0), z0);
+#else
             if (write_kf) stg(v.Kf_top, ib, Kf_out_top);
             if (RICHARDS) {
 #ifndef TRM_DIAG_NO_2D_STORES
                 stg(v.S, ib, S);
                 stg(v.wt, ib, z0);
+#endif
 #endif
                 if (finalize) stg(v.G_S, ib, GS_out);
             }

@@ -416,7 +416,8 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     auto store = [&](bool act, int cib, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft, float gu, float gs,
                      float S_new, float GS, float wt, float Ts_old /* already stepped */) {
         if (!act) return;
-        const unsigned cb = block_local(cb_), ib = block_local(ib_);   // keeps the saddr form inside this block
+        // (block_local in EVERY block that stores: instruction selection works one basic block at a time, and an offset defined in
+        // another block has been widened to 64 bits there -- each store then pays a 64-bit address add and loses the saddr form)
         if (is_top && staged) {   // the column's 0-D outputs through the workgroup's staging table (store_small_outputs, trm_column.hpp)
             float* st = small_stage<float>();
             if (write_kf) st[SMALL_KF_TOP * cpb + cib] = kft;
@@ -433,24 +434,29 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
             }
         } else if (is_top) {   // the column's 0-D state (top lane)
             if (RICHARDS) {
-                if (finalize) stg(v.G_S, ib, GS);
+                if (finalize) stg(v.G_S, block_local(ib_), GS);
+                const unsigned ib = block_local(ib_);
                 stg(v.S, ib, S_new);
                 stg(v.wt, ib, wt);
             }
-            if (seb) stg(v.Ts, ib, Ts_old);
+            if (seb) stg(v.Ts, block_local(ib_), Ts_old);
         }
         if (finalize) {   // state.tendencies of the last step (k_step_wave)
+            const unsigned cb = block_local(cb_);
             stg(v.G_U, cb, gu);
             if (RICHARDS) stg(v.G_sat, cb, gs);
         }
-        stg(v.U, cb, u);
-        stg(v.T, cb, t);
-        stg(v.liq, cb, l);
-        if (RICHARDS) { stg(v.sat, cb, s); stg(v.psi, cb, ps); }
-        if (is_top && seb && !staged) { stg(v.top_T, ib, t); stg(v.top_sat, ib, s); stg(v.top_liq, ib, l); }
+        {
+            const unsigned cb = block_local(cb_);
+            stg(v.U, cb, u);
+            stg(v.T, cb, t);
+            stg(v.liq, cb, l);
+            if (RICHARDS) { stg(v.sat, cb, s); stg(v.psi, cb, ps); }
+        }
+        if (is_top && seb && !staged) { const unsigned ib = block_local(ib_); stg(v.top_T, ib, t); stg(v.top_sat, ib, s); stg(v.top_liq, ib, l); }
         if (write_kf) {
-            stg(v.Kf, cb, kf);
-            if (is_top && !staged) stg(v.Kf_top, ib, kft);
+            stg(v.Kf, block_local(cb_), kf);
+            if (is_top && !staged) stg(v.Kf_top, block_local(ib_), kft);
         }
     };
     // every loaded value has been consumed before the first store is issued (nothing is waited for behind the stores)
