@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 14
+#define TRM_ABI_VERSION 15
 
 typedef struct trm_ctx trm_ctx;
 
@@ -170,6 +170,8 @@ enum {
                                     /* (DESIGN 4.1, 4.3); 3: the liquid fraction alone (one read less); 4: the liquid fraction   */
                                     /* and, on the packed fp32 step with Richards, the pressure head from the stored saturation */
                                     /* and water table (two reads less; elsewhere as 3)                                          */
+                                    /* 5: on the fp64 column program with Richards, temperature, liquid fraction AND pressure  */
+                                    /* head (the step reads internal_energy and saturation alone; measured slower: DESIGN 4.3)  */
     TRM_OPT_STEPS_PER_LAUNCH = 6,   /* trm_step keeps every column in registers for up to m steps per launch and writes the */
                                     /* fields once per launch (temporal blocking of run!'s loop, model_integrator.jl:72-88;  */
                                     /* bit-identical to m = 1).  0 (default): the library chooses -- 50 wherever the program  */
@@ -208,8 +210,8 @@ enum {
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */
                                 /* wavefront shuffles for the vertical stencil (Nz <= 64; two levels per lane */
-                                /* for 65 ... 128 levels: ForwardEuler with every boundary kind, Heun with    */
-                                /* the branch-free ones; anything deeper takes the unfused kernels)           */
+                                /* for 65 ... 128 levels, four for 129 ... 256: ForwardEuler and Heun with    */
+                                /* every boundary kind; anything deeper takes the unfused kernels)            */
     TRM_KERNEL_UNFUSED = 1      /* one launch per reference kernel, in the reference's order (A/B comparator) */
 };
 

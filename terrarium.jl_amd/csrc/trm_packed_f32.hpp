@@ -262,6 +262,14 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     };
 
     TRM_PHASE("loads+derive");
+#if TRM_LOAD_POINTERS_UPFRONT
+    {   // the base pointers of every field read in ONE batch of scalar loads in front of the first: fetched where each is first used,
+        // the later ones put a scalar load and its wait between the field loads.  (k_step_pk only: in k_column the same
+        // statement made the scheduler put the level records first and wait for them in front of the field loads)
+        const float* const pU = v.U; const float* const ps = v.sat; const float* const pT = v.T; const float* const pp = v.psi;
+        asm volatile("" : : "s"(pU), "s"(ps), "s"(pT), "s"(pp));
+    }
+#endif
     const v2f U = ld2(v.U, cb0, cb1), sat = ld2(v.sat, cb0, cb1);
     v2f psi = splat(0.0f);
     // ---- the per-column inputs
