@@ -2,7 +2,7 @@
 field / level-record / per-column VECTOR load of a wave's prologue is issued before the wave waits for any of them.  An inline
 asm statement, a reused destination register or a branch in the wrong place puts an `s_waitcnt vmcnt` between two loads, and the
 later ones start their trip to memory one full latency late -- invisible in the tests, 2 ... 5 % in time.
-    make -C terrarium.jl_amd/csrc asm F=trm_launch_column_sig_f64_rich_a ; make -C terrarium.jl_amd/csrc asm F=trm_launch_packed
+    for f in trm_launch_column_sig_f64_rich_a trm_launch_column_sig_f64_rich_b trm_launch_column_sig_f64_noflow trm_launch_column_f64_euler_rich trm_launch_packed; do make -C terrarium.jl_amd/csrc asm F=$f; done
     python profiles/tools/check_load_order.py            (exit code 1 if a listed kernel waits between its prologue loads)"""
 import re
 import sys
@@ -10,6 +10,9 @@ import sys
 CHECK = [("build/obj/trm_launch_column_sig_f64_rich_a.s", "_ZN3trm8k_columnIdLb1ELi0ELi32ELi1ELi0ELb0ELb0ELb0ELb1ELi2E", 3),   # C3: fields only (inputs by s_load)
          ("build/obj/trm_launch_column_sig_f64_rich_a.s", "_ZN3trm8k_columnIdLb1ELi0ELi32ELi1ELi0ELb0ELb0ELb1ELb0ELi2E", 5),   # 8 x N145: fields + 2 per-column
          ("build/obj/trm_launch_column_sig_f64_rich_b.s", "_ZN3trm8k_columnIdLb1ELi0ELi32ELi1ELi0ELb0ELb0ELb1ELb1ELi64E", 3),  # C4
+         ("build/obj/trm_launch_column_sig_f64_rich_b.s", "_ZN3trm8k_columnIdLb1ELi1ELi32ELi0ELi0ELb0ELb0ELb0ELb1ELi64E", 5),  # vegetation-coupled: T, liq read
+         ("build/obj/trm_launch_column_sig_f64_noflow.s", "_ZN3trm8k_columnIdLb0ELi0ELi32ELi0ELi0ELb0ELb0ELb0ELb1ELi2E", 4),   # C2: heat-only, small grid
+         ("build/obj/trm_launch_column_f64_euler_rich.s", "_ZN3trm8k_columnIdLb1ELi1ELi32ELi0ELi0ELb0ELb0ELb0ELb1ELin1E", 5),  # the run-time kinds
          ("build/obj/trm_launch_packed.s", "_ZN3trm9k_step_pkILb1ELi64ELi0ELi2ELi64E", 8)]                                     # C5: 4 fields x 2 columns
 bad = 0
 for path, kernel, nfield in CHECK:

@@ -262,7 +262,6 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     const bool upper = CPW == 2 && lane_in(0xffffffff00000000ull);
     ln.is_bot = lane_in(level_lanes<LPC>(0));
     ln.is_top = lane_in(level_lanes<LPC>(Nz - 1));
-    const LevelGeom<NF> L = level_geom(v, ln.k);
     const NF dt = a.dt;
     const int finalize = a.finalize, write_kf = a.write_kf;
     const bool need_kc = RICHARDS || write_kf;
@@ -282,7 +281,6 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     const bool upper = sub != 0;
     ln.is_bot = ln.k == 0;
     ln.is_top = ln.k == Nz - 1;
-    const LevelGeom<NF> L = level_geom(v, ln.k);
     const NF dt = a.dt;
     const int finalize = a.finalize, write_kf = a.write_kf;
     const bool need_kc = RICHARDS || write_kf;
@@ -305,6 +303,8 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     c.sat = ldg(v.sat, cb0);
     constexpr bool DERIVE_TL = DERIVE == DERIVE_T_LIQ || DERIVE == DERIVE_ALL;
     c.psi = (RICHARDS && DERIVE != DERIVE_ALL) ? ldg(v.psi, cb0) : NF(0);
+    if (!DERIVE_TL) { c.T = ldg(v.T, cb0); if (DERIVE != DERIVE_LIQ) c.liq = ldg(v.liq, cb0); }
+    const LevelGeom<NF> L = level_geom(v, ln.k);      // (behind the field loads: see level_geom)
     // (BCSIG >= 0: the launcher has matched the context's kinds against the signature -- constants from here on)
     constexpr bool SIG = BCSIG >= 0;
     const bool seb = SIG ? (BCSIG & BCSIG_LAND) != 0 : p.seb != 0;
@@ -317,36 +317,46 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     // (SCALAR_IN, chosen per launch; profiles/r03/exp26: C4 34.1 -> 32.7 us, vegetation-coupled 48.2 -> 46.0, C3 25.3 -> 24.8, but
     // 8 x N145 200.8 -> 208.0: from HBM the scalar cache's 64-byte lines for 16 useful bytes cost more than the vector path).
     const unsigned jo0 = (unsigned)(col_first < Nh ? col_first : Nh - 1) * (unsigned)sizeof(NF), jo1 = (unsigned)(col_first + 1 < Nh ? col_first + 1 : Nh - 1) * (unsigned)sizeof(NF);
-    auto col_ld = [&](const NF* ptr) -> NF {
-        if (!SCALAR_IN) return ldg(ptr, ib0);
+    // (a request and its use are two steps: on the scalar path the select between the wave's two columns is a VECTOR instruction that
+    // needs both values -- formed where the value is requested, inside the branch of a condition that is set, it puts a wait for
+    // the scalar load right behind it, one exposed trip to L2 per condition)
+    struct ColVal { NF x0, x1; };
+    // (with the kinds read at run time every request sits in a branch and eleven pending pairs would not fit the scalar registers:
+    // that instance resolves each value where it requests it, as round 3 did)
+    constexpr bool DEFER = SCALAR_IN && CPW == 2 && BCSIG >= 0;
+    auto col_req = [&](const NF* ptr) -> ColVal {
+        if (!SCALAR_IN) return ColVal{ldg(ptr, ib0), NF(0)};
         const NF x0 = sld_off<NF>(ptr, jo0);
-        if (CPW == 1) return x0;
+        if (CPW == 1) return ColVal{x0, NF(0)};
         const NF x1 = sld_off<NF>(ptr, jo1);
-        return upper ? x1 : x0;
+        if (DEFER) return ColVal{x0, x1};
+        return ColVal{upper ? x1 : x0, NF(0)};
     };
+    auto col_get = [&](const ColVal& q) -> NF { return (DEFER && upper) ? q.x1 : q.x0; };
     // ALL of them are requested HERE, behind the field loads and in front of the derivation: the derivation waits for U and sat and
     // branches (the phase-change divide), and a load issued behind it starts its trip to memory only then -- a second full memory
     // latency in every wave's life (round 4: in the round-3 order the boundary values of the HBM-resident step were requested ~110
     // instructions after the fields).  surface_excess_water and the skin temperature likewise: vector memory retires in order, loads and
     // stores through the one counter, so a load issued behind the field stores would hold the wave until its stores were acknowledged.
-    NF in_Tb = NF(0), in_Tt = NF(0), in_Ub = NF(0), in_Sb = NF(0), in_Ut = NF(0), in_St = NF(0), in_wt = NF(0), in_Tb2 = NF(0), in_Tt2 = NF(0);
-    NF S_in = NF(0), Ts_in = NF(0), S_stage_out = NF(0);
+    const ColVal none{NF(0), NF(0)};
+    ColVal q_Tb = none, q_Tt = none, q_Ub = none, q_Sb = none, q_Ut = none, q_St = none, q_wt = none, q_Tb2 = none, q_Tt2 = none, q_S = none, q_Ts = none;
+    NF S_stage_out = NF(0);
     auto request_inputs = [&] {
-        if (vTb) in_Tb = col_ld(bcval(v, 2, 0));
-        if (vTt) in_Tt = col_ld(bcval(v, 2, 1));
-        if (bU) in_Ub = col_ld(bcval(v, 0, 0));
-        if (bS) in_Sb = col_ld(bcval(v, 1, 0));
+        if (vTb) q_Tb = col_req(bcval(v, 2, 0));
+        if (vTt) q_Tt = col_req(bcval(v, 2, 1));
+        if (bU) q_Ub = col_req(bcval(v, 0, 0));
+        if (bS) q_Sb = col_req(bcval(v, 1, 0));
         // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this launch
-        if (tU) in_Ut = col_ld(seb ? v.ghf : bcval(v, 0, 1));
-        if (tS) in_St = col_ld(seb ? v.infil : bcval(v, 1, 1));
-        if (RICHARDS && DERIVE == DERIVE_ALL) in_wt = col_ld(v.wt);
+        if (tU) q_Ut = col_req(seb ? v.ghf : bcval(v, 0, 1));
+        if (tS) q_St = col_req(seb ? v.infil : bcval(v, 1, 1));
+        if (RICHARDS && DERIVE == DERIVE_ALL) q_wt = col_req(v.wt);
         if (PROG == PROG_HEUN) {      // the stage's temperature boundary values, taken at t + dt (heun.jl:52-59)
-            if (vTb) in_Tb2 = col_ld(a.bcT_bot_stage);
-            if (vTt) in_Tt2 = col_ld(a.bcT_top_stage);
+            if (vTb) q_Tb2 = col_req(a.bcT_bot_stage);
+            if (vTt) q_Tt2 = col_req(a.bcT_top_stage);
         }
         if (PROG != PROG_MULTI) {
-            if (RICHARDS) S_in = col_ld(v.S);
-            if (seb) Ts_in = col_ld(v.Ts);
+            if (RICHARDS) q_S = col_req(v.S);
+            if (seb) q_Ts = col_req(v.Ts);
         }
     };
     // ... on the VECTOR path only.  Scalar loads return out of order, so every use of one waits for ALL of them (lgkmcnt(0)): requested
@@ -361,15 +371,13 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     } else if (DERIVE == DERIVE_LIQ) {
         // the liquid fraction alone: one compare and, for waves with a cell in phase change, the ballot-guarded divide;
         // temperature -- the expensive half of the closure (composition, heat capacity, a full divide) -- is read
-        c.T = ldg(v.T, cb0);
         c.liq = liquid_fraction_wave(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat);
-    } else {
-        c.T = ldg(v.T, cb0);
-        c.liq = ldg(v.liq, cb0);
     }
     // ---- boundary inputs of the column --------------------------------------------------------------------------------
     TRM_PHASE_FENCE("inputs", c.U, c.sat, c.psi, c.T, c.liq);
     if (!EARLY) request_inputs();
+    const NF in_Tb = col_get(q_Tb), in_Tt = col_get(q_Tt), in_Ub = col_get(q_Ub), in_Sb = col_get(q_Sb), in_Ut = col_get(q_Ut), in_St = col_get(q_St);
+    const NF in_wt = col_get(q_wt), in_Tb2 = col_get(q_Tb2), in_Tt2 = col_get(q_Tt2), S_in = col_get(q_S), Ts_in = col_get(q_Ts);
     ColumnBC<NF> bc;
     if (RICHARDS && DERIVE == DERIVE_ALL) {
         // saturation_to_pressure! of the stored state from the stored saturation and the stored water table: what the launch that
@@ -763,7 +771,6 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const int Nz = v.Nz, Nh = (int)v.Nh;
     ln.is_bot = ln.k == 0;
     ln.is_top = ln.k == Nz - 1;
-    const LevelGeom<NF> L = level_geom(v, ln.k);
     const NF dt = a.dt;
     const int finalize = a.finalize, write_kf = a.write_kf;
     const bool need_kc = RICHARDS || write_kf;
@@ -784,6 +791,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
     c.T = ldg(v.T, cb0);
     c.liq = ldg(v.liq, cb0);
+    const LevelGeom<NF> L = level_geom(v, ln.k);      // (behind the field loads: see level_geom)
     // compute_z_bcs! terms of the STATE (both explicit steps use them: the stage's clock is still t for its predictor)
     ColumnBC<NF> bc{};
     {

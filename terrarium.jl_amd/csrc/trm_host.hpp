@@ -418,7 +418,7 @@ template <class NF, bool RICH, int PROG> struct ColumnLaunch { static int run(tr
 // the ForwardEuler program with the derivation of T / liq and the boundary-condition signature compiled in (BCSIG, trm_kernels.hpp):
 // one explicit instantiation per signature in the trm_launch_column_sig_*.hip files; `supported` lists them.
 template <class NF, bool RICH, int SIG> struct ColumnSigLaunch {
-    static void run(trm_ctx* c, const View<NF>& v, const DevParams<NF>& p, const ColumnArgs<NF>& a, dim3 grid, dim3 block, int lpc, int staged, int scalar_in);
+    static void run(trm_ctx* c, const View<NF>& v, const DevParams<NF>& p, const ColumnArgs<NF>& a, dim3 grid, dim3 block, int lpc, int derive, int staged, int scalar_in);
 };
 // generic boundary kinds: k_step_wave (Euler) and k_heun_generic (trm_launch_generic*.hip)
 template <class NF> struct GenericLaunch {

@@ -440,7 +440,12 @@ template <class NF> struct alignas(16) LevelPack { NF w[8]; };
 template <class NF> TRM_DEV LevelGeom<NF> level_geom(const View<NF>& v, int k) {
     const int Nz = v.Nz;
     const int kk = k < Nz ? k : Nz - 1;
-    // one 16-byte-aligned record per level: 4 (fp64) / 2 (fp32) wide loads instead of 7 narrow ones
+    // one 16-byte-aligned record per level: 4 (fp64) / 2 (fp32) wide loads instead of 7 narrow ones.
+    // CALL IT BEHIND THE FIELD LOADS of a kernel: the record's unused eighth value lands in a register pair nobody reads, the allocator
+    // hands that pair to whatever arithmetic follows, and if that is the address arithmetic of the field loads the write-after-write
+    // hazard puts an `s_waitcnt vmcnt` -- a full trip to memory -- between the record and the fields (round 4: found in every
+    // k_column instance that reads T / liq; profiles/tools/check_load_order.py).  (Loading 7 values does not help: the backend
+    // widens the last 8-byte piece to 16 again.)
     const LevelPack<NF> q = *reinterpret_cast<const LevelPack<NF>*>(reinterpret_cast<const char*>(v.lvl) + (unsigned)kk * (unsigned)sizeof(LevelPack<NF>));
     LevelGeom<NF> L;
     L.zC = q.w[0]; L.psiz = q.w[1]; L.zFlo = q.w[2]; L.dzc = q.w[3]; L.rdzc = q.w[4]; L.rdzf_lo = q.w[5]; L.rdzf_hi = q.w[6];

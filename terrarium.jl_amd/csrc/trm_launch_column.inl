@@ -35,23 +35,33 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
         else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
         else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, false>), grid, block, 0, c->stream, v, p, a);
     } else if constexpr (PROG == PROG_EULER) {
+        // the context's boundary kinds as a signature; the instantiated ones take the program with the kinds compiled in (fp64; with
+        // the derivation of T / liq or without it)
+        int use_sig = -1;
+        if constexpr (std::is_same<NF, double>::value) {
+            if (c->opt_bc_signature && (derive == DERIVE_T_LIQ || derive == DERIVE_NONE)) use_sig = bc_signature_of(c);
+        }
+        const int staged = derive == DERIVE_T_LIQ ? P::template staged_now<RICH>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::template scalar_inputs_now<RICH>(c) : 1;
+        bool launched = false;
+        if constexpr (std::is_same<NF, double>::value) {
+            launched = true;
+            if (use_sig == 0) ColumnSigLaunch<NF, RICH, 0>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
+            else if (use_sig == BCSIG_T_TOP) ColumnSigLaunch<NF, RICH, BCSIG_T_TOP>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
+            else if (use_sig == (BCSIG_T_TOP | BCSIG_FU_BOT)) ColumnSigLaunch<NF, RICH, BCSIG_T_TOP | BCSIG_FU_BOT>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
+            else if (RICH && use_sig == BCSIG_LAND) {
+                if constexpr (RICH) ColumnSigLaunch<NF, RICH, BCSIG_LAND>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
+            }
+            else launched = false;
+        }
+        if (launched) {
+        }
         // with the derivation (every large or HBM-resident fp64 state): how the per-column outputs leave / inputs arrive
-        if (derive == DERIVE_T_LIQ) {
+        else if (derive == DERIVE_T_LIQ) {
             if constexpr (!std::is_same<NF, double>::value) {
                 // (fp32 off the packed kernel derives only on request: one instance)
                 hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
             } else {
-                const int staged = P::template staged_now<RICH>(c), scalar_in = P::template scalar_inputs_now<RICH>(c);
-                // the context's boundary kinds as a signature; the instantiated ones take the program with the kinds compiled in
-                const int sig = bc_signature_of(c);
-                const int use_sig = c->opt_bc_signature ? sig : -1;
-                if (use_sig == 0) ColumnSigLaunch<NF, RICH, 0>::run(c, v, p, a, grid, block, LPC, staged, scalar_in);
-                else if (use_sig == BCSIG_T_TOP) ColumnSigLaunch<NF, RICH, BCSIG_T_TOP>::run(c, v, p, a, grid, block, LPC, staged, scalar_in);
-                else if (use_sig == (BCSIG_T_TOP | BCSIG_FU_BOT)) ColumnSigLaunch<NF, RICH, BCSIG_T_TOP | BCSIG_FU_BOT>::run(c, v, p, a, grid, block, LPC, staged, scalar_in);
-                else if (RICH && use_sig == BCSIG_LAND) {
-                    if constexpr (RICH) ColumnSigLaunch<NF, RICH, BCSIG_LAND>::run(c, v, p, a, grid, block, LPC, staged, scalar_in);
-                }
-                else if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
+                if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
                 else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
                 else if (scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
                 else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, false>), grid, block, 0, c->stream, v, p, a);
