@@ -420,6 +420,10 @@ template <class NF, bool RICH, int PROG> struct ColumnLaunch { static int run(tr
 template <class NF, bool RICH, int SIG> struct ColumnSigLaunch {
     static void run(trm_ctx* c, const View<NF>& v, const DevParams<NF>& p, const ColumnArgs<NF>& a, dim3 grid, dim3 block, int lpc, int derive, int staged, int scalar_in);
 };
+// the same for the one-launch Heun program (trm_launch_column_sig_heun_*.hip)
+template <class NF, bool RICH, int SIG> struct ColumnSigHeunLaunch {
+    static void run(trm_ctx* c, const View<NF>& v, const DevParams<NF>& p, const ColumnArgs<NF>& a, dim3 grid, dim3 block, int lpc);
+};
 // generic boundary kinds: k_step_wave (Euler) and k_heun_generic (trm_launch_generic*.hip)
 template <class NF> struct GenericLaunch {
     static int step(trm_ctx* c, double dt, int finalize);

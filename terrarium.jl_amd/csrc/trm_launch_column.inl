@@ -78,7 +78,23 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
         else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
         else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
     } else {
-        hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);
+        // (Heun: the same signatures)
+        int use_sig = -1;
+        if constexpr (std::is_same<NF, double>::value) {
+            if (c->opt_bc_signature) use_sig = bc_signature_of(c);
+        }
+        bool launched = false;
+        if constexpr (std::is_same<NF, double>::value) {
+            launched = true;
+            if (use_sig == 0) ColumnSigHeunLaunch<NF, RICH, 0>::run(c, v, p, a, grid, block, LPC);
+            else if (use_sig == BCSIG_T_TOP) ColumnSigHeunLaunch<NF, RICH, BCSIG_T_TOP>::run(c, v, p, a, grid, block, LPC);
+            else if (use_sig == (BCSIG_T_TOP | BCSIG_FU_BOT)) ColumnSigHeunLaunch<NF, RICH, BCSIG_T_TOP | BCSIG_FU_BOT>::run(c, v, p, a, grid, block, LPC);
+            else if (RICH && use_sig == BCSIG_LAND) {
+                if constexpr (RICH) ColumnSigHeunLaunch<NF, RICH, BCSIG_LAND>::run(c, v, p, a, grid, block, LPC);
+            }
+            else launched = false;
+        }
+        if (!launched) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);
     }
     TRM_HIP(c, hipGetLastError());
     return TRM_OK;

@@ -327,9 +327,10 @@ SIGNATURES = [("heat", {}, 2), ("heat", {("internal_energy", "bottom"): ("flux",
               ("land", {("internal_energy", "bottom"): ("flux", 0.05)}, 68), ("richards", {("saturation_water_ice", "top"): ("flux", -2.0e-7)}, 34)]
 
 
+@pytest.mark.parametrize("heun", [False, True])
 @pytest.mark.parametrize("hydraulics,Nz", [("default", 32), ("vg", 50)])
 @pytest.mark.parametrize("config,extra,signature", SIGNATURES)
-def test_programs_with_the_boundary_signature_compiled_in_equal_the_runtime_program_bitwise(config, extra, signature, hydraulics, Nz):
+def test_programs_with_the_boundary_signature_compiled_in_equal_the_runtime_program_bitwise(config, extra, signature, hydraulics, Nz, heun):
     """TRM_OPT_BC_SIGNATURE (BCSIG of k_column): the deriving ForwardEuler program with the boundary kinds as compile-time constants --
     no conditions, a prescribed surface temperature, that + a bottom heat flux, the LandModel wiring -- against the same program reading
     the kinds at run time and against the reference-order kernels; signatures without an instance (68, 34) take the run-time program."""
@@ -346,9 +347,10 @@ def test_programs_with_the_boundary_signature_compiled_in_equal_the_runtime_prog
     ref.set_option("step_kernel", "unfused")
     for d in (sig, run, ref):
         d.set_option("derive_closure_fields", 1)
-        d.step(w["dt"], 1, finalize=False)
-        d.step(w["dt"], 17, finalize=False)
-        d.step(w["dt"], 1, finalize=True)
+        step = d.step_heun if heun else d.step          # (Heun: the one-launch program, the stage's boundary values compiled in alike)
+        step(w["dt"], 1, finalize=False)                # the first step reads T / liq as stored: the instances without the derivation
+        step(w["dt"], 17, finalize=False)
+        step(w["dt"], 1, finalize=True)
     for n in all_fields(w) + ["tend_internal_energy"]:
         a = ref.get(n)
         assert np.array_equal(sig.get(n), a, equal_nan=True), n
