@@ -1,5 +1,5 @@
 """A/B of library options on one box, variants interleaved in one process (boxes of the pool differ by +-4 %):
-    python profiles/tools/ab_options.py WORKLOAD name:opt=val,opt=val name:opt=val ...  [--steps N] [--reps R] [--shard P]
+    python profiles/tools/ab_options.py WORKLOAD name:opt=val,opt=val name:opt=val ...  [--steps N] [--reps R] [--shard P] [--heun]
 Each variant is one context of the workload with the given trm_set_option values; the timed quantity is the device time of
 N steps (HIP events on the context stream, trm_step_timed) and the wall time around the same call.  Prints medians."""
 import os, sys, time, json
@@ -16,6 +16,9 @@ def flag(name, default):
         i = args.index(name); v = args[i + 1]; del args[i:i + 2]; return int(v)
     return default
 steps, reps, shard = flag("--steps", 100), flag("--reps", 7), flag("--shard", 0)
+heun = "--heun" in args
+if heun:
+    args.remove("--heun")
 if shard:
     os.environ["TRM_BENCH_SHARD_OF"] = str(shard)
 wl, specs = args[0], args[1:]
@@ -37,11 +40,12 @@ for rep in range(reps):
     for name in rng.permutation(list(devs)):
         d = devs[name]
         d.restore_state()
-        d.step_timed(w["dt"], steps, finalize=False)      # untimed: this variant's own clock / cache state
+        timed = d.step_heun_timed if heun else d.step_timed
+        timed(w["dt"], steps, finalize=False)      # untimed: this variant's own clock / cache state
         d.restore_state()
         d.synchronize()
         t0 = time.perf_counter()
-        ms = d.step_timed(w["dt"], steps, finalize=False)
+        ms = timed(w["dt"], steps, finalize=False)
         d.synchronize()
         wall[name].append((time.perf_counter() - t0) * 1e6 / steps)
         res[name].append(ms * 1e3 / steps)
