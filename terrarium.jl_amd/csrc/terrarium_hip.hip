@@ -843,12 +843,13 @@ bool parse_env_int(const char* name, long lo, long hi, long multiple_of, long& o
     return true;
 }
 struct EnvSwitches {
-    long field_skew = 16640, derive_default = -1;
+    long field_skew = 16640, derive_default = -1, debug_placement = 0;
     std::string error;
     EnvSwitches() {
         long v;
         if (parse_env_int("TRM_FIELD_SKEW", 0, 1 << 20, 256, v, error)) field_skew = v;
         if (error.empty() && parse_env_int("TRM_DERIVE_DEFAULT", 0, 5, 1, v, error)) derive_default = v;
+        if (error.empty() && parse_env_int("TRM_DEBUG_PLACEMENT", 0, 1, 1, v, error)) debug_placement = v;   // (prints every field's allocation: profiles/tools/placement_probe.sh)
         if (error.empty() && parse_env_int("TRM_STAGED_SMALL", 0, 1, 1, v, error)) { /* read by Policy::staged_now */ }
         if (error.empty() && parse_env_int("TRM_SCALAR_INPUTS", 0, 1, 1, v, error)) { /* read by Policy::scalar_inputs_now */ }
     }
@@ -866,6 +867,7 @@ int alloc_fields(trm_ctx* c, FieldSet& s) {
         const size_t skew = field_skew_bytes() * (size_t)(f % 32);
         TRM_HIP(c, hipMalloc(&s.raw[f], bytes + skew));
         s.f[f] = (char*)s.raw[f] + skew;
+        if (env_switches().debug_placement) std::fprintf(stderr, "trm placement: field %d raw %p bytes %zu skew %zu\n", f, s.raw[f], bytes, skew);
         TRM_HIP(c, hipMemsetAsync(s.f[f], 0, bytes, c->stream));
     }
     if (!s.kf_top) {
