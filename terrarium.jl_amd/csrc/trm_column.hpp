@@ -377,7 +377,8 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     TRM_PHASE_FENCE("inputs", c.U, c.sat, c.psi, c.T, c.liq);
     if (!EARLY) request_inputs();
     const NF in_Tb = col_get(q_Tb), in_Tt = col_get(q_Tt), in_Ub = col_get(q_Ub), in_Sb = col_get(q_Sb), in_Ut = col_get(q_Ut), in_St = col_get(q_St);
-    const NF in_wt = col_get(q_wt), in_Tb2 = col_get(q_Tb2), in_Tt2 = col_get(q_Tt2), S_in = col_get(q_S), Ts_in = col_get(q_Ts);
+    const NF in_wt = col_get(q_wt), in_Tb2 = col_get(q_Tb2), in_Tt2 = col_get(q_Tt2);
+    NF S_in = col_get(q_S), Ts_in = col_get(q_Ts);
     ColumnBC<NF> bc;
     if (RICHARDS && DERIVE == DERIVE_ALL) {
         // saturation_to_pressure! of the stored state from the stored saturation and the stored water table: what the launch that
