@@ -79,6 +79,19 @@ __global__ void __launch_bounds__(256) k_e(Ptrs p, int Nh, double dt) {
     p.f[0][c] = a0 + dt; p.f[1][c] = a1 + dt; p.f[2][c] = a0 * dt; p.f[3][c] = a1 * dt; p.f[4][c] = a0 - a1; p.f[5][c] = a0 + a1;
 }
 
+// F: as D (3 reads + 6 writes) on a TILED layout: the six fields of a workgroup's 8 columns adjacent in memory (8 x 32 x 8 B = 2 KB per
+// field, 12 KB per tile) -- a workgroup's nine streams touch one 12 KB run instead of nine places ~115 MB apart
+__global__ void __launch_bounds__(256) k_f(double* base, int Nh, double dt) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int i = wave * 2 + (lane >> 5), k = lane & 31;
+    if (i >= Nh) return;
+    const size_t tile = (size_t)(i >> 3) * (6 * 256), in_tile = (size_t)(i & 7) * 32 + k;
+    double* f0 = base + tile + in_tile;
+    double a0 = f0[0], a1 = f0[256], a4 = f0[4 * 256];
+    f0[0] = a0 + dt; f0[256] = a1 + dt; f0[2 * 256] = a0 * dt; f0[3 * 256] = a1 * dt; f0[4 * 256] = a4 + dt; f0[5 * 256] = a0 + a1;
+}
+
 int main(int argc, char** argv) {
     const int Nh = argc > 1 ? atoi(argv[1]) : 56951;
     const size_t n = (size_t)Nh * 32;
@@ -105,6 +118,8 @@ int main(int argc, char** argv) {
     run("A lane=level 8B/lane", [&] { hipLaunchKernelGGL(k_a, dim3((wavesA + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
     run("D 3 reads 6 writes (x9/11)", [&] { hipLaunchKernelGGL(k_d, dim3((wavesA + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
     run("E 2 reads 6 writes (x8/11)", [&] { hipLaunchKernelGGL(k_e, dim3((wavesA + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
+    double* tiled; CK(hipMalloc(&tiled, 6 * n * 8 + (1 << 20))); CK(hipMemset(tiled, 0, 6 * n * 8));
+    run("F 3 reads 6 writes, tiled layout (x9/11)", [&] { hipLaunchKernelGGL(k_f, dim3((wavesA + 3) / 4), dim3(256), 0, 0, tiled, Nh, 1.0); });
     run("B 4 levels/lane 2x16B", [&] { hipLaunchKernelGGL(k_b, dim3((wavesB + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
     run("C2 two groups per wave", [&] { hipLaunchKernelGGL(k_c<2>, dim3(((wavesA + 1) / 2 + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
     run("C4 four groups per wave", [&] { hipLaunchKernelGGL(k_c<4>, dim3(((wavesA + 3) / 4 + 3) / 4), dim3(256), 0, 0, p, Nh, 1.0); });
