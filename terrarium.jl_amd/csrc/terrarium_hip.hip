@@ -610,9 +610,9 @@ template <class NF> struct Ops {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
         // deeper takes the reference-order kernels
-        // the fused kernels map one soil level to one lane (two for 65 ... 128 levels, four for 129 ... 256 -- the latter without the
-        // coupled vegetation); anything deeper takes the reference-order kernels
-        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c) || (wide_columns(c) && !coupled(c)));
+        // the fused kernels map one soil level to one lane (two for 65 ... 128 levels, four for 129 ... 256); anything deeper takes the
+        // reference-order kernels.  (The coupled vegetation on 129 ... 256 levels: ForwardEuler here, Heun on the reference-order kernels.)
+        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c) || wide_columns(c));
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
         // (columns of 65 ... 128 levels: contexts without the surface energy balance and without series)
