@@ -424,6 +424,20 @@ template <class NF, bool RICH, int SIG> struct ColumnSigLaunch {
 template <class NF, bool RICH, int SIG> struct ColumnSigHeunLaunch {
     static void run(trm_ctx* c, const View<NF>& v, const DevParams<NF>& p, const ColumnArgs<NF>& a, dim3 grid, dim3 block, int lpc);
 };
+// the signatures that have instances: launches L<NF, RICH, sig>::run(args...) and returns true, or returns false (the caller then takes
+// the program that reads the kinds at run time)
+template <template <class, bool, int> class L, class NF, bool RICH, class... A> bool launch_by_signature(int sig, A&&... args) {
+    if constexpr (!std::is_same<NF, double>::value) return false;
+    else switch (sig) {
+        case 0: L<NF, RICH, 0>::run(args...); return true;
+        case BCSIG_T_TOP: L<NF, RICH, BCSIG_T_TOP>::run(args...); return true;
+        case BCSIG_T_TOP | BCSIG_FU_BOT: L<NF, RICH, BCSIG_T_TOP | BCSIG_FU_BOT>::run(args...); return true;
+        case BCSIG_LAND:
+            if constexpr (RICH) { L<NF, RICH, BCSIG_LAND>::run(args...); return true; }
+            return false;
+        default: return false;
+    }
+}
 // generic boundary kinds: k_step_wave (Euler) and k_heun_generic (trm_launch_generic*.hip)
 template <class NF> struct GenericLaunch {
     static int step(trm_ctx* c, double dt, int finalize);

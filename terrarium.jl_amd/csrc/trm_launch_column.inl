@@ -37,23 +37,9 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
     } else if constexpr (PROG == PROG_EULER) {
         // the context's boundary kinds as a signature; the instantiated ones take the program with the kinds compiled in (fp64; with
         // the derivation of T / liq or without it)
-        int use_sig = -1;
-        if constexpr (std::is_same<NF, double>::value) {
-            if (c->opt_bc_signature && (derive == DERIVE_T_LIQ || derive == DERIVE_NONE)) use_sig = bc_signature_of(c);
-        }
+        const int sig = (c->opt_bc_signature && (derive == DERIVE_T_LIQ || derive == DERIVE_NONE)) ? bc_signature_of(c) : -1;
         const int staged = derive == DERIVE_T_LIQ ? P::template staged_now<RICH>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::template scalar_inputs_now<RICH>(c) : 1;
-        bool launched = false;
-        if constexpr (std::is_same<NF, double>::value) {
-            launched = true;
-            if (use_sig == 0) ColumnSigLaunch<NF, RICH, 0>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
-            else if (use_sig == BCSIG_T_TOP) ColumnSigLaunch<NF, RICH, BCSIG_T_TOP>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
-            else if (use_sig == (BCSIG_T_TOP | BCSIG_FU_BOT)) ColumnSigLaunch<NF, RICH, BCSIG_T_TOP | BCSIG_FU_BOT>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
-            else if (RICH && use_sig == BCSIG_LAND) {
-                if constexpr (RICH) ColumnSigLaunch<NF, RICH, BCSIG_LAND>::run(c, v, p, a, grid, block, LPC, derive, staged, scalar_in);
-            }
-            else launched = false;
-        }
-        if (launched) {
+        if (launch_by_signature<ColumnSigLaunch, NF, RICH>(sig, c, v, p, a, grid, block, LPC, derive, staged, scalar_in)) {
         }
         // with the derivation (every large or HBM-resident fp64 state): how the per-column outputs leave / inputs arrive
         else if (derive == DERIVE_T_LIQ) {
@@ -79,21 +65,7 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
         else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
     } else {
         // (Heun: the same signatures)
-        int use_sig = -1;
-        if constexpr (std::is_same<NF, double>::value) {
-            if (c->opt_bc_signature) use_sig = bc_signature_of(c);
-        }
-        bool launched = false;
-        if constexpr (std::is_same<NF, double>::value) {
-            launched = true;
-            if (use_sig == 0) ColumnSigHeunLaunch<NF, RICH, 0>::run(c, v, p, a, grid, block, LPC);
-            else if (use_sig == BCSIG_T_TOP) ColumnSigHeunLaunch<NF, RICH, BCSIG_T_TOP>::run(c, v, p, a, grid, block, LPC);
-            else if (use_sig == (BCSIG_T_TOP | BCSIG_FU_BOT)) ColumnSigHeunLaunch<NF, RICH, BCSIG_T_TOP | BCSIG_FU_BOT>::run(c, v, p, a, grid, block, LPC);
-            else if (RICH && use_sig == BCSIG_LAND) {
-                if constexpr (RICH) ColumnSigHeunLaunch<NF, RICH, BCSIG_LAND>::run(c, v, p, a, grid, block, LPC);
-            }
-            else launched = false;
-        }
+        const bool launched = launch_by_signature<ColumnSigHeunLaunch, NF, RICH>(c->opt_bc_signature ? bc_signature_of(c) : -1, c, v, p, a, grid, block, LPC);
         if (!launched) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);
     }
     TRM_HIP(c, hipGetLastError());
