@@ -611,7 +611,7 @@ template <class NF> struct Ops {
         // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
         // deeper takes the reference-order kernels
         // the fused kernels map one soil level to one lane (two for 65 ... 128 levels, four for 129 ... 256); anything deeper takes the
-        // reference-order kernels.  (The coupled vegetation on 129 ... 256 levels: ForwardEuler here, Heun on the reference-order kernels.)
+        // reference-order kernels.
         const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c) || wide_columns(c));
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
@@ -725,7 +725,8 @@ template <class NF> struct Ops {
         a.store_paw = c->opt_write_kf != 0;
         a.st_w_can = vg.w_can; a.st_C_veg = vg.C_veg; a.st_nu = vg.nu; a.st_An = vg.An; a.st_Ts = sv.Ts;
         rc = surface_veg_launch(c, v0, vs, a);
-        if (!rc) rc = deep_columns(c) ? DeepLaunch<NF>::run(c, PROG_HEUN, false, dt, finalize, 1) : column_program<PROG_HEUN>(c, dt, finalize, 1);
+        if (!rc) rc = wide_columns(c) ? WideLaunch<NF>::run(c, PROG_HEUN, false, dt, finalize)
+                              : (deep_columns(c) ? DeepLaunch<NF>::run(c, PROG_HEUN, false, dt, finalize, 1) : column_program<PROG_HEUN>(c, dt, finalize, 1));
         if (rc) return rc;
         c->closure_consistent = true;
         c->tend_valid = finalize != 0;
@@ -797,7 +798,7 @@ template <class NF> struct Ops {
     static int heun_step(trm_ctx* c, double dt, int finalize) {
         if (int rr = refresh_user_stage_buffers(c)) return rr;
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
-        if (c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c)) && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
+        if (c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c) || wide_columns(c)) && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && !generic_bcs(c) && !coupled(c)) return heun_step_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && (deep_columns(c) || wide_columns(c)) && !coupled(c)) return heun_step_deep(c, dt, finalize);      // (every boundary kind)
         c->top_valid = false;

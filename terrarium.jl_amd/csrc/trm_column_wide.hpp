@@ -371,6 +371,16 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         NF z0s;
         over_stage = advance(gU, gS, flux_U, flux_S, Us, ss, z0s);
         closure(Us, ss, z0s, ls, Ts, ps);
+        if (a.stage_T) {   // (wave-uniform: the vegetation-coupled LandModel evaluates its 0-D processes AT the stage: k_column<PROG_HEUN>)
+            const unsigned cbs = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)ln.k0) * (unsigned)sizeof(NF);
+            for (int j = 0; j < M; ++j) {
+                if (!ln.act[j]) continue;
+                const unsigned cb = block_local(cbs + (unsigned)j * (unsigned)sizeof(NF));
+                stg(a.stage_sat, cb, ss.x[j]);
+                stg(a.stage_liq, cb, ls.x[j]);
+                stg(a.stage_T, cb, Ts.x[j]);
+            }
+        }
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59); with GENERIC every
         // boundary kind and value of the stage's view
         const NF bTb2 = (!GENERIC && vTb) ? ldg(a.bcT_bot_stage, ib_late) : NF(0), bTt2 = (!GENERIC && vTt) ? ldg(a.bcT_top_stage, ib_late) : NF(0);
@@ -401,12 +411,12 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         Kc_top = Kn;
     }
     // surface_excess_water after the step, formed before the first store (column_program)
-    NF S = NF(0), GS = NF(0);
+    NF S = NF(0), GS = NF(0), S_stage = NF(0);
     if (RICHARDS) {
         S = S_in;
         GS = NF(0) + jl_min(NF(0), S);
         if (PROG == PROG_HEUN) {
-            const NF S_stage = (S + GS * dt) + over_stage;
+            S_stage = (S + GS * dt) + over_stage;
             GS = (GS + (NF(0) + jl_min(NF(0), S_stage))) / NF(2);
         }
         S = (S + GS * dt) + over;
@@ -438,6 +448,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
             stg(vo.S, ib, S);
             stg(vo.wt, ib, z0);
             if (finalize) stg(vo.G_S, ib, GS);
+            if (PROG == PROG_HEUN && a.stage_S) stg(a.stage_S, ib, S_stage);
         }
         if (seb) {
             stg(vo.top_T, ib, Tt);

@@ -14,6 +14,12 @@ template <class NF, bool RICH, int H, int PROG, bool GENERIC> static int launch_
     a.nsteps = 1;
     a.bcT_bot_stage = la.w.bcT_bot;      // Heun: the stage's temperature boundary values (evaluated at t + dt)
     a.bcT_top_stage = la.w.bcT_top;
+    if (PROG == PROG_HEUN && Policy<NF>::coupled(c)) {   // the stage's soil state is needed by the 0-D processes evaluated at the stage
+        a.stage_sat = (NF*)c->stage.f[TRM_FIELD_SATURATION_WATER_ICE];
+        a.stage_liq = (NF*)c->stage.f[TRM_FIELD_LIQUID_WATER_FRACTION];
+        a.stage_T = (NF*)c->stage.f[TRM_FIELD_TEMPERATURE];
+        a.stage_S = (NF*)c->stage.f[TRM_FIELD_SURFACE_EXCESS_WATER];
+    }
     const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
     hipLaunchKernelGGL((k_column_wide<NF, RICH, H, 4, PROG, GENERIC>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a, la.stage);
     TRM_HIP(c, hipGetLastError());
