@@ -573,14 +573,11 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     TRM_PHASE_FENCE("stores", Kf_out, Kf_out_top, S, GS_out, Ts_new);
     if (ln.act) {
         const View<NF>& v = kernarg_reload<View<NF>>(0);
-#if TRM_STORE_POINTERS_UPFRONT
         // every base pointer the store phase may need in ONE batch of scalar loads: fetched where they are used -- inside the
         // finalize / write_kf / top-lane branches -- each is a scalar load and a wait of its own in front of its store
         NF* const pGU = v.G_U; NF* const pGS3 = v.G_sat; NF* const pKf = v.Kf; NF* const pKft = v.Kf_top; NF* const pS = v.S; NF* const pwt = v.wt;
         asm volatile("" : : "s"(pGU), "s"(pGS3), "s"(pKf), "s"(pKft), "s"(pS), "s"(pwt));
-#else
-        NF* const pGU = v.G_U; NF* const pGS3 = v.G_sat; NF* const pKf = v.Kf;
-#endif
+        // (block_local in EVERY block that stores: an offset defined in another block has been widened to 64 bits there)
         const unsigned cb = block_local(cb0), ib = block_local(ib0);
         stg(v.U, cb, n.U);
         stg(v.T, cb, n.T);
@@ -613,30 +610,20 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
                 st[SMALL_TS * cpb + cib] = SEB_INLINE ? sf.out.Ts : Ts_new;
             }
         } else if (ln.is_top) {
-            const unsigned ib = block_local(ib0);     // (in THIS block: see block_local -- else every store below pays a 64-bit address add)
-#if TRM_STORE_POINTERS_UPFRONT
             if (write_kf) stg(pKft, block_local(ib0), Kf_out_top);
             if (RICHARDS) {
-                stg(pS, block_local(ib0), S);
-                stg(pwt, block_local(ib0), z0);
-#else
-            if (write_kf) stg(v.Kf_top, ib, Kf_out_top);
-            if (RICHARDS) {
-#ifndef TRM_DIAG_NO_2D_STORES
-                stg(v.S, ib, S);
-                stg(v.wt, ib, z0);
-#endif
-#endif
-                if (finalize) stg(v.G_S, ib, GS_out);
+                const unsigned ib = block_local(ib0);
+                stg(pS, ib, S);
+                stg(pwt, ib, z0);
+                if (finalize) stg(v.G_S, block_local(ib0), GS_out);
             }
-#ifndef TRM_DIAG_NO_TOP_STORES
             if (seb) {   // the next surface energy balance reads these
+                const unsigned ib = block_local(ib0);
                 stg(v.top_T, ib, n.T);
                 stg(v.top_sat, ib, n.sat);
                 stg(v.top_liq, ib, n.liq);
                 stg(v.Ts, ib, SEB_INLINE ? sf.out.Ts : Ts_new);
             }
-#endif
         }
         viol |= bad ? 1u : 0u;
     }

@@ -40,9 +40,6 @@ template <class... T> __device__ __forceinline__ void phase_fence_values(T&... x
 #ifndef TRM_LOAD_POINTERS_UPFRONT    // the base pointers of the field reads fetched in one batch in front of the first load
 #define TRM_LOAD_POINTERS_UPFRONT 1
 #endif
-#ifndef TRM_STORE_POINTERS_UPFRONT   // the base pointers of the conditional stores fetched in one batch in front of the store phase
-#define TRM_STORE_POINTERS_UPFRONT 1
-#endif
 #ifndef TRM_EARLY_INPUTS   // the per-column inputs requested right behind the field loads, in front of the derivation (trm_column.hpp)
 #define TRM_EARLY_INPUTS 1
 #endif
