@@ -176,6 +176,13 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const int last_group = ((Nz - 1) / M) * M;
     const int k_ld = ln.k0 <= last_group ? ln.k0 : last_group;
     const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
+    // (one column per wave: the per-column inputs through the scalar memory path, as in k_column_deep -- profiles/r04/exp18)
+#if TRM_DEEP_SCALAR_INPUTS
+    const unsigned ib_u = (unsigned)__builtin_amdgcn_readfirstlane((int)ib0);
+    auto col_ld = [&](const NF* ptr, unsigned) -> NF { return sld_off<NF>(ptr, ib_u); };
+#else
+    auto col_ld = [&](const NF* ptr, unsigned off) -> NF { return ldg(ptr, off); };
+#endif
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)k_ld) * (unsigned)sizeof(NF);
     const NF dt = a.dt;
     const int finalize = a.finalize, write_kf = a.write_kf;
@@ -204,7 +211,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const L4 T = ld_cells<NF, M>(v.T, cb0), liq = ld_cells<NF, M>(v.liq, cb0);
     const bool seb = p.seb != 0;
     const bool vTb = v.bc.kind[2][0] == 1, vTt = v.bc.kind[2][1] == 1;
-    const NF bTb = vTb ? ldg(bcval(v, 2, 0), ib0) : NF(0), bTt = vTt ? ldg(bcval(v, 2, 1), ib0) : NF(0);
+    const NF bTb = vTb ? col_ld(bcval(v, 2, 0), ib0) : NF(0), bTt = vTt ? col_ld(bcval(v, 2, 1), ib0) : NF(0);
 
     // ---- compute_auxiliary! + compute_tendencies! (column_tendencies / column_tendencies_generic, trm_column.hpp, per cell) -----
     struct Tend { L4 gU, gS, Kf_lo, Kc; };
@@ -347,14 +354,14 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     unsigned ib_late = ib0;
     asm volatile("" : "+v"(ib_late));
     NF eU_b = NF(0), eU_t = NF(0), eS_b = NF(0), eS_t = NF(0);
-    if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(ldg(bcval(v, 0, 0), ib_late), v.g);
-    if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(ldg(bcval(v, 1, 0), ib_late), v.g);
-    if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(ldg(seb ? v.ghf : bcval(v, 0, 1), ib_late), v.g);
+    if (v.bc.kind[0][0] == 2) eU_b = flux_term_bottom(col_ld(bcval(v, 0, 0), ib_late), v.g);
+    if (RICHARDS && v.bc.kind[1][0] == 2) eS_b = flux_term_bottom(col_ld(bcval(v, 1, 0), ib_late), v.g);
+    if (seb || v.bc.kind[0][1] == 2) eU_t = -flux_term_top(col_ld(seb ? v.ghf : bcval(v, 0, 1), ib_late), v.g);
     if (RICHARDS && (seb || v.bc.kind[1][1] == 2)) {
-        const NF fS = ldg(seb ? v.infil : bcval(v, 1, 1), ib_late);
+        const NF fS = col_ld(seb ? v.infil : bcval(v, 1, 1), ib_late);
         eS_t = -flux_term_top(seb ? -fS : fS, v.g);
     }
-    const NF S_in = RICHARDS ? ldg(v.S, ib_late) : NF(0), Ts_in = seb ? ldg(v.Ts, ib_late) : NF(0);
+    const NF S_in = RICHARDS ? col_ld(v.S, ib_late) : NF(0), Ts_in = seb ? col_ld(v.Ts, ib_late) : NF(0);
     L4 flux_U, flux_S;
     for (int j = 0; j < M; ++j) {
         const bool b = ln.bot && j == 0;
@@ -383,7 +390,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
         }
         // stage 2: tendencies at the stage, its temperature boundary values taken at t + dt (heun.jl:52-59); with GENERIC every
         // boundary kind and value of the stage's view
-        const NF bTb2 = (!GENERIC && vTb) ? ldg(a.bcT_bot_stage, ib_late) : NF(0), bTt2 = (!GENERIC && vTt) ? ldg(a.bcT_top_stage, ib_late) : NF(0);
+        const NF bTb2 = (!GENERIC && vTb) ? col_ld(a.bcT_bot_stage, ib_late) : NF(0), bTt2 = (!GENERIC && vTt) ? col_ld(a.bcT_top_stage, ib_late) : NF(0);
         uint32_t vs[M];
         for (int j = 0; j < M; ++j) vs[j] = 0;
         const Tend t2 = tendencies(kernarg_reload<View<NF>>(GENERIC ? off_vs : 0u), kernarg_reload<DevParams<NF>>(off_p), Ts, ls, ss, ps, bTb2, bTt2, RICHARDS, vs);

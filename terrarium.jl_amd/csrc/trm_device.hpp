@@ -37,6 +37,9 @@ template <class... T> __device__ __forceinline__ void phase_fence_values(T&... x
 // (profiles/r04/exp3_instruction_cuts.log): together they take 27 ... 40 vector instructions per wave out of the step
 // kernels and move the step time by 0 ... -2 %; the two that put a NEW wave-uniform branch into the hot path (FLUX, POWRARE) cost
 // the HBM-resident step +4 % and are off; the others are on.
+#ifndef TRM_DEEP_SCALAR_INPUTS       // k_column_deep: the per-column inputs through the scalar memory path (one column per wave)
+#define TRM_DEEP_SCALAR_INPUTS 1
+#endif
 #ifndef TRM_LOAD_POINTERS_UPFRONT    // the base pointers of the field reads fetched in one batch in front of the first load
 #define TRM_LOAD_POINTERS_UPFRONT 1
 #endif
