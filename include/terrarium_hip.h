@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 15
+#define TRM_ABI_VERSION 16
 
 typedef struct trm_ctx trm_ctx;
 
@@ -196,6 +196,11 @@ enum {
                                     /* compiled into the library (none; prescribed surface temperature; that + a bottom heat flux;    */
                                     /* the LandModel wiring) takes the program with the kinds as compile-time constants (-3 ... -5 %, */
                                     /* DESIGN 4.3); 0: always the program that reads the kinds at run time (same results; A/B, tests)  */
+    ,TRM_OPT_ZERO_GRADIENT_FAST = 10 /* 1 (default): a Gradient condition on temperature or pressure head at the BOTTOM whose values   */
+                                    /* trm_set_bc received as +0 everywhere -- the reference's FreeDrainage(), soil_model_bcs.jl:40 --  */
+                                    /* forms the same halo, bit for bit, as no condition at all, and the context keeps the branch-free */
+                                    /* programs (derivation, resident multi-step program, ...) instead of the generic-boundary kernels; */
+                                    /* handing the value buffer out (trm_bc_device_ptr) or attaching a series ends it.  0: off (A/B)    */
 };
 /* DIAGNOSTIC, read-only (trm_get_option): which fast paths the NEXT step will take -- what the library tracks about its own
  * buffers.  Tests pin them (a wrong value costs speed, never correctness, so nothing else would notice). */
@@ -204,6 +209,7 @@ enum {
                                        /* fused step wrote (coalesced) instead of gathering one word per column from the fields   */
     TRM_INFO_CLOSURE_CONSISTENT = 101,  /* 1: the stored temperature / liquid fraction are the closure of the stored state, so a  */
                                        /* step may re-derive them in registers (TRM_OPT_DERIVE_CLOSURE_FIELDS)                   */
+    TRM_INFO_GENERIC_BOUNDARY_KERNELS = 103, /* 1: the context's boundary kinds need the generic-boundary kernels (k_step_wave, ...)   */
     TRM_INFO_BC_SIGNATURE = 102        /* the boundary-condition signature of the context's current kinds (BCSIG bits: 1 / 2 Value on  */
                                        /* temperature bottom / top, 4 / 8 Flux on energy / saturation bottom, 16 / 32 top, 64 LandModel) */
 };

@@ -1474,6 +1474,7 @@ int trm_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
     for (const auto& sr : c->series)
         if (sr.is_bc && sr.var == var && sr.side == side) return fail(c, TRM_EINVAL, "trm_bc_device_ptr: the boundary values are evaluated from a time series every step");
     *dev = c->bc_value[var][side];
+    c->bc_zero_gradient[var][side] = false;      // (the caller may write the buffer from now on)
     return TRM_OK;
 }
 
@@ -1493,6 +1494,7 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
         }
     }
     c->bc_kind[var][side] = kind;
+    c->bc_zero_gradient[var][side] = false;
     c->args_valid = false;
     if (kind == TRM_BC_NOFLUX) return TRM_OK;
     size_t bytes = (size_t)c->Nh * c->esize;
@@ -1509,6 +1511,11 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
     }
     TRM_HIP(c, hipMemcpyAsync(c->bc_value[var][side], h.data(), bytes, hipMemcpyHostToDevice, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
+    if (kind == TRM_BC_GRADIENT) {   // every value +0 (all bits clear): see trm_ctx::bc_zero_gradient
+        bool zero = true;
+        for (size_t n = 0; n < bytes && zero; ++n) zero = h[n] == 0;
+        c->bc_zero_gradient[var][side] = zero;
+    }
     return TRM_OK;
 }
 
@@ -1578,6 +1585,7 @@ int trm_set_bc_series(trm_ctx* c, int var, int side, int kind, int nt, const dou
     int rc = add_series(c, std::move(sr), nt, times, values, "trm_set_bc_series");
     if (rc) return rc;
     c->bc_kind[var][side] = kind;
+    c->bc_zero_gradient[var][side] = false;      // (the values come from the series from now on)
     c->args_valid = false;
     if (!c->bc_value[var][side]) {
         TRM_HIP(c, hipMalloc(&c->bc_value[var][side], (size_t)c->Nh * c->esize));
@@ -2012,6 +2020,7 @@ int trm_stage_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
     if (c->bc_kind[var][side] == TRM_BC_NOFLUX || !c->bc_value[var][side]) return fail(c, TRM_EINVAL, "trm_stage_bc_device_ptr: the condition carries no values (set it with trm_set_bc first)");
     for (const auto& sr : c->series)
         if (sr.is_bc && sr.var == var && sr.side == side) return fail(c, TRM_EINVAL, "trm_stage_bc_device_ptr: the boundary values are evaluated from a time series at both stages");
+    c->bc_zero_gradient[var][side] = false;      // (the stage's values become the caller's)
     const size_t bytes = (size_t)c->Nh * c->esize;
     if (!c->bc_value_stage[var][side]) {
         TRM_HIP(c, hipMalloc(&c->bc_value_stage[var][side], bytes));
@@ -2455,6 +2464,7 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             c->opt_single_step = value;
             return TRM_OK;
         case TRM_OPT_BC_SIGNATURE: c->opt_bc_signature = value != 0; return TRM_OK;
+        case TRM_OPT_ZERO_GRADIENT_FAST: c->opt_zero_gradient_fast = value != 0; c->args_valid = false; return TRM_OK;
         default: break;
     }
     return fail(c, TRM_EINVAL, "trm_set_option: unknown option or value");
@@ -2472,6 +2482,8 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_PIPELINE_PARTS: *value = c->opt_pipeline; return TRM_OK;
         case TRM_OPT_SINGLE_STEP_PROGRAM: *value = c->opt_single_step; return TRM_OK;
         case TRM_OPT_BC_SIGNATURE: *value = c->opt_bc_signature; return TRM_OK;
+        case TRM_OPT_ZERO_GRADIENT_FAST: *value = c->opt_zero_gradient_fast; return TRM_OK;
+        case TRM_INFO_GENERIC_BOUNDARY_KERNELS: *value = (c->precision == TRM_F64 ? trmh::Policy<double>::generic_bcs(c) : trmh::Policy<float>::generic_bcs(c)) ? 1 : 0; return TRM_OK;
         case TRM_INFO_BC_SIGNATURE: *value = trmh::bc_signature_of(c); return TRM_OK;
         case TRM_INFO_TOP_ARRAYS_CURRENT: *value = c->top_valid ? 1 : 0; return TRM_OK;
         case TRM_INFO_CLOSURE_CONSISTENT: *value = (c->closure_consistent && !c->closure_escaped) ? 1 : 0; return TRM_OK;

@@ -42,6 +42,11 @@ struct trm_ctx {
     bool saved_tend_valid = true;
     void* bc_value[TRM_BCV_COUNT][2] = {};
     int bc_kind[TRM_BCV_COUNT][2] = {};
+    // A Gradient condition whose values the library KNOWS to be +0 everywhere (set through trm_set_bc from host values, the device
+    // buffer never handed out since): at the BOTTOM its halo, edge + (+0) * (-dz) = edge + (-0), IS the edge value bit for bit -- the
+    // halo the branch-free programs form where no condition is set.  The reference's FreeDrainage() (GradientBoundaryCondition(0) on
+    // the pressure head, soil_model_bcs.jl:40) is that case, and need not take the generic-boundary kernels (Policy::generic_bcs).
+    bool bc_zero_gradient[TRM_BCV_COUNT][2] = {};
     void *d_zC = nullptr, *d_zF = nullptr, *d_dzc = nullptr, *d_rdzc = nullptr, *d_rdzf = nullptr, *d_psiz = nullptr, *d_lvl = nullptr;
     void* d_rootf = nullptr;   // static root fraction per level [Nz] (root_distribution.jl:45-63)
     std::vector<double> h_zF, h_zC, h_dzc, h_dzf;  // as derived in NF, widened
@@ -102,6 +107,7 @@ struct trm_ctx {
     // Two halves of the columns (TRM_OPT_PIPELINE_PARTS): the per-step LandModel path runs the latency-bound 0-D surface
     // processes of one half in the same launch as the soil columns of the other (k_land_euler).  Columns are independent.
     int opt_pipeline = 2;           // 0: off, 1: whenever legal, 2: auto (column threshold)
+    int opt_zero_gradient_fast = 1; // TRM_OPT_ZERO_GRADIENT_FAST: FreeDrainage()-like conditions on the branch-free programs
     int opt_bc_signature = 1;       // TRM_OPT_BC_SIGNATURE: 1 the program with the boundary kinds compiled in where one matches
     int opt_single_step = 2;        // TRM_OPT_SINGLE_STEP_PROGRAM: 0 off, 1 whenever legal, 2 the library's rule
     int part = -1;                  // part the launch helpers currently address (-1: all columns)
@@ -229,10 +235,15 @@ template <class NF> struct Policy {
     // the branch-free fused kernel covers Value on temperature and Flux on the prognostics; anything else is generic
     static bool generic_bcs(const trm_ctx* c) {
         bool generic = c->opt_vwc_field != 0;   // a per-cell vwc_forcing field is read by the generic instance only
+        // (a zero gradient on temperature or pressure head at the bottom is the edge-value halo of the branch-free programs: see
+        // trm_ctx::bc_zero_gradient.  Not on saturation / liquid fraction, whose unset halo follows the halo policy, and not at the top,
+        // where edge + (+0) * dz turns an edge value of -0.0 into +0.0)
+        auto plain = [&](int var, int side) { return side == 0 && c->opt_zero_gradient_fast && c->bc_kind[var][side] == TRM_BC_GRADIENT && c->bc_zero_gradient[var][side]; };
         for (int side = 0; side < 2; ++side) {
-            generic = generic || c->bc_kind[TRM_BCV_TEMPERATURE][side] == TRM_BC_GRADIENT;
+            generic = generic || (c->bc_kind[TRM_BCV_TEMPERATURE][side] == TRM_BC_GRADIENT && !plain(TRM_BCV_TEMPERATURE, side));
             for (int var : {TRM_BCV_SATURATION_WATER_ICE, TRM_BCV_LIQUID_WATER_FRACTION, TRM_BCV_PRESSURE_HEAD})
-                generic = generic || c->bc_kind[var][side] == TRM_BC_VALUE || c->bc_kind[var][side] == TRM_BC_GRADIENT;
+                generic = generic || c->bc_kind[var][side] == TRM_BC_VALUE ||
+                          (c->bc_kind[var][side] == TRM_BC_GRADIENT && !(var == TRM_BCV_PRESSURE_HEAD && plain(var, side)));
         }
         return generic;
     }
