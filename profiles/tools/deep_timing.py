@@ -52,13 +52,16 @@ def timed(d, step, dt, n=20):
         d.restore_state()
         ts.append(step(dt, n, finalize=False) * 1e3 / n)
     return round(float(np.median(ts)), 2)
+# FreeDrainage(): since round 4 on the branch-free program (TRM_OPT_ZERO_GRADIENT_FAST); with the option off: the GENERIC instance
 w = W.make_workload("richards", lat, lon, 100)
 w["bcs"][("pressure_head", "bottom")] = ("gradient", 0.0)
-for kernel in ("fused", "unfused"):
+for kernel, fast in (("fused", 1), ("fused", 0), ("unfused", 1)):
     d = W.setup_device(w)
     d.set_option("step_kernel", kernel)
+    d.set_option("zero_gradient_fast", fast)
     d.step_heun(w["dt"], 5, finalize=False)
-    out[f"richards_Nz100_free_drainage_heun_{kernel}"] = {"us_per_step": timed(d, d.step_heun_timed, w["dt"]), "status": d.status()}
+    name = kernel if fast else "fused_generic_instance"
+    out[f"richards_Nz100_free_drainage_heun_{name}"] = {"us_per_step": timed(d, d.step_heun_timed, w["dt"]), "status": d.status()}
     d.close()
 ncol = min(lat.size, 14017)
 wv = W.make_workload("landveg", lat[:ncol], lon[:ncol], 100, hydraulics="vg")
