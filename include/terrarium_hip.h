@@ -194,7 +194,8 @@ enum {
                                     /* step is bound by launch latency: DESIGN 4.9)                                                  */
     ,TRM_OPT_BC_SIGNATURE = 9       /* 1 (default): a per-step ForwardEuler launch whose boundary kinds match one of the signatures    */
                                     /* compiled into the library (none; prescribed surface temperature; that + a bottom heat flux;    */
-                                    /* the LandModel wiring) takes the program with the kinds as compile-time constants (-3 ... -5 %, */
+                                    /* that + an infiltration flux; the LandModel wiring) takes the program with the kinds as          */
+                                    /* compile-time constants (-3 ... -10 %,                                                            */
                                     /* DESIGN 4.3); 0: always the program that reads the kinds at run time (same results; A/B, tests)  */
     ,TRM_OPT_ZERO_GRADIENT_FAST = 10 /* 1 (default): a Gradient condition on temperature or pressure head at the BOTTOM whose values   */
                                     /* trm_set_bc received as +0 everywhere -- the reference's FreeDrainage(), soil_model_bcs.jl:40 --  */

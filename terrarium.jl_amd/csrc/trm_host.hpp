@@ -446,6 +446,9 @@ template <template <class, bool, int> class L, class NF, bool RICH, class... A> 
         case BCSIG_LAND:
             if constexpr (RICH) { L<NF, RICH, BCSIG_LAND>::run(args...); return true; }
             return false;
+        case BCSIG_T_TOP | BCSIG_FS_TOP:      // prescribed surface temperature + InfiltrationFlux (soil_model_bcs.jl:28)
+            if constexpr (RICH) { L<NF, RICH, BCSIG_T_TOP | BCSIG_FS_TOP>::run(args...); return true; }
+            return false;
         default: return false;
     }
 }

@@ -372,7 +372,8 @@ def test_free_drainage_keeps_the_branch_free_programs(dtype):
 
 SIGNATURES = [("heat", {}, 2), ("heat", {("internal_energy", "bottom"): ("flux", 0.05)}, 6), ("richards", {}, 2),
               ("richards", {("internal_energy", "bottom"): ("flux", 0.05)}, 6), ("richards", "closed", 0), ("land", {}, 64),
-              ("land", {("internal_energy", "bottom"): ("flux", 0.05)}, 68), ("richards", {("saturation_water_ice", "top"): ("flux", -2.0e-7)}, 34)]
+              ("land", {("internal_energy", "bottom"): ("flux", 0.05)}, 68), ("richards", {("saturation_water_ice", "top"): ("flux", -2.0e-7)}, 34),
+              ("richards", {("saturation_water_ice", "top"): ("flux", -2.0e-7), ("internal_energy", "bottom"): ("flux", 0.05)}, 38)]
 
 
 @pytest.mark.parametrize("heun", [False, True])
@@ -381,7 +382,7 @@ SIGNATURES = [("heat", {}, 2), ("heat", {("internal_energy", "bottom"): ("flux",
 def test_programs_with_the_boundary_signature_compiled_in_equal_the_runtime_program_bitwise(config, extra, signature, hydraulics, Nz, heun):
     """TRM_OPT_BC_SIGNATURE (BCSIG of k_column): the deriving ForwardEuler program with the boundary kinds as compile-time constants --
     no conditions, a prescribed surface temperature, that + a bottom heat flux, the LandModel wiring -- against the same program reading
-    the kinds at run time and against the reference-order kernels; signatures without an instance (68, 34) take the run-time program."""
+    the kinds at run time and against the reference-order kernels; signatures without an instance (68, 38) take the run-time program."""
     lat, lon = small_columns(333)
     w = W.make_workload(config, lat, lon, Nz, hydraulics=hydraulics)
     if extra == "closed":
