@@ -368,6 +368,13 @@ def test_free_drainage_keeps_the_branch_free_programs(dtype):
     neg = W.setup_device(W.make_workload("richards", lat, lon, 32, dtype=dtype))
     neg.set_bc("pressure_head", "bottom", "gradient", np.full(lat.size, -0.0))          # -0.0 is not +0.0
     assert neg.get_option("info_generic_boundary_kernels") == 1
+    # the host mirror's alias arrives as the scalar 0.0
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=20), 40)
+    bcs = trm.merge_boundary_conditions(trm.PrescribedSurfaceTemperature("Ts", 1.0), trm.FreeDrainage())
+    integ = trm.initialize(trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq()))), trm.ForwardEuler(dt=60.0),
+                           boundary_conditions=bcs, initializers=dict(temperature=2.0, saturation_water_ice=0.7))
+    assert integ.state.get_option("info_generic_boundary_kernels") == 0 and integ.state.get_option("info_bc_signature") == 2
+    trm.run(integ, steps=5)
 
 
 SIGNATURES = [("heat", {}, 2), ("heat", {("internal_energy", "bottom"): ("flux", 0.05)}, 6), ("richards", {}, 2),
