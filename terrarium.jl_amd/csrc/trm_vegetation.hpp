@@ -296,22 +296,33 @@ TRM_DEV bool block_soil_moisture_limit(const NF* __restrict__ sat, const NF* __r
     const int k = threadIdx.x % NZP, c0 = threadIdx.x / NZP;
     const bool level = k < Nz;
     const NF rf = level ? rootf[k] : NF(0), dz = level ? dzc[k] : NF(1), rdz = level ? rdzc[k] : NF(1);
-    NF s_[PASSES], l_[PASSES];
+    // Loads and stores WITHOUT a branch per pass: a conditional load or store is its own basic block, and where such blocks meet the
+    // compiler waits for every vector memory operation that may be pending (`s_waitcnt vmcnt(0)`) -- with the store of pass j
+    // conditional, pass j + 1 waited for it: eight serialised trips to memory per thread (round 4, from the disassembly).  The loads
+    // take clamped indices (a lane beyond the column count or the level count re-reads a valid cell), the terms of rows beyond the
+    // column count go to LDS rows nobody sums, and the stores of a FULL block (every block but the last) sit in one block.
+    const int kc = level ? k : Nz - 1;
+    NF s_[PASSES], l_[PASSES], w_[PASSES], t_[PASSES];
 #pragma unroll
     for (int j = 0; j < PASSES; ++j) {
-        const int col = c0 + j * CPP;
-        const bool on = level && col < ncol;
-        s_[j] = on ? sat[base + col * NZP + k] : NF(0);
-        l_[j] = on ? liq[base + col * NZP + k] : NF(0);
+        const int col = c0 + j * CPP, colc = col < ncol ? col : ncol - 1;
+        s_[j] = sat[base + colc * NZP + kc];
+        l_[j] = liq[base + colc * NZP + kc];
     }
 #pragma unroll
-    for (int j = 0; j < PASSES; ++j) {
-        const int col = c0 + j * CPP;
-        if (level && col < ncol) {
-            NF w;
-            const NF t = paw_term(vp, por, s_[j], l_[j], rf, dz, rdz, w);
-            if (paw) paw[base + col * NZP + k] = w;
-            terms[col * (NZP + 1) + k] = t;
+    for (int j = 0; j < PASSES; ++j) t_[j] = paw_term(vp, por, s_[j], l_[j], rf, dz, rdz, w_[j]);
+    if (level) {
+#pragma unroll
+        for (int j = 0; j < PASSES; ++j) terms[(c0 + j * CPP) * (NZP + 1) + k] = t_[j];
+        if (paw) {
+            if (ncol == 64) {
+#pragma unroll
+                for (int j = 0; j < PASSES; ++j) paw[base + (c0 + j * CPP) * NZP + k] = w_[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < PASSES; ++j)
+                    if (c0 + j * CPP < ncol) paw[base + (c0 + j * CPP) * NZP + k] = w_[j];
+            }
         }
     }
     __syncthreads();
