@@ -665,3 +665,17 @@ def test_integrator_interface_helpers():
     trm.reset(integ)
     assert trm.iteration(integ) == 0 and trm.current_time(integ) == 0.0
     assert np.array_equal(integ.state.temperature, T0) and np.array_equal(integ.state.internal_energy, U0)
+
+
+def test_example_restart_and_device_group(capsys):
+    """examples/restart_and_device_group.py: a run resumed from a checkpoint and the columns stepped by one host thread in three
+    block-sharded contexts both reproduce the uninterrupted single-context run bit for bit (the example prints its own verdicts)."""
+    import sys
+    ex = _load_example("restart_and_device_group")
+    argv, sys.argv = sys.argv, ["restart_and_device_group.py", "3"]
+    try:
+        ex.main()
+    finally:
+        sys.argv = argv
+    out = capsys.readouterr().out
+    assert "== 100 steps: True" in out and "gathered == single context: True" in out and out.rstrip().endswith("status 0"), out
