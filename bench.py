@@ -268,6 +268,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     n_gpus = world
     stat_device = "cuda" if backend == "nccl" else "cpu"
+    # a CPU-side group for waits that must not put a kernel on the waiting ranks' devices (an RCCL barrier spins ON the GPU): the
+    # ranks that idle while rank 0 drives every device from one host thread (single_process_leg)
+    cpu_group = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
 
     import workloads as W
     from terrarium_jl_amd import parallel
@@ -382,12 +385,13 @@ def main():
 
     if not hung and not args.no_single_process and args.workload == "c3" and args.scaling == "weak" and args.kernel == "fused" and not heun:
         # ONE host thread driving one context per device (the reference's host is one Julia process): rank 0 alone, the other
-        # ranks idle at the barrier below
+        # ranks idle at the HOST-side barrier below
         if rank == 0:
             ndev = torch.cuda.device_count()      # (a rehearsal with several ranks on one GPU: the contexts share it)
             out["single_process"] = single_process_leg(W, parallel, args, [d % ndev for d in range(world)] if world > 1 else [local_rank, local_rank], torch)
         if world > 1:
-            dist.barrier()
+            torch.cuda.synchronize()
+            dist.barrier(group=cpu_group)       # (gloo: the idle ranks wait on the host, their devices stay free for rank 0's contexts)
 
     single = rank == 0 and n_gpus == 1
     if single and args.multistep > 1 and args.kernel == "fused" and not heun and not args.series and args.steps_per_launch == 1:
