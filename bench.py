@@ -270,7 +270,12 @@ def main():
     stat_device = "cuda" if backend == "nccl" else "cpu"
     # a CPU-side group for waits that must not put a kernel on the waiting ranks' devices (an RCCL barrier spins ON the GPU): the
     # ranks that idle while rank 0 drives every device from one host thread (single_process_leg)
-    cpu_group = dist.new_group(backend="gloo") if (world > 1 and backend == "nccl") else None
+    cpu_group = None
+    if world > 1 and backend == "nccl":
+        try:
+            cpu_group = dist.new_group(backend="gloo")
+        except Exception as e:   # noqa: BLE001 -- (no gloo transport on this node: the default group's barrier serves)
+            print(f"bench.py: no host-side group ({type(e).__name__}: {e}); idle ranks will wait in an RCCL barrier", file=sys.stderr)
 
     import workloads as W
     from terrarium_jl_amd import parallel
