@@ -407,8 +407,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if hung:
-        os._exit(3)
+    if hung or out.get("single_process", {}).get("global_diagnostics", {}).get("timeout"):
+        os._exit(3)          # (a collective that did not return: the line says so, and no thread stuck in it keeps the process alive)
     if world > 1:
         dist.destroy_process_group()
 
