@@ -393,7 +393,10 @@ def main():
         # ranks idle at the HOST-side barrier below
         if rank == 0:
             ndev = torch.cuda.device_count()      # (a rehearsal with several ranks on one GPU: the contexts share it)
-            out["single_process"] = single_process_leg(W, parallel, args, [d % ndev for d in range(world)] if world > 1 else [local_rank, local_rank], torch)
+            try:
+                out["single_process"] = single_process_leg(W, parallel, args, [d % ndev for d in range(world)] if world > 1 else [local_rank, local_rank], torch)
+            except Exception as e:   # noqa: BLE001 -- a companion leg: its failure is reported in the line, the ranks waiting below are released
+                out["single_process"] = {"error": f"{type(e).__name__}: {e}"}
         if world > 1:
             torch.cuda.synchronize()
             dist.barrier(group=cpu_group)       # (gloo: the idle ranks wait on the host, their devices stay free for rank 0's contexts)
