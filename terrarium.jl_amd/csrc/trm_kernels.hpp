@@ -131,23 +131,30 @@ template <class NF, int HYD> __global__ void k_hydraulics(View<NF> v, DevParams<
 // hydraulic_conductivity field -- used in front of the fused step kernel, which does not
 // materialise K before the surface processes run.
 // TOP_ARRAYS (with FROM_STATE): the top cell's (T, sat, liq) come from the compact per-column arrays the fused step wrote.
+template <class NF> TRM_DEV NF ldg(const NF* base, unsigned byte_off);          // (defined with the fused step's helpers below)
+template <class NF> TRM_DEV void stg(NF* base, unsigned byte_off, NF x);
+TRM_DEV unsigned block_local(unsigned byte_off);
 template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> TRM_DEV void surface_program(const View<NF>& v, const DevParams<NF>& p, long i) {
     const long top = i * v.Nzp + (v.Nz - 1);
-    SebIn<NF> in = {v.Tair[i], v.pres[i], v.wind[i], v.qair[i], v.rain[i], v.swd[i], v.lwd[i], NF(0), NF(0), NF(0)};
-    seb_radiation_inputs(p, v.albedo, v.emissivity, (unsigned)i * (unsigned)sizeof(NF), in);
+    // (scalar base + 32-bit byte offset for every per-column access: ldg / stg -- 22 accesses without a 64-bit address each)
+    const unsigned ib = (unsigned)i * (unsigned)sizeof(NF);
+    SebIn<NF> in = {ldg(v.Tair, ib), ldg(v.pres, ib), ldg(v.wind, ib), ldg(v.qair, ib), ldg(v.rain, ib), ldg(v.swd, ib), ldg(v.lwd, ib), NF(0), NF(0), NF(0)};
+    seb_radiation_inputs(p, v.albedo, v.emissivity, ib, in);
     SebOut<NF> o;
     uint32_t viol = 0;
-    const NF T_top = TOP_ARRAYS ? v.top_T[i] : v.T[top], sat_top = TOP_ARRAYS ? v.top_sat[i] : v.sat[top];
+    const unsigned ib2 = block_local(ib);      // (behind seb_radiation_inputs' branch: see block_local)
+    const NF T_top = TOP_ARRAYS ? ldg(v.top_T, ib2) : v.T[top], sat_top = TOP_ARRAYS ? ldg(v.top_sat, ib2) : v.sat[top];
     NF Kf_top;
-    const NF liq_top = (FROM_STATE && TOP_ARRAYS) ? v.top_liq[i] : v.liq[top];
+    const NF liq_top = (FROM_STATE && TOP_ARRAYS) ? ldg(v.top_liq, ib2) : v.liq[top];
     if (FROM_STATE) {
         Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));   // (in front of the fused step)
     } else {
         Kf_top = v.Kf[top];
     }
-    surface_processes(p, in, v.Ts[i], T_top, sat_top, liq_top, Kf_top, v.S[i], RICHARDS, v.dzc[v.Nz - 1], o);
-    v.Ts[i] = o.Ts; v.ghf[i] = o.ghf; v.swu[i] = o.swu; v.lwu[i] = o.lwu; v.rnet[i] = o.rnet;
-    v.Hs[i] = o.Hs; v.Hl[i] = o.Hl; v.evap[i] = o.evap; v.infil[i] = o.infil; v.runoff[i] = o.runoff;
+    surface_processes(p, in, ldg(v.Ts, ib2), T_top, sat_top, liq_top, Kf_top, ldg(v.S, ib2), RICHARDS, v.dzc[v.Nz - 1], o);
+    const unsigned ob = block_local(ib);
+    stg(v.Ts, ob, o.Ts); stg(v.ghf, ob, o.ghf); stg(v.swu, ob, o.swu); stg(v.lwu, ob, o.lwu); stg(v.rnet, ob, o.rnet);
+    stg(v.Hs, ob, o.Hs); stg(v.Hl, ob, o.Hl); stg(v.evap, ob, o.evap); stg(v.infil, ob, o.infil); stg(v.runoff, ob, o.runoff);
 }
 template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
