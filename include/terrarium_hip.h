@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 16
+#define TRM_ABI_VERSION 17
 
 typedef struct trm_ctx trm_ctx;
 
@@ -202,6 +202,15 @@ enum {
                                     /* forms the same halo, bit for bit, as no condition at all, and the context keeps the branch-free */
                                     /* programs (derivation, resident multi-step program, ...) instead of the generic-boundary kernels; */
                                     /* handing the value buffer out (trm_bc_device_ptr) or attaching a series ends it.  0: off (A/B)    */
+    ,TRM_OPT_TAIL_SURFACE = 11      /* bare-ground LandModel stepped one launch per step (fp64, Richards, the LandModel's boundary wiring, */
+                                    /* constant inputs): the column launch of step n also evaluates the surface processes of step n + 1   */
+                                    /* (land_model.jl:79-88) at its tail, per 64 columns by the last workgroup to finish them, into a     */
+                                    /* second set of the ten surface arrays; step n + 1 swaps the two sets instead of launching the 0-D   */
+                                    /* surface kernel -- unless a call that may change an input (trm_upload, trm_set_forcing*, trm_set_bc,  */
+                                    /* trm_set_clock, trm_restore_state, ...) came in between, in which case the set is dropped and the     */
+                                    /* kernel launched as before.  Same operations per column: bit-identical.  A device pointer handed out */
+                                    /* (trm_field_device_ptr, trm_bc_device_ptr) ends it for the context.  0: off; 1: whenever legal;       */
+                                    /* 2 (default): the library's rule                                                         */
 };
 /* DIAGNOSTIC, read-only (trm_get_option): which fast paths the NEXT step will take -- what the library tracks about its own
  * buffers.  Tests pin them (a wrong value costs speed, never correctness, so nothing else would notice). */
@@ -211,8 +220,12 @@ enum {
     TRM_INFO_CLOSURE_CONSISTENT = 101,  /* 1: the stored temperature / liquid fraction are the closure of the stored state, so a  */
                                        /* step may re-derive them in registers (TRM_OPT_DERIVE_CLOSURE_FIELDS)                   */
     TRM_INFO_GENERIC_BOUNDARY_KERNELS = 103, /* 1: the context's boundary kinds need the generic-boundary kernels (k_step_wave, ...)   */
-    TRM_INFO_BC_SIGNATURE = 102        /* the boundary-condition signature of the context's current kinds (BCSIG bits: 1 / 2 Value on  */
+    TRM_INFO_BC_SIGNATURE = 102,       /* the boundary-condition signature of the context's current kinds (BCSIG bits: 1 / 2 Value on  */
                                        /* temperature bottom / top, 4 / 8 Flux on energy / saturation bottom, 16 / 32 top, 64 LandModel) */
+    TRM_INFO_TAIL_PENDING = 104,       /* 1: the last step's launch left the surface processes of the next step pending and nothing has  */
+                                       /* invalidated them (TRM_OPT_TAIL_SURFACE): the next trm_step launches ONE kernel                  */
+    TRM_INFO_LAST_PROGRAM = 105        /* which kernel instance the last step launch of the context selected (TRM_PROGRAM_* below), 0     */
+                                       /* before the first step: family in bits 0-7, then one field per selection rule                    */
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

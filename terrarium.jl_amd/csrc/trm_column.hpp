@@ -25,6 +25,15 @@
 namespace trm {
 
 enum { PROG_EULER = 0, PROG_HEUN = 1, PROG_MULTI = 2 };
+// (diagnostic builds of the tail evaluation -- wrong results by construction: 1 no chain, 2 no acquire, 4 no arrival count, 8 plain
+// stores, 16 no wait for the stores, 32 nothing behind the staged store)
+#ifndef TRM_TAIL_DIAG
+#define TRM_TAIL_DIAG 0
+#endif
+// words between the arrival counters of two clusters (one 128-byte line each: the adds of different clusters do not meet on a line)
+#ifndef TRM_TAIL_COUNTER_STRIDE
+#define TRM_TAIL_COUNTER_STRIDE 32u
+#endif
 
 template <class NF> struct Cell { NF U, sat, T, liq, psi; };
 // what one lane knows about its place in the column
@@ -240,10 +249,13 @@ template <class NF> struct ColumnArgs {
 // those that run the program.
 // STAGED / SCALAR_IN: how the per-column outputs leave and the per-column inputs arrive (see below) -- compile-time: as
 // wave-uniform run-time branches they cost the field loads their back-to-back issue (profiles/r03/exp28: 8 x N145 +7 %).
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME>
+// TAIL (with STAGED, LandModel): the surface processes of the NEXT step at the end of this launch (surface_tail, trm_kernels.hpp);
+// the kernel's fourth argument is then a TailArgs.
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME, bool TAIL = false>
 TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, const ColumnArgs<NF>& a, unsigned block) {
     // (kernarg layout: the arguments in order, each at its natural alignment)
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+    static_assert(!TAIL || (STAGED && PROG == PROG_EULER && !SEB_INLINE), "the tail evaluation hands the staged per-column outputs of a per-step launch on");
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
     static_assert(!SEB_INLINE || PROG == PROG_MULTI, "the in-kernel surface energy balance belongs to the multi-step program");
@@ -631,10 +643,33 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         const unsigned enabled = (write_kf ? 1u << SMALL_KF_TOP : 0u) | (RICHARDS ? (1u << SMALL_S) | (1u << SMALL_WT) : 0u) |
                                  ((RICHARDS && finalize) ? 1u << SMALL_G_S : 0u) |
                                  (seb ? (1u << SMALL_TOP_T) | (1u << SMALL_TOP_SAT) | (1u << SMALL_TOP_LIQ) | (1u << SMALL_TS) : 0u);
-        store_small_outputs<NF>(enabled, (int)(blockDim.x >> 6) * CPW, block, Nh);
+        store_small_outputs<NF, TAIL && !(TRM_TAIL_DIAG & 8)>(enabled, (int)(blockDim.x >> 6) * CPW, block, Nh);
     }
     // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
     if (viol && ln.act) atomicOr(v_arg.status, viol);
+    if (TAIL) {
+        // The workgroup's first wave has just stored the per-column outputs (write-through); it counts the workgroup in, and in the
+        // workgroup that arrives last of its 64-column cluster it evaluates the surface processes of those columns for the next step.
+        if ((threadIdx.x >> 6) == 0 && !(TRM_TAIL_DIAG & 32)) {
+            if (!(TRM_TAIL_DIAG & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left before the workgroup is counted in
+            constexpr unsigned off_a = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(ColumnArgs<NF>));
+            constexpr unsigned off_t = round_up_to(off_a + (unsigned)sizeof(ColumnArgs<NF>), (unsigned)alignof(TailArgs<NF>));
+            const TailArgs<NF>& ta = kernarg_reload<TailArgs<NF>>(off_t);
+            constexpr unsigned WGPC = 64u / (unsigned)((TRM_STEP_BLOCK / 64) * CPW);     // workgroups per 64-column cluster
+            const unsigned cluster = block / WGPC;
+            const unsigned nblocks = gridDim.x;
+            const unsigned members = (nblocks - cluster * WGPC) < WGPC ? (nblocks - cluster * WGPC) : WGPC;
+            unsigned arrived = 0;
+            if (ln.lane == 0 && !(TRM_TAIL_DIAG & 4)) arrived = __hip_atomic_fetch_add(ta.counter + cluster * TRM_TAIL_COUNTER_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
+            if (arrived == members - 1u) {
+                if (ln.lane == 0) __hip_atomic_store(ta.counter + cluster * TRM_TAIL_COUNTER_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!(TRM_TAIL_DIAG & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const int col = (int)(cluster * 64u) + ln.lane;
+                if (col < Nh && !(TRM_TAIL_DIAG & 1)) surface_tail<NF, RICHARDS, HYD>(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), ta.out, col);
+            }
+        }
+    }
 }
 
 template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME>
@@ -645,6 +680,15 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
 #endif
     k_column(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a) {
     column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES, STAGED, SCALAR_IN, BCSIG>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
+}
+
+// The ForwardEuler program of a bare-ground LandModel with the NEXT step's surface processes at its tail (TRM_OPT_TAIL_SURFACE)
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, bool SCALAR_IN>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK)
+    __attribute__((amdgpu_waves_per_eu(HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5, 8)))
+    k_column_tail(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a, TailArgs<NF> tail) {
+    (void)tail;     // (read from the kernel argument segment by the wave that evaluates the tail)
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG_EULER, false, false, true, SCALAR_IN, BCSIG_LAND, true>(v_arg, p_arg, a, blockIdx.x);
 }
 
 // ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the

@@ -133,8 +133,21 @@ struct trm_ctx {
     RowStage row_stage[4];
     int row_stage_next = 0;
     bool args_valid = false;
-    void* args = nullptr;   // LaunchArgs<NF>*, owned
+    void* args = nullptr;   // LaunchArgs<NF>[2]*, owned: one set per `flip` (see below)
+    bool args_built[2] = {false, false};
     void (*args_free)(void*) = nullptr;
+    // LandModel, TRM_OPT_TAIL_SURFACE: the surface processes of the NEXT step evaluated at the tail of a per-step column launch
+    // (k_column_tail) into a second set of the ten arrays k_surface writes (skin temperature, ground heat flux, ... runoff).  A step
+    // that finds them valid SWAPS the two sets (state.f[] <-> pend.f[]) instead of launching k_surface; anything that may change an
+    // input of the surface processes in between clears `tail_valid`.
+    FieldSet pend{};                  // only the ten surface fields are allocated
+    unsigned* tail_counter = nullptr; // [tail_clusters] arrival counters of the 64-column clusters, zero between launches
+    long tail_clusters = 0;
+    bool tail_valid = false;          // pend holds compute_auxiliary!(surface processes) of the state as it is now
+    bool tail_escaped = false;        // a device pointer into the state or its inputs was handed out: the library cannot know what changes
+    int flip = 0;                     // parity of the swaps so far: which of the two cached argument sets describes state.f[]
+    int opt_tail = 2;                 // TRM_OPT_TAIL_SURFACE: 0 off, 1 whenever legal, 2 the library's rule
+    int last_program = 0;             // TRM_INFO_LAST_PROGRAM: the kernel instance the last step launch selected (program_id)
     std::string err;
 };
 
@@ -467,5 +480,7 @@ template <> int LandLaunch<double>::run(trm_ctx* c, int qcol, int qsurf, double 
 template <> int LandLaunch<float>::run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays);
 // the packed fp32 step k_step_pk (trm_launch_packed.hip)
 struct PackedLaunch { static int step(trm_ctx* c, double dt, int finalize); };
+// the LandModel's per-step program with the next step's surface processes at its tail: k_column_tail (fp64; trm_launch_column_tail.hip)
+struct TailLaunch { static int run(trm_ctx* c, double dt, int finalize); };
 
 }  // namespace trmh

@@ -641,7 +641,17 @@ template <class NF> TRM_DEV NF* small_stage() {
 // After a barrier, lane l of the workgroup's first waves stores entry l of the table: array l / cpb, column l % cpb of the
 // workgroup -- every array receives one contiguous run of cpb values from a single instruction.  The array pointers come from
 // the kernel argument segment (View::small), indexed per lane.  `enabled`: bit per array (wave-uniform).
-template <class NF> TRM_DEV void store_small_outputs(unsigned enabled, int cpb, unsigned block, int Nh) {
+// AGENT: the store is write-through at agent scope (sc1) -- the values are handed to ANOTHER workgroup of this launch (the surface
+// processes at the tail of the column program, surface_tail below), whose XCD does not share this one's L2.
+template <class NF> TRM_DEV void st_agent(NF* p, NF x) {
+    if constexpr (sizeof(NF) == 8) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class NF> TRM_DEV NF ld_agent(const NF* p) {
+    if constexpr (sizeof(NF) == 8) return __builtin_bit_cast(NF, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return __builtin_bit_cast(NF, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+template <class NF, bool AGENT = false> TRM_DEV void store_small_outputs(unsigned enabled, int cpb, unsigned block, int Nh) {
     __syncthreads();
     const int l = (int)threadIdx.x;
     if (l < SMALL_COUNT * cpb) {
@@ -649,9 +659,44 @@ template <class NF> TRM_DEV void store_small_outputs(unsigned enabled, int cpb, 
         const long i = (long)block * cpb + col;
         if (i < Nh && ((enabled >> slot) & 1u)) {
             NF* const* tbl = kernarg_reload<View<NF>>(0).small;
-            tbl[slot][i] = small_stage<NF>()[l];
+            if (AGENT) st_agent(tbl[slot] + i, small_stage<NF>()[l]);
+            else tbl[slot][i] = small_stage<NF>()[l];
         }
     }
+}
+
+// ---- LandModel: the surface processes of step n + 1 at the TAIL of step n's column launch (TRM_OPT_TAIL_SURFACE) --------------
+// k_surface in front of every column launch is a latency-bound chain of ~450 dependent fp64 instructions on 890 waves (N145): 5.4 us
+// of which ~4 are the fixed cost of a launch between two others.  Its inputs -- the new top cell, the skin temperature, the surface
+// excess water -- exist the moment a column's step has finished, so the chain is evaluated right there, for the NEXT step, with the
+// forcings as they are now, into PENDING arrays; the next step accepts them (the host swaps the array pointers) unless an input has
+// changed since, in which case it discards them and launches k_surface as before.
+// One lane per column keeps the chain at one instruction stream per 64 columns (8 lanes of a workgroup's own columns would add a third
+// to the launch's vector instructions): the workgroups of a 64-column CLUSTER (8 at two columns per wave) store their per-column
+// outputs write-through, count themselves in on an agent-scope counter, and the one whose add comes last evaluates the 64 columns.
+// Nobody waits for anybody: every wave reaches the end of the program whatever the others do.  Hand-off after MI355X_MICROARCH.md
+// (inter-workgroup visibility): sc1 stores -> the storing wave's s_waitcnt vmcnt(0) -> one lane's agent-scope add -> the last
+// arriver's agent-scope acquire -> sc1 loads.
+template <class NF> struct TailArgs {
+    unsigned* counter;     // [clusters]: arrivals of a cluster's workgroups; zero between launches (the last arriver resets it)
+    NF* out[10];           // the pending arrays, [Nh] each: Ts, ghf, swu, lwu, rnet, Hs, Hl, evap, infil, runoff
+};
+enum { TAIL_TS = 0, TAIL_GHF, TAIL_SWU, TAIL_LWU, TAIL_RNET, TAIL_HS, TAIL_HL, TAIL_EVAP, TAIL_INFIL, TAIL_RUNOFF, TAIL_COUNT };
+// compute_auxiliary! of the surface processes of column i (land_model.jl:79-88) from what the column program has just stored --
+// surface_program<FROM_STATE, TOP_ARRAYS> with the handed-off values read through the coherent path and the results left pending
+template <class NF, bool RICHARDS, int HYD> TRM_DEV void surface_tail(const View<NF>& v, const DevParams<NF>& p, NF* const* out, int i) {
+    const unsigned ib = (unsigned)i * (unsigned)sizeof(NF);
+    SebIn<NF> in = {ldg(v.Tair, ib), ldg(v.pres, ib), ldg(v.wind, ib), ldg(v.qair, ib), ldg(v.rain, ib), ldg(v.swd, ib), ldg(v.lwd, ib), NF(0), NF(0), NF(0)};
+    seb_radiation_inputs(p, v.albedo, v.emissivity, ib, in);
+    const NF T_top = ld_agent(v.top_T + i), sat_top = ld_agent(v.top_sat + i), liq_top = ld_agent(v.top_liq + i);
+    const NF Ts = ld_agent(v.Ts + i), S = RICHARDS ? ld_agent(v.S + i) : NF(0);
+    uint32_t viol = 0;
+    const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));
+    SebOut<NF> o;
+    surface_processes(p, in, Ts, T_top, sat_top, liq_top, Kf_top, S, RICHARDS, v.g.dzc_top, o);
+    const unsigned ob = block_local(ib);
+    stg(out[TAIL_TS], ob, o.Ts); stg(out[TAIL_GHF], ob, o.ghf); stg(out[TAIL_SWU], ob, o.swu); stg(out[TAIL_LWU], ob, o.lwu); stg(out[TAIL_RNET], ob, o.rnet);
+    stg(out[TAIL_HS], ob, o.Hs); stg(out[TAIL_HL], ob, o.Hl); stg(out[TAIL_EVAP], ob, o.evap); stg(out[TAIL_INFIL], ob, o.infil); stg(out[TAIL_RUNOFF], ob, o.runoff);
 }
 
 constexpr unsigned round_up_to(unsigned x, unsigned a) { return (x + a - 1) / a * a; }
