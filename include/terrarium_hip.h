@@ -150,7 +150,8 @@ enum {
 enum { TRM_REDUCE_SUM = 0, TRM_REDUCE_MIN = 1, TRM_REDUCE_MAX = 2, TRM_REDUCE_HASNAN = 3, TRM_REDUCE_VOLUME_INTEGRAL_Z = 4 };
 /* trm_status flag bits: replace the reference's CPU-side @assert / DEBUG NaN scans
  * (soil_volume.jl:26-28,85; diagnostics/debugging.jl:19-25). */
-enum { TRM_STATUS_NAN = 1u, TRM_STATUS_COMPOSITION_OUT_OF_RANGE = 2u };
+enum { TRM_STATUS_NAN = 1u, TRM_STATUS_COMPOSITION_OUT_OF_RANGE = 2u,
+       TRM_STATUS_HANDOFF_TIMEOUT = 4u /* TRM_OPT_SURFACE_IN_LAUNCH: a column wave gave up waiting for its surface fluxes; its columns are NaN */ };
 
 /* ---- options (trm_set_option) --------------------------------------------- */
 enum {
@@ -202,15 +203,14 @@ enum {
                                     /* forms the same halo, bit for bit, as no condition at all, and the context keeps the branch-free */
                                     /* programs (derivation, resident multi-step program, ...) instead of the generic-boundary kernels; */
                                     /* handing the value buffer out (trm_bc_device_ptr) or attaching a series ends it.  0: off (A/B)    */
-    ,TRM_OPT_TAIL_SURFACE = 11      /* bare-ground LandModel stepped one launch per step (fp64, Richards, the LandModel's boundary wiring, */
-                                    /* constant inputs): the column launch of step n also evaluates the surface processes of step n + 1   */
-                                    /* (land_model.jl:79-88) at its tail, per 64 columns by the last workgroup to finish them, into a     */
-                                    /* second set of the ten surface arrays; step n + 1 swaps the two sets instead of launching the 0-D   */
-                                    /* surface kernel -- unless a call that may change an input (trm_upload, trm_set_forcing*, trm_set_bc,  */
-                                    /* trm_set_clock, trm_restore_state, ...) came in between, in which case the set is dropped and the     */
-                                    /* kernel launched as before.  Same operations per column: bit-identical.  A device pointer handed out */
-                                    /* (trm_field_device_ptr, trm_bc_device_ptr) ends it for the context.  0: off; 1: whenever legal;       */
-                                    /* 2 (default): the library's rule                                                         */
+    ,TRM_OPT_SURFACE_IN_LAUNCH = 11 /* bare-ground LandModel stepped one launch per step (fp64, Richards, the LandModel's boundary wiring,  */
+                                    /* one level per lane): 1 = the 0-D surface processes (land_model.jl:79-88) run in the FIRST workgroups */
+                                    /* of the step launch, one lane per column, and hand ground heat flux, infiltration and the skin        */
+                                    /* temperature to the column workgroups of the same launch through tagged 8-byte words -- ONE launch     */
+                                    /* per step instead of the k_surface + k_column pair, same operations per column (bit-identical); the   */
+                                    /* inputs may change every step (nothing is evaluated ahead).  A column wave whose bounded wait for     */
+                                    /* its words ends unanswered raises TRM_STATUS_HANDOFF_TIMEOUT instead of hanging.  0: the launch pair;  */
+                                    /* 2 (default): the library's rule                                                          */
 };
 /* DIAGNOSTIC, read-only (trm_get_option): which fast paths the NEXT step will take -- what the library tracks about its own
  * buffers.  Tests pin them (a wrong value costs speed, never correctness, so nothing else would notice). */
@@ -222,10 +222,16 @@ enum {
     TRM_INFO_GENERIC_BOUNDARY_KERNELS = 103, /* 1: the context's boundary kinds need the generic-boundary kernels (k_step_wave, ...)   */
     TRM_INFO_BC_SIGNATURE = 102,       /* the boundary-condition signature of the context's current kinds (BCSIG bits: 1 / 2 Value on  */
                                        /* temperature bottom / top, 4 / 8 Flux on energy / saturation bottom, 16 / 32 top, 64 LandModel) */
-    TRM_INFO_TAIL_PENDING = 104,       /* 1: the last step's launch left the surface processes of the next step pending and nothing has  */
-                                       /* invalidated them (TRM_OPT_TAIL_SURFACE): the next trm_step launches ONE kernel                  */
     TRM_INFO_LAST_PROGRAM = 105        /* which kernel instance the last step launch of the context selected (TRM_PROGRAM_* below), 0     */
                                        /* before the first step: family in bits 0-7, then one field per selection rule                    */
+};
+/* kernel families reported in the low byte of TRM_INFO_LAST_PROGRAM; bits 8-9 the hydraulics instance (0 the reference default, 1 van
+ * Genuchten n = 2, 2 run-time exponents), 10-11 lanes per column / 32, 12-14 which closure fields are derived, 15 per-column outputs
+ * staged, 16 per-column inputs through the scalar path, 17-24 the compiled-in boundary signature + 1 (0: kinds read at run time) */
+enum {
+    TRM_PROGRAM_NONE = 0, TRM_PROGRAM_COLUMN_EULER = 1, TRM_PROGRAM_COLUMN_HEUN = 2, TRM_PROGRAM_COLUMN_MULTI = 3,
+    TRM_PROGRAM_PACKED_F32 = 4, TRM_PROGRAM_GENERIC_EULER = 5, TRM_PROGRAM_GENERIC_HEUN = 6, TRM_PROGRAM_COLUMN_LAND = 7,
+    TRM_PROGRAM_DEEP = 8, TRM_PROGRAM_WIDE = 9, TRM_PROGRAM_LAND_INTERLEAVED = 10, TRM_PROGRAM_UNFUSED = 11, TRM_PROGRAM_VEGETATION = 12
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

@@ -41,11 +41,11 @@ VEG_PARAM_NAMES = ("tau25 Kc25 Ko25 q10_tau q10_Kc q10_Ko alpha_leaf alpha_a alp
                    "gamma_v_min root_a root_b wilting_point field_capacity C_mass alpha_int canopy_k_ext w_can_max tau_w C_can").split()
 REDUCE = dict(sum=0, min=1, max=2, hasnan=3, volume_integral_z=4)
 OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_field=3, packed_f32=4,
-              derive_closure_fields=5, steps_per_launch=6, pipeline_parts=7, single_step_program=8, bc_signature=9, zero_gradient_fast=10, tail_surface=11,
+              derive_closure_fields=5, steps_per_launch=6, pipeline_parts=7, single_step_program=8, bc_signature=9, zero_gradient_fast=10, surface_in_launch=11,
               info_top_arrays_current=100, info_closure_consistent=101, info_bc_signature=102, info_generic_boundary_kernels=103,
-              info_tail_pending=104, info_last_program=105)
+              info_last_program=105)
 KERNEL = dict(fused=0, unfused=1)
-STATUS_NAN, STATUS_COMPOSITION = 1, 2
+STATUS_NAN, STATUS_COMPOSITION, STATUS_HANDOFF_TIMEOUT = 1, 2, 4
 TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE, TRM_ECOMM = range(7)
 
 EXPORTS = (

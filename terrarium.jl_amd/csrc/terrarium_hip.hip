@@ -251,16 +251,11 @@ template <class NF> StageView<NF> make_stage_view(const trm_ctx* c) {
 namespace trmh {
 template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
     if (!c->args) {
-        c->args = new LaunchArgs<NF>[2];
-        c->args_free = [](void* q) { delete[] (LaunchArgs<NF>*)q; };
+        c->args = new LaunchArgs<NF>();
+        c->args_free = [](void* q) { delete (LaunchArgs<NF>*)q; };
     }
-    // one cached set per parity of the surface-array swaps (trm_ctx::flip): a swap exchanges state.f[] of ten fields, and with
-    // it the pointers of the views; the two sets alternate without being rebuilt
-    if (!c->args_valid) c->args_built[0] = c->args_built[1] = false;
-    c->args_valid = true;
-    LaunchArgs<NF>* a = (LaunchArgs<NF>*)c->args + c->flip;
-    if (!c->args_built[c->flip]) {
-        c->args_built[c->flip] = true;
+    LaunchArgs<NF>* a = (LaunchArgs<NF>*)c->args;
+    if (!c->args_valid) {
         a->p = make_dev_params<NF>(c->params);
         a->state = make_view<NF>(c, c->state);
         a->stage = make_view<NF>(c, c->stage);
@@ -341,7 +336,6 @@ namespace {
 #endif
 
 template <class NF> int upload_impl(trm_ctx* c, int field, const NF* host);
-size_t field_skew_bytes();
 
 // The step sequences of one precision.  The launches themselves are Unfused / Veg / ColumnLaunch / GenericLaunch / DeepLaunch /
 // LandLaunch / PackedLaunch (trm_host.hpp); the forwarders below keep their reference names in the sequences.
@@ -383,6 +377,7 @@ template <class NF> struct Ops {
 
     // nsteps steps of the standalone VegetationModel; time series inputs are evaluated by the host between launches
     static int veg_step(trm_ctx* c, double dt, int nsteps, int finalize, bool heun) {
+        c->last_program = TRM_PROGRAM_VEGETATION;
         int n = 0;
         while (n < nsteps) {
             const int m = c->series.empty() ? nsteps - n : 1;
@@ -528,6 +523,7 @@ template <class NF> struct Ops {
         return rc;
     }
     static int unfused_step(trm_ctx* c, double dt, int finalize) {
+        c->last_program = TRM_PROGRAM_UNFUSED;
         int rc = update_state(c, c->state, true);
         if (!rc) rc = explicit_step(c, c->state, dt);
         if (!rc) rc = closure(c, c->state);
@@ -590,77 +586,33 @@ template <class NF> struct Ops {
     // processes as their own small launch in front of the column kernel (LandModel), and once more after it when finalizing.
     // (+ the 0-D prognostics' step of the coupled vegetation; the per-cell plant_available_water field is materialised with the
     // other per-cell auxiliaries: by the finalizing launch, or every step under TRM_OPT_WRITE_KF_EVERY_STEP)
+    // TRM_OPT_SURFACE_IN_LAUNCH: a per-step launch of this context can carry its own surface processes (k_column_land) -- a
+    // bare-ground LandModel in fp64 on the branch-free program with the LandModel's boundary wiring, one level per lane, every
+    // column in one launch, the top-cell arrays current (the surface workgroups read them).
+    static bool surface_in_launch(trm_ctx* c) {
+        if (!std::is_same<NF, double>::value || c->opt_front == 0) return false;
+        if (!c->params.seb || !richards(c) || coupled(c) || c->Nz > 64 || generic_bcs(c) || c->part >= 0) return false;
+        if (c->opt_kernel != TRM_KERNEL_FUSED || !c->opt_bc_signature || bc_signature_of(c) != BCSIG_LAND) return false;
+        if (hyd(c) != HYD_BC_LINEAR && hyd(c) != HYD_VG_N2) return false;
+        if (!c->top_valid || !tops_current(c)) return false;
+        const int d = P::template derive_now<true>(c);
+        return d == DERIVE_NONE || d == DERIVE_T_LIQ;
+    }
     static int fused_step(trm_ctx* c, double dt, int fin) {
         int rc = update_inputs(c, c->state, c->time);
         if (rc) return rc;
-        const bool tail = tail_capable(c);
-        if (tail && (rc = ensure_tail_buffers(c))) return rc;
+        const bool in_launch = surface_in_launch(c);
         if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt, c->opt_write_kf != 0);
-        else if (c->params.seb) {
-            // the surface processes of the state: what the previous step's launch left pending, if nothing has touched an input since
-            if (tail && c->tail_valid) swap_surface_arrays(c);
-            else rc = surface(c, c->state, true);
-        }
-        c->tail_valid = false;
-        if (!rc && tail) {
-            rc = TailLaunch::run(c, dt, fin);
+        else if (c->params.seb && !in_launch) rc = surface(c, c->state, true);
+        if (!rc && in_launch) {
+            rc = FrontLaunch::run(c, dt, fin);
             if (!rc) c->closure_consistent = true;
         } else if (!rc) rc = wave_step(c, dt, fin);
         c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies
         c->top_valid = c->params.seb != 0 && !rc && tops_current(c);
-        if (!rc && tail) {
-            // the launch has evaluated the surface processes of the NEW state: compute_auxiliary!'s values when finalizing
-            // (model_integrator.jl:127-129), else the next step's -- kept pending until it asks for them
-            if (fin) swap_surface_arrays(c);
-            else c->tail_valid = true;
-        }
-        else if (!rc && fin && coupled(c)) rc = surface_veg<true, false>(c, c->state, 0.0);
+        if (!rc && fin && coupled(c)) rc = surface_veg<true, false>(c, c->state, 0.0);
         else if (!rc && fin && c->params.seb) rc = surface(c, c->state, true);
         return rc;
-    }
-    // ---- TRM_OPT_TAIL_SURFACE (trm_kernels.hpp: surface_tail) ---------------------------------------------------------------
-    // the ten arrays the surface processes write: the skin temperature and the nine diagnostics
-    static const int* surface_fields() {
-        static const int f[TAIL_COUNT] = {TRM_FIELD_SKIN_TEMPERATURE, TRM_FIELD_GROUND_HEAT_FLUX, TRM_FIELD_SURFACE_SHORTWAVE_UP, TRM_FIELD_SURFACE_LONGWAVE_UP,
-                                          TRM_FIELD_SURFACE_NET_RADIATION, TRM_FIELD_SENSIBLE_HEAT_FLUX, TRM_FIELD_LATENT_HEAT_FLUX, TRM_FIELD_EVAPORATION_GROUND,
-                                          TRM_FIELD_INFILTRATION, TRM_FIELD_SURFACE_RUNOFF};
-        return f;
-    }
-    // A per-step launch of this context may evaluate the next step's surface processes at its tail: a bare-ground LandModel in fp64
-    // on the branch-free program with the LandModel signature, constant inputs (a series is evaluated by the host at the NEXT
-    // step's clock, which this step does not know), every column in one launch, and nobody outside the library holding a pointer
-    // into the state or its inputs.
-    static bool tail_capable(trm_ctx* c) {
-        if (!std::is_same<NF, double>::value || c->opt_tail == 0 || c->tail_escaped) return false;
-        if (!c->params.seb || !richards(c) || coupled(c) || c->Nz > 64 || generic_bcs(c) || !c->series.empty()) return false;
-        if (c->part >= 0 || c->opt_kernel != TRM_KERNEL_FUSED || !c->opt_bc_signature || bc_signature_of(c) != BCSIG_LAND) return false;
-        if (hyd(c) != HYD_BC_LINEAR && hyd(c) != HYD_VG_N2) return false;
-        if (!tops_current(c)) return false;
-        const int d = P::template derive_now<true>(c);
-        if (d != DERIVE_NONE && d != DERIVE_T_LIQ) return false;
-        return true;
-    }
-    static int ensure_tail_buffers(trm_ctx* c) {
-        if (c->tail_counter) return TRM_OK;
-        for (int n = 0; n < TAIL_COUNT; ++n) {
-            const int f = surface_fields()[n];
-            const size_t bytes = field_elems(c, f) * c->esize, skew = field_skew_bytes() * (size_t)((f + 7) % 32);
-            TRM_HIP(c, hipMalloc(&c->pend.raw[f], bytes + skew));
-            c->pend.f[f] = (char*)c->pend.raw[f] + skew;
-            TRM_HIP(c, hipMemsetAsync(c->pend.f[f], 0, bytes, c->stream));
-        }
-        c->tail_clusters = (c->Nh + 63) / 64 + 1;
-        TRM_HIP(c, hipMalloc((void**)&c->tail_counter, (size_t)c->tail_clusters * TRM_TAIL_COUNTER_STRIDE * sizeof(unsigned)));
-        TRM_HIP(c, hipMemsetAsync(c->tail_counter, 0, (size_t)c->tail_clusters * TRM_TAIL_COUNTER_STRIDE * sizeof(unsigned), c->stream));
-        return TRM_OK;
-    }
-    static void swap_surface_arrays(trm_ctx* c) {
-        for (int n = 0; n < TAIL_COUNT; ++n) {
-            const int f = surface_fields()[n];
-            std::swap(c->state.f[f], c->pend.f[f]);
-            std::swap(c->state.raw[f], c->pend.raw[f]);
-        }
-        c->flip ^= 1;
     }
     // TRM_OPT_SINGLE_STEP_PROGRAM: a bare-ground LandModel stepped ONE step per call (its inputs change every step: a coupled
     // atmosphere) takes the resident column program with the surface processes inline -- one launch instead of the
@@ -673,7 +625,7 @@ template <class NF> struct Ops {
         return c->Nh <= TRM_SINGLE_STEP_PROGRAM_MAX_COLUMNS;
     }
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
-        if (c->veg_mode == TRM_VEGETATION_STANDALONE) { c->tail_valid = false; return veg_step(c, dt, nsteps, finalize, false); }
+        if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
         // deeper takes the reference-order kernels
         // the fused kernels map one soil level to one lane (two for 65 ... 128 levels, four for 129 ... 256); anything deeper takes the
@@ -690,14 +642,12 @@ template <class NF> struct Ops {
             int m = std::min(spl, nsteps - n);
             const int fin = (finalize && n + m == nsteps) ? 1 : 0;
             if (!fused) {
-                c->tail_valid = false;
                 rc = update_inputs(c, c->state, c->time);
                 c->top_valid = false;
                 c->tend_valid = true;
                 if (!rc) rc = unfused_step(c, dt, fin);
                 if (!rc) c->closure_consistent = true;   // closure! has just run
             } else if (m > 1 || (program_ok && single_step_program(c))) {
-                c->tail_valid = false;
                 rc = c->series.empty() ? update_inputs(c, c->state, c->time) : upload_series_rows(c, dt, m);
                 if (!rc) rc = deep_columns(c) ? deep_program(c, dt, fin, m) : column_program<PROG_MULTI>(c, dt, fin, m);
                 if (!rc) c->closure_consistent = true;
@@ -707,7 +657,6 @@ template <class NF> struct Ops {
             } else if (interleave_now(c, nsteps - n)) {
                 // every remaining step of the call in one go (the clock is ticked inside)
                 m = nsteps - n;
-                c->tail_valid = false;
                 rc = land_steps_interleaved(c, dt, m, finalize);
                 n += m;
                 continue;
@@ -865,7 +814,6 @@ template <class NF> struct Ops {
         return rc;
     }
     static int heun_step(trm_ctx* c, double dt, int finalize) {
-        c->tail_valid = false;
         if (int rr = refresh_user_stage_buffers(c)) return rr;
         if (c->opt_kernel == TRM_KERNEL_FUSED && c->Nz <= 64 && generic_bcs(c) && !coupled(c)) return heun_step_generic_fused(c, dt, finalize);
         if (c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c) || wide_columns(c)) && !generic_bcs(c) && coupled(c)) return heun_step_coupled_fused(c, dt, finalize);
@@ -874,6 +822,7 @@ template <class NF> struct Ops {
         c->top_valid = false;
         c->tend_valid = true;
         c->closure_consistent = true;   // (ends with closure!)
+        c->last_program = TRM_PROGRAM_UNFUSED;
         int rc = heun_predict(c, dt);
         if (!rc) rc = heun_correct(c, dt, finalize);
         return rc;
@@ -1333,14 +1282,9 @@ int comm_allreduce(trm_ctx* c, double* host, int n, ncclRedOp_t op) {
 // ======================================================================================================
 extern "C" {
 
-// TRM_ENTER: an entry point that may change the state, an input or the way the step runs -- what a per-step LandModel launch left
-// pending for the next step (trm_ctx::tail_valid) is dropped.  TRM_ENTER_KEEP: the steps themselves and the read-only calls.
-#define TRM_ENTER_KEEP(c)                                    \
+#define TRM_ENTER(c)                                         \
     if (!(c)) return TRM_EINVAL;                             \
     TRM_HIP(c, hipSetDevice((c)->device));
-#define TRM_ENTER(c)                                         \
-    TRM_ENTER_KEEP(c)                                        \
-    (c)->tail_valid = false;
 
 int trm_abi_version(void) { return TRM_ABI_VERSION; }
 
@@ -1448,9 +1392,7 @@ int trm_destroy(trm_ctx* c) {
         if (c->stage.f[f]) (void)hipFree(c->stage.raw[f]);
         if (c->saved.f[f]) (void)hipFree(c->saved.raw[f]);
     }
-    for (int f = 0; f < TRM_FIELD_COUNT; ++f)
-        if (c->pend.raw[f]) (void)hipFree(c->pend.raw[f]);
-    if (c->tail_counter) (void)hipFree(c->tail_counter);
+    if (c->d_gran) (void)hipFree(c->d_gran);
     if (c->state.kf_top) (void)hipFree(c->state.kf_top);
     if (c->stage.kf_top) (void)hipFree(c->stage.kf_top);
     if (c->saved.kf_top) (void)hipFree(c->saved.kf_top);
@@ -1506,7 +1448,6 @@ int trm_upload(trm_ctx* c, int field, const void* host) {
         return fail(c, TRM_EINVAL, "trm_upload: root_fraction is a static function of the root distribution parameters "
                                    "(root_distribution.jl:45-63): set them with trm_set_vegetation");
     TRM_HIP(c, hipSetDevice(c->device));
-    c->tail_valid = false;
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
     if (field <= TRM_FIELD_PRESSURE_HEAD || field == TRM_FIELD_WATER_TABLE) c->closure_consistent = false;   // (U, sat, T, liq, psi, water table)
     if (!rc && field == TRM_FIELD_VWC_FORCING) {
@@ -1539,9 +1480,6 @@ int trm_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     *dev = c->state.f[field];
     if (pitch_elems) *pitch_elems = is_3d(field) ? c->Nzp : 1;
-    // (the pointer must stay the field's: no more swaps of the surface arrays, and nothing evaluated ahead of a caller who may write)
-    c->tail_escaped = true;
-    c->tail_valid = false;
     // the caller may write the state behind the library's back from now on: stop trusting the top-cell copies
     if (field == TRM_FIELD_TEMPERATURE || field == TRM_FIELD_SATURATION_WATER_ICE || field == TRM_FIELD_LIQUID_WATER_FRACTION)
         c->top_escaped = true;
@@ -1556,7 +1494,6 @@ int trm_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
     for (const auto& sr : c->series)
         if (sr.is_bc && sr.var == var && sr.side == side) return fail(c, TRM_EINVAL, "trm_bc_device_ptr: the boundary values are evaluated from a time series every step");
     *dev = c->bc_value[var][side];
-    c->tail_valid = false;
     c->bc_zero_gradient[var][side] = false;      // (the caller may write the buffer from now on)
     return TRM_OK;
 }
@@ -1579,7 +1516,6 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
     c->bc_kind[var][side] = kind;
     c->bc_zero_gradient[var][side] = false;
     c->args_valid = false;
-    c->tail_valid = false;
     if (kind == TRM_BC_NOFLUX) return TRM_OK;
     size_t bytes = (size_t)c->Nh * c->esize;
     if (!c->bc_value[var][side]) TRM_HIP(c, hipMalloc(&c->bc_value[var][side], bytes));
@@ -1840,7 +1776,7 @@ int trm_reset(trm_ctx* c) {
 
 // ---- output: rows of a field, and the full ring grid (column_ring_grid.jl:102-149) -----------------------------------------
 int trm_download_rows(trm_ctx* c, int field, int row0, int nrows, void* host) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (!host || !valid_field(field) || !c->state.f[field]) return fail(c, TRM_EINVAL, "trm_download_rows: bad argument");
     if (row0 < 0 || nrows < 1 || row0 + nrows > field_rows(c, field)) return fail(c, TRM_EINVAL, "trm_download_rows: rows out of range");
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
@@ -1852,7 +1788,7 @@ int trm_download_rows(trm_ctx* c, int field, int row0, int nrows, void* host) {
 }
 
 int trm_set_ring_grid(trm_ctx* c, int64_t num_points, const int64_t* mask_index) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (num_points < c->Nh || num_points >= ((int64_t)1 << 31) || !mask_index) return fail(c, TRM_EINVAL, "trm_set_ring_grid: bad argument");
     std::vector<int32_t> inv((size_t)num_points, -1), idx((size_t)c->Nh);
     for (long i = 0; i < c->Nh; ++i) {
@@ -1884,12 +1820,12 @@ static int ring_args_ok(trm_ctx* c, int field, int row0, int nrows, const void* 
     return TRM_OK;
 }
 int trm_download_ring(trm_ctx* c, int field, int row0, int nrows, double fill, void* host) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (int rc = ring_args_ok(c, field, row0, nrows, host, "trm_download_ring")) return rc;
     return c->precision == TRM_F64 ? scatter_ring_impl<double>(c, field, row0, nrows, fill, host, false) : scatter_ring_impl<float>(c, field, row0, nrows, fill, host, false);
 }
 int trm_scatter_ring_device(trm_ctx* c, int field, int row0, int nrows, double fill, void* dev_out) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (int rc = ring_args_ok(c, field, row0, nrows, dev_out, "trm_scatter_ring_device")) return rc;
     return c->precision == TRM_F64 ? scatter_ring_impl<double>(c, field, row0, nrows, fill, dev_out, true) : scatter_ring_impl<float>(c, field, row0, nrows, fill, dev_out, true);
 }
@@ -1970,7 +1906,7 @@ int trm_invclosure(trm_ctx* c) {
 }
 
 int trm_step(trm_ctx* c, double dt, int nsteps, int finalize) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (nsteps < 0) return fail(c, TRM_EINVAL, "trm_step: nsteps < 0");
     return finish(c, DISPATCH(c, step(c, dt, nsteps, finalize)));
 }
@@ -1991,7 +1927,7 @@ int wait_polling(trm_ctx* c, hipEvent_t ev) {
 }  // namespace
 
 int trm_step_timed(trm_ctx* c, double dt, int nsteps, int finalize, float* ms) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (nsteps < 0 || !ms) return fail(c, TRM_EINVAL, "trm_step_timed: bad argument");
     TRM_HIP(c, hipEventRecord(c->ev0, c->stream));
     int rc = DISPATCH(c, step(c, dt, nsteps, finalize));
@@ -2119,7 +2055,7 @@ int trm_stage_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
 }
 
 int trm_save_state(trm_ctx* c) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     {   // (allocates what is missing: everything the first time, the vegetation fields once they exist)
         int rc = alloc_fields(c, c->saved);
         if (rc) return rc;
@@ -2159,14 +2095,13 @@ int trm_clock(const trm_ctx* c, double* time, int64_t* iteration) {
 }
 int trm_set_clock(trm_ctx* c, double time, int64_t iteration) {
     if (!c) return TRM_EINVAL;
-    c->tail_valid = false;
     c->time = time;
     c->iteration = iteration;
     return TRM_OK;
 }
 
 int trm_reduce(trm_ctx* c, int field, int op, double* out) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (!out || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_reduce: bad argument");
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     return c->precision == TRM_F64 ? reduce_impl<double>(c, field, op, out) : reduce_impl<float>(c, field, op, out);
@@ -2237,7 +2172,7 @@ int trm_comm_unique_id(void* id128) {
 }
 
 int trm_comm_init(trm_ctx* c, int rank, int world, const void* id128) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(c, TRM_EINVAL, "trm_comm_init: bad argument");
     if (c->comm) return fail(c, TRM_EINVAL, "trm_comm_init: the context already has a communicator");
     Rccl* r = rccl();
@@ -2513,7 +2448,7 @@ int trm_status_global_all(trm_ctx** ctxs, int n, uint32_t* flags) {
 }
 
 int trm_status(trm_ctx* c, uint32_t* flags) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     if (!flags) return TRM_EINVAL;
     TRM_HIP(c, hipMemcpyAsync(flags, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
@@ -2523,7 +2458,6 @@ int trm_status(trm_ctx* c, uint32_t* flags) {
 int trm_set_option(trm_ctx* c, int option, int value) {
     if (!c) return TRM_EINVAL;
     c->args_valid = false;
-    c->tail_valid = false;
     switch (option) {
         case TRM_OPT_ASYNC: c->opt_async = value != 0; return TRM_OK;
         case TRM_OPT_STEP_KERNEL:
@@ -2551,9 +2485,9 @@ int trm_set_option(trm_ctx* c, int option, int value) {
             return TRM_OK;
         case TRM_OPT_BC_SIGNATURE: c->opt_bc_signature = value != 0; return TRM_OK;
         case TRM_OPT_ZERO_GRADIENT_FAST: c->opt_zero_gradient_fast = value != 0; c->args_valid = false; return TRM_OK;
-        case TRM_OPT_TAIL_SURFACE:
+        case TRM_OPT_SURFACE_IN_LAUNCH:
             if (value < 0 || value > 2) break;
-            c->opt_tail = value;
+            c->opt_front = value;
             return TRM_OK;
         default: break;
     }
@@ -2573,8 +2507,7 @@ int trm_get_option(const trm_ctx* c, int option, int* value) {
         case TRM_OPT_SINGLE_STEP_PROGRAM: *value = c->opt_single_step; return TRM_OK;
         case TRM_OPT_BC_SIGNATURE: *value = c->opt_bc_signature; return TRM_OK;
         case TRM_OPT_ZERO_GRADIENT_FAST: *value = c->opt_zero_gradient_fast; return TRM_OK;
-        case TRM_OPT_TAIL_SURFACE: *value = c->opt_tail; return TRM_OK;
-        case TRM_INFO_TAIL_PENDING: *value = c->tail_valid ? 1 : 0; return TRM_OK;
+        case TRM_OPT_SURFACE_IN_LAUNCH: *value = c->opt_front; return TRM_OK;
         case TRM_INFO_LAST_PROGRAM: *value = c->last_program; return TRM_OK;
         case TRM_INFO_GENERIC_BOUNDARY_KERNELS: *value = (c->precision == TRM_F64 ? trmh::Policy<double>::generic_bcs(c) : trmh::Policy<float>::generic_bcs(c)) ? 1 : 0; return TRM_OK;
         case TRM_INFO_BC_SIGNATURE: *value = trmh::bc_signature_of(c); return TRM_OK;
@@ -2591,7 +2524,7 @@ int trm_set_stream(trm_ctx* c, void* hip_stream) {
     return TRM_OK;
 }
 int trm_synchronize(trm_ctx* c) {
-    TRM_ENTER_KEEP(c);
+    TRM_ENTER(c);
     TRM_HIP(c, hipStreamSynchronize(c->stream));
     return TRM_OK;
 }

@@ -25,14 +25,16 @@
 namespace trm {
 
 enum { PROG_EULER = 0, PROG_HEUN = 1, PROG_MULTI = 2 };
-// (diagnostic builds of the tail evaluation -- wrong results by construction: 1 no chain, 2 no acquire, 4 no arrival count, 8 plain
-// stores, 16 no wait for the stores, 32 nothing behind the staged store)
-#ifndef TRM_TAIL_DIAG
-#define TRM_TAIL_DIAG 0
+// (diagnostic builds of the in-launch surface processes, wrong results by construction: 1 no surface chain, 2 no granule poll,
+// 4 the granules taken as valid whatever their tags)
+#ifndef TRM_FRONT_DIAG
+#define TRM_FRONT_DIAG 0
 #endif
-// words between the arrival counters of two clusters (one 128-byte line each: the adds of different clusters do not meet on a line)
-#ifndef TRM_TAIL_COUNTER_STRIDE
-#define TRM_TAIL_COUNTER_STRIDE 32u
+#ifndef TRM_FRONT_POLL_SLEEP
+#define TRM_FRONT_POLL_SLEEP 4       // s_sleep between two polls of the granules (x 64 clocks)
+#endif
+#ifndef TRM_FRONT_PRIO
+#define TRM_FRONT_PRIO 3             // s_setprio of the surface waves
 #endif
 
 template <class NF> struct Cell { NF U, sat, T, liq, psi; };
@@ -224,6 +226,19 @@ template <class NF> TRM_DEV NF series_value(const SeriesTable<NF>* tb, const Ser
     return (NF)((double)x2 * r.f + (double)x1 * (1.0 - r.f));
 }
 
+// the six granules of one column as the scalar path delivers them (see FrontArgs)
+struct FrontGranules {
+    unsigned long long w[FRONT_GRANULES];
+    TRM_DEV void load(const unsigned long long* gran, unsigned byte_off_uniform) {     // (adjacent scalar loads: the backend widens them)
+        for (int n = 0; n < FRONT_GRANULES; ++n) w[n] = sld_off<unsigned long long>(gran, byte_off_uniform + (unsigned)n * 8u);
+    }
+    TRM_DEV bool valid(unsigned epoch) const {
+        bool ok = true;
+        for (int n = 0; n < FRONT_GRANULES; ++n) ok = ok && (unsigned)(w[n] >> 32) == epoch;
+        return ok;
+    }
+    TRM_DEV double value(int q) const { return __builtin_bit_cast(double, (w[q + 1] << 32) | (w[q] & 0xffffffffull)); }
+};
 template <class NF> struct ColumnArgs {
     NF dt;
     int finalize, write_kf, nsteps;
@@ -249,13 +264,15 @@ template <class NF> struct ColumnArgs {
 // those that run the program.
 // STAGED / SCALAR_IN: how the per-column outputs leave and the per-column inputs arrive (see below) -- compile-time: as
 // wave-uniform run-time branches they cost the field loads their back-to-back issue (profiles/r03/exp28: 8 x N145 +7 %).
-// TAIL (with STAGED, LandModel): the surface processes of the NEXT step at the end of this launch (surface_tail, trm_kernels.hpp);
-// the kernel's fourth argument is then a TailArgs.
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME, bool TAIL = false>
+// FRONT (LandModel, BCSIG_LAND): ground heat flux, infiltration and the new skin temperature come from the surface workgroups of THIS
+// launch (surface_front, trm_kernels.hpp) as granules; the kernel's fourth argument is then a FrontArgs.
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME, bool FRONT = false>
 TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, const ColumnArgs<NF>& a, unsigned block) {
     // (kernarg layout: the arguments in order, each at its natural alignment)
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
-    static_assert(!TAIL || (STAGED && PROG == PROG_EULER && !SEB_INLINE), "the tail evaluation hands the staged per-column outputs of a per-step launch on");
+    constexpr unsigned off_args = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(ColumnArgs<NF>));
+    constexpr unsigned off_front = round_up_to(off_args + (unsigned)sizeof(ColumnArgs<NF>), (unsigned)alignof(FrontArgs));
+    static_assert(!FRONT || (PROG == PROG_EULER && BCSIG == BCSIG_LAND && RICHARDS && !SEB_INLINE && sizeof(NF) == 8), "the in-launch surface processes feed the per-step fp64 LandModel program");
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
     static_assert(!SEB_INLINE || PROG == PROG_MULTI, "the in-kernel surface energy balance belongs to the multi-step program");
@@ -353,14 +370,16 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     const ColVal none{NF(0), NF(0)};
     ColVal q_Tb = none, q_Tt = none, q_Ub = none, q_Sb = none, q_Ut = none, q_St = none, q_wt = none, q_Tb2 = none, q_Tt2 = none, q_S = none, q_Ts = none;
     NF S_stage_out = NF(0);
+    FrontGranules fg0{}, fg1{};
+    unsigned front_epoch = 0;
     auto request_inputs = [&] {
         if (vTb) q_Tb = col_req(bcval(v, 2, 0));
         if (vTt) q_Tt = col_req(bcval(v, 2, 1));
         if (bU) q_Ub = col_req(bcval(v, 0, 0));
         if (bS) q_Sb = col_req(bcval(v, 1, 0));
         // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this launch
-        if (tU) q_Ut = col_req(seb ? v.ghf : bcval(v, 0, 1));
-        if (tS) q_St = col_req(seb ? v.infil : bcval(v, 1, 1));
+        if (tU && !FRONT) q_Ut = col_req(seb ? v.ghf : bcval(v, 0, 1));
+        if (tS && !FRONT) q_St = col_req(seb ? v.infil : bcval(v, 1, 1));
         if (RICHARDS && DERIVE == DERIVE_ALL) q_wt = col_req(v.wt);
         if (PROG == PROG_HEUN) {      // the stage's temperature boundary values, taken at t + dt (heun.jl:52-59)
             if (vTb) q_Tb2 = col_req(a.bcT_bot_stage);
@@ -368,7 +387,13 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         }
         if (PROG != PROG_MULTI) {
             if (RICHARDS) q_S = col_req(v.S);
-            if (seb) q_Ts = col_req(v.Ts);
+            if (seb && !FRONT) q_Ts = col_req(v.Ts);
+        }
+        if constexpr (FRONT) {   // the granules of the wave's columns through the scalar path: valid if the surface workgroups have published them
+            const FrontArgs& fa = kernarg_reload<FrontArgs>(off_front);
+            fg0.load(fa.gran, jo0 * (unsigned)(FRONT_GRANULES * sizeof(unsigned long long) / sizeof(NF)));
+            if (CPW == 2) fg1.load(fa.gran, jo1 * (unsigned)(FRONT_GRANULES * sizeof(unsigned long long) / sizeof(NF)));
+            front_epoch = fa.epoch;
         }
     };
     // ... on the VECTOR path only.  Scalar loads return out of order, so every use of one waits for ALL of them (lgkmcnt(0)): requested
@@ -388,9 +413,17 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     // ---- boundary inputs of the column --------------------------------------------------------------------------------
     TRM_PHASE_FENCE("inputs", c.U, c.sat, c.psi, c.T, c.liq);
     if (!EARLY) request_inputs();
-    const NF in_Tb = col_get(q_Tb), in_Tt = col_get(q_Tt), in_Ub = col_get(q_Ub), in_Sb = col_get(q_Sb), in_Ut = col_get(q_Ut), in_St = col_get(q_St);
+    const NF in_Tb = col_get(q_Tb), in_Tt = col_get(q_Tt), in_Ub = col_get(q_Ub), in_Sb = col_get(q_Sb);
+    NF in_Ut = col_get(q_Ut), in_St = col_get(q_St);
     const NF in_wt = col_get(q_wt), in_Tb2 = col_get(q_Tb2), in_Tt2 = col_get(q_Tt2);
     NF S_in = col_get(q_S), Ts_in = col_get(q_Ts);
+    NF front_Ut = NF(0), front_St = NF(0);
+    bool front_ready = true;
+    if constexpr (FRONT) {
+        front_ready = (TRM_FRONT_DIAG & 4) || (fg0.valid(front_epoch) && (CPW == 1 || fg1.valid(front_epoch)));      // (wave-uniform, on the scalar unit)
+        const FrontGranules& g = (CPW == 2 && upper) ? fg1 : fg0;
+        front_Ut = g.value(FRONT_GHF); front_St = g.value(FRONT_INFIL); Ts_in = g.value(FRONT_TS);
+    }
     ColumnBC<NF> bc;
     if (RICHARDS && DERIVE == DERIVE_ALL) {
         // saturation_to_pressure! of the stored state from the stored saturation and the stored water table: what the launch that
@@ -399,6 +432,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         // load -- is slower still: profiles/r04/exp5b)
         c.psi = pressure_head<NF, HYD>(kernarg_reload<DevParams<NF>>(off_p), c.sat, L.zC, L.psiz, in_wt);
     }
+    if (FRONT) { in_Ut = front_Ut; in_St = front_St; }
     bc.bTb = in_Tb;
     bc.bTt = in_Tt;
     {   // flux conditions: a term for the edge lane of every condition that is SET (wave-uniform branches), nothing otherwise.
@@ -540,6 +574,39 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol, pre);
             NF gU = t.gU, gS = t.gS;
             TRM_PHASE_FENCE("advance", gU, gS, t.Kf_lo, t.Kc);
+            if constexpr (FRONT && !(TRM_FRONT_DIAG & 2)) if (!front_ready) {
+                // the scalar read came before the surface workgroups had published: poll the granules (vector loads at agent scope,
+                // every lane k < 6 of a column its granule k), here, where the values are first needed
+                TRM_PHASE("rare+ granule poll");
+                const FrontArgs& fa = kernarg_reload<FrontArgs>(off_front);
+                const unsigned long long* gp = fa.gran + (size_t)ii * FRONT_GRANULES + (ln.k < FRONT_GRANULES ? ln.k : FRONT_GRANULES - 1);
+                unsigned long long g = 0;
+                bool ok = false;
+                for (int spin = 0; spin < FRONT_SPIN_LIMIT && !ok; ++spin) {
+                    g = ld_agent(gp);
+                    ok = wave_ballot((unsigned)(g >> 32) != fa.epoch) == 0ull;
+                    if (!ok) __builtin_amdgcn_s_sleep(TRM_FRONT_POLL_SLEEP);
+                }
+                const int w = (int)(unsigned)g;                 // the granule's payload: one 32-bit half of a value
+                auto value = [&](int q, int base) {
+                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(w, base + q), hi = (unsigned)__builtin_amdgcn_readlane(w, base + q + 1);
+                    return __builtin_bit_cast(NF, ((unsigned long long)hi << 32) | lo);
+                };
+                NF ut = value(FRONT_GHF, 0), st = value(FRONT_INFIL, 0), ts = value(FRONT_TS, 0);
+                if (CPW == 2) {
+                    const NF ut1 = value(FRONT_GHF, LPC), st1 = value(FRONT_INFIL, LPC), ts1 = value(FRONT_TS, LPC);
+                    ut = upper ? ut1 : ut; st = upper ? st1 : st; ts = upper ? ts1 : ts;
+                }
+                if (!ok) {   // gave up: no hang, the columns of the wave are flagged and NaN
+                    viol |= 4u;
+                    ut = st = ts = __builtin_nan("");
+                }
+                Ts_in = ts;
+                const NF eU_t = -flux_term_top_nsz(ut, v.g), eS_t = -flux_term_top_nsz(-st, v.g);
+                bc.flux_U = ln.is_top ? eU_t : NF(0);
+                bc.flux_S = ln.is_top ? eS_t : NF(0);
+                TRM_PHASE("rare-");
+            }
             over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
             if (PROG == PROG_MULTI && RICHARDS) {   // surface_excess_water carried in the top lane's register
                 GS_out = NF(0) + jl_min(NF(0), S);
@@ -643,33 +710,10 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         const unsigned enabled = (write_kf ? 1u << SMALL_KF_TOP : 0u) | (RICHARDS ? (1u << SMALL_S) | (1u << SMALL_WT) : 0u) |
                                  ((RICHARDS && finalize) ? 1u << SMALL_G_S : 0u) |
                                  (seb ? (1u << SMALL_TOP_T) | (1u << SMALL_TOP_SAT) | (1u << SMALL_TOP_LIQ) | (1u << SMALL_TS) : 0u);
-        store_small_outputs<NF, TAIL && !(TRM_TAIL_DIAG & 8)>(enabled, (int)(blockDim.x >> 6) * CPW, block, Nh);
+        store_small_outputs<NF>(enabled, (int)(blockDim.x >> 6) * CPW, block, Nh);
     }
     // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
     if (viol && ln.act) atomicOr(v_arg.status, viol);
-    if (TAIL) {
-        // The workgroup's first wave has just stored the per-column outputs (write-through); it counts the workgroup in, and in the
-        // workgroup that arrives last of its 64-column cluster it evaluates the surface processes of those columns for the next step.
-        if ((threadIdx.x >> 6) == 0 && !(TRM_TAIL_DIAG & 32)) {
-            if (!(TRM_TAIL_DIAG & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have left before the workgroup is counted in
-            constexpr unsigned off_a = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(ColumnArgs<NF>));
-            constexpr unsigned off_t = round_up_to(off_a + (unsigned)sizeof(ColumnArgs<NF>), (unsigned)alignof(TailArgs<NF>));
-            const TailArgs<NF>& ta = kernarg_reload<TailArgs<NF>>(off_t);
-            constexpr unsigned WGPC = 64u / (unsigned)((TRM_STEP_BLOCK / 64) * CPW);     // workgroups per 64-column cluster
-            const unsigned cluster = block / WGPC;
-            const unsigned nblocks = gridDim.x;
-            const unsigned members = (nblocks - cluster * WGPC) < WGPC ? (nblocks - cluster * WGPC) : WGPC;
-            unsigned arrived = 0;
-            if (ln.lane == 0 && !(TRM_TAIL_DIAG & 4)) arrived = __hip_atomic_fetch_add(ta.counter + cluster * TRM_TAIL_COUNTER_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arrived = (unsigned)__builtin_amdgcn_readfirstlane((int)arrived);
-            if (arrived == members - 1u) {
-                if (ln.lane == 0) __hip_atomic_store(ta.counter + cluster * TRM_TAIL_COUNTER_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (!(TRM_TAIL_DIAG & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const int col = (int)(cluster * 64u) + ln.lane;
-                if (col < Nh && !(TRM_TAIL_DIAG & 1)) surface_tail<NF, RICHARDS, HYD>(kernarg_reload<View<NF>>(0), kernarg_reload<DevParams<NF>>(off_p), ta.out, col);
-            }
-        }
-    }
 }
 
 template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, int PROG, bool SEB_INLINE, bool SERIES = false, bool STAGED = false, bool SCALAR_IN = true, int BCSIG = BCSIG_RUNTIME>
@@ -682,13 +726,24 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, SEB_INLINE, SERIES, STAGED, SCALAR_IN, BCSIG>(v_arg, p_arg, a, xcd_block<TRM_XCD_REMAP != 0>(blockIdx.x, gridDim.x));
 }
 
-// The ForwardEuler program of a bare-ground LandModel with the NEXT step's surface processes at its tail (TRM_OPT_TAIL_SURFACE)
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, bool SCALAR_IN>
+// ---- LandModel, ONE launch per step (TRM_OPT_SURFACE_IN_LAUNCH): the first workgroups evaluate the 0-D surface processes of 256
+// columns each (surface_front), the others run the ForwardEuler column program, which receives ground heat flux, infiltration and
+// the new skin temperature from them through granules.  Same operations per column as the k_surface / k_column pair: bit-identical.
+#ifndef TRM_LAND_WAVES
+#define TRM_LAND_WAVES 7
+#endif
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, bool STAGED, bool SCALAR_IN>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
-    __attribute__((amdgpu_waves_per_eu(HYD == HYD_BC_LINEAR ? TRM_COLUMN_WAVES_EULER : 5, 8)))
-    k_column_tail(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a, TailArgs<NF> tail) {
-    (void)tail;     // (read from the kernel argument segment by the wave that evaluates the tail)
-    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG_EULER, false, false, true, SCALAR_IN, BCSIG_LAND, true>(v_arg, p_arg, a, blockIdx.x);
+    __attribute__((amdgpu_waves_per_eu(TRM_LAND_WAVES, 8)))
+    k_column_land(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a, FrontArgs fa) {
+    if ((int)blockIdx.x < fa.chain_blocks) {
+        // (the surface waves share their SIMDs with up to seven column waves, all of which will wait for them: they issue first)
+        __builtin_amdgcn_s_setprio(TRM_FRONT_PRIO);
+        const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i - (long)(threadIdx.x & 63u) < v_arg.Nh && !(TRM_FRONT_DIAG & 1)) surface_front<NF, RICHARDS, HYD>(v_arg, p_arg, fa, i);     // (wave-uniform)
+        return;
+    }
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG_EULER, false, false, STAGED, SCALAR_IN, BCSIG_LAND, true>(v_arg, p_arg, a, blockIdx.x - (unsigned)fa.chain_blocks);
 }
 
 // ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the

@@ -132,22 +132,15 @@ struct trm_ctx {
     struct RowStage { void* h = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
     RowStage row_stage[4];
     int row_stage_next = 0;
+    // LandModel, TRM_OPT_SURFACE_IN_LAUNCH: the surface processes run in the first workgroups of the step launch (k_column_land) and
+    // hand ground heat flux, infiltration and skin temperature to the column workgroups through granules tagged with the launch's epoch
+    unsigned long long* d_gran = nullptr;   // [Nh][6], zero at allocation (epoch 0 is never used)
+    uint32_t front_epoch = 0;               // epoch of the last such launch
+    int opt_front = 2;                      // 0 off, 1 whenever legal, 2 the library's rule
+    int last_program = 0;                   // TRM_INFO_LAST_PROGRAM: the kernel instance the last step launch selected
     bool args_valid = false;
-    void* args = nullptr;   // LaunchArgs<NF>[2]*, owned: one set per `flip` (see below)
-    bool args_built[2] = {false, false};
+    void* args = nullptr;   // LaunchArgs<NF>*, owned
     void (*args_free)(void*) = nullptr;
-    // LandModel, TRM_OPT_TAIL_SURFACE: the surface processes of the NEXT step evaluated at the tail of a per-step column launch
-    // (k_column_tail) into a second set of the ten arrays k_surface writes (skin temperature, ground heat flux, ... runoff).  A step
-    // that finds them valid SWAPS the two sets (state.f[] <-> pend.f[]) instead of launching k_surface; anything that may change an
-    // input of the surface processes in between clears `tail_valid`.
-    FieldSet pend{};                  // only the ten surface fields are allocated
-    unsigned* tail_counter = nullptr; // [tail_clusters] arrival counters of the 64-column clusters, zero between launches
-    long tail_clusters = 0;
-    bool tail_valid = false;          // pend holds compute_auxiliary!(surface processes) of the state as it is now
-    bool tail_escaped = false;        // a device pointer into the state or its inputs was handed out: the library cannot know what changes
-    int flip = 0;                     // parity of the swaps so far: which of the two cached argument sets describes state.f[]
-    int opt_tail = 2;                 // TRM_OPT_TAIL_SURFACE: 0 off, 1 whenever legal, 2 the library's rule
-    int last_program = 0;             // TRM_INFO_LAST_PROGRAM: the kernel instance the last step launch selected (program_id)
     std::string err;
 };
 
@@ -404,6 +397,11 @@ inline int bc_signature_of(const trm_ctx* c) {
     if (c->params.seb) return sig | BCSIG_LAND;      // (the LandModel's wiring owns the top flux conditions: land_model.jl:56-61)
     return sig | (c->bc_kind[TRM_BCV_INTERNAL_ENERGY][1] == TRM_BC_FLUX ? BCSIG_FU_TOP : 0) | ((rich && c->bc_kind[TRM_BCV_SATURATION_WATER_ICE][1] == TRM_BC_FLUX) ? BCSIG_FS_TOP : 0);
 }
+// TRM_INFO_LAST_PROGRAM: which kernel instance a step launch selected -- family | HYD << 8 | (LPC / 32) << 10 | DERIVE << 12 |
+// STAGED << 15 | SCALAR_IN << 16 | (BCSIG + 1) << 17 (0 there: the kinds are read at run time)
+inline int program_id(int family, int hyd, int lpc, int derive, int staged, int scalar_in, int bcsig) {
+    return family | (hyd << 8) | ((lpc / 32) << 10) | (derive << 12) | ((staged ? 1 : 0) << 15) | ((scalar_in ? 1 : 0) << 16) | ((bcsig + 1) << 17);
+}
 #define TRM_BY_HYD(c, CALL)                                   \
     switch (::trmh::Policy<NF>::hyd(c)) {                     \
         case HYD_BC_LINEAR: { constexpr int H = HYD_BC_LINEAR; CALL; } break; \
@@ -480,7 +478,10 @@ template <> int LandLaunch<double>::run(trm_ctx* c, int qcol, int qsurf, double 
 template <> int LandLaunch<float>::run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays);
 // the packed fp32 step k_step_pk (trm_launch_packed.hip)
 struct PackedLaunch { static int step(trm_ctx* c, double dt, int finalize); };
-// the LandModel's per-step program with the next step's surface processes at its tail: k_column_tail (fp64; trm_launch_column_tail.hip)
-struct TailLaunch { static int run(trm_ctx* c, double dt, int finalize); };
+// the LandModel's per-step launch with the surface processes in its first workgroups: k_column_land (fp64; trm_launch_column_land_*.hip)
+struct FrontLaunch {
+    static int run(trm_ctx* c, double dt, int finalize);
+    template <int H> static int run_hyd(trm_ctx* c, double dt, int finalize);
+};
 
 }  // namespace trmh

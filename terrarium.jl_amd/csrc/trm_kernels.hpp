@@ -156,6 +156,91 @@ template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> TR
     stg(v.Ts, ob, o.Ts); stg(v.ghf, ob, o.ghf); stg(v.swu, ob, o.swu); stg(v.lwu, ob, o.lwu); stg(v.rnet, ob, o.rnet);
     stg(v.Hs, ob, o.Hs); stg(v.Hl, ob, o.Hl); stg(v.evap, ob, o.evap); stg(v.infil, ob, o.infil); stg(v.runoff, ob, o.runoff);
 }
+// ---- LandModel: the surface processes INSIDE the step launch (TRM_OPT_SURFACE_IN_LAUNCH, k_column_land in trm_column.hpp) -------
+// k_surface in front of every column launch is a latency-bound chain of ~450 dependent fp64 instructions on 890 waves (N145): 5.4 us
+// of a 30 us step, ~4 of them the fixed cost of a launch between two others.  Here the first workgroups of the column launch
+// evaluate the chain -- one lane per column, as k_surface does -- and hand its three results the column program needs (ground heat
+// flux, infiltration, the new skin temperature) to the column workgroups of the SAME launch, which need them only at the explicit
+// step, half-way through their arithmetic.  Hand-off after MI355X_MICROARCH.md (inter-workgroup visibility, recipe R2: the data is
+// the flag): every 32-bit half of a value travels in an 8-byte granule {epoch, half} written by ONE agent-scope (write-through)
+// store and read by agent-scope loads; a granule whose tag is the launch's epoch is valid, whatever the caches did.  The epoch
+// counts the context's launches of this kind (never 0: the granules start zeroed), so nothing is cleared between launches.
+// The column program reads its granules first through the scalar path (a stale line there shows an old tag, never a wrong value)
+// and polls them with vector loads only if that read came too early; the poll is bounded -- a wave that gives up raises
+// TRM_STATUS_HANDOFF_TIMEOUT and NaN in its columns instead of hanging the device (the surface workgroups are the first of the
+// grid and wait for nothing, so this needs a dispatcher that starts later workgroups first AND fills the device with them).
+#ifndef TRM_STEP_BLOCK
+#define TRM_STEP_BLOCK 256
+#endif
+#ifndef TRM_FRONT_GRANULE_STORE
+#define TRM_FRONT_GRANULE_STORE 1      // (0: lane-by-lane, 2: none -- diagnostic builds)
+#endif
+struct FrontArgs {
+    unsigned long long* gran;   // [Nh][6]: {ghf.lo, ghf.hi, infil.lo, infil.hi, Ts.lo, Ts.hi}, each (epoch << 32) | half
+    unsigned epoch;
+    int chain_blocks;           // the first workgroups of the grid evaluate the surface processes, 256 columns each
+};
+enum { FRONT_GHF = 0, FRONT_INFIL = 2, FRONT_TS = 4, FRONT_GRANULES = 6, FRONT_SPIN_LIMIT = 1 << 14 };
+TRM_DEV void st_agent(unsigned long long* p, unsigned long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TRM_DEV unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+TRM_DEV void publish_granules(unsigned long long* g, unsigned epoch, double x) {
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, x), tag = (unsigned long long)epoch << 32;
+    st_agent(g, tag | (b & 0xffffffffull));
+    st_agent(g + 1, tag | (b >> 32));
+}
+// compute_auxiliary! of the surface processes of column i (land_model.jl:79-88): surface_program<FROM_STATE, TOP_ARRAYS> except
+// for where the results go -- the skin temperature is NOT stored (the column program stores skin_temperature + 0 * dt, as
+// explicit_step! leaves it, from the value it is handed here).
+// Called by EVERY lane of a surface wave whose first column exists (the lanes beyond the last column repeat it and store nothing of
+// their own: the transposed granule store needs the whole wave).
+template <class NF, bool RICHARDS, int HYD> TRM_DEV void surface_front(const View<NF>& v, const DevParams<NF>& p, const FrontArgs& fa, long i_lane) {
+    static_assert(sizeof(NF) == 8, "two 32-bit halves per value");
+    const bool real = i_lane < v.Nh;
+    const long i = real ? i_lane : v.Nh - 1;
+    const unsigned ib = (unsigned)i * (unsigned)sizeof(NF);
+    SebIn<NF> in = {ldg(v.Tair, ib), ldg(v.pres, ib), ldg(v.wind, ib), ldg(v.qair, ib), ldg(v.rain, ib), ldg(v.swd, ib), ldg(v.lwd, ib), NF(0), NF(0), NF(0)};
+    seb_radiation_inputs(p, v.albedo, v.emissivity, ib, in);
+    SebOut<NF> o;
+    uint32_t viol = 0;
+    const unsigned ib2 = block_local(ib);
+    const NF T_top = ldg(v.top_T, ib2), sat_top = ldg(v.top_sat, ib2), liq_top = ldg(v.top_liq, ib2);
+    const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));
+    surface_processes(p, in, ldg(v.Ts, ib2), T_top, sat_top, liq_top, Kf_top, ldg(v.S, ib2), RICHARDS, v.dzc[v.Nz - 1], o);
+#if TRM_FRONT_GRANULE_STORE == 0
+    // one 8-byte store per granule and lane, 48 bytes apart: 384 partial-line write-through transactions per wave
+    unsigned long long* g = fa.gran + (size_t)i * FRONT_GRANULES;      // (lanes beyond the last column rewrite its granules with the same values)
+    publish_granules(g + FRONT_GHF, fa.epoch, o.ghf);
+    publish_granules(g + FRONT_INFIL, fa.epoch, o.infil);
+    publish_granules(g + FRONT_TS, fa.epoch, o.Ts);
+#elif TRM_FRONT_GRANULE_STORE == 1
+    // The wave's 64 columns own 384 consecutive granules (3 KB).  Written lane by lane they are 8-byte pieces 48 bytes apart, each
+    // its own write-through transaction of a partial line; transposed through LDS, store j of lane l writes granule 64 j + l --
+    // 512 contiguous bytes per instruction, whole lines, every granule still ONE 8-byte store of one lane.
+    {
+        __shared__ unsigned long long stage[(TRM_STEP_BLOCK / 64) * 64 * FRONT_GRANULES];
+        const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+        unsigned long long* st = stage + wv * 64 * FRONT_GRANULES;
+        const unsigned long long tag = (unsigned long long)fa.epoch << 32;
+        const unsigned long long bg = __builtin_bit_cast(unsigned long long, o.ghf), bi = __builtin_bit_cast(unsigned long long, o.infil), bt = __builtin_bit_cast(unsigned long long, o.Ts);
+        unsigned long long* mine = st + lane * FRONT_GRANULES;
+        mine[FRONT_GHF] = tag | (bg & 0xffffffffull); mine[FRONT_GHF + 1] = tag | (bg >> 32);
+        mine[FRONT_INFIL] = tag | (bi & 0xffffffffull); mine[FRONT_INFIL + 1] = tag | (bi >> 32);
+        mine[FRONT_TS] = tag | (bt & 0xffffffffull); mine[FRONT_TS + 1] = tag | (bt >> 32);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (LDS operations of a wave complete in order; this orders the compiler)
+        __builtin_amdgcn_wave_barrier();
+        const long first = (i_lane - lane) * FRONT_GRANULES, total = (long)v.Nh * FRONT_GRANULES;     // (i_lane - lane: the wave's first column)
+        for (int j = 0; j < FRONT_GRANULES; ++j) {
+            const long q = first + j * 64 + lane;
+            if (q < total) st_agent(fa.gran + q, st[j * 64 + lane]);
+        }
+    }
+#endif
+    if (real) {
+        const unsigned ob = block_local(ib);
+        stg(v.ghf, ob, o.ghf); stg(v.swu, ob, o.swu); stg(v.lwu, ob, o.lwu); stg(v.rnet, ob, o.rnet);
+        stg(v.Hs, ob, o.Hs); stg(v.Hl, ob, o.Hl); stg(v.evap, ob, o.evap); stg(v.infil, ob, o.infil); stg(v.runoff, ob, o.runoff);
+    }
+}
 template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> __global__ void k_surface(View<NF> v, DevParams<NF> p) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < v.Nh) surface_program<NF, RICHARDS, HYD, FROM_STATE, TOP_ARRAYS>(v, p, i);
@@ -609,9 +694,6 @@ __global__ void k_closure_hydrology_wave(View<NF> v, DevParams<NF> p) {
 // lane = level, one column per LPC lanes; every wave is independent (no LDS, no barrier):
 // 5 coalesced loads, ~300 fp64 instructions, 6 coalesced stores per cell.
 // ===========================================================================
-#ifndef TRM_STEP_BLOCK
-#define TRM_STEP_BLOCK 256
-#endif
 
 // k_step_wave serves every boundary kind -- Gradient conditions, Value conditions on liquid fraction / saturation /
 // pressure head, a per-cell vwc_forcing field -- with the halo values formed by the edge lanes.  The common case (Value
@@ -641,17 +723,7 @@ template <class NF> TRM_DEV NF* small_stage() {
 // After a barrier, lane l of the workgroup's first waves stores entry l of the table: array l / cpb, column l % cpb of the
 // workgroup -- every array receives one contiguous run of cpb values from a single instruction.  The array pointers come from
 // the kernel argument segment (View::small), indexed per lane.  `enabled`: bit per array (wave-uniform).
-// AGENT: the store is write-through at agent scope (sc1) -- the values are handed to ANOTHER workgroup of this launch (the surface
-// processes at the tail of the column program, surface_tail below), whose XCD does not share this one's L2.
-template <class NF> TRM_DEV void st_agent(NF* p, NF x) {
-    if constexpr (sizeof(NF) == 8) __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-template <class NF> TRM_DEV NF ld_agent(const NF* p) {
-    if constexpr (sizeof(NF) == 8) return __builtin_bit_cast(NF, __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else return __builtin_bit_cast(NF, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-template <class NF, bool AGENT = false> TRM_DEV void store_small_outputs(unsigned enabled, int cpb, unsigned block, int Nh) {
+template <class NF> TRM_DEV void store_small_outputs(unsigned enabled, int cpb, unsigned block, int Nh) {
     __syncthreads();
     const int l = (int)threadIdx.x;
     if (l < SMALL_COUNT * cpb) {
@@ -659,44 +731,9 @@ template <class NF, bool AGENT = false> TRM_DEV void store_small_outputs(unsigne
         const long i = (long)block * cpb + col;
         if (i < Nh && ((enabled >> slot) & 1u)) {
             NF* const* tbl = kernarg_reload<View<NF>>(0).small;
-            if (AGENT) st_agent(tbl[slot] + i, small_stage<NF>()[l]);
-            else tbl[slot][i] = small_stage<NF>()[l];
+            tbl[slot][i] = small_stage<NF>()[l];
         }
     }
-}
-
-// ---- LandModel: the surface processes of step n + 1 at the TAIL of step n's column launch (TRM_OPT_TAIL_SURFACE) --------------
-// k_surface in front of every column launch is a latency-bound chain of ~450 dependent fp64 instructions on 890 waves (N145): 5.4 us
-// of which ~4 are the fixed cost of a launch between two others.  Its inputs -- the new top cell, the skin temperature, the surface
-// excess water -- exist the moment a column's step has finished, so the chain is evaluated right there, for the NEXT step, with the
-// forcings as they are now, into PENDING arrays; the next step accepts them (the host swaps the array pointers) unless an input has
-// changed since, in which case it discards them and launches k_surface as before.
-// One lane per column keeps the chain at one instruction stream per 64 columns (8 lanes of a workgroup's own columns would add a third
-// to the launch's vector instructions): the workgroups of a 64-column CLUSTER (8 at two columns per wave) store their per-column
-// outputs write-through, count themselves in on an agent-scope counter, and the one whose add comes last evaluates the 64 columns.
-// Nobody waits for anybody: every wave reaches the end of the program whatever the others do.  Hand-off after MI355X_MICROARCH.md
-// (inter-workgroup visibility): sc1 stores -> the storing wave's s_waitcnt vmcnt(0) -> one lane's agent-scope add -> the last
-// arriver's agent-scope acquire -> sc1 loads.
-template <class NF> struct TailArgs {
-    unsigned* counter;     // [clusters]: arrivals of a cluster's workgroups; zero between launches (the last arriver resets it)
-    NF* out[10];           // the pending arrays, [Nh] each: Ts, ghf, swu, lwu, rnet, Hs, Hl, evap, infil, runoff
-};
-enum { TAIL_TS = 0, TAIL_GHF, TAIL_SWU, TAIL_LWU, TAIL_RNET, TAIL_HS, TAIL_HL, TAIL_EVAP, TAIL_INFIL, TAIL_RUNOFF, TAIL_COUNT };
-// compute_auxiliary! of the surface processes of column i (land_model.jl:79-88) from what the column program has just stored --
-// surface_program<FROM_STATE, TOP_ARRAYS> with the handed-off values read through the coherent path and the results left pending
-template <class NF, bool RICHARDS, int HYD> TRM_DEV void surface_tail(const View<NF>& v, const DevParams<NF>& p, NF* const* out, int i) {
-    const unsigned ib = (unsigned)i * (unsigned)sizeof(NF);
-    SebIn<NF> in = {ldg(v.Tair, ib), ldg(v.pres, ib), ldg(v.wind, ib), ldg(v.qair, ib), ldg(v.rain, ib), ldg(v.swd, ib), ldg(v.lwd, ib), NF(0), NF(0), NF(0)};
-    seb_radiation_inputs(p, v.albedo, v.emissivity, ib, in);
-    const NF T_top = ld_agent(v.top_T + i), sat_top = ld_agent(v.top_sat + i), liq_top = ld_agent(v.top_liq + i);
-    const NF Ts = ld_agent(v.Ts + i), S = RICHARDS ? ld_agent(v.S + i) : NF(0);
-    uint32_t viol = 0;
-    const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));
-    SebOut<NF> o;
-    surface_processes(p, in, Ts, T_top, sat_top, liq_top, Kf_top, S, RICHARDS, v.g.dzc_top, o);
-    const unsigned ob = block_local(ib);
-    stg(out[TAIL_TS], ob, o.Ts); stg(out[TAIL_GHF], ob, o.ghf); stg(out[TAIL_SWU], ob, o.swu); stg(out[TAIL_LWU], ob, o.lwu); stg(out[TAIL_RNET], ob, o.rnet);
-    stg(out[TAIL_HS], ob, o.Hs); stg(out[TAIL_HL], ob, o.Hl); stg(out[TAIL_EVAP], ob, o.evap); stg(out[TAIL_INFIL], ob, o.infil); stg(out[TAIL_RUNOFF], ob, o.runoff);
 }
 
 constexpr unsigned round_up_to(unsigned x, unsigned a) { return (x + a - 1) / a * a; }

@@ -28,8 +28,10 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
     }
     const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
     const int derive = P::template derive_now<RICH>(c);
+    int pid = 0;    // TRM_INFO_LAST_PROGRAM of the instance that is launched below
     if constexpr (PROG == PROG_MULTI) {
         const bool series = !c->series.empty();
+        pid = program_id(TRM_PROGRAM_COLUMN_MULTI, H, LPC, DERIVE_NONE, 0, 1, -1) | (c->params.seb ? 1 << 25 : 0) | (series ? 1 << 26 : 0);
         if (c->params.seb && series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, true>), grid, block, 0, c->stream, v, p, a);
         else if (c->params.seb) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, true, false>), grid, block, 0, c->stream, v, p, a);
         else if (series) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_MULTI, false, true>), grid, block, 0, c->stream, v, p, a);
@@ -40,9 +42,12 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
         const int sig = (c->opt_bc_signature && (derive == DERIVE_T_LIQ || derive == DERIVE_NONE)) ? bc_signature_of(c) : -1;
         const int staged = derive == DERIVE_T_LIQ ? P::template staged_now<RICH>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::template scalar_inputs_now<RICH>(c) : 1;
         if (launch_by_signature<ColumnSigLaunch, NF, RICH>(sig, c, v, p, a, grid, block, LPC, derive, staged, scalar_in)) {
+            // (trm_launch_column_sig.inl: without the derivation the signature instances store directly and take the scalar path)
+            pid = derive == DERIVE_T_LIQ ? program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_T_LIQ, staged, scalar_in, sig) : program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_NONE, 0, 1, sig);
         }
         // with the derivation (every large or HBM-resident fp64 state): how the per-column outputs leave / inputs arrive
         else if (derive == DERIVE_T_LIQ) {
+            pid = std::is_same<NF, double>::value ? program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_T_LIQ, staged, scalar_in, -1) : program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_T_LIQ, 0, 1, -1);
             if constexpr (!std::is_same<NF, double>::value) {
                 // (fp32 off the packed kernel derives only on request: one instance)
                 hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
@@ -56,19 +61,23 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
         else if (derive == DERIVE_ALL) {
             if constexpr (std::is_same<NF, double>::value && RICH) {
                 const int staged = P::template staged_now<RICH>(c), scalar_in = P::template scalar_inputs_now<RICH>(c);
+                pid = program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_ALL, staged, staged ? scalar_in : 1, -1);
                 if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
                 else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
                 else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
             }
         }
-        else if (derive == DERIVE_LIQ) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
-        else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a);
+        else if (derive == DERIVE_LIQ) { pid = program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_LIQ, 0, 1, -1); hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a); }
+        else { pid = program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_NONE, 0, 1, -1); hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a); }
     } else {
         // (Heun: the same signatures)
-        const bool launched = launch_by_signature<ColumnSigHeunLaunch, NF, RICH>(c->opt_bc_signature ? bc_signature_of(c) : -1, c, v, p, a, grid, block, LPC);
+        const int hsig = c->opt_bc_signature ? bc_signature_of(c) : -1;
+        const bool launched = launch_by_signature<ColumnSigHeunLaunch, NF, RICH>(hsig, c, v, p, a, grid, block, LPC);
+        pid = program_id(TRM_PROGRAM_COLUMN_HEUN, H, LPC, DERIVE_NONE, 0, 1, launched ? hsig : -1);
         if (!launched) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);
     }
     TRM_HIP(c, hipGetLastError());
+    c->last_program = pid;
     return TRM_OK;
 }
 

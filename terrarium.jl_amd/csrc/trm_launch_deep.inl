@@ -25,6 +25,8 @@ template <class NF, bool RICH, int H, int PROG, bool GENERIC> static int launch_
     else if (Policy<NF>::template derive_now<RICH>(c) == DERIVE_T_LIQ) hipLaunchKernelGGL((k_column_deep<NF, RICH, H, true, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a, la.stage);
     else hipLaunchKernelGGL((k_column_deep<NF, RICH, H, false, PROG>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a, la.stage);
     TRM_HIP(c, hipGetLastError());
+    // (lanes per column: 64, two levels each; bits 25-26 the program, 27 the generic boundary kinds)
+    c->last_program = program_id(TRM_PROGRAM_DEEP, H, 64, (!GENERIC && Policy<NF>::template derive_now<RICH>(c) == DERIVE_T_LIQ) ? DERIVE_T_LIQ : DERIVE_NONE, 0, 1, -1) | (PROG << 25) | ((GENERIC ? 1 : 0) << 27);
     return TRM_OK;
 }
 template <class NF, int PROG, bool GENERIC> static int deep_by_flow(trm_ctx* c, double dt, int finalize, int nsteps) {

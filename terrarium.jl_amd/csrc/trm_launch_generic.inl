@@ -12,6 +12,7 @@ template <class NF, bool RICH, int H, int LPC> static int launch_wave(trm_ctx* c
     const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
     hipLaunchKernelGGL((k_step_wave<NF, RICH, H, LPC>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, v, p, (NF)dt, finalize, wkf);
     TRM_HIP(c, hipGetLastError());
+    c->last_program = program_id(TRM_PROGRAM_GENERIC_EULER, H, LPC, DERIVE_NONE, 0, 0, -1);
     return TRM_OK;
 }
 template <class NF> int GenericLaunch<NF>::step(trm_ctx* c, double dt, int finalize) {
@@ -32,6 +33,7 @@ template <class NF, bool RICH, int H, int LPC> static int launch_heun_generic(tr
     a.nsteps = 1;
     hipLaunchKernelGGL((k_heun_generic<NF, RICH, H, LPC>), column_grid(c, LPC), dim3(TRM_STEP_BLOCK), 0, c->stream, la.state, la.p, la.stage, a);
     TRM_HIP(c, hipGetLastError());
+    c->last_program = program_id(TRM_PROGRAM_GENERIC_HEUN, H, LPC, DERIVE_NONE, 0, 0, -1);
     return TRM_OK;
 }
 template <class NF> int GenericLaunch<NF>::heun(trm_ctx* c, double dt, int finalize) {

@@ -28,6 +28,7 @@ template <int H, int LPC> static int launch_land(trm_ctx* c, int qcol, int qsurf
     else { if (top_arrays) TRM_LAND(DERIVE_NONE, true); else TRM_LAND(DERIVE_NONE, false); }
 #undef TRM_LAND
     TRM_HIP(c, hipGetLastError());
+    c->last_program = program_id(TRM_PROGRAM_LAND_INTERLEAVED, H, LPC, derive ? DERIVE_T_LIQ : DERIVE_NONE, 0, 1, -1);
     return TRM_OK;
 }
 template <> int LandLaunch<double>::run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) {

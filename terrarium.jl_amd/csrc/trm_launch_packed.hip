@@ -32,6 +32,10 @@ template <bool RICH, int LPC> static int launch_packed(trm_ctx* c, double dt, in
     else TRM_LAUNCH_PK(HYD_BC_LINEAR);
 #undef TRM_LAUNCH_PK
     TRM_HIP(c, hipGetLastError());
+    {
+        const bool sig_instance = derive == DERIVE_LIQ && RICH && (sig == BCSIG_LAND || sig == BCSIG_T_TOP);
+        c->last_program = program_id(TRM_PROGRAM_PACKED_F32, P::hyd(c) == HYD_VG_N2 ? HYD_VG_N2 : HYD_BC_LINEAR, LPC, derive, staged, 1, sig_instance ? sig : -1);
+    }
     return TRM_OK;
 }
 int PackedLaunch::step(trm_ctx* c, double dt, int finalize) {
@@ -54,6 +58,7 @@ template <int H, int LPC> static int launch_land_pk(trm_ctx* c, int qcol, int qs
     if (top_arrays) hipLaunchKernelGGL((k_land_pk<true, LPC, H, true>), grid, block, 0, c->stream, vc, la.p, (float)dt, finalize, wkf, vs, (int)sblocks);
     else hipLaunchKernelGGL((k_land_pk<true, LPC, H, false>), grid, block, 0, c->stream, vc, la.p, (float)dt, finalize, wkf, vs, (int)sblocks);
     TRM_HIP(c, hipGetLastError());
+    c->last_program = program_id(TRM_PROGRAM_LAND_INTERLEAVED, H, LPC, DERIVE_NONE, 0, 1, -1);
     return TRM_OK;
 }
 template <> int LandLaunch<float>::run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays) {

@@ -23,6 +23,7 @@ template <class NF, bool RICH, int H, int PROG, bool GENERIC> static int launch_
     const dim3 grid((unsigned)((ncols(c) + (TRM_STEP_BLOCK / 64) - 1) / (TRM_STEP_BLOCK / 64)));
     hipLaunchKernelGGL((k_column_wide<NF, RICH, H, 4, PROG, GENERIC>), grid, dim3(TRM_STEP_BLOCK), 0, c->stream, state_view<NF>(c), la.p, a, la.stage);
     TRM_HIP(c, hipGetLastError());
+    c->last_program = program_id(TRM_PROGRAM_WIDE, H, 64, DERIVE_NONE, 0, 1, -1) | (PROG << 25) | ((GENERIC ? 1 : 0) << 27);
     return TRM_OK;
 }
 template <class NF, int PROG, bool GENERIC> static int wide_by_flow(trm_ctx* c, double dt, int finalize) {

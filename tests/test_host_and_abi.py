@@ -175,7 +175,7 @@ def test_python_constants_match_the_header():
                "info_top_arrays_current": "TRM_INFO_TOP_ARRAYS_CURRENT", "info_closure_consistent": "TRM_INFO_CLOSURE_CONSISTENT",
                "bc_signature": "TRM_OPT_BC_SIGNATURE", "info_bc_signature": "TRM_INFO_BC_SIGNATURE",
                "zero_gradient_fast": "TRM_OPT_ZERO_GRADIENT_FAST", "info_generic_boundary_kernels": "TRM_INFO_GENERIC_BOUNDARY_KERNELS",
-               "tail_surface": "TRM_OPT_TAIL_SURFACE", "info_tail_pending": "TRM_INFO_TAIL_PENDING", "info_last_program": "TRM_INFO_LAST_PROGRAM"}[name]
+               "surface_in_launch": "TRM_OPT_SURFACE_IN_LAUNCH", "info_last_program": "TRM_INFO_LAST_PROGRAM"}[name]
         assert enum[key] == oid, name
     for code, key in enumerate(("TRM_OK", "TRM_EINVAL", "TRM_EHIP", "TRM_ENOMEM", "TRM_EUNSUPPORTED", "TRM_ESTALE", "TRM_ECOMM")):
         assert enum[key] == code
