@@ -45,6 +45,21 @@ OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_
               info_top_arrays_current=100, info_closure_consistent=101, info_bc_signature=102, info_generic_boundary_kernels=103,
               info_last_program=105)
 KERNEL = dict(fused=0, unfused=1)
+# TRM_INFO_LAST_PROGRAM (include/terrarium_hip.h: TRM_PROGRAM_*; trm_host.hpp: program_id)
+PROGRAM = ("none", "column_euler", "column_heun", "column_multi", "packed_f32", "generic_euler", "generic_heun", "column_land", "deep", "wide",
+           "land_interleaved", "unfused", "vegetation")
+DERIVE = ("none", "T_liq", "liq", "liq_psi", "all")
+
+
+def decode_program(pid: int) -> dict:
+    d = dict(family=PROGRAM[pid & 0xff], hydraulics=("default", "vg_n2", "generic")[(pid >> 8) & 3], lanes_per_column=32 * ((pid >> 10) & 3),
+             derive=DERIVE[(pid >> 12) & 7], staged=bool((pid >> 15) & 1), scalar_inputs=bool((pid >> 16) & 1), bc_signature=((pid >> 17) & 0xff) - 1)
+    extra = pid >> 25
+    if d["family"] == "column_multi":
+        d.update(surface_inline=bool(extra & 1), series=bool(extra & 2))
+    if d["family"] in ("deep", "wide"):
+        d.update(program=("euler", "heun", "multi")[extra & 3], generic_boundaries=bool(extra & 4))
+    return d
 STATUS_NAN, STATUS_COMPOSITION, STATUS_HANDOFF_TIMEOUT = 1, 2, 4
 TRM_OK, TRM_EINVAL, TRM_EHIP, TRM_ENOMEM, TRM_EUNSUPPORTED, TRM_ESTALE, TRM_ECOMM = range(7)
 

@@ -483,6 +483,12 @@ class DeviceState:
         self._check(self._lib.trm_get_option(self._ctx, _capi.OPTION[option], C.byref(v)), "trm_get_option")
         return int(v.value)
 
+    def last_program(self) -> dict:
+        """Which kernel instance the last step launch of this context selected (TRM_INFO_LAST_PROGRAM), decoded: the selection
+        rules of the library are pure host logic on sizes, kinds and options -- a wrong rule costs speed, never correctness, so
+        nothing but a look at this id would notice."""
+        return _capi.decode_program(self.get_option("info_last_program"))
+
     def set_stream(self, hip_stream_handle):
         self._check(self._lib.trm_set_stream(self._ctx, C.c_void_p(hip_stream_handle)), "trm_set_stream")
 

@@ -1,12 +1,14 @@
 """Output path on the device: rows of a field (trm_download_rows) and ColumnRingGrid scatter / gather
 (src/grids/column_ring_grid.jl:102-149: RingGrids.Field(field, grid; fill_value) and Oceananigans.Field(ring_field, grid))
-against the host-side numpy restatement in terrarium.jl_amd/grids.py and the reference's own scatter / gather identity
-(test/grids.jl:44-139)."""
+against the independent CPU restatement oracle/ring_oracle.py (explicit loops over the grid points; the product's host mirror
+terrarium.jl_amd/grids.py is checked against the same restatement on the CPU in tests/test_oracle_known_answers.py) and the
+reference's own scatter / gather identity (test/grids.jl:44-139)."""
 import numpy as np
 import pytest
 
 import workloads as W
 import terrarium_jl_amd as trm
+import ring_oracle as R
 
 pytestmark = pytest.mark.gpu
 
@@ -43,20 +45,20 @@ def test_ring_scatter_and_gather_on_the_device(dtype):
     T, wt = d.get("temperature"), d.get("water_table")
     full = d.get_ring("temperature")                          # [Nz][P]
     assert full.shape == (20, mask.size) and full.dtype == np.dtype(dtype)
-    assert np.array_equal(full.reshape(20, *mask.shape), grid.scatter(T), equal_nan=True)
-    assert np.array_equal(d.get_ring("water_table", fill=-999.0).reshape(mask.shape), grid.scatter(wt, -999.0))
+    assert np.array_equal(full, R.ring_field_from_columns(T, mask), equal_nan=True)
+    assert np.array_equal(d.get_ring("water_table", fill=-999.0), R.ring_field_from_columns(wt, mask, -999.0))
     g = d.get_ring("ground_temperature", fill=0.0)            # a view of the top row: one row scattered
-    assert g.shape == (mask.size,) and np.array_equal(g.reshape(mask.shape), grid.scatter(T[-1], 0.0))
-    assert np.array_equal(d.get_ring("hydraulic_conductivity", row0=19, nrows=2).reshape(2, *mask.shape), grid.scatter(d.get("hydraulic_conductivity")[19:]), equal_nan=True)
+    assert g.shape == (mask.size,) and np.array_equal(g, R.ring_field_from_columns(T[-1], mask, 0.0))
+    assert np.array_equal(d.get_ring("hydraulic_conductivity", row0=19, nrows=2), R.ring_field_from_columns(d.get("hydraulic_conductivity")[19:], mask), equal_nan=True)
     # gather: a full-grid array becomes the field (test/grids.jl: scatter then gather is the identity)
     rng = np.random.default_rng(5)
     new_full = rng.normal(size=(20, mask.size)).astype(dtype)
     d.set_ring("temperature", new_full)
-    assert np.array_equal(d.get("temperature"), grid.gather(new_full.reshape(20, *mask.shape)))
+    assert np.array_equal(d.get("temperature"), R.columns_from_ring_field(new_full, mask))
     d.set_ring("surface_excess_water", new_full[0])
-    assert np.array_equal(d.get("surface_excess_water"), grid.gather(new_full[0].reshape(mask.shape)))
+    assert np.array_equal(d.get("surface_excess_water"), R.columns_from_ring_field(new_full[0], mask))
     d.set_ring("temperature", d.get_ring("temperature", fill=0.0))
-    assert np.array_equal(d.get("temperature"), grid.gather(new_full.reshape(20, *mask.shape)))
+    assert np.array_equal(d.get("temperature"), R.columns_from_ring_field(new_full, mask))
 
 
 def test_ring_scatter_of_one_shard_and_into_a_device_buffer():

@@ -635,3 +635,37 @@ def test_forcing_time_series_of_ones():
     E1 = np.sum(o.get("internal_energy") * dz, axis=0)
     assert np.allclose(E1, 0.1, rtol=1e-12)                     # x ~ 0.1: the unit flux of the series over one step of 0.1
     assert o.clock()[0] == pytest.approx(0.1)
+
+
+# ---- ColumnRingGrid <-> ring grid conversions (oracle/ring_oracle.py) ------------------------------------------------------
+def test_ring_oracle_reproduces_the_reference_conversion_tests():
+    """test/grids.jl:44-139 on oracle/ring_oracle.py: a 2-D and a 3-D ring field through a full grid and a random mask
+    (`ocean[:, 1, k] == ring.data[mask, k]`), columns 1..Nh back onto the ring grid (`ring.data[mask] == 1:Nh`), the fill value
+    at the inactive points -- and the product's host mirror (terrarium.jl_amd/grids.py) against the same restatement."""
+    import ring_oracle as R
+    import terrarium_jl_amd as trm
+    rng = np.random.default_rng(8)
+    P, nz = 12 * 8 * 8, 10                                     # FullHEALPixGrid(8): 768 points
+    full_mask = np.ones(P, dtype=bool)
+    ring2, ring3 = rng.random(P), rng.random((nz, P))
+    assert np.array_equal(R.columns_from_ring_field(ring2, full_mask), ring2)
+    assert np.array_equal(R.columns_from_ring_field(ring3, full_mask), ring3)
+    mask = rng.random(P) < 0.5
+    cols = R.columns_from_ring_field(ring2, mask)
+    assert cols.shape == (mask.sum(),) and np.array_equal(cols, ring2[mask])
+    cols3 = R.columns_from_ring_field(ring3, mask)
+    for k in range(nz):
+        assert np.array_equal(cols3[k], ring3[k][mask])
+    back = R.ring_field_from_columns(np.arange(1.0, P + 1.0, dtype=np.float32), full_mask)
+    assert np.array_equal(back[full_mask], np.arange(1.0, P + 1.0, dtype=np.float32))
+    lvl = np.repeat(np.arange(1.0, nz + 1.0, dtype=np.float32)[:, None], P, axis=1)
+    assert np.array_equal(R.ring_field_from_columns(lvl, full_mask), lvl)
+    filled = R.ring_field_from_columns(np.ones(mask.sum(), dtype=np.float32), mask, fill_value=-1.0)
+    assert np.all(filled[mask] == 1.0) and np.all(filled[~mask] == -1.0)
+    assert np.array_equal(R.columns_from_ring_field(R.ring_field_from_columns(cols3, mask, 0.0), mask), cols3)   # scatter, gather: identity
+    # the product's host mirror on a shaped mask (C order = ring order)
+    m2 = mask.reshape(24, 32)
+    grid = trm.ColumnRingGrid(trm.UniformSpacing(dz=0.5, N=nz), m2)
+    assert np.array_equal(grid.scatter(cols3, fill=-7.0).reshape(nz, -1), R.ring_field_from_columns(cols3, m2, -7.0))
+    assert np.array_equal(grid.gather(ring3.reshape(nz, 24, 32)), R.columns_from_ring_field(ring3, m2))
+    assert np.array_equal(grid.mask_index, np.flatnonzero(np.asarray([bool(x) for x in m2.reshape(-1)])))
