@@ -624,6 +624,15 @@ template <class NF> struct Ops {
         if (c->opt_single_step == 1) return true;
         return c->Nh <= TRM_SINGLE_STEP_PROGRAM_MAX_COLUMNS;
     }
+    // how many steps ONE launch of trm_step covers for this context: 1 unless the resident multi-step program applies
+    static bool program_applies(const trm_ctx* c) {
+        const bool fused = c->opt_kernel == TRM_KERNEL_FUSED && (c->Nz <= 64 || deep_columns(c) || wide_columns(c));
+        return fused && !generic_bcs(c) && !coupled(c) && c->veg_mode != TRM_VEGETATION_STANDALONE &&
+               ((c->Nz <= 64 && series_fit_program(c)) || (deep_columns(c) && !c->params.seb && c->series.empty()));
+    }
+    static int steps_per_launch_now(trm_ctx* c) {
+        return !program_applies(c) ? 1 : (c->opt_steps_per_launch > 0 ? c->opt_steps_per_launch : auto_steps_per_launch(c));
+    }
     static int step(trm_ctx* c, double dt, int nsteps, int finalize) {
         if (c->veg_mode == TRM_VEGETATION_STANDALONE) return veg_step(c, dt, nsteps, finalize, false);
         // the fused kernels map one soil level (two for 65 ... 128 levels, branch-free boundary kinds) to one lane; anything
@@ -634,9 +643,8 @@ template <class NF> struct Ops {
         // Resident-column multi-step program: legal when nothing the host evaluates changes between the steps of a launch --
         // constants, or device-resident time series the program interpolates itself -- and the branch-free boundary kinds apply.
         // (columns of 65 ... 128 levels: contexts without the surface energy balance and without series)
-        const bool program_ok = fused && !generic_bcs(c) && !coupled(c) &&
-                                ((c->Nz <= 64 && series_fit_program(c)) || (deep_columns(c) && !c->params.seb && c->series.empty()));
-        const int spl = !program_ok ? 1 : (c->opt_steps_per_launch > 0 ? c->opt_steps_per_launch : auto_steps_per_launch(c));
+        const bool program_ok = program_applies(c);
+        const int spl = steps_per_launch_now(c);
         int n = 0, rc = TRM_OK;
         while (n < nsteps && !rc) {
             int m = std::min(spl, nsteps - n);
@@ -1241,9 +1249,17 @@ struct Rccl {
 Rccl* rccl() {
     static Rccl r;
     if (r.handle || !r.error.empty()) return &r;
-    for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (r.handle) break;
+    // TRM_RCCL_LIBRARY (tests): the collective library to open instead -- tests/fake_rccl.c, a stand-in that implements the seven
+    // entry points through host memory for n communicators in ONE process, so that the grouped call sequences below run with
+    // n > 1 on a one-GPU box (with torch in the process its own librccl.so is already mapped: dlsym on OUR handle still
+    // resolves to the library named here)
+    if (const char* over = std::getenv("TRM_RCCL_LIBRARY")) {
+        r.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.handle) break;
+        }
     }
     if (!r.handle) {
         r.error = std::string("librccl.so could not be loaded: ") + dlerror();
@@ -2171,6 +2187,23 @@ int trm_comm_unique_id(void* id128) {
     return TRM_OK;
 }
 
+namespace {
+// communicators of one ncclUniqueId form one group: the grouped calls of trm_*_all refuse a list that mixes groups (RCCL would
+// wait in ncclGroupEnd for ranks nobody posts)
+uint64_t unique_id_hash(const ncclUniqueId& id) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t n = 0; n < sizeof(id); ++n) h = (h ^ (unsigned char)id.internal[n]) * 1099511628211ull;
+    return h ? h : 1;
+}
+// the side stream and the send | receive buffer of a context's collectives
+int comm_buffers(trm_ctx* c) {
+    TRM_HIP(c, hipSetDevice(c->device));
+    TRM_HIP(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    TRM_HIP(c, hipMalloc((void**)&c->d_comm, (size_t)(4 * (c->Nz + 1) + 16) * sizeof(double)));
+    return TRM_OK;
+}
+}  // namespace
+
 int trm_comm_init(trm_ctx* c, int rank, int world, const void* id128) {
     TRM_ENTER(c);
     if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(c, TRM_EINVAL, "trm_comm_init: bad argument");
@@ -2182,8 +2215,11 @@ int trm_comm_init(trm_ctx* c, int rank, int world, const void* id128) {
     TRM_NCCL(c, r->CommInitRank(&c->comm, world, id, rank));
     c->comm_rank = rank;
     c->comm_world = world;
-    TRM_HIP(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-    TRM_HIP(c, hipMalloc((void**)&c->d_comm, (size_t)(4 * (c->Nz + 1) + 16) * sizeof(double)));
+    c->comm_group = unique_id_hash(id);
+    if (int rc = comm_buffers(c)) {
+        (void)trm_comm_destroy(c);
+        return rc;
+    }
     return TRM_OK;
 }
 
@@ -2199,6 +2235,7 @@ int trm_comm_destroy(trm_ctx* c) {
     c->d_comm = nullptr;
     c->comm_world = 1;
     c->comm_rank = 0;
+    c->comm_group = 0;
     return TRM_OK;
 }
 
@@ -2243,11 +2280,20 @@ void fold_packed(int op, int n, std::vector<double>& acc, const std::vector<doub
         else acc[j] += x[j];
     }
 }
-bool all_have_comm(trm_ctx** ctxs, int n) {
+// 1: every context holds rank i of n of ONE communicator group (the grouped all-reduce applies); 0: none has a communicator (host
+// fold); -1: anything else -- communicators of different groups, a subset of a group, ranks out of order: refused, because the
+// grouped call would post an incomplete set of ranks and RCCL would wait for the others forever
+int comm_state(trm_ctx** ctxs, int n) {
+    int with = 0;
+    for (int i = 0; i < n; ++i) with += ctxs[i]->comm != nullptr;
+    if (with == 0) return 0;
+    if (with != n) return -1;
     for (int i = 0; i < n; ++i)
-        if (!ctxs[i]->comm || ctxs[i]->comm_world != n || ctxs[i]->comm_rank != i) return false;
-    return true;
+        if (ctxs[i]->comm_world != n || ctxs[i]->comm_rank != i || ctxs[i]->comm_group != ctxs[0]->comm_group) return -1;
+    return 1;
 }
+const char* kMixedCommunicators = ": the contexts hold communicators that do not form ONE group in rank order (all of trm_comm_init_all's "
+                                  "contexts, in its order) -- a grouped collective over them would wait for ranks nobody posts";
 // n all-reduces of `count` doubles, one per context, issued from ONE thread inside a group (RCCL would otherwise block in the
 // first one waiting for ranks this thread has not reached yet)
 int grouped_allreduce(trm_ctx** ctxs, int n, std::vector<std::vector<double>>& bufs, int count, ncclRedOp_t op) {
@@ -2281,6 +2327,8 @@ int check_ctx_list(trm_ctx** ctxs, int n, const char* who) {
         if (!ctxs[i]) return fail(nullptr, TRM_EINVAL, std::string(who) + ": null context in the list");
     for (int i = 1; i < n; ++i)
         if (ctxs[i]->Nz != ctxs[0]->Nz) return fail(ctxs[0], TRM_EINVAL, std::string(who) + ": the contexts are shards of one grid: same number of levels expected");
+    // (a caller that holds only the list reads the first non-empty message: none may be left over from an earlier call)
+    for (int i = 0; i < n; ++i) ctxs[i]->err.clear();
     return TRM_OK;
 }
 }  // namespace
@@ -2319,7 +2367,7 @@ int trm_comm_init_all(trm_ctx** ctxs, int n) {
     for (int i = 0; i < n; ++i) {
         if (ctxs[i]->comm) return fail(ctxs[i], TRM_EINVAL, "trm_comm_init_all: the context already has a communicator");
         for (int j = 0; j < i; ++j)
-            if (ctxs[j]->device == ctxs[i]->device)
+            if (ctxs[j]->device == ctxs[i]->device && !std::getenv("TRM_RCCL_ALLOW_SHARED_DEVICE"))      // (tests: with tests/fake_rccl.c)
                 return fail(ctxs[i], TRM_EINVAL, "trm_comm_init_all: two contexts on one device (RCCL takes one rank per device; without communicators "
                                                  "trm_reduce_global_all / trm_status_global_all combine the shards on the host)");
     }
@@ -2335,6 +2383,7 @@ int trm_comm_init_all(trm_ctx** ctxs, int n) {
         if (e == ncclSuccess) e = r->CommInitRank(&c->comm, n, id, i);
         if (e != ncclSuccess) {
             (void)r->GroupEnd();
+            // (the communicators handed out so far were never completed by a ncclGroupEnd that succeeded: nothing to destroy)
             for (int j = 0; j <= i; ++j) ctxs[j]->comm = nullptr;
             return fail(c, TRM_ECOMM, std::string("ncclCommInitRank (grouped): ") + r->GetErrorString(e));
         }
@@ -2350,9 +2399,17 @@ int trm_comm_init_all(trm_ctx** ctxs, int n) {
         trm_ctx* c = ctxs[i];
         c->comm_rank = i;
         c->comm_world = n;
-        TRM_HIP(c, hipSetDevice(c->device));
-        TRM_HIP(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
-        TRM_HIP(c, hipMalloc((void**)&c->d_comm, (size_t)(4 * (c->Nz + 1) + 16) * sizeof(double)));
+        c->comm_group = unique_id_hash(id);
+    }
+    for (int i = 0; i < n; ++i) {
+        trm_ctx* c = ctxs[i];
+        if (int rc = comm_buffers(c)) {
+            // a context without its stream / buffer must not keep a communicator (the grouped all-reduce would write through a
+            // null pointer): the whole group goes, the failing context's message is the one reported
+            const std::string msg = c->err;
+            for (int j = 0; j < n; ++j) (void)trm_comm_destroy(ctxs[j]);
+            return fail(ctxs[0], rc, "trm_comm_init_all: context " + std::to_string(i) + ": " + msg);
+        }
     }
     return TRM_OK;
 }
@@ -2368,24 +2425,43 @@ int step_all(trm_ctx** ctxs, int n, const char* who, int (*step)(trm_ctx*, doubl
     // 50 with the resident program) before the next context is visited -- so that all devices start at once instead of device
     // d waiting for the host to have enqueued all nsteps launches of devices 0 .. d - 1.  Same results as one call per context
     // (a call of m steps equals m calls of one step, bit for bit).
+    // A context that launches per step (steps_per_launch = 1, or a model the resident program does not take: generic boundary
+    // kinds, the coupled vegetation, Heun) would receive 50 launches before the next device is visited: the chunk is the smallest
+    // number of steps ONE launch of any context covers.
     int chunk = 50;
+    const bool heun = step == trm_step_heun;
     for (int i = 0; i < n; ++i) {
         async[(size_t)i] = ctxs[i]->opt_async;
         ctxs[i]->opt_async = 1;
-        chunk = std::min(chunk, ctxs[i]->opt_steps_per_launch > 0 ? ctxs[i]->opt_steps_per_launch : 50);
+        chunk = std::min(chunk, heun ? 1 : (ctxs[i]->precision == TRM_F64 ? Ops<double>::steps_per_launch_now(ctxs[i]) : Ops<float>::steps_per_launch_now(ctxs[i])));
     }
+    int failed = -1;
     for (int done = 0; done < nsteps && !rc; done += chunk) {
         const int m = std::min(chunk, nsteps - done);
         const int fin = (finalize && done + m == nsteps) ? 1 : 0;
-        for (int i = 0; i < n && !rc; ++i) rc = step(ctxs[i], dt, m, fin);
+        for (int i = 0; i < n && !rc; ++i) {
+            rc = step(ctxs[i], dt, m, fin);
+            if (rc) failed = i;
+        }
     }
     if (nsteps == 0 && finalize)
-        for (int i = 0; i < n && !rc; ++i) rc = step(ctxs[i], dt, 0, finalize);
+        for (int i = 0; i < n && !rc; ++i) {
+            rc = step(ctxs[i], dt, 0, finalize);
+            if (rc) failed = i;
+        }
     for (int i = 0; i < n; ++i) ctxs[i]->opt_async = async[(size_t)i];
     for (int i = 0; i < n; ++i) {
-        if (async[(size_t)i]) continue;
+        if (async[(size_t)i] && failed < 0) continue;
         const int rs = trm_synchronize(ctxs[i]);      // (also after a failure: nothing is left running behind the caller's back)
-        if (!rc) rc = rs;
+        if (!rc) { rc = rs; if (rs) failed = i; }
+    }
+    if (failed >= 0) {
+        // the contexts stand at different clocks now: say which one failed and where every one stands (its message moves to
+        // the first context, where a caller that holds only the list looks)
+        std::string msg = std::string(who) + ": context " + std::to_string(failed) + " failed: " + ctxs[failed]->err + " [iterations:";
+        for (int i = 0; i < n; ++i) msg += " " + std::to_string((long long)ctxs[i]->iteration);
+        msg += "]";
+        for (int i = 0; i < n; ++i) ctxs[i]->err = msg;
     }
     return rc;
 }
@@ -2418,7 +2494,9 @@ int trm_reduce_global_all(trm_ctx** ctxs, int n, int field, int op, double* out)
         if (rc) return rc;
         count = pack_reduce(op, rows, local.data(), bufs[(size_t)i]);
     }
-    if (n > 1 && all_have_comm(ctxs, n)) {
+    const int cs = comm_state(ctxs, n);
+    if (cs < 0) return fail(ctxs[0], TRM_EINVAL, std::string("trm_reduce_global_all") + kMixedCommunicators);
+    if (n > 1 && cs == 1) {
         if (int rc = grouped_allreduce(ctxs, n, bufs, count, reduce_operator(op))) return rc;
     } else {
         for (int i = 1; i < n; ++i) fold_packed(op, count, bufs[0], bufs[(size_t)i]);
@@ -2437,7 +2515,9 @@ int trm_status_global_all(trm_ctx** ctxs, int n, uint32_t* flags) {
         if (rc) return rc;
         for (int b = 0; b < 8; ++b) bufs[(size_t)i][(size_t)b] = (double)((local >> b) & 1u);
     }
-    if (n > 1 && all_have_comm(ctxs, n)) {
+    const int cs = comm_state(ctxs, n);
+    if (cs < 0) return fail(ctxs[0], TRM_EINVAL, std::string("trm_status_global_all") + kMixedCommunicators);
+    if (n > 1 && cs == 1) {
         if (int rc = grouped_allreduce(ctxs, n, bufs, 8, ncclMax)) return rc;
     } else {
         for (int i = 1; i < n; ++i) fold_packed(TRM_REDUCE_MAX, 8, bufs[0], bufs[(size_t)i]);

@@ -118,6 +118,7 @@ struct trm_ctx {
     // multi-device diagnostics: one RCCL communicator per context, collectives on a side stream (never on the step path)
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 1;
+    uint64_t comm_group = 0;    // hash of the ncclUniqueId the communicator was created from (0: none)
     hipStream_t comm_stream = nullptr;
     double* d_comm = nullptr;   // [2 * (Nz + 1) + 8] doubles: send | recv
     // vegetation (trm_set_vegetation)

@@ -457,6 +457,14 @@ class DeviceState:
         self._check(self._lib.trm_comm_info(self._ctx, C.byref(r), C.byref(w)), "trm_comm_info")
         return int(w.value)
 
+    def comm_rank(self) -> int:
+        r, w = C.c_int(), C.c_int()
+        self._check(self._lib.trm_comm_info(self._ctx, C.byref(r), C.byref(w)), "trm_comm_info")
+        return int(r.value)
+
+    def comm_destroy(self):
+        self._check(self._lib.trm_comm_destroy(self._ctx), "trm_comm_destroy")
+
     def reduce_global(self, name, op) -> np.ndarray:
         rows = 1 if op == "volume_integral_z" else self.rows(name)
         out = np.zeros(rows, dtype=np.float64)
