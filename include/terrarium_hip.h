@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 17
+#define TRM_ABI_VERSION 18
 
 typedef struct trm_ctx trm_ctx;
 
@@ -490,13 +490,23 @@ int trm_step_heun_timed(trm_ctx* ctx, double dt, int nsteps, int finalize, float
  *                                             closure!(stage), tick!(stage.clock); series are evaluated at t + dt for the stage
  *     (the caller evaluates its function on the STAGE's buffers -- trm_stage_field_device_ptr -- into the stage's boundary /
  *      input / vwc_forcing buffers -- trm_stage_bc_device_ptr, trm_stage_field_device_ptr of the input --, on the context stream)
- *     trm_heun_correct(ctx, dt, finalize)  -- heun.jl:54-71: update_state!(stage), average_tendencies!, explicit_step!(state),
- *                                             closure!(state), tick!(clock) (+ compute_auxiliary! if `finalize`)
+ *     [trm_heun_stage_auxiliary(ctx)       -- the first half of update_state!(stage): reset tendencies, compute_auxiliary!(stage).
+ *      (then the caller evaluates what the reference evaluates INSIDE compute_tendencies!(stage): a forcing function)]
+ *     trm_heun_correct(ctx, dt, finalize)  -- heun.jl:54-71: update_state!(stage) (what is left of it), average_tendencies!,
+ *                                             explicit_step!(state), closure!(state), tick!(clock) (+ compute_auxiliary! if `finalize`)
+ * WHAT THE STAGE'S FIELDS HOLD when the caller reads them: after trm_heun_predict every field of the stage is the reference's at
+ * the same point -- prognostic and closure fields of the predicted state, auxiliary fields (hydraulic_conductivity, the surface
+ * fluxes, ...) still the STATE's copies (copyto!(stage, state), heun.jl:45): what a boundary-value function finds when
+ * fill_halo_regions! evaluates it, BEFORE compute_auxiliary!(stage).  After trm_heun_stage_auxiliary the auxiliary fields are the
+ * stage's own: what a forcing function finds inside the tendency kernel.  The stage's clock has ticked: time t + dt, iteration + 1.
  * The pair equals one trm_step_heun(ctx, dt, 1, finalize) bit for bit when the stage's values are the ones the library would
  * have used itself.  It runs on the reference-order kernels (the stage lives in memory between the two calls by construction).
  * A boundary condition or input whose stage buffer has been handed out keeps it; trm_step_heun refreshes such buffers from
- * the state's values at every step, so mixing the two forms is safe. */
+ * the state's values at every step, so mixing the two forms is safe.
+ * Any other call that writes the state, the clock, a boundary condition or an option between trm_heun_predict and trm_heun_correct
+ * drops the predicted stage: trm_heun_correct then fails with TRM_EINVAL instead of correcting with a stage of another state. */
 int trm_heun_predict(trm_ctx* ctx, double dt);
+int trm_heun_stage_auxiliary(trm_ctx* ctx);
 int trm_heun_correct(trm_ctx* ctx, double dt, int finalize);
 /* Device address of a field of the Heun STAGE (layout as trm_field_device_ptr): the predicted state after trm_heun_predict --
  * to read --, or an input field / TRM_FIELD_VWC_FORCING of the stage -- to write before trm_heun_correct. */

@@ -293,10 +293,12 @@ class Oracle:
     def tick(self, dt): self.lib.trm_oracle_tick(self.h, float(dt))
     def average_tendencies(self, stage): self.lib.trm_oracle_average_tendencies(self.h, stage.h)
 
-    def timestep_heun_by_hand(self, dt, finalize=True, at_state=None, at_stage=None):
-        """timestep!(integrator, ::Heun) with callbacks: `at_state(oracle)` before update_state!(state), `at_stage(stage)`
-        before update_state!(stage) (its clock has ticked) -- where the reference's tendency kernels would evaluate a
-        state-dependent forcing / boundary value."""
+    def timestep_heun_by_hand(self, dt, finalize=True, at_state=None, at_stage=None, at_stage_tendencies=None):
+        """timestep!(integrator, ::Heun) (heun.jl:37-71) with callbacks: `at_state(oracle)` before update_state!(state);
+        `at_stage(stage)` before update_state!(stage) (its clock has ticked) -- where fill_halo_regions! evaluates a boundary-value
+        function, the stage's auxiliary fields still the state's copies (copyto!, heun.jl:45); `at_stage_tendencies(stage)` between
+        compute_auxiliary!(stage) and compute_tendencies!(stage) (state_variables.jl:72-80) -- where the tendency kernel evaluates a
+        forcing function, the stage's auxiliary fields its own."""
         if at_state:
             at_state(self)
         self.update_state(True)
@@ -306,7 +308,12 @@ class Oracle:
         stage.tick(dt)
         if at_stage:
             at_stage(stage)
-        stage.update_state(True)
+        if at_stage_tendencies:
+            stage.update_state(False)           # reset tendencies, compute_auxiliary!
+            at_stage_tendencies(stage)
+            stage.compute_tendencies()
+        else:
+            stage.update_state(True)
         self.average_tendencies(stage)
         self.explicit_step(dt)
         self.closure()

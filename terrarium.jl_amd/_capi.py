@@ -74,7 +74,7 @@ EXPORTS = (
     "trm_default_vegetation_params trm_set_vegetation trm_compute_plant_available_water "
     "trm_series_append trm_series_trim_before trm_series_info trm_reset trm_download_rows trm_set_ring_grid trm_download_ring "
     "trm_scatter_ring_device trm_upload_ring trm_gather_ring_device "
-    "trm_heun_predict trm_heun_correct trm_stage_field_device_ptr trm_stage_bc_device_ptr trm_set_forcing_device "
+    "trm_heun_predict trm_heun_stage_auxiliary trm_heun_correct trm_stage_field_device_ptr trm_stage_bc_device_ptr trm_set_forcing_device "
     "trm_series_window trm_comm_init_all trm_step_all trm_step_heun_all trm_synchronize_all trm_reduce_global_all trm_status_global_all").split()
 TIME_INDEXING = dict(linear=0, clamp=1, cyclical=2, raster=3)
 
@@ -208,6 +208,7 @@ def lib():
     L.trm_upload_ring.argtypes = [vp, i32, vp]
     L.trm_gather_ring_device.argtypes = [vp, i32, vp]
     L.trm_heun_predict.argtypes = [vp, dbl]
+    L.trm_heun_stage_auxiliary.argtypes = [vp]
     L.trm_heun_correct.argtypes = [vp, dbl, i32]
     L.trm_stage_field_device_ptr.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i64)]
     L.trm_stage_bc_device_ptr.argtypes = [vp, i32, i32, C.POINTER(vp)]

@@ -685,13 +685,18 @@ template <class NF> struct Ops {
     // liquid fraction, pressure head, hydraulic conductivity and plant available water of the stage are outputs of
     // closure!(stage) / compute_auxiliary!(stage) and are never read before that (k_explicit_step reads U, sat, S, Ts, the
     // tendencies and the boundary fluxes only): 4 of 9 per-cell copies instead of all of them.
-    static int copy_state_to_stage(trm_ctx* c) {
+    // `everything`: the per-cell closure and auxiliary fields too -- the two-call Heun, where the caller's functions may READ the
+    // stage's fields before update_state!(stage) has recomputed them and must find what the reference's copyto! left there.
+    static int copy_state_to_stage(trm_ctx* c, bool everything = false) {
         for (int f = 0; f < TRM_FIELD_COUNT; ++f) {
             if (!c->state.f[f] || !c->stage.f[f]) continue;
-            const bool needed = !is_3d(f) || f == TRM_FIELD_INTERNAL_ENERGY || f == TRM_FIELD_SATURATION_WATER_ICE ||
+            if (f == TRM_FIELD_VWC_FORCING && c->stage_vwc_own) continue;      // (the caller's stage buffer: refresh_user_stage_buffers)
+            const bool needed = everything || !is_3d(f) || f == TRM_FIELD_INTERNAL_ENERGY || f == TRM_FIELD_SATURATION_WATER_ICE ||
                                 f == TRM_FIELD_TEND_INTERNAL_ENERGY || f == TRM_FIELD_TEND_SATURATION_WATER_ICE;
             if (needed) TRM_HIP(c, hipMemcpyAsync(c->stage.f[f], c->state.f[f], field_elems(c, f) * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
         }
+        if (everything && c->state.kf_top && c->stage.kf_top)
+            TRM_HIP(c, hipMemcpyAsync(c->stage.kf_top, c->state.kf_top, (size_t)c->Nh * sizeof(NF), hipMemcpyDeviceToDevice, c->stream));
         return TRM_OK;
     }
     // Heun in ONE launch (TRM_KERNEL_FUSED, Nz <= 64, branch-free boundary kinds): both stages on the column in registers
@@ -796,10 +801,10 @@ template <class NF> struct Ops {
         return TRM_OK;
     }
     // heun.jl:41-52: the first half of timestep!(integrator, ::Heun) on the reference-order kernels
-    static int heun_predict(trm_ctx* c, double dt) {
+    static int heun_predict(trm_ctx* c, double dt, bool copy_everything = false) {
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_state(c, c->state, true);
-        if (!rc) rc = copy_state_to_stage(c);
+        if (!rc) rc = copy_state_to_stage(c, copy_everything);
         if (!rc) rc = refresh_user_stage_buffers(c);
         if (!rc) rc = update_inputs(c, c->stage, c->time);   // the stage's clock is still t for its predictor step (heun.jl:47-50)
         if (!rc) rc = explicit_step(c, c->stage, dt);
@@ -808,8 +813,15 @@ template <class NF> struct Ops {
         return rc;
     }
     // heun.jl:54-71: the second half
-    static int heun_correct(trm_ctx* c, double dt, int finalize) {
-        int rc = update_state(c, c->stage, true);
+    // update_state!(stage) up to and including compute_auxiliary!(stage) (heun.jl:54, state_variables.jl:72-80): what a forcing
+    // function evaluated inside compute_tendencies!(stage) finds in `fields`
+    static int heun_stage_auxiliary(trm_ctx* c) {
+        int rc = reset_tendencies(c, c->stage);
+        if (!rc) rc = compute_auxiliary(c, c->stage);
+        return rc;
+    }
+    static int heun_correct(trm_ctx* c, double dt, int finalize, bool stage_auxiliary_done = false) {
+        int rc = stage_auxiliary_done ? compute_tendencies(c, c->stage) : update_state(c, c->stage, true);
         if (!rc) rc = average(c, TRM_FIELD_TEND_INTERNAL_ENERGY);
         if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SATURATION_WATER_ICE);
         if (!rc && richards(c)) rc = average(c, TRM_FIELD_TEND_SURFACE_EXCESS_WATER);
@@ -1298,9 +1310,15 @@ int comm_allreduce(trm_ctx* c, double* host, int n, ncclRedOp_t op) {
 // ======================================================================================================
 extern "C" {
 
-#define TRM_ENTER(c)                                         \
+// TRM_ENTER: any entry point but the three of the two-call Heun step and the read-only ones.  A stage predicted by
+// trm_heun_predict belongs to the state and clock it was predicted from: whatever else runs in between drops it, and a later
+// trm_heun_correct fails ("call trm_heun_predict first") instead of averaging tendencies of a stage that describes another state.
+#define TRM_ENTER_HEUN(c)                                    \
     if (!(c)) return TRM_EINVAL;                             \
     TRM_HIP(c, hipSetDevice((c)->device));
+#define TRM_ENTER(c)                                         \
+    TRM_ENTER_HEUN(c)                                        \
+    (c)->heun_pending = false;
 
 int trm_abi_version(void) { return TRM_ABI_VERSION; }
 
@@ -1464,6 +1482,7 @@ int trm_upload(trm_ctx* c, int field, const void* host) {
         return fail(c, TRM_EINVAL, "trm_upload: root_fraction is a static function of the root distribution parameters "
                                    "(root_distribution.jl:45-63): set them with trm_set_vegetation");
     TRM_HIP(c, hipSetDevice(c->device));
+    c->heun_pending = false;
     int rc = c->precision == TRM_F64 ? upload_impl<double>(c, field, (const double*)host) : upload_impl<float>(c, field, (const float*)host);
     if (field <= TRM_FIELD_PRESSURE_HEAD || field == TRM_FIELD_WATER_TABLE) c->closure_consistent = false;   // (U, sat, T, liq, psi, water table)
     if (!rc && field == TRM_FIELD_VWC_FORCING) {
@@ -1532,6 +1551,7 @@ int trm_set_bc(trm_ctx* c, int var, int side, int kind, const void* values, doub
     c->bc_kind[var][side] = kind;
     c->bc_zero_gradient[var][side] = false;
     c->args_valid = false;
+    c->heun_pending = false;
     if (kind == TRM_BC_NOFLUX) return TRM_OK;
     size_t bytes = (size_t)c->Nh * c->esize;
     if (!c->bc_value[var][side]) TRM_HIP(c, hipMalloc(&c->bc_value[var][side], bytes));
@@ -1565,6 +1585,8 @@ int trm_set_forcing_device(trm_ctx* c, int input_field, const void* dev_per_colu
     TRM_ENTER(c);
     if (!is_input_field(input_field) || !dev_per_column) return fail(c, TRM_EINVAL, "trm_set_forcing_device: not an input field / null pointer");
     if (!c->state.f[input_field]) return fail(c, TRM_EINVAL, "trm_set_forcing_device: the field exists only after trm_set_vegetation");
+    for (const auto& sr : c->series)
+        if (!sr.is_bc && sr.field == input_field) return fail(c, TRM_EINVAL, "trm_set_forcing_device: the input is evaluated from a time series every step (trm_clear_series / trm_set_forcing first)");
     // stream-ordered: behind the steps already enqueued, in front of the next one; the host does not wait
     TRM_HIP(c, hipMemcpyAsync(c->state.f[input_field], dev_per_column, (size_t)c->Nh * c->esize, hipMemcpyDeviceToDevice, c->stream));
     return TRM_OK;
@@ -1792,7 +1814,7 @@ int trm_reset(trm_ctx* c) {
 
 // ---- output: rows of a field, and the full ring grid (column_ring_grid.jl:102-149) -----------------------------------------
 int trm_download_rows(trm_ctx* c, int field, int row0, int nrows, void* host) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (!host || !valid_field(field) || !c->state.f[field]) return fail(c, TRM_EINVAL, "trm_download_rows: bad argument");
     if (row0 < 0 || nrows < 1 || row0 + nrows > field_rows(c, field)) return fail(c, TRM_EINVAL, "trm_download_rows: rows out of range");
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
@@ -1804,7 +1826,7 @@ int trm_download_rows(trm_ctx* c, int field, int row0, int nrows, void* host) {
 }
 
 int trm_set_ring_grid(trm_ctx* c, int64_t num_points, const int64_t* mask_index) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (num_points < c->Nh || num_points >= ((int64_t)1 << 31) || !mask_index) return fail(c, TRM_EINVAL, "trm_set_ring_grid: bad argument");
     std::vector<int32_t> inv((size_t)num_points, -1), idx((size_t)c->Nh);
     for (long i = 0; i < c->Nh; ++i) {
@@ -1836,12 +1858,12 @@ static int ring_args_ok(trm_ctx* c, int field, int row0, int nrows, const void* 
     return TRM_OK;
 }
 int trm_download_ring(trm_ctx* c, int field, int row0, int nrows, double fill, void* host) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (int rc = ring_args_ok(c, field, row0, nrows, host, "trm_download_ring")) return rc;
     return c->precision == TRM_F64 ? scatter_ring_impl<double>(c, field, row0, nrows, fill, host, false) : scatter_ring_impl<float>(c, field, row0, nrows, fill, host, false);
 }
 int trm_scatter_ring_device(trm_ctx* c, int field, int row0, int nrows, double fill, void* dev_out) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (int rc = ring_args_ok(c, field, row0, nrows, dev_out, "trm_scatter_ring_device")) return rc;
     return c->precision == TRM_F64 ? scatter_ring_impl<double>(c, field, row0, nrows, fill, dev_out, true) : scatter_ring_impl<float>(c, field, row0, nrows, fill, dev_out, true);
 }
@@ -2006,25 +2028,37 @@ int ensure_stage(trm_ctx* c) {
 }  // namespace
 
 int trm_heun_predict(trm_ctx* c, double dt) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (c->veg_mode == TRM_VEGETATION_STANDALONE) return fail(c, TRM_EUNSUPPORTED, "trm_heun_predict: the standalone VegetationModel has no state-dependent callbacks; use trm_step_heun");
     if (int rc = ensure_stage(c)) return rc;
     c->top_valid = false;
     c->tend_valid = true;
     c->closure_consistent = false;     // (the state is untouched so far; the flag is set again by trm_heun_correct)
-    const int rc = DISPATCH(c, heun_predict(c, dt));
+    const int rc = DISPATCH(c, heun_predict(c, dt, true));
     if (rc) return rc;
     c->heun_pending = true;
+    c->heun_stage_aux = false;
     c->heun_dt = dt;
     return finish(c, TRM_OK);
 }
 
+int trm_heun_stage_auxiliary(trm_ctx* c) {
+    TRM_ENTER_HEUN(c);
+    if (!c->heun_pending) return fail(c, TRM_EINVAL, "trm_heun_stage_auxiliary: call trm_heun_predict first");
+    if (c->heun_stage_aux) return TRM_OK;
+    const int rc = DISPATCH(c, heun_stage_auxiliary(c));
+    if (rc) return rc;
+    c->heun_stage_aux = true;
+    return finish(c, TRM_OK);
+}
+
 int trm_heun_correct(trm_ctx* c, double dt, int finalize) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (!c->heun_pending) return fail(c, TRM_EINVAL, "trm_heun_correct: call trm_heun_predict first");
     if (dt != c->heun_dt) return fail(c, TRM_EINVAL, "trm_heun_correct: dt differs from the dt of trm_heun_predict");
     c->heun_pending = false;
-    const int rc = DISPATCH(c, heun_correct(c, dt, finalize));
+    const int rc = DISPATCH(c, heun_correct(c, dt, finalize, c->heun_stage_aux));
+    c->heun_stage_aux = false;
     if (rc) return rc;
     c->top_valid = false;
     c->tend_valid = true;
@@ -2035,7 +2069,7 @@ int trm_heun_correct(trm_ctx* c, double dt, int finalize) {
 }
 
 int trm_stage_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch_elems) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (!dev || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_stage_field_device_ptr: bad argument");
     if (!c->state.f[field]) return fail(c, TRM_EINVAL, "trm_stage_field_device_ptr: the field exists only after trm_set_vegetation");
     if (int rc = ensure_stage(c)) return rc;
@@ -2051,7 +2085,7 @@ int trm_stage_field_device_ptr(trm_ctx* c, int field, void** dev, int64_t* pitch
 }
 
 int trm_stage_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (!dev || var < 0 || var >= TRM_BCV_COUNT || (side != TRM_TOP && side != TRM_BOTTOM)) return fail(c, TRM_EINVAL, "trm_stage_bc_device_ptr: bad argument");
     if (c->bc_kind[var][side] == TRM_BC_NOFLUX || !c->bc_value[var][side]) return fail(c, TRM_EINVAL, "trm_stage_bc_device_ptr: the condition carries no values (set it with trm_set_bc first)");
     for (const auto& sr : c->series)
@@ -2071,7 +2105,7 @@ int trm_stage_bc_device_ptr(trm_ctx* c, int var, int side, void** dev) {
 }
 
 int trm_save_state(trm_ctx* c) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     {   // (allocates what is missing: everything the first time, the vegetation fields once they exist)
         int rc = alloc_fields(c, c->saved);
         if (rc) return rc;
@@ -2111,13 +2145,14 @@ int trm_clock(const trm_ctx* c, double* time, int64_t* iteration) {
 }
 int trm_set_clock(trm_ctx* c, double time, int64_t iteration) {
     if (!c) return TRM_EINVAL;
+    c->heun_pending = false;
     c->time = time;
     c->iteration = iteration;
     return TRM_OK;
 }
 
 int trm_reduce(trm_ctx* c, int field, int op, double* out) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (!out || !valid_field(field)) return fail(c, TRM_EINVAL, "trm_reduce: bad argument");
     if (is_tendency(field) && !c->tend_valid) return fail(c, TRM_ESTALE, kStaleTendencies);
     return c->precision == TRM_F64 ? reduce_impl<double>(c, field, op, out) : reduce_impl<float>(c, field, op, out);
@@ -2205,7 +2240,7 @@ int comm_buffers(trm_ctx* c) {
 }  // namespace
 
 int trm_comm_init(trm_ctx* c, int rank, int world, const void* id128) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(c, TRM_EINVAL, "trm_comm_init: bad argument");
     if (c->comm) return fail(c, TRM_EINVAL, "trm_comm_init: the context already has a communicator");
     Rccl* r = rccl();
@@ -2528,7 +2563,7 @@ int trm_status_global_all(trm_ctx** ctxs, int n, uint32_t* flags) {
 }
 
 int trm_status(trm_ctx* c, uint32_t* flags) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     if (!flags) return TRM_EINVAL;
     TRM_HIP(c, hipMemcpyAsync(flags, c->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TRM_HIP(c, hipStreamSynchronize(c->stream));
@@ -2538,6 +2573,7 @@ int trm_status(trm_ctx* c, uint32_t* flags) {
 int trm_set_option(trm_ctx* c, int option, int value) {
     if (!c) return TRM_EINVAL;
     c->args_valid = false;
+    c->heun_pending = false;
     switch (option) {
         case TRM_OPT_ASYNC: c->opt_async = value != 0; return TRM_OK;
         case TRM_OPT_STEP_KERNEL:
@@ -2604,7 +2640,7 @@ int trm_set_stream(trm_ctx* c, void* hip_stream) {
     return TRM_OK;
 }
 int trm_synchronize(trm_ctx* c) {
-    TRM_ENTER(c);
+    TRM_ENTER_HEUN(c);
     TRM_HIP(c, hipStreamSynchronize(c->stream));
     return TRM_OK;
 }

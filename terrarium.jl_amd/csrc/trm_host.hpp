@@ -84,6 +84,7 @@ struct trm_ctx {
     bool stage_bc_user[TRM_BCV_COUNT][2] = {};    // handed out by trm_stage_bc_device_ptr
     bool stage_vwc_own = false;                   // the stage reads its own per-cell vwc_forcing (else the state's)
     bool heun_pending = false;                    // trm_heun_predict has run, trm_heun_correct has not
+    bool heun_stage_aux = false;                  // ... and trm_heun_stage_auxiliary has (compute_auxiliary!(stage) is done)
     double heun_dt = 0.0;
     void* d_top3 = nullptr;  // LandModel: [3][Nh] (T, sat, liq) of the top cell as left by the last fused step
     bool top_valid = false;  // ... and whether they still describe the state (any other writer clears it)

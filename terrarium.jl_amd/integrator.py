@@ -405,6 +405,11 @@ class DeviceState:
         """heun.jl:41-52: update_state!(state), stage := state, explicit_step!(stage), closure!(stage) (trm_heun_predict)."""
         self._check(self._lib.trm_heun_predict(self._ctx, float(dt)), "trm_heun_predict")
 
+    def heun_stage_auxiliary(self):
+        """reset tendencies + compute_auxiliary!(stage): the first half of update_state!(stage) (trm_heun_stage_auxiliary) -- after
+        it the stage's auxiliary fields are its own, as a forcing function inside the tendency kernel finds them."""
+        self._check(self._lib.trm_heun_stage_auxiliary(self._ctx), "trm_heun_stage_auxiliary")
+
     def heun_correct(self, dt, finalize=True):
         """heun.jl:54-71: update_state!(stage), average_tendencies!, explicit_step!(state), closure!(state) (trm_heun_correct)."""
         self._check(self._lib.trm_heun_correct(self._ctx, float(dt), int(finalize)), "trm_heun_correct")
@@ -666,7 +671,18 @@ class ModelIntegrator:
             self._bind_stage_functions()
         t, it = self.state.clock()
         self.state.heun_predict(dt)
-        self._evaluate(self._sf_stage, self._sf_stage_fields, _Clock(t + dt, it))
+        # The stage's clock has ticked (heun.jl:52: time t + dt, iteration + 1).  Boundary values and inputs are evaluated where the
+        # reference fills halos / updates inputs -- BEFORE compute_auxiliary!(stage): the stage's auxiliary fields still hold the
+        # state's copies (copyto!, heun.jl:45) --, the forcing where the reference evaluates it -- inside compute_tendencies!(stage),
+        # AFTER compute_auxiliary!(stage) (state_variables.jl:72-80).
+        clock = _Clock(t + dt, it + 1)
+        early = [(fn, dest) for (fn, dest), (_, _, target) in zip(self._sf_stage, self._sf) if target[0] != "vwc_forcing"]
+        late = [(fn, dest) for (fn, dest), (_, _, target) in zip(self._sf_stage, self._sf) if target[0] == "vwc_forcing"]
+        if early:
+            self._evaluate(early, self._sf_stage_fields, clock)
+        if late:
+            self.state.heun_stage_auxiliary()
+            self._evaluate(late, self._sf_stage_fields, clock)
         self.state.heun_correct(dt, finalize)
 
     # -- windowed series: a record streamed through a fixed device window ------------------------------------------------

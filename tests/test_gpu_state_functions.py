@@ -100,7 +100,7 @@ def test_boundary_value_that_reads_the_top_cell(stepper):
 def test_atmospheric_input_that_follows_the_skin_temperature(stepper):
     """LandModel input air_temperature = skin temperature + 2 K: an input source driven by the land state (the coupling
     direction of speedy_dry_land.jl:45-66, here as a function of `fields`); the clock reaches the function -- under Heun twice
-    per step: (t, n) at the state and (t + dt, n) at the stage"""
+    per step: (t, n) at the state and (t + dt, n + 1) at the stage, whose clock has ticked (heun.jl:52)"""
     Nz, Nh, dt = 20, 90, 60.0
     u = columns(Nh)
     grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
@@ -131,7 +131,7 @@ def test_atmospheric_input_that_follows_the_skin_temperature(stepper):
     for n in range(15):
         oracle_step(o, stepper == "heun", dt, n == 14, lambda q: q.set("air_temperature", np.ravel(q.get("skin_temperature")) + 2.0))
     if stepper == "heun":
-        assert seen == [x for n in range(15) for x in ((n * dt, n), (n * dt + dt, n))]
+        assert seen == [x for n in range(15) for x in ((n * dt, n), (n * dt + dt, n + 1))]
     else:
         assert seen == [(n * dt, n) for n in range(15)]
     for name in ("skin_temperature", "internal_energy", "saturation_water_ice", "ground_heat_flux", "sensible_heat_flux"):
@@ -173,6 +173,114 @@ def test_two_call_heun_equals_the_one_call_when_nothing_is_changed_at_the_stage(
     a.heun_predict(w["dt"])
     with pytest.raises(trm.TerrariumHipError, match="dt differs"):
         a.heun_correct(2 * w["dt"])
+
+
+def test_a_forcing_that_reads_an_auxiliary_field_sees_the_stages_own_under_heun():
+    """The reference evaluates a Forcing inside compute_tendencies!(stage), AFTER compute_auxiliary!(stage) (heun.jl:54,
+    state_variables.jl:72-80): the ground heat flux / hydraulic conductivity it reads there are the STAGE's.  A boundary-value
+    function is evaluated by fill_halo_regions!, BEFORE compute_auxiliary!(stage): it finds the state's copies (copyto!,
+    heun.jl:45).  Both against the oracle stepped by hand in the reference's order (trm_heun_stage_auxiliary)."""
+    Nz, Nh, dt = 20, 70, 60.0
+    u = columns(Nh)
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
+    zc = grid.z_centers()
+    hp = trm.ConstantSoilHydraulics(swrc=trm.VanGenuchten(alpha=2.0, n=2.0), unsat_hydraulic_cond=trm.UnsatKVanGenuchten())
+
+    # a sink of soil water proportional to the ground heat flux of the column and to the conductivity of the cell's lower face
+    def sink(f, clock, p):
+        return -1.0e-9 * f.ground_heat_flux[:, None] - 1.0e-3 * f.hydraulic_conductivity[:, :Nz]
+
+    land = trm.LandModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq(), hydraulic_properties=hp,
+                                                                                         vwc_forcing=trm.StateFunction(sink))))
+    T_init = (5.0 + u)[None, :] - 0.02 * zc[:, None]
+    sat = np.clip(np.minimum(1.0, 0.8 - 0.05 * zc)[:, None] * (1.0 + 0.05 * u)[None, :], 0.05, 1.0)
+    inputs = dict(air_temperature=8.0 + 3.0 * u, air_pressure=101325.0, windspeed=1.0 + 2.0 * np.abs(u), specific_humidity=2.0e-3,
+                  surface_shortwave_down=300.0 + 100.0 * u, surface_longwave_down=300.0, rainfall=1.0e-8 * (u > 0))
+    integ = trm.initialize(land, trm.Heun(dt=dt), initializers=dict(temperature=T_init, saturation_water_ice=sat), inputs=inputs)
+    o = oracle_like(integ, land=True)
+    o.set("temperature", T_init)
+    o.set("saturation_water_ice", sat)
+    for k, v in inputs.items():
+        o.set(k, v)
+    o.set("vwc_forcing", np.zeros((Nz, Nh)))
+    o.initialize()
+
+    def sink_np(q):
+        q.set("vwc_forcing", -1.0e-9 * np.ravel(q.get("ground_heat_flux"))[None, :] - 1.0e-3 * q.get("hydraulic_conductivity")[:Nz])
+    trm.run(integ, steps=10)
+    for n in range(10):
+        # at the state the function runs before update_state!(state): the auxiliaries it reads are the previous step's (both sides)
+        o.timestep_heun_by_hand(dt, n == 9, at_state=sink_np, at_stage_tendencies=sink_np)
+    for name in ("saturation_water_ice", "internal_energy", "ground_heat_flux", "hydraulic_conductivity", "skin_temperature"):
+        a, b = integ.state.get(name), o.get(name)
+        assert np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))) < 1e-10, name
+    # ... and the stale variant (the function at the stage evaluated before compute_auxiliary!(stage)) is measurably different
+    o2 = oracle_like(integ, land=True)
+    o2.set("temperature", T_init); o2.set("saturation_water_ice", sat)
+    for k, v in inputs.items():
+        o2.set(k, v)
+    o2.set("vwc_forcing", np.zeros((Nz, Nh)))
+    o2.initialize()
+    for n in range(10):
+        o2.timestep_heun_by_hand(dt, n == 9, at_state=sink_np, at_stage=sink_np)
+    assert np.max(np.abs(o2.get("saturation_water_ice") - o.get("saturation_water_ice"))) > 1e-12
+
+
+def test_a_boundary_value_that_reads_an_auxiliary_field_sees_the_states_copy_at_the_stage():
+    Nz, Nh, dt = 20, 50, 60.0
+    u = columns(Nh)
+    grid = trm.ColumnGrid(trm.ExponentialSpacing(N=Nz), Nh)
+    zc = grid.z_centers()
+    top = trm.StateFunction(lambda f, clock, p: 4.0 + 2.0e5 * f.hydraulic_conductivity[:, Nz - 1])      # (K of the top cell's lower face)
+    model = trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq())))
+    T_init = (3.0 + 2.0 * u)[None, :] - 0.05 * zc[:, None]
+    sat = np.clip(np.minimum(1.0, 0.8 - 0.05 * zc)[:, None] * (1.0 + 0.1 * u)[None, :], 0.05, 1.0)
+    integ = trm.initialize(model, trm.Heun(dt=dt), boundary_conditions=trm.PrescribedSurfaceTemperature("Ts", top),
+                           initializers=dict(temperature=T_init, saturation_water_ice=sat))
+    o = oracle_like(integ)
+    o.set("temperature", T_init)
+    o.set("saturation_water_ice", sat)
+    o.set_bc("temperature", "top", "value", np.zeros(Nh))
+    o.initialize()
+    bc = lambda q: q.set_bc("temperature", "top", "value", 4.0 + 2.0e5 * q.get("hydraulic_conductivity")[Nz - 1])
+    trm.run(integ, steps=8)
+    for n in range(8):
+        o.timestep_heun_by_hand(dt, n == 7, at_state=bc, at_stage=bc)       # (the clone carries the state's hydraulic_conductivity)
+    for name in ("temperature", "internal_energy", "saturation_water_ice"):
+        assert np.array_equal(integ.state.get(name), o.get(name)), name
+
+
+def test_a_predicted_stage_is_dropped_by_whatever_else_touches_the_context():
+    """trm_heun_predict, then a step / an upload / a new clock / a boundary condition / a restore: trm_heun_correct refuses
+    (the stage describes another state) instead of averaging its tendencies in; read-only calls in between are fine."""
+    import workloads as W
+    lat, lon = W.synthetic_columns(60)
+    w = W.make_workload("richards", lat, lon, 20)
+    d = W.setup_device(w)
+    d.step_heun(w["dt"], 1)
+    d.save_state()
+    spoilers = [lambda: d.step(w["dt"], 1), lambda: d.step_heun(w["dt"], 1), lambda: d.set("temperature", d.get("temperature")),
+                lambda: d.set_clock(0.0, 0), lambda: d.set_bc("internal_energy", "bottom", "flux", 0.01), lambda: d.restore_state(),
+                lambda: d.compute_auxiliary(), lambda: d.set_option("write_kf_every_step", 1)]
+    for spoil in spoilers:
+        d.heun_predict(w["dt"])
+        spoil()
+        with pytest.raises(trm.TerrariumHipError, match="trm_heun_predict first"):
+            d.heun_correct(w["dt"])
+    ref = W.setup_device(w)
+    ref.step_heun(w["dt"], 1)
+    ref.set_bc("internal_energy", "bottom", "flux", 0.01)      # (one of the spoilers: a boundary condition is not part of the snapshot)
+    d.restore_state()
+    d.heun_predict(w["dt"])
+    d.get("temperature"); d.status(); d.reduce("temperature", "max"); d.clock(); d.get_rows("temperature", 0, 2)      # read-only
+    d.heun_stage_auxiliary()
+    d.heun_stage_auxiliary()                                                                                          # (idempotent)
+    d.heun_correct(w["dt"])
+    ref.step_heun(w["dt"], 1)
+    for name in W.compared_fields(w):
+        assert np.array_equal(d.get(name), ref.get(name), equal_nan=True), name
+    with pytest.raises(trm.TerrariumHipError, match="trm_heun_predict first"):
+        d.heun_stage_auxiliary()
 
 
 def test_library_loaded_before_torch_shares_one_hip_runtime():
