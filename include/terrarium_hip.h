@@ -171,8 +171,9 @@ enum {
                                     /* (DESIGN 4.1, 4.3); 3: the liquid fraction alone (one read less); 4: the liquid fraction   */
                                     /* and, on the packed fp32 step with Richards, the pressure head from the stored saturation */
                                     /* and water table (two reads less; elsewhere as 3)                                          */
-                                    /* 5: on the fp64 column program with Richards, temperature, liquid fraction AND pressure  */
-                                    /* head (the step reads internal_energy and saturation alone; measured slower: DESIGN 4.3)  */
+                                    /* 5: as 1 (until round 5 the fp64 column program had an instance that derived the pressure */
+                                    /* head as well: measured slower twice, removed; EXPERIMENTS.md).  On the fp64 column       */
+                                    /* program 3 and 4 select 1 as well: its "liquid fraction alone" instance went the same way */
     TRM_OPT_STEPS_PER_LAUNCH = 6,   /* trm_step keeps every column in registers for up to m steps per launch and writes the */
                                     /* fields once per launch (temporal blocking of run!'s loop, model_integrator.jl:72-88;  */
                                     /* bit-identical to m = 1).  0 (default): the library chooses -- 50 wherever the program  */

@@ -330,9 +330,11 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     Cell<NF> c;
     c.U = ldg(v.U, cb0);
     c.sat = ldg(v.sat, cb0);
-    constexpr bool DERIVE_TL = DERIVE == DERIVE_T_LIQ || DERIVE == DERIVE_ALL;
-    c.psi = (RICHARDS && DERIVE != DERIVE_ALL) ? ldg(v.psi, cb0) : NF(0);
-    if (!DERIVE_TL) { c.T = ldg(v.T, cb0); if (DERIVE != DERIVE_LIQ) c.liq = ldg(v.liq, cb0); }
+    static_assert(DERIVE == DERIVE_NONE || DERIVE == DERIVE_T_LIQ, "the column program reads T / liq or derives both (the liquid fraction alone and the "
+                  "pressure head as well were measured and lost: EXPERIMENTS.md; their instances were removed in round 5)");
+    constexpr bool DERIVE_TL = DERIVE == DERIVE_T_LIQ;
+    c.psi = RICHARDS ? ldg(v.psi, cb0) : NF(0);
+    if (!DERIVE_TL) { c.T = ldg(v.T, cb0); c.liq = ldg(v.liq, cb0); }
     const LevelGeom<NF> L = level_geom(v, ln.k);      // (behind the field loads: see level_geom)
     // (BCSIG >= 0: the launcher has matched the context's kinds against the signature -- constants from here on)
     constexpr bool SIG = BCSIG >= 0;
@@ -368,7 +370,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     // instructions after the fields).  surface_excess_water and the skin temperature likewise: vector memory retires in order, loads and
     // stores through the one counter, so a load issued behind the field stores would hold the wave until its stores were acknowledged.
     const ColVal none{NF(0), NF(0)};
-    ColVal q_Tb = none, q_Tt = none, q_Ub = none, q_Sb = none, q_Ut = none, q_St = none, q_wt = none, q_Tb2 = none, q_Tt2 = none, q_S = none, q_Ts = none;
+    ColVal q_Tb = none, q_Tt = none, q_Ub = none, q_Sb = none, q_Ut = none, q_St = none, q_Tb2 = none, q_Tt2 = none, q_S = none, q_Ts = none;
     NF S_stage_out = NF(0);
     FrontGranules fg0{}, fg1{};
     unsigned front_epoch = 0;
@@ -380,7 +382,6 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         // LandModel wires ground_heat_flux / -infiltration (land_model.jl:56-61), produced by k_surface just before this launch
         if (tU && !FRONT) q_Ut = col_req(seb ? v.ghf : bcval(v, 0, 1));
         if (tS && !FRONT) q_St = col_req(seb ? v.infil : bcval(v, 1, 1));
-        if (RICHARDS && DERIVE == DERIVE_ALL) q_wt = col_req(v.wt);
         if (PROG == PROG_HEUN) {      // the stage's temperature boundary values, taken at t + dt (heun.jl:52-59)
             if (vTb) q_Tb2 = col_req(a.bcT_bot_stage);
             if (vTt) q_Tt2 = col_req(a.bcT_top_stage);
@@ -405,17 +406,13 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     if (DERIVE_TL) {
         uint32_t viol_in = 0;
         f_in = energy_closure_wave<NF, 0>(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat, c.liq, c.T, viol_in);   // (its scalars die right here)
-    } else if (DERIVE == DERIVE_LIQ) {
-        // the liquid fraction alone: one compare and, for waves with a cell in phase change, the ballot-guarded divide;
-        // temperature -- the expensive half of the closure (composition, heat capacity, a full divide) -- is read
-        c.liq = liquid_fraction_wave(kernarg_reload<DevParams<NF>>(off_p), c.U, c.sat);
     }
     // ---- boundary inputs of the column --------------------------------------------------------------------------------
     TRM_PHASE_FENCE("inputs", c.U, c.sat, c.psi, c.T, c.liq);
     if (!EARLY) request_inputs();
     const NF in_Tb = col_get(q_Tb), in_Tt = col_get(q_Tt), in_Ub = col_get(q_Ub), in_Sb = col_get(q_Sb);
     NF in_Ut = col_get(q_Ut), in_St = col_get(q_St);
-    const NF in_wt = col_get(q_wt), in_Tb2 = col_get(q_Tb2), in_Tt2 = col_get(q_Tt2);
+    const NF in_Tb2 = col_get(q_Tb2), in_Tt2 = col_get(q_Tt2);
     NF S_in = col_get(q_S), Ts_in = col_get(q_Ts);
     NF front_Ut = NF(0), front_St = NF(0);
     bool front_ready = true;
@@ -425,13 +422,6 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         front_Ut = g.value(FRONT_GHF); front_St = g.value(FRONT_INFIL); Ts_in = g.value(FRONT_TS);
     }
     ColumnBC<NF> bc;
-    if (RICHARDS && DERIVE == DERIVE_ALL) {
-        // saturation_to_pressure! of the stored state from the stored saturation and the stored water table: what the launch that
-        // wrote the field evaluated (column_closure: same function, same operands, same bits) instead of a third field read
-        // (re-deriving the water table as well -- a ballot of the stored saturation and a scalar search instead of the per-column
-        // load -- is slower still: profiles/r04/exp5b)
-        c.psi = pressure_head<NF, HYD>(kernarg_reload<DevParams<NF>>(off_p), c.sat, L.zC, L.psiz, in_wt);
-    }
     if (FRONT) { in_Ut = front_Ut; in_St = front_St; }
     bc.bTb = in_Tb;
     bc.bTt = in_Tt;

@@ -267,9 +267,13 @@ template <class NF> struct Policy {
         // (the coupled vegetation reads T and liq of the whole column from memory every step)
         if (!c->closure_consistent || c->closure_escaped || coupled(c) || c->opt_derive == 0) return DERIVE_NONE;
         if (c->opt_derive == 1) return DERIVE_T_LIQ;
-        if (c->opt_derive == 3) return DERIVE_LIQ;
-        if (c->opt_derive == 5) return (std::is_same<NF, double>::value && RICH) ? DERIVE_ALL : DERIVE_T_LIQ;   // (experiment: psi derived as well)
-        if (c->opt_derive == 4) return (std::is_same<NF, float>::value && RICH && packed_path(const_cast<trm_ctx*>(c))) ? DERIVE_LIQ_PSI : DERIVE_LIQ;
+        // (3, 4: the packed fp32 step's modes -- the liquid fraction alone; that and the pressure head.  The fp64 column program had
+        // instances for "liquid fraction alone" and "pressure head as well" (value 5) until round 5: both measured slower than
+        // deriving T and liq, EXPERIMENTS.md; the values now select what the library offers there: both T and liq)
+        const bool packed = std::is_same<NF, float>::value && packed_path(const_cast<trm_ctx*>(c));
+        if (c->opt_derive == 3) return packed ? DERIVE_LIQ : DERIVE_T_LIQ;
+        if (c->opt_derive == 5) return DERIVE_T_LIQ;
+        if (c->opt_derive == 4) return packed ? (RICH ? DERIVE_LIQ_PSI : DERIVE_LIQ) : DERIVE_T_LIQ;
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
         const bool beyond_cache = state_bytes > ((size_t)256 << 20);
         const bool large = c->Nh >= 24576;
@@ -299,6 +303,15 @@ template <class NF> struct Policy {
         const size_t state_bytes = (size_t)(RICH ? 6 : 4) * (size_t)c->Nh * (size_t)c->Nzp * sizeof(NF);
         const bool beyond_cache = state_bytes > ((size_t)256 << 20);
         return (beyond_cache || (c->params.seb != 0 && c->Nh >= 24576)) ? 1 : 0;
+    }
+    // The (STAGED, SCALAR_IN) combinations that have instances (round 5: the ones no rule selects were removed).  The rules above
+    // give (0, 1) for cache-resident states, (1, 1) for large cache-resident LandModels, (1, 0) beyond the cache; the environment
+    // switches of the tests can ask for anything: (0, 0) -- direct 2-lane stores AND vector loads of one address -- has no
+    // instance anywhere (-> (0, 1)); (1, 1) exists where a surface energy balance can run: the LandModel signature and the
+    // programs that read the kinds at run time (elsewhere -> (1, 0)).
+    static void io_paths(bool land_or_runtime_kinds, int& staged, int& scalar_in) {
+        if (!staged && !scalar_in) scalar_in = 1;
+        if (staged && scalar_in && !land_or_runtime_kinds) scalar_in = 0;
     }
     // fp32: two columns per lane with packed math (trm_packed_f32.hpp) -- the reference-default hydraulics, and van
     // Genuchten retention with Mualem conductivity
@@ -465,6 +478,13 @@ template <template <class, bool, int> class L, class NF, bool RICH, class... A> 
         default: return false;
     }
 }
+// the signature instances exist for the two compiled hydraulics (the reference default; van Genuchten n = 2): a context with
+// run-time exponents takes the program that reads the kinds at run time too
+#define TRM_BY_COMPILED_HYD(c, CALL)                          \
+    switch (::trmh::Policy<NF>::hyd(c)) {                     \
+        case HYD_BC_LINEAR: { constexpr int H = HYD_BC_LINEAR; CALL; } break; \
+        default: { constexpr int H = HYD_VG_N2; CALL; } break;               \
+    }
 // generic boundary kinds: k_step_wave (Euler) and k_heun_generic (trm_launch_generic*.hip)
 template <class NF> struct GenericLaunch {
     static int step(trm_ctx* c, double dt, int finalize);

@@ -27,7 +27,8 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
         a.stage_S = (NF*)c->stage.f[TRM_FIELD_SURFACE_EXCESS_WATER];
     }
     const dim3 grid = column_grid(c, LPC), block(TRM_STEP_BLOCK);
-    const int derive = P::template derive_now<RICH>(c);
+    const int derive = P::template derive_now<RICH>(c);     // (for this kernel: DERIVE_NONE or DERIVE_T_LIQ)
+    if (derive != DERIVE_NONE && derive != DERIVE_T_LIQ) return fail(c, TRM_EINVAL, "k_column: no instance for this derivation mode");
     int pid = 0;    // TRM_INFO_LAST_PROGRAM of the instance that is launched below
     if constexpr (PROG == PROG_MULTI) {
         const bool series = !c->series.empty();
@@ -39,8 +40,10 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
     } else if constexpr (PROG == PROG_EULER) {
         // the context's boundary kinds as a signature; the instantiated ones take the program with the kinds compiled in (fp64; with
         // the derivation of T / liq or without it)
-        const int sig = (c->opt_bc_signature && (derive == DERIVE_T_LIQ || derive == DERIVE_NONE)) ? bc_signature_of(c) : -1;
-        const int staged = derive == DERIVE_T_LIQ ? P::template staged_now<RICH>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::template scalar_inputs_now<RICH>(c) : 1;
+        const int sig = (c->opt_bc_signature && H != HYD_GENERIC) ? bc_signature_of(c) : -1;
+        int staged = derive == DERIVE_T_LIQ ? P::template staged_now<RICH>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::template scalar_inputs_now<RICH>(c) : 1;
+        const bool has_instance = sig == 0 || sig == BCSIG_T_TOP || sig == (BCSIG_T_TOP | BCSIG_FU_BOT) || (RICH && (sig == BCSIG_LAND || sig == (BCSIG_T_TOP | BCSIG_FS_TOP)));
+        P::io_paths(!has_instance || sig == BCSIG_LAND, staged, scalar_in);
         if (launch_by_signature<ColumnSigLaunch, NF, RICH>(sig, c, v, p, a, grid, block, LPC, derive, staged, scalar_in)) {
             // (trm_launch_column_sig.inl: without the derivation the signature instances store directly and take the scalar path)
             pid = derive == DERIVE_T_LIQ ? program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_T_LIQ, staged, scalar_in, sig) : program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_NONE, 0, 1, sig);
@@ -54,24 +57,13 @@ template <class NF, bool RICH, int H, int LPC, int PROG> static int launch_colum
             } else {
                 if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
                 else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
-                else if (scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
-                else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, false>), grid, block, 0, c->stream, v, p, a);
+                else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_T_LIQ, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);     // (io_paths: never (0, 0))
             }
         }
-        else if (derive == DERIVE_ALL) {
-            if constexpr (std::is_same<NF, double>::value && RICH) {
-                const int staged = P::template staged_now<RICH>(c), scalar_in = P::template scalar_inputs_now<RICH>(c);
-                pid = program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_ALL, staged, staged ? scalar_in : 1, -1);
-                if (staged && scalar_in) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, true, true>), grid, block, 0, c->stream, v, p, a);
-                else if (staged) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, true, false>), grid, block, 0, c->stream, v, p, a);
-                else hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_ALL, PROG_EULER, false, false, false, true>), grid, block, 0, c->stream, v, p, a);
-            }
-        }
-        else if (derive == DERIVE_LIQ) { pid = program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_LIQ, 0, 1, -1); hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_LIQ, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a); }
         else { pid = program_id(TRM_PROGRAM_COLUMN_EULER, H, LPC, DERIVE_NONE, 0, 1, -1); hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG_EULER, false>), grid, block, 0, c->stream, v, p, a); }
     } else {
         // (Heun: the same signatures)
-        const int hsig = c->opt_bc_signature ? bc_signature_of(c) : -1;
+        const int hsig = (c->opt_bc_signature && H != HYD_GENERIC) ? bc_signature_of(c) : -1;
         const bool launched = launch_by_signature<ColumnSigHeunLaunch, NF, RICH>(hsig, c, v, p, a, grid, block, LPC);
         pid = program_id(TRM_PROGRAM_COLUMN_HEUN, H, LPC, DERIVE_NONE, 0, 1, launched ? hsig : -1);
         if (!launched) hipLaunchKernelGGL((k_column<NF, RICH, H, LPC, DERIVE_NONE, PROG, false>), grid, block, 0, c->stream, v, p, a);

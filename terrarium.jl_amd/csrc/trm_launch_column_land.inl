@@ -36,14 +36,14 @@ template <int H, int LPC> static int launch_column_land(trm_ctx* c, double dt, i
     grid.x += (unsigned)fa.chain_blocks;
     const dim3 block(TRM_STEP_BLOCK);
     const int derive = P::derive_now<true>(c);
-    const int staged = derive == DERIVE_T_LIQ ? P::staged_now<true>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::scalar_inputs_now<true>(c) : 1;
+    int staged = derive == DERIVE_T_LIQ ? P::staged_now<true>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::scalar_inputs_now<true>(c) : 1;
+    P::io_paths(true, staged, scalar_in);
 #define TRM_LAND1(D, ST, SC) hipLaunchKernelGGL((k_column_land<NF, true, H, LPC, D, ST, SC>), grid, block, 0, c->stream, v, la.p, a, fa)
     if (derive == DERIVE_NONE) TRM_LAND1(DERIVE_NONE, false, true);
     else if (derive != DERIVE_T_LIQ) return fail(c, TRM_EINVAL, "k_column_land: no instance for this derivation mode");
     else if (staged && scalar_in) TRM_LAND1(DERIVE_T_LIQ, true, true);
     else if (staged) TRM_LAND1(DERIVE_T_LIQ, true, false);
-    else if (scalar_in) TRM_LAND1(DERIVE_T_LIQ, false, true);
-    else TRM_LAND1(DERIVE_T_LIQ, false, false);
+    else TRM_LAND1(DERIVE_T_LIQ, false, true);
 #undef TRM_LAND1
     TRM_HIP(c, hipGetLastError());
     c->last_program = program_id(TRM_PROGRAM_COLUMN_LAND, H, LPC, derive, staged, scalar_in, BCSIG_LAND);

@@ -10,7 +10,7 @@ static void launch_column_sig_heun(trm_ctx* c, const View<NF>& v, const DevParam
 }
 template <class NF, bool RICH, int SIG>
 void ColumnSigHeunLaunch<NF, RICH, SIG>::run(trm_ctx* c, const View<NF>& v, const DevParams<NF>& p, const ColumnArgs<NF>& a, dim3 grid, dim3 block, int lpc) {
-    TRM_BY_HYD(c, (lpc == 64 ? (launch_column_sig_heun<NF, RICH, SIG, H, 64>(c, v, p, a, grid, block)) : (launch_column_sig_heun<NF, RICH, SIG, H, 32>(c, v, p, a, grid, block))));
+    TRM_BY_COMPILED_HYD(c, (lpc == 64 ? (launch_column_sig_heun<NF, RICH, SIG, H, 64>(c, v, p, a, grid, block)) : (launch_column_sig_heun<NF, RICH, SIG, H, 32>(c, v, p, a, grid, block))));
 }
 
 }  // namespace trmh

@@ -597,29 +597,22 @@ def test_packed_fp32_with_the_pressure_head_derived_equals_the_stored_one_bitwis
     assert a.status() == b.status() and a.clock() == b.clock()
 
 
-@pytest.mark.parametrize("hydraulics", ["default", "vg"])
-@pytest.mark.parametrize("config,Nz,Nh", [("richards", 32, 130), ("land", 64, 77), ("land", 20, 33)])
-def test_fp64_column_program_with_the_pressure_head_derived_equals_the_stored_one_bitwise(config, Nz, Nh, hydraulics):
-    """TRM_OPT_DERIVE_CLOSURE_FIELDS = 5: the fp64 column program reads internal energy and saturation ALONE -- temperature, liquid
-    fraction and pressure head are re-derived (the last from the stored water table) -- and leaves the same bits as the launches
-    that read all five fields; an upload of the pressure head makes the next step read the fields again."""
-    lat, lon = small_columns(Nh)
-    w = W.make_workload(config, lat, lon, Nz, hydraulics=hydraulics)
-    a, b = W.setup_device(w), W.setup_device(w)
-    a.set_option("derive_closure_fields", 5)
-    b.set_option("derive_closure_fields", 0)
-    for d in (a, b):
-        d.step(w["dt"], 1, False)
-        d.step(w["dt"], 9, False)
-    psi = b.get("pressure_head")
-    psi[2] += 0.125
-    for d in (a, b):
-        d.set("pressure_head", psi)
-        d.step(w["dt"], 1, False)
-        d.step(w["dt"], 6, True)
-    for n in W.compared_fields(w):
-        assert np.array_equal(a.get(n), b.get(n), equal_nan=True), n
-    assert a.status() == b.status() and a.clock() == b.clock()
+def test_derivation_modes_the_fp64_column_program_no_longer_has_select_what_it_offers():
+    """TRM_OPT_DERIVE_CLOSURE_FIELDS = 3 / 4 / 5 on an fp64 context: the instances for "liquid fraction alone" and "pressure head as
+    well" were measured slower than deriving T and liq (EXPERIMENTS.md) and removed in round 5; the values stay legal and select the
+    derivation the column program offers -- same bits as reading the fields."""
+    lat, lon = small_columns(140)
+    w = W.make_workload("richards", lat, lon, 32)
+    ref = W.setup_device(w)
+    ref.set_option("derive_closure_fields", 0)
+    ref.step(w["dt"], 12, True)
+    for mode in (3, 4, 5):
+        d = W.setup_device(w)
+        d.set_option("derive_closure_fields", mode)
+        d.step(w["dt"], 12, True)
+        assert d.last_program()["derive"] == "T_liq"
+        for n in W.compared_fields(w):
+            assert np.array_equal(d.get(n), ref.get(n), equal_nan=True), (mode, n)
 
 
 def test_external_stream_and_async_option():
