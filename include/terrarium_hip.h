@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define TRM_ABI_VERSION 18
+#define TRM_ABI_VERSION 19
 
 typedef struct trm_ctx trm_ctx;
 
@@ -532,6 +532,9 @@ int trm_set_clock(trm_ctx* ctx, double time, int64_t iteration);
  * combines the devices' results. */
 int trm_reduce(trm_ctx* ctx, int field, int op, double* out);
 int trm_status(trm_ctx* ctx, uint32_t* flags);
+/* Sets the status word: a restart puts back the flags its checkpoint carried (the word is sticky: steps only OR into it), so a run
+ * that had produced a NaN before the checkpoint does not report a clean status after the restart; 0 clears it. */
+int trm_set_status(trm_ctx* ctx, uint32_t flags);
 
 /* ---- multi-device diagnostics ----------------------------------------------------------------------------------------
  * The global grid of laterally independent columns is block-sharded over the devices of a node, one context (and one

@@ -67,7 +67,7 @@ EXPORTS = (
     "trm_abi_version trm_default_params trm_create trm_destroy trm_last_error trm_field_rows trm_get_grid "
     "trm_upload trm_download trm_field_device_ptr trm_bc_device_ptr trm_set_bc trm_set_forcing trm_initialize trm_update_state "
     "trm_compute_auxiliary trm_compute_tendencies trm_reset_tendencies trm_explicit_step trm_closure trm_invclosure "
-    "trm_step trm_step_heun trm_step_timed trm_step_heun_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_option "
+    "trm_step trm_step_heun trm_step_timed trm_step_heun_timed trm_clock trm_set_clock trm_reduce trm_status trm_set_status trm_set_option "
     "trm_get_option trm_set_stream trm_synchronize "
     "trm_set_forcing_series trm_set_bc_series trm_clear_series trm_update_inputs trm_save_state trm_restore_state "
     "trm_comm_unique_id trm_comm_init trm_comm_destroy trm_comm_info trm_reduce_global trm_status_global "

@@ -2570,6 +2570,13 @@ int trm_status(trm_ctx* c, uint32_t* flags) {
     return TRM_OK;
 }
 
+int trm_set_status(trm_ctx* c, uint32_t flags) {
+    TRM_ENTER(c);
+    TRM_HIP(c, hipMemcpyAsync(c->d_status, &flags, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    TRM_HIP(c, hipStreamSynchronize(c->stream));      // (`flags` lives on this call's stack)
+    return TRM_OK;
+}
+
 int trm_set_option(trm_ctx* c, int option, int value) {
     if (!c) return TRM_EINVAL;
     c->args_valid = false;

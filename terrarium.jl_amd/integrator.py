@@ -486,6 +486,10 @@ class DeviceState:
         self._check(self._lib.trm_status(self._ctx, C.byref(f)), "trm_status")
         return int(f.value)
 
+    def set_status(self, flags: int):
+        """Puts a status word back (trm_set_status): what a restart does with the flags of its checkpoint."""
+        self._check(self._lib.trm_set_status(self._ctx, C.c_uint32(int(flags))), "trm_set_status")
+
     def set_option(self, option, value):
         if option == "step_kernel" and isinstance(value, str):
             value = _capi.KERNEL[value]
@@ -716,6 +720,23 @@ class ModelIntegrator:
                 ok = min(ok, k)
         return ok
 
+    def _rewind_windows(self, t):
+        """A restore that goes BACK in time in a used integrator: a device window whose head has been trimmed past `t` no longer
+        holds the bracket of `t` -- the series starts over from the head of its record (`_seek_windows` then moves it forward)."""
+        for target, fts in self._windowed():
+            info = self.state.series_info(target)
+            if info["t_first"] <= t or fts.times[0] > t and info["t_first"] == fts.times[0]:
+                continue
+            n = min(fts.window, fts.times.size)
+            if isinstance(target, tuple):
+                var, side = target
+                kind = self.boundary_conditions[(var, side)][0]
+                self.state.set_bc_series(var, side, kind, fts.times[:n], np.asarray(fts.values[:n]), fts.time_indexing)
+            else:
+                self.state.set_forcing_series(target, fts.times[:n], np.asarray(fts.values[:n]), fts.time_indexing)
+            self.state.series_window(target, fts.window)
+            self._next_level[id(fts)] = n
+
     def _seek_windows(self, t):
         """Moves the device windows forward until they hold the bracket of time `t` (a restart into a fresh integrator, whose
         windows start at the head of their records)."""
@@ -933,6 +954,8 @@ def restore(integ: ModelIntegrator, ckpt: dict) -> ModelIntegrator:
     for name in restart_fields(integ):
         st.set(name, ckpt["fields"][name])
     st.set_clock(ckpt["time"], ckpt["iteration"])
+    st.set_status(ckpt.get("status", 0))      # (sticky flags raised before the checkpoint stay raised after the restart)
+    integ._rewind_windows(ckpt["time"])
     integ._seek_windows(ckpt["time"])
     st.update_inputs()      # the inputs as update_inputs! leaves them at the restored clock
     return integ

@@ -95,6 +95,46 @@ def test_restart_with_a_windowed_series(stepper, dtype):
         assert np.array_equal(fresh.state.get(name), whole.state.get(name), equal_nan=True), name
 
 
+def test_restore_back_in_time_in_a_used_integrator_and_the_status_word():
+    """A restore that goes BACK in time in the integrator that wrote the checkpoint: its window has been trimmed past the
+    checkpoint's clock and is started over from the head of the record; the status word the checkpoint carried is put back (a NaN
+    raised before the checkpoint is still reported after the restart, a clean checkpoint clears a later flag)."""
+    lat, lon = W.synthetic_columns(130)
+    w = W.make_workload("richards", lat, lon, 32)
+    nt = 120
+    t = 150.0 * np.arange(nt) + 40.0 * np.sin(np.arange(nt))
+    vals = w["T0"][None, :] + 10.0 * np.sin(2 * np.pi * t[:, None] / 86400.0 - w["lon"][None, :])
+
+    def make():
+        grid = trm.ColumnGrid(trm.PrescribedSpacing(dz=list(w["thickness"])), w["Nh"])
+        model = trm.SoilModel(grid, soil=trm.SoilEnergyWaterCarbon(hydrology=trm.SoilHydrology(vertical_flow=trm.RichardsEq())))
+        bc = trm.PrescribedSurfaceTemperature("Ts", trm.FieldTimeSeries(t, vals).windowed(10))
+        return trm.initialize(model, trm.ForwardEuler(dt=w["dt"]), boundary_conditions=bc,
+                              initializers=dict(temperature=w["fields"]["temperature"], saturation_water_ice=w["fields"]["saturation_water_ice"]))
+
+    whole = make()
+    trm.run(whole, steps=160)
+    used = make()
+    trm.run(used, steps=40)
+    ckpt = trm.checkpoint(used)                       # clean, at step 40
+    trm.run(used, steps=100)                          # the window moves on: its head is far beyond the checkpoint's clock now
+    assert used.state.series_info(("temperature", "top"))["t_first"] > ckpt["time"]
+    T = used.state.get("temperature"); T[0, 0] = np.nan
+    used.state.set("temperature", T)
+    trm.run(used, steps=1)
+    assert used.state.status() & 1
+    trm.restore(used, ckpt)
+    assert used.state.status() == 0 and used.state.clock() == (40 * w["dt"], 40)
+    info = used.state.series_info(("temperature", "top"))
+    assert info["t_first"] <= ckpt["time"] < info["t_last"]
+    trm.run(used, steps=120)
+    for name in W.compared_fields(w):
+        assert np.array_equal(used.state.get(name), whole.state.get(name), equal_nan=True), name
+    flagged = dict(ckpt, status=1)
+    trm.restore(used, flagged)
+    assert used.state.status() == 1
+
+
 def test_restore_refuses_a_checkpoint_of_another_grid():
     a, b = coupled_integrator(20, trm.ForwardEuler), coupled_integrator(21, trm.ForwardEuler)
     with pytest.raises(ValueError, match="another grid"):
