@@ -381,9 +381,9 @@ def main():
     value = total_columns * args.steps / m["wall_s"]
     packed = dt_name == "f32" and args.kernel == "fused" and not heun and args.steps_per_launch == 1      # (fp32: two columns per lane)
     program = dev.last_program()      # the instance the library selected for the measured launches (TRM_INFO_LAST_PROGRAM)
-    kernel_name = {"column_land": "k_column_land", "packed_f32": "k_step_pk", "column_euler": "k_column", "column_heun": "k_column", "column_multi": "k_column",
+    kernel_name = {"column_land": "k_column_land", "packed_f32": "k_step_pk", "packed_land": "k_step_pk_land", "column_euler": "k_column", "column_heun": "k_column", "column_multi": "k_column",
                    "deep": "k_column_deep", "wide": "k_column_wide", "generic_euler": "k_step_wave", "generic_heun": "k_heun_generic"}.get(program["family"], "unfused sequence")
-    assert packed == (program["family"] == "packed_f32")
+    assert packed == (program["family"] in ("packed_f32", "packed_land"))
     pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series and args.steps_per_launch == 1) else None
 
     out = {

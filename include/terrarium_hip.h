@@ -232,7 +232,8 @@ enum {
 enum {
     TRM_PROGRAM_NONE = 0, TRM_PROGRAM_COLUMN_EULER = 1, TRM_PROGRAM_COLUMN_HEUN = 2, TRM_PROGRAM_COLUMN_MULTI = 3,
     TRM_PROGRAM_PACKED_F32 = 4, TRM_PROGRAM_GENERIC_EULER = 5, TRM_PROGRAM_GENERIC_HEUN = 6, TRM_PROGRAM_COLUMN_LAND = 7,
-    TRM_PROGRAM_DEEP = 8, TRM_PROGRAM_WIDE = 9, TRM_PROGRAM_LAND_INTERLEAVED = 10, TRM_PROGRAM_UNFUSED = 11, TRM_PROGRAM_VEGETATION = 12
+    TRM_PROGRAM_DEEP = 8, TRM_PROGRAM_WIDE = 9, TRM_PROGRAM_LAND_INTERLEAVED = 10, TRM_PROGRAM_UNFUSED = 11, TRM_PROGRAM_VEGETATION = 12,
+    TRM_PROGRAM_PACKED_LAND = 13
 };
 enum {
     TRM_KERNEL_FUSED = 0,       /* one launch per step: lane = soil level, a column per (half-)wavefront,     */

@@ -47,7 +47,7 @@ OPTION = dict(asynchronous=0, step_kernel=1, write_kf_every_step=2, vwc_forcing_
 KERNEL = dict(fused=0, unfused=1)
 # TRM_INFO_LAST_PROGRAM (include/terrarium_hip.h: TRM_PROGRAM_*; trm_host.hpp: program_id)
 PROGRAM = ("none", "column_euler", "column_heun", "column_multi", "packed_f32", "generic_euler", "generic_heun", "column_land", "deep", "wide",
-           "land_interleaved", "unfused", "vegetation")
+           "land_interleaved", "unfused", "vegetation", "packed_land")
 DERIVE = ("none", "T_liq", "liq", "liq_psi", "all")
 
 

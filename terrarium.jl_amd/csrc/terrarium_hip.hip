@@ -249,6 +249,19 @@ template <class NF> StageView<NF> make_stage_view(const trm_ctx* c) {
 }  // namespace
 
 namespace trmh {
+int front_epoch_next(trm_ctx* c) {
+    const size_t bytes = (size_t)c->Nh * FRONT_GRANULES * sizeof(unsigned long long);
+    if (!c->d_gran) {
+        TRM_HIP(c, hipMalloc((void**)&c->d_gran, bytes));
+        TRM_HIP(c, hipMemsetAsync(c->d_gran, 0, bytes, c->stream));
+        c->front_epoch = 0;
+    }
+    if (++c->front_epoch == 0) {      // (wrapped: stale granules may carry any tag again -- start over)
+        TRM_HIP(c, hipMemsetAsync(c->d_gran, 0, bytes, c->stream));
+        c->front_epoch = 1;
+    }
+    return TRM_OK;
+}
 template <class NF> const LaunchArgs<NF>& launch_args(trm_ctx* c) {
     if (!c->args) {
         c->args = new LaunchArgs<NF>();
@@ -590,13 +603,22 @@ template <class NF> struct Ops {
     // bare-ground LandModel in fp64 on the branch-free program with the LandModel's boundary wiring, one level per lane, every
     // column in one launch, the top-cell arrays current (the surface workgroups read them).
     static bool surface_in_launch(trm_ctx* c) {
-        if (!std::is_same<NF, double>::value || c->opt_front == 0) return false;
+        if (c->opt_front == 0) return false;
         if (!c->params.seb || !richards(c) || coupled(c) || c->Nz > 64 || generic_bcs(c) || c->part >= 0) return false;
         if (c->opt_kernel != TRM_KERNEL_FUSED || !c->opt_bc_signature || bc_signature_of(c) != BCSIG_LAND) return false;
         if (hyd(c) != HYD_BC_LINEAR && hyd(c) != HYD_VG_N2) return false;
         if (!c->top_valid || !tops_current(c)) return false;
         const int d = P::template derive_now<true>(c);
-        return d == DERIVE_NONE || d == DERIVE_T_LIQ;
+        if (std::is_same<NF, float>::value ? !(packed_path(c) && (d == DERIVE_NONE || d == DERIVE_LIQ))         // k_step_pk_land
+                                           : !(d == DERIVE_NONE || d == DERIVE_T_LIQ)) return false;          // k_column_land
+        if (c->opt_front == 1) return true;
+        // The library's rule (2).  What the single launch saves is the FIXED cost of the second launch (~3-4 us); the surface chain
+        // itself is still evaluated, and the column waves of the first generation wait for it.  Measured, same box, pair -> one launch
+        // (profiles/r05/exp3d_prio_sleep.log, exp4_packed_surface_in_launch.log, exp4b_in_launch_by_size.log): fp64 1 780 columns
+        // 9.8 -> 7.1 us, 7 119 (the shard of BASELINE config 4) 11.1 -> 8.6, C4-VG shard 12.3 -> 9.2, 28 476 19.7 -> 19.3, N145
+        // (56 951) 30.3 -> 29.6 ... 30.0; fp32 12 696 columns 15.2 -> 10.6, 50 782 29.5 -> 31.2, 203 125 108.6 -> 106.6, C5
+        // (812 500) 425.4 -> 426.7, C5-VG 437.1 -> 451.0: a clear win where the step is launch-bound, nothing beyond.
+        return c->Nh <= (std::is_same<NF, float>::value ? 32768 : 65536);
     }
     static int fused_step(trm_ctx* c, double dt, int fin) {
         int rc = update_inputs(c, c->state, c->time);
@@ -605,7 +627,7 @@ template <class NF> struct Ops {
         if (coupled(c)) rc = surface_veg<true, true>(c, c->state, dt, c->opt_write_kf != 0);
         else if (c->params.seb && !in_launch) rc = surface(c, c->state, true);
         if (!rc && in_launch) {
-            rc = FrontLaunch::run(c, dt, fin);
+            rc = std::is_same<NF, float>::value ? PackedLaunch::step_land(c, dt, fin) : FrontLaunch::run(c, dt, fin);
             if (!rc) c->closure_consistent = true;
         } else if (!rc) rc = wave_step(c, dt, fin);
         c->tend_valid = fin != 0;   // only the finalizing launch stores state.tendencies

@@ -499,7 +499,12 @@ template <class NF> struct LandLaunch { static int run(trm_ctx* c, int qcol, int
 template <> int LandLaunch<double>::run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays);
 template <> int LandLaunch<float>::run(trm_ctx* c, int qcol, int qsurf, double dt, int finalize, bool top_arrays);
 // the packed fp32 step k_step_pk (trm_launch_packed.hip)
-struct PackedLaunch { static int step(trm_ctx* c, double dt, int finalize); };
+struct PackedLaunch {
+    static int step(trm_ctx* c, double dt, int finalize);
+    static int step_land(trm_ctx* c, double dt, int finalize);      // k_step_pk_land: the surface processes in the launch
+};
+// the granule buffer and the epoch of the next launch that carries its own surface processes (k_column_land, k_step_pk_land)
+int front_epoch_next(trm_ctx* c);
 // the LandModel's per-step launch with the surface processes in its first workgroups: k_column_land (fp64; trm_launch_column_land_*.hip)
 struct FrontLaunch {
     static int run(trm_ctx* c, double dt, int finalize);

@@ -172,29 +172,24 @@ template <class NF, bool RICHARDS, int HYD, bool FROM_STATE, bool TOP_ARRAYS> TR
 #ifndef TRM_STEP_BLOCK
 #define TRM_STEP_BLOCK 256
 #endif
-#ifndef TRM_FRONT_GRANULE_STORE
-#define TRM_FRONT_GRANULE_STORE 1      // (0: lane-by-lane, 2: none -- diagnostic builds)
-#endif
 struct FrontArgs {
-    unsigned long long* gran;   // [Nh][6]: {ghf.lo, ghf.hi, infil.lo, infil.hi, Ts.lo, Ts.hi}, each (epoch << 32) | half
+    unsigned long long* gran;   // fp64 [Nh][6]: {ghf.lo, ghf.hi, infil.lo, infil.hi, Ts.lo, Ts.hi}, fp32 [Nh][3]: {ghf, infil, Ts}; each (epoch << 32) | 32 bits
     unsigned epoch;
     int chain_blocks;           // the first workgroups of the grid evaluate the surface processes, 256 columns each
 };
 enum { FRONT_GHF = 0, FRONT_INFIL = 2, FRONT_TS = 4, FRONT_GRANULES = 6, FRONT_SPIN_LIMIT = 1 << 14 };
+// granules per column: one per 32-bit half of the three values -- 6 in fp64 (offsets FRONT_GHF / FRONT_INFIL / FRONT_TS), 3 in fp32
+// (value q at granule q)
+template <class NF> constexpr int front_granules() { return 3 * (int)(sizeof(NF) / 4); }
 TRM_DEV void st_agent(unsigned long long* p, unsigned long long x) { __hip_atomic_store(p, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 TRM_DEV unsigned long long ld_agent(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-TRM_DEV void publish_granules(unsigned long long* g, unsigned epoch, double x) {
-    const unsigned long long b = __builtin_bit_cast(unsigned long long, x), tag = (unsigned long long)epoch << 32;
-    st_agent(g, tag | (b & 0xffffffffull));
-    st_agent(g + 1, tag | (b >> 32));
-}
 // compute_auxiliary! of the surface processes of column i (land_model.jl:79-88): surface_program<FROM_STATE, TOP_ARRAYS> except
 // for where the results go -- the skin temperature is NOT stored (the column program stores skin_temperature + 0 * dt, as
 // explicit_step! leaves it, from the value it is handed here).
 // Called by EVERY lane of a surface wave whose first column exists (the lanes beyond the last column repeat it and store nothing of
 // their own: the transposed granule store needs the whole wave).
 template <class NF, bool RICHARDS, int HYD> TRM_DEV void surface_front(const View<NF>& v, const DevParams<NF>& p, const FrontArgs& fa, long i_lane) {
-    static_assert(sizeof(NF) == 8, "two 32-bit halves per value");
+    constexpr int G = front_granules<NF>();
     const bool real = i_lane < v.Nh;
     const long i = real ? i_lane : v.Nh - 1;
     const unsigned ib = (unsigned)i * (unsigned)sizeof(NF);
@@ -206,35 +201,34 @@ template <class NF, bool RICHARDS, int HYD> TRM_DEV void surface_front(const Vie
     const NF T_top = ldg(v.top_T, ib2), sat_top = ldg(v.top_sat, ib2), liq_top = ldg(v.top_liq, ib2);
     const NF Kf_top = conductivity_hydraulic<NF, HYD, false>(p, liq_top, fractions(p, sat_top, liq_top, viol));
     surface_processes(p, in, ldg(v.Ts, ib2), T_top, sat_top, liq_top, Kf_top, ldg(v.S, ib2), RICHARDS, v.dzc[v.Nz - 1], o);
-#if TRM_FRONT_GRANULE_STORE == 0
-    // one 8-byte store per granule and lane, 48 bytes apart: 384 partial-line write-through transactions per wave
-    unsigned long long* g = fa.gran + (size_t)i * FRONT_GRANULES;      // (lanes beyond the last column rewrite its granules with the same values)
-    publish_granules(g + FRONT_GHF, fa.epoch, o.ghf);
-    publish_granules(g + FRONT_INFIL, fa.epoch, o.infil);
-    publish_granules(g + FRONT_TS, fa.epoch, o.Ts);
-#elif TRM_FRONT_GRANULE_STORE == 1
-    // The wave's 64 columns own 384 consecutive granules (3 KB).  Written lane by lane they are 8-byte pieces 48 bytes apart, each
-    // its own write-through transaction of a partial line; transposed through LDS, store j of lane l writes granule 64 j + l --
-    // 512 contiguous bytes per instruction, whole lines, every granule still ONE 8-byte store of one lane.
+    // The wave's 64 columns own 64 G consecutive granules.  Written lane by lane they are 8-byte pieces 8 G bytes apart, each its
+    // own write-through transaction of a partial line (measured: +2.7 us on the N145 step, profiles/r05/exp3c); transposed through
+    // LDS, store j of lane l writes granule 64 j + l -- 512 contiguous bytes per instruction, whole lines, every granule still ONE
+    // 8-byte store of one lane.
     {
         __shared__ unsigned long long stage[(TRM_STEP_BLOCK / 64) * 64 * FRONT_GRANULES];
         const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
-        unsigned long long* st = stage + wv * 64 * FRONT_GRANULES;
+        unsigned long long* st = stage + wv * 64 * G;
         const unsigned long long tag = (unsigned long long)fa.epoch << 32;
-        const unsigned long long bg = __builtin_bit_cast(unsigned long long, o.ghf), bi = __builtin_bit_cast(unsigned long long, o.infil), bt = __builtin_bit_cast(unsigned long long, o.Ts);
-        unsigned long long* mine = st + lane * FRONT_GRANULES;
-        mine[FRONT_GHF] = tag | (bg & 0xffffffffull); mine[FRONT_GHF + 1] = tag | (bg >> 32);
-        mine[FRONT_INFIL] = tag | (bi & 0xffffffffull); mine[FRONT_INFIL + 1] = tag | (bi >> 32);
-        mine[FRONT_TS] = tag | (bt & 0xffffffffull); mine[FRONT_TS + 1] = tag | (bt >> 32);
+        unsigned long long* mine = st + lane * G;
+        const NF vals[3] = {o.ghf, o.infil, o.Ts};
+        for (int q = 0; q < 3; ++q) {
+            if constexpr (sizeof(NF) == 8) {
+                const unsigned long long b = __builtin_bit_cast(unsigned long long, vals[q]);
+                mine[2 * q] = tag | (b & 0xffffffffull);
+                mine[2 * q + 1] = tag | (b >> 32);
+            } else {
+                mine[q] = tag | (unsigned long long)__builtin_bit_cast(unsigned, vals[q]);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (LDS operations of a wave complete in order; this orders the compiler)
         __builtin_amdgcn_wave_barrier();
-        const long first = (i_lane - lane) * FRONT_GRANULES, total = (long)v.Nh * FRONT_GRANULES;     // (i_lane - lane: the wave's first column)
-        for (int j = 0; j < FRONT_GRANULES; ++j) {
+        const long first = (i_lane - lane) * G, total = (long)v.Nh * G;     // (i_lane - lane: the wave's first column)
+        for (int j = 0; j < G; ++j) {
             const long q = first + j * 64 + lane;
             if (q < total) st_agent(fa.gran + q, st[j * 64 + lane]);
         }
     }
-#endif
     if (real) {
         const unsigned ob = block_local(ib);
         stg(v.ghf, ob, o.ghf); stg(v.swu, ob, o.swu); stg(v.lwu, ob, o.lwu); stg(v.rnet, ob, o.rnet);

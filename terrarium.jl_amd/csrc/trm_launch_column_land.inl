@@ -11,16 +11,7 @@ template <int H, int LPC> static int launch_column_land(trm_ctx* c, double dt, i
     const LaunchArgs<NF>& la = launch_args<NF>(c);
     const View<NF>& v = la.state;
     if (!v.top_T || !c->top_valid) return fail(c, TRM_EINVAL, "k_column_land: the surface workgroups read the top-cell arrays, which are not current");
-    if (!c->d_gran) {
-        const size_t bytes = (size_t)c->Nh * FRONT_GRANULES * sizeof(unsigned long long);
-        TRM_HIP(c, hipMalloc((void**)&c->d_gran, bytes));
-        TRM_HIP(c, hipMemsetAsync(c->d_gran, 0, bytes, c->stream));
-        c->front_epoch = 0;
-    }
-    if (++c->front_epoch == 0) {      // (wrapped: stale granules may carry any tag again -- start over)
-        TRM_HIP(c, hipMemsetAsync(c->d_gran, 0, (size_t)c->Nh * FRONT_GRANULES * sizeof(unsigned long long), c->stream));
-        c->front_epoch = 1;
-    }
+    if (int rc = front_epoch_next(c)) return rc;
     ColumnArgs<NF> a{};
     a.dt = (NF)dt;
     a.finalize = finalize;

@@ -38,6 +38,37 @@ template <bool RICH, int LPC> static int launch_packed(trm_ctx* c, double dt, in
     }
     return TRM_OK;
 }
+// k_step_pk_land: the packed LandModel step with the surface processes in the first workgroups of the launch
+template <int LPC> static int launch_packed_land(trm_ctx* c, double dt, int finalize) {
+    using P = Policy<float>;
+    const LaunchArgs<float>& la = launch_args<float>(c);
+    const View<float>& sv = la.state;
+    if (!sv.top_T || !c->top_valid) return fail(c, TRM_EINVAL, "k_step_pk_land: the surface workgroups read the top-cell arrays, which are not current");
+    if (int rc = front_epoch_next(c)) return rc;
+    FrontArgs fa{};
+    fa.gran = c->d_gran;
+    fa.epoch = c->front_epoch;
+    fa.chain_blocks = (int)((c->Nh + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK);
+    const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
+    const long pairs = (c->Nh + 1) / 2;
+    const long waves = (pairs + (64 / LPC) - 1) / (64 / LPC);
+    const dim3 pg((unsigned)fa.chain_blocks + (unsigned)((waves * 64 + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK)), blk(TRM_STEP_BLOCK);
+    const int derive = P::derive_now<true>(c);
+    const int staged = P::staged_now<true>(c, true);
+    const bool vg = P::hyd(c) == HYD_VG_N2;
+#define TRM_PK_LAND(HYDV, D) hipLaunchKernelGGL((k_step_pk_land<LPC, HYDV, D>), pg, blk, 0, c->stream, sv, la.p, (float)dt, finalize, wkf, staged, fa)
+    if (derive == DERIVE_LIQ) { if (vg) TRM_PK_LAND(HYD_VG_N2, DERIVE_LIQ); else TRM_PK_LAND(HYD_BC_LINEAR, DERIVE_LIQ); }
+    else if (derive == DERIVE_NONE) { if (vg) TRM_PK_LAND(HYD_VG_N2, DERIVE_NONE); else TRM_PK_LAND(HYD_BC_LINEAR, DERIVE_NONE); }
+    else return fail(c, TRM_EINVAL, "k_step_pk_land: no instance for this derivation mode");
+#undef TRM_PK_LAND
+    TRM_HIP(c, hipGetLastError());
+    c->last_program = program_id(TRM_PROGRAM_PACKED_LAND, vg ? HYD_VG_N2 : HYD_BC_LINEAR, LPC, derive, staged, 1, BCSIG_LAND);
+    return TRM_OK;
+}
+int PackedLaunch::step_land(trm_ctx* c, double dt, int finalize) {
+    return c->Nz > 32 ? launch_packed_land<64>(c, dt, finalize) : launch_packed_land<32>(c, dt, finalize);
+}
+
 int PackedLaunch::step(trm_ctx* c, double dt, int finalize) {
     const bool deep = c->Nz > 32;
     if (Policy<float>::richards(c)) return deep ? launch_packed<true, 64>(c, dt, finalize) : launch_packed<true, 32>(c, dt, finalize);

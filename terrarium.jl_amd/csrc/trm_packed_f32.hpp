@@ -200,8 +200,21 @@ TRM_DEV v2f upwind2(v2f g, v2f Kdn, v2f Kmid, v2f Kup) { return min2(Kmid, sel(l
 // per step -- the packed kernel is not short of bytes -- and is not offered.)
 // DERIVE_LIQ: the incoming liquid fraction is re-derived from (U, sat) instead of being read (legal when the stored fields
 // are the closure of the stored state, trm_ctx::closure_consistent): one of the five field reads less.
-template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE, int BCSIG = BCSIG_RUNTIME>
-TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p_arg, float dt, int finalize, int write_kf, unsigned block, int staged = 0) {
+// the three granules of one column as the scalar path delivers them (fp32: one granule per value; see FrontArgs, trm_kernels.hpp)
+struct FrontGranulesF {
+    unsigned long long w[3];
+    TRM_DEV void load(const unsigned long long* gran, unsigned byte_off_uniform) {
+        for (int n = 0; n < 3; ++n) w[n] = sld_off<unsigned long long>(gran, byte_off_uniform + (unsigned)n * 8u);
+    }
+    TRM_DEV bool valid(unsigned epoch) const { return (unsigned)(w[0] >> 32) == epoch && (unsigned)(w[1] >> 32) == epoch && (unsigned)(w[2] >> 32) == epoch; }
+    TRM_DEV float value(int q) const { return __builtin_bit_cast(float, (unsigned)w[q]); }
+};
+// FRONT (LandModel, BCSIG_LAND): ground heat flux, infiltration and the new skin temperature come from the surface workgroups of THIS
+// launch as granules (k_step_pk_land below; the fp64 form is column_program<FRONT> in trm_column.hpp)
+template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE, int BCSIG = BCSIG_RUNTIME, bool FRONT = false>
+TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p_arg, float dt, int finalize, int write_kf, unsigned block, int staged = 0,
+                             const FrontArgs* fa = nullptr) {
+    static_assert(!FRONT || (BCSIG == BCSIG_LAND && RICHARDS), "the in-launch surface processes feed the LandModel step");
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
     const View<float>& v = v_arg;
     const DevParams<float>& p = p_arg;
@@ -281,19 +294,30 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const bool fSb = RICHARDS && (SIG ? (BCSIG & BCSIG_FS_BOT) != 0 : v.bc.kind[1][0] == 2), fSt = RICHARDS && (seb || (SIG ? (BCSIG & BCSIG_FS_TOP) != 0 : v.bc.kind[1][1] == 2));
     v2f in_Tb = splat(0.0f), in_Tt = splat(0.0f), in_Ub = splat(0.0f), in_Ut = splat(0.0f), in_Sb = splat(0.0f), in_St = splat(0.0f), in_wt = splat(0.0f);
     v2f S_in = splat(0.0f), Ts_in = splat(0.0f);
+    FrontGranulesF fg[4] = {};
+    bool front_ready = true;
     auto request_inputs = [&] {
         if (vTb) in_Tb = col_ld2(bcval(v, 2, 0));
         if (vTt) in_Tt = col_ld2(bcval(v, 2, 1));
         if (fUb) in_Ub = col_ld2(bcval(v, 0, 0));
-        if (fUt) in_Ut = col_ld2(seb ? v.ghf : bcval(v, 0, 1));
+        if (fUt && !FRONT) in_Ut = col_ld2(seb ? v.ghf : bcval(v, 0, 1));
         if (fSb) in_Sb = col_ld2(bcval(v, 1, 0));
-        if (fSt) in_St = col_ld2(seb ? v.infil : bcval(v, 1, 1));
+        if (fSt && !FRONT) in_St = col_ld2(seb ? v.infil : bcval(v, 1, 1));
         if (RICHARDS && DERIVE == DERIVE_LIQ_PSI) in_wt = col_ld2(v.wt);
         // surface_excess_water and the skin temperature of the two columns: with the other inputs.  Vector memory retires in order,
         // loads and stores through the one counter: a load issued behind a store holds the whole wave until that store has been
         // acknowledged by memory (the top-lane block used to do that three times per wave).
         if (RICHARDS) S_in = col_ld2(v.S);
-        if (seb) Ts_in = col_ld2(v.Ts);
+        if (seb && !FRONT) Ts_in = col_ld2(v.Ts);
+        if constexpr (FRONT) {   // the granules of the wave's columns through the scalar path: valid if the surface workgroups have published them
+            constexpr unsigned GB = 3u * 8u / 4u;      // granule bytes per column / bytes per float: q* are byte offsets of floats
+            fg[0].load(fa->gran, q0 * GB); fg[1].load(fa->gran, q1 * GB);
+            if (CPW == 2) { fg[2].load(fa->gran, q2 * GB); fg[3].load(fa->gran, q3 * GB); }
+            const unsigned e = fa->epoch;
+            front_ready = fg[0].valid(e) && fg[1].valid(e) && (CPW == 1 || (fg[2].valid(e) && fg[3].valid(e)));
+            auto pick = [&](int q) { return CPW == 1 ? v2f{fg[0].value(q), fg[1].value(q)} : v2f{upper ? fg[2].value(q) : fg[0].value(q), upper ? fg[3].value(q) : fg[1].value(q)}; };
+            in_Ut = pick(0); in_St = pick(1); Ts_in = pick(2);
+        }
     };
     // (they travel through the scalar path, whose loads return out of order: requested in front of the derivation they hold up its
     // parameter reloads -- C5 +4 %, profiles/r04/exp8 -- so the request stays behind it; k_column's vector path requests early)
@@ -381,6 +405,37 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         const v2f qW_hi = sel(is_top, qW_t, qW_sh);
         const v2f dtheta = -((qW_hi - qW_lo) * L.rdzc) + splat(0.0f) + p.vwc_forcing;
         gS = splat(0.0f) + div_const2_nsz(dtheta, p.por, p.rpor);
+    }
+    bool front_timeout = false;
+    if constexpr (FRONT) if (!front_ready) {
+        // the scalar read came before the surface workgroups had published: poll the granules (vector loads at agent scope; lanes
+        // 0 .. 2 of a half-wave read the granules of its first column, 3 .. 5 of its second), here, where the values are first needed
+        TRM_PHASE("rare+ granule poll");
+        const unsigned long long* gp = fa->gran + (size_t)(k < 3 ? j0 : j1) * 3 + (k < 6 ? k % 3 : 2);
+        unsigned long long g = 0;
+        bool ok = false;
+        for (int spin = 0; spin < FRONT_SPIN_LIMIT && !ok; ++spin) {
+            g = ld_agent(gp);
+            ok = wave_ballot((unsigned)(g >> 32) != fa->epoch) == 0ull;
+            if (!ok) __builtin_amdgcn_s_sleep(4);
+        }
+        const int w = (int)(unsigned)g;
+        auto value = [&](int q, int col, int base) { return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readlane(w, base + col * 3 + q)); };
+        auto pick = [&](int q) {
+            const v2f lo = v2f{value(q, 0, 0), value(q, 1, 0)};
+            if (CPW == 1) return lo;
+            const v2f hi = v2f{value(q, 0, LPC), value(q, 1, LPC)};
+            return v2f{upper ? hi.x : lo.x, upper ? hi.y : lo.y};
+        };
+        v2f ut = pick(0), st = pick(1), ts = pick(2);
+        if (!ok) {   // gave up: no hang, the columns of the wave are flagged and NaN
+            front_timeout = true;
+            ut = st = ts = splat(__builtin_nanf(""));
+        }
+        Ts_in = ts;
+        flux_U = sel(is_top, -div_const2_nsz(ut * v.g.Az, v.g.V_top, v.g.rV_top), splat(0.0f));
+        flux_S = sel(is_top, -div_const2_nsz((-st) * v.g.Az, v.g.V_top, v.g.rV_top), splat(0.0f));
+        TRM_PHASE("rare-");
     }
 #if TRM_CUT_FLUX
     if (fUb || fUt) gU += flux_U;
@@ -482,12 +537,25 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         store_small_outputs<float>(enabled, cpb, block, Nh);
     }
     // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
-    const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u);
+    const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u) | (front_timeout ? 4u : 0u);
     if (flags) atomicOr(v.status, flags);
 }
 template <bool RICHARDS, int LPC, int HYD, int DERIVE = DERIVE_NONE, int BCSIG = BCSIG_RUNTIME>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf, int staged) {
     step_pk_program<RICHARDS, LPC, HYD, DERIVE, BCSIG>(v_arg, p_arg, dt, finalize, write_kf, xcd_block<TRM_XCD_REMAP_PK != 0>(blockIdx.x, gridDim.x), staged);
+}
+// LandModel in fp32, ONE launch per step (TRM_OPT_SURFACE_IN_LAUNCH): the first workgroups evaluate the 0-D surface processes of 256
+// columns each (surface_front), the others run the packed step, which receives ground heat flux, infiltration and the new skin
+// temperature from them through granules (k_column_land, trm_column.hpp, in fp64)
+template <int LPC, int HYD, int DERIVE>
+__global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk_land(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf, int staged, FrontArgs fa) {
+    if ((int)blockIdx.x < fa.chain_blocks) {
+        __builtin_amdgcn_s_setprio(3);
+        const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i - (long)(threadIdx.x & 63u) < v_arg.Nh) surface_front<float, true, HYD>(v_arg, p_arg, fa, i);      // (wave-uniform)
+        return;
+    }
+    step_pk_program<true, LPC, HYD, DERIVE, BCSIG_LAND, true>(v_arg, p_arg, dt, finalize, write_kf, blockIdx.x - (unsigned)fa.chain_blocks, staged, &fa);
 }
 // LandModel in fp32: the packed column step of one half of the columns beside the surface processes of the other half in one
 // launch (k_land_euler, trm_column.hpp).  (View, DevParams) first: step_pk_program re-reads them from the kernarg segment.

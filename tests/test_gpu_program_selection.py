@@ -85,7 +85,9 @@ def test_c5_fp32_shard():
     lat, lon = W.synthetic_columns(812500)
     w = W.make_workload("land", lat, lon, 64, dtype=np.float32)
     _, p = steady_program(w)
-    expect(p, family="packed_f32", hydraulics="default", lanes_per_column=64, derive="liq", staged=False, bc_signature=LAND)
+    expect(p, family="packed_f32", hydraulics="default", lanes_per_column=64, derive="liq", staged=False, bc_signature=LAND)      # (beyond the size where the single launch pays)
+    _, s = steady_program(W.make_workload("land", lat[:12696], lon[:12696], 64, dtype=np.float32))
+    expect(s, family="packed_land", derive="none", bc_signature=LAND)
 
 
 def test_deep_columns():

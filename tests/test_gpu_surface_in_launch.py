@@ -12,6 +12,7 @@ import workloads as W
 pytestmark = pytest.mark.gpu
 
 PROGRAM_LAND = 7       # TRM_PROGRAM_COLUMN_LAND: family id in the low byte of TRM_INFO_LAST_PROGRAM
+PROGRAM_PACKED_LAND = 13
 
 
 def small_columns(n):
@@ -70,6 +71,33 @@ def test_surface_in_launch_equals_the_launch_pair_bitwise(hydraulics, Nz, Nh, de
     for d in (a, b):
         d.step(w["dt"], 2, finalize=False)
     assert family(a) == PROGRAM_LAND
+    assert_same(a, b, w, tendencies=False)
+
+
+@pytest.mark.parametrize("derive", [0, 2])
+@pytest.mark.parametrize("hydraulics,Nz,Nh", [("default", 64, 131), ("vg", 50, 257), ("default", 20, 64), ("vg", 32, 65), ("default", 32, 1), ("default", 64, 7),
+                                              ("default", 32, 2), ("vg", 64, 4099), ("default", 32, 4098)])
+def test_packed_fp32_surface_in_launch_equals_the_launch_pair_bitwise(hydraulics, Nz, Nh, derive):
+    """k_step_pk_land: the packed fp32 step (two columns per lane, two or four columns per wave) with the surface processes in the
+    first workgroups of the launch; one granule per value."""
+    lat, lon = small_columns(Nh)
+    w = W.make_workload("land", lat, lon, Nz, hydraulics=hydraulics, dtype=np.float32)
+    a, b = pair(w, derive)      # (2: the library's rule -- at these sizes T / liq are read; 0: never derived)
+    if derive == 2:
+        for d in (a, b):
+            d.set_option("derive_closure_fields", 3)      # the liquid fraction derived, as on the HBM-resident C5 shard
+    for d in (a, b):
+        d.step(w["dt"], 9, finalize=False)
+    assert family(a) == PROGRAM_PACKED_LAND and family(b) != PROGRAM_PACKED_LAND
+    assert_same(a, b, w, tendencies=False)
+    for d in (a, b):
+        d.step(w["dt"], 1, finalize=False)
+        d.step(w["dt"], 3, finalize=True)
+    assert_same(a, b, w)
+    for d in (a, b):
+        d.set_forcing("air_temperature", w["inputs"]["air_temperature"].astype(np.float32) + 2.0)
+        d.step(w["dt"], 2, finalize=False)
+    assert family(a) == PROGRAM_PACKED_LAND
     assert_same(a, b, w, tendencies=False)
 
 
@@ -176,14 +204,16 @@ def test_a_device_pointer_into_the_state_keeps_the_launch_pair():
 
 
 def test_where_the_in_launch_surface_does_not_apply():
-    """The coupled vegetation, fp32, a SoilModel: the launch pair / the single launch as before."""
+    """The coupled vegetation, a SoilModel, fp32 off the packed kernel: the launch pair / the single launch as before."""
     lat, lon = small_columns(150)
     for config, hyd, dtype in (("landveg", "vg", np.float64), ("richards", "default", np.float64), ("land", "default", np.float32)):
         w = W.make_workload(config, lat, lon, 32, hydraulics=hyd, dtype=dtype)
         a, b = pair(w)
         for d in (a, b):
+            if dtype == np.float32:
+                d.set_option("packed_f32", 0)
             d.step(w["dt"], 5, finalize=False)
-        assert family(a) != PROGRAM_LAND
+        assert family(a) not in (PROGRAM_LAND, PROGRAM_PACKED_LAND)
         for d in (a, b):
             d.step(w["dt"], 2, finalize=True)
         for n in all_fields(w):
@@ -204,3 +234,16 @@ def test_full_size_under_load_every_word():
         assert family(b) != PROGRAM_LAND
         assert_same(a, b, w)
         assert a.status() & 4 == 0
+
+
+def test_fp32_shard_under_load_every_word():
+    """The C5 shape at a tenth of its size (81 250 columns x 64 levels, fp32: 318 surface workgroups in front of 10 157 column
+    workgroups): 30 steps, every word against the launch pair."""
+    lat, lon = W.synthetic_columns(81250)
+    w = W.make_workload("land", lat, lon, 64, dtype=np.float32)
+    a, b = pair(w)
+    for d in (a, b):
+        d.step(w["dt"], 30, finalize=False)
+        d.step(w["dt"], 1, finalize=True)
+    assert_same(a, b, w)
+    assert a.status() & 4 == 0
