@@ -8,7 +8,7 @@
 #      --no-cpu-baseline` -> kernel_stats_<wl>.csv: the dominant kernel's average is one row, one launch size;
 #   3. the bench line of the same command without the profiler -> bench_<wl>.json.
 # Output: gpurun_out/prof_<round>/ (scratch); copy kernel_stats_* / pmc_summary_* / bench_*.json into profiles/<round>/.
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 COMMIT=${2:-unknown}
 # A step that fails for ANY reason (a timeout, an abort or a fault under the profiler: rc 134 / 139, a Python error) ends the collection:
 # no GPU work follows a faulted step, and no summary is made of partial counters.
