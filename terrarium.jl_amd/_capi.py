@@ -57,6 +57,8 @@ def decode_program(pid: int) -> dict:
     extra = pid >> 25
     if d["family"] == "column_multi":
         d.update(surface_inline=bool(extra & 1), series=bool(extra & 2))
+    if d["family"] == "column_land":
+        d.update(program=("euler", "heun", "multi")[extra & 3])
     if d["family"] in ("deep", "wide"):
         d.update(program=("euler", "heun", "multi")[extra & 3], generic_boundaries=bool(extra & 4))
     return d

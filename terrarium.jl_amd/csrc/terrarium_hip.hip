@@ -602,13 +602,13 @@ template <class NF> struct Ops {
     // TRM_OPT_SURFACE_IN_LAUNCH: a per-step launch of this context can carry its own surface processes (k_column_land) -- a
     // bare-ground LandModel in fp64 on the branch-free program with the LandModel's boundary wiring, one level per lane, every
     // column in one launch, the top-cell arrays current (the surface workgroups read them).
-    static bool surface_in_launch(trm_ctx* c) {
-        if (c->opt_front == 0) return false;
+    static bool surface_in_launch(trm_ctx* c, bool heun = false) {
+        if (c->opt_front == 0 || (heun && std::is_same<NF, float>::value)) return false;
         if (!c->params.seb || !richards(c) || coupled(c) || c->Nz > 64 || generic_bcs(c) || c->part >= 0) return false;
         if (c->opt_kernel != TRM_KERNEL_FUSED || !c->opt_bc_signature || bc_signature_of(c) != BCSIG_LAND) return false;
         if (hyd(c) != HYD_BC_LINEAR && hyd(c) != HYD_VG_N2) return false;
         if (!c->top_valid || !tops_current(c)) return false;
-        const int d = P::template derive_now<true>(c);
+        const int d = heun ? DERIVE_NONE : P::template derive_now<true>(c);      // (the Heun program reads T / liq as stored)
         if (std::is_same<NF, float>::value ? !(packed_path(c) && (d == DERIVE_NONE || d == DERIVE_LIQ))         // k_step_pk_land
                                            : !(d == DERIVE_NONE || d == DERIVE_T_LIQ)) return false;          // k_column_land
         if (c->opt_front == 1) return true;
@@ -727,8 +727,9 @@ template <class NF> struct Ops {
     static int heun_step_fused(trm_ctx* c, double dt, int finalize) {
         int rc = update_inputs(c, c->state, c->time);
         if (!rc) rc = update_inputs(c, c->stage, c->time + dt);   // boundary value series at the stage's clock (heun.jl:52)
-        if (!rc && c->params.seb) rc = surface(c, c->state, true);
-        if (!rc) rc = column_program<PROG_HEUN>(c, dt, finalize, 1);
+        const bool in_launch = !rc && surface_in_launch(c, true);      // (k_column_land<..., PROG_HEUN>: the state's surface processes in the launch)
+        if (!rc && c->params.seb && !in_launch) rc = surface(c, c->state, true);
+        if (!rc) rc = in_launch ? FrontLaunch::run(c, dt, finalize, true) : column_program<PROG_HEUN>(c, dt, finalize, 1);
         if (!rc) c->closure_consistent = true;
         c->tend_valid = finalize != 0;
         c->top_valid = c->params.seb != 0 && !rc && tops_current(c);

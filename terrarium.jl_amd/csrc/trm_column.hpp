@@ -272,7 +272,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
     constexpr unsigned off_args = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(ColumnArgs<NF>));
     constexpr unsigned off_front = round_up_to(off_args + (unsigned)sizeof(ColumnArgs<NF>), (unsigned)alignof(FrontArgs));
-    static_assert(!FRONT || (PROG == PROG_EULER && BCSIG == BCSIG_LAND && RICHARDS && !SEB_INLINE && sizeof(NF) == 8), "the in-launch surface processes feed the per-step fp64 LandModel program");
+    static_assert(!FRONT || (PROG != PROG_MULTI && BCSIG == BCSIG_LAND && RICHARDS && !SEB_INLINE && sizeof(NF) == 8), "the in-launch surface processes feed the per-step fp64 LandModel programs");
     const View<NF>& v = v_arg;
     const DevParams<NF>& p = p_arg;
     static_assert(!SEB_INLINE || PROG == PROG_MULTI, "the in-kernel surface energy balance belongs to the multi-step program");
@@ -464,6 +464,43 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         }
     }
 
+    // FRONT: the values are first needed by the explicit step (of the stage under Heun); if the scalar read at the top came before the
+    // surface workgroups had published, the wave polls its granules here
+    auto front_wait = [&] {
+        if constexpr (FRONT && !(TRM_FRONT_DIAG & 2)) if (!front_ready) {
+            // the scalar read came before the surface workgroups had published: poll the granules (vector loads at agent scope,
+            // every lane k < 6 of a column its granule k), here, where the values are first needed
+            TRM_PHASE("rare+ granule poll");
+            const FrontArgs& fa = kernarg_reload<FrontArgs>(off_front);
+            const unsigned long long* gp = fa.gran + (size_t)ii * FRONT_GRANULES + (ln.k < FRONT_GRANULES ? ln.k : FRONT_GRANULES - 1);
+            unsigned long long g = 0;
+            bool ok = false;
+            for (int spin = 0; spin < FRONT_SPIN_LIMIT && !ok; ++spin) {
+                g = ld_agent(gp);
+                ok = wave_ballot((unsigned)(g >> 32) != fa.epoch) == 0ull;
+                if (!ok) __builtin_amdgcn_s_sleep(TRM_FRONT_POLL_SLEEP);
+            }
+            const int w = (int)(unsigned)g;                 // the granule's payload: one 32-bit half of a value
+            auto value = [&](int q, int base) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane(w, base + q), hi = (unsigned)__builtin_amdgcn_readlane(w, base + q + 1);
+                return __builtin_bit_cast(NF, ((unsigned long long)hi << 32) | lo);
+            };
+            NF ut = value(FRONT_GHF, 0), st = value(FRONT_INFIL, 0), ts = value(FRONT_TS, 0);
+            if (CPW == 2) {
+                const NF ut1 = value(FRONT_GHF, LPC), st1 = value(FRONT_INFIL, LPC), ts1 = value(FRONT_TS, LPC);
+                ut = upper ? ut1 : ut; st = upper ? st1 : st; ts = upper ? ts1 : ts;
+            }
+            if (!ok) {   // gave up: no hang, the columns of the wave are flagged and NaN
+                viol |= 4u;
+                ut = st = ts = __builtin_nan("");
+            }
+            Ts_in = ts;
+            const NF eU_t = -flux_term_top_nsz(ut, v.g), eS_t = -flux_term_top_nsz(-st, v.g);
+            bc.flux_U = ln.is_top ? eU_t : NF(0);
+            bc.flux_S = ln.is_top ? eS_t : NF(0);
+            TRM_PHASE("rare-");
+        }
+    };
     Cell<NF> n = c;          // the state after the program's last step
     Tendency<NF> t{};        // tendencies of the last evaluation at the STATE (hydraulic_conductivity comes from here)
     NF gU_out = NF(0), gS_out = NF(0), GS_out = NF(0), z0 = NF(0);
@@ -476,6 +513,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         const NF G1U = t.gU, G1S = t.gS;
         NF gU = G1U, gS = G1S, z0s;
         Cell<NF> s;
+        front_wait();
         over_stage = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, s, z0s, bad);
         const Frac<NF> f_stage = column_closure<NF, RICHARDS, HYD>(kernarg_reload<DevParams<NF>>(off_p), L, z0s, s, viol);
         if (a.stage_T && ln.act) {   // (wave-uniform: the stage leaves the registers only for the coupled vegetation)
@@ -564,39 +602,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             t = column_tendencies<NF, RICHARDS, HYD, LPC>(v, p, L, ln, c, bc.bTb, bc.bTt, need_kc, viol, pre);
             NF gU = t.gU, gS = t.gS;
             TRM_PHASE_FENCE("advance", gU, gS, t.Kf_lo, t.Kc);
-            if constexpr (FRONT && !(TRM_FRONT_DIAG & 2)) if (!front_ready) {
-                // the scalar read came before the surface workgroups had published: poll the granules (vector loads at agent scope,
-                // every lane k < 6 of a column its granule k), here, where the values are first needed
-                TRM_PHASE("rare+ granule poll");
-                const FrontArgs& fa = kernarg_reload<FrontArgs>(off_front);
-                const unsigned long long* gp = fa.gran + (size_t)ii * FRONT_GRANULES + (ln.k < FRONT_GRANULES ? ln.k : FRONT_GRANULES - 1);
-                unsigned long long g = 0;
-                bool ok = false;
-                for (int spin = 0; spin < FRONT_SPIN_LIMIT && !ok; ++spin) {
-                    g = ld_agent(gp);
-                    ok = wave_ballot((unsigned)(g >> 32) != fa.epoch) == 0ull;
-                    if (!ok) __builtin_amdgcn_s_sleep(TRM_FRONT_POLL_SLEEP);
-                }
-                const int w = (int)(unsigned)g;                 // the granule's payload: one 32-bit half of a value
-                auto value = [&](int q, int base) {
-                    const unsigned lo = (unsigned)__builtin_amdgcn_readlane(w, base + q), hi = (unsigned)__builtin_amdgcn_readlane(w, base + q + 1);
-                    return __builtin_bit_cast(NF, ((unsigned long long)hi << 32) | lo);
-                };
-                NF ut = value(FRONT_GHF, 0), st = value(FRONT_INFIL, 0), ts = value(FRONT_TS, 0);
-                if (CPW == 2) {
-                    const NF ut1 = value(FRONT_GHF, LPC), st1 = value(FRONT_INFIL, LPC), ts1 = value(FRONT_TS, LPC);
-                    ut = upper ? ut1 : ut; st = upper ? st1 : st; ts = upper ? ts1 : ts;
-                }
-                if (!ok) {   // gave up: no hang, the columns of the wave are flagged and NaN
-                    viol |= 4u;
-                    ut = st = ts = __builtin_nan("");
-                }
-                Ts_in = ts;
-                const NF eU_t = -flux_term_top_nsz(ut, v.g), eS_t = -flux_term_top_nsz(-st, v.g);
-                bc.flux_U = ln.is_top ? eU_t : NF(0);
-                bc.flux_S = ln.is_top ? eS_t : NF(0);
-                TRM_PHASE("rare-");
-            }
+            front_wait();
             over = column_advance<NF, RICHARDS, LPC>(v, L, ln, Nz, bc, c.U, c.sat, gU, gS, dt, n, z0, bad);
             if (PROG == PROG_MULTI && RICHARDS) {   // surface_excess_water carried in the top lane's register
                 GS_out = NF(0) + jl_min(NF(0), S);
@@ -722,9 +728,9 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
 #ifndef TRM_LAND_WAVES
 #define TRM_LAND_WAVES 7
 #endif
-template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, bool STAGED, bool SCALAR_IN>
+template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, bool STAGED, bool SCALAR_IN, int PROG = PROG_EULER>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
-    __attribute__((amdgpu_waves_per_eu(TRM_LAND_WAVES, 8)))
+    __attribute__((amdgpu_waves_per_eu(PROG == PROG_HEUN ? 5 : TRM_LAND_WAVES, 8)))
     k_column_land(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a, FrontArgs fa) {
     if ((int)blockIdx.x < fa.chain_blocks) {
         // (the surface waves share their SIMDs with up to seven column waves, all of which will wait for them: they issue first)
@@ -733,7 +739,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK)
         if (i - (long)(threadIdx.x & 63u) < v_arg.Nh && !(TRM_FRONT_DIAG & 1)) surface_front<NF, RICHARDS, HYD>(v_arg, p_arg, fa, i);     // (wave-uniform)
         return;
     }
-    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG_EULER, false, false, STAGED, SCALAR_IN, BCSIG_LAND, true>(v_arg, p_arg, a, blockIdx.x - (unsigned)fa.chain_blocks);
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, false, false, STAGED, SCALAR_IN, BCSIG_LAND, true>(v_arg, p_arg, a, blockIdx.x - (unsigned)fa.chain_blocks);
 }
 
 // ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the

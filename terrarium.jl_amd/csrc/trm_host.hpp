@@ -507,8 +507,8 @@ struct PackedLaunch {
 int front_epoch_next(trm_ctx* c);
 // the LandModel's per-step launch with the surface processes in its first workgroups: k_column_land (fp64; trm_launch_column_land_*.hip)
 struct FrontLaunch {
-    static int run(trm_ctx* c, double dt, int finalize);
-    template <int H> static int run_hyd(trm_ctx* c, double dt, int finalize);
+    static int run(trm_ctx* c, double dt, int finalize, bool heun = false);
+    template <int H> static int run_hyd(trm_ctx* c, double dt, int finalize, bool heun);
 };
 
 }  // namespace trmh

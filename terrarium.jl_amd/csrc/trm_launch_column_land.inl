@@ -5,7 +5,7 @@
 
 namespace trmh {
 
-template <int H, int LPC> static int launch_column_land(trm_ctx* c, double dt, int finalize) {
+template <int H, int LPC> static int launch_column_land(trm_ctx* c, double dt, int finalize, bool heun) {
     using NF = double;
     using P = Policy<NF>;
     const LaunchArgs<NF>& la = launch_args<NF>(c);
@@ -26,6 +26,12 @@ template <int H, int LPC> static int launch_column_land(trm_ctx* c, double dt, i
     dim3 grid = column_grid(c, LPC);
     grid.x += (unsigned)fa.chain_blocks;
     const dim3 block(TRM_STEP_BLOCK);
+    if (heun) {      // the one-launch Heun program: T / liq read as stored, direct stores, scalar inputs (as k_column<..., PROG_HEUN>)
+        hipLaunchKernelGGL((k_column_land<NF, true, H, LPC, DERIVE_NONE, false, true, PROG_HEUN>), grid, block, 0, c->stream, v, la.p, a, fa);
+        TRM_HIP(c, hipGetLastError());
+        c->last_program = program_id(TRM_PROGRAM_COLUMN_LAND, H, LPC, DERIVE_NONE, 0, 1, BCSIG_LAND) | (PROG_HEUN << 25);
+        return TRM_OK;
+    }
     const int derive = P::derive_now<true>(c);
     int staged = derive == DERIVE_T_LIQ ? P::staged_now<true>(c) : 0, scalar_in = derive == DERIVE_T_LIQ ? P::scalar_inputs_now<true>(c) : 1;
     P::io_paths(true, staged, scalar_in);
@@ -41,8 +47,8 @@ template <int H, int LPC> static int launch_column_land(trm_ctx* c, double dt, i
     return TRM_OK;
 }
 
-template <int H> int FrontLaunch::run_hyd(trm_ctx* c, double dt, int finalize) {
-    return c->Nz > 32 ? launch_column_land<H, 64>(c, dt, finalize) : launch_column_land<H, 32>(c, dt, finalize);
+template <int H> int FrontLaunch::run_hyd(trm_ctx* c, double dt, int finalize, bool heun) {
+    return c->Nz > 32 ? launch_column_land<H, 64>(c, dt, finalize, heun) : launch_column_land<H, 32>(c, dt, finalize, heun);
 }
 
 }  // namespace trmh

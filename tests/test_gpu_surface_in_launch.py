@@ -101,6 +101,26 @@ def test_packed_fp32_surface_in_launch_equals_the_launch_pair_bitwise(hydraulics
     assert_same(a, b, w, tendencies=False)
 
 
+@pytest.mark.parametrize("hydraulics,Nz,Nh", [("default", 32, 131), ("vg", 50, 257), ("default", 20, 64), ("default", 64, 7), ("vg", 32, 4099)])
+def test_heun_with_the_surface_processes_in_the_launch_equals_the_launch_pair_bitwise(hydraulics, Nz, Nh):
+    """k_column_land<..., PROG_HEUN>: the one-launch Heun step (heun.jl:37-71; both stages in registers) with the STATE's surface
+    processes in the first workgroups of the launch -- the stage's are not evaluated (its fluxes would only enter through
+    compute_z_bcs!, which the reference runs for the state alone)."""
+    lat, lon = small_columns(Nh)
+    w = W.make_workload("land", lat, lon, Nz, hydraulics=hydraulics)
+    a, b = pair(w)
+    for d in (a, b):
+        d.step_heun(w["dt"], 7, finalize=False)
+    assert family(a) == PROGRAM_LAND and a.last_program()["program"] == "heun" and family(b) != PROGRAM_LAND
+    assert_same(a, b, w, tendencies=False)
+    for d in (a, b):
+        d.set_forcing("air_temperature", w["inputs"]["air_temperature"] - 1.5)
+        d.step_heun(w["dt"], 1, finalize=False)
+        d.step(w["dt"], 2, finalize=False)
+        d.step_heun(w["dt"], 3, finalize=True)
+    assert_same(a, b, w)
+
+
 def test_surface_in_launch_matches_the_oracle():
     lat, lon = small_columns(300)
     for hyd in ("default", "vg"):
