@@ -267,3 +267,31 @@ def test_fp32_shard_under_load_every_word():
         d.step(w["dt"], 1, finalize=True)
     assert_same(a, b, w)
     assert a.status() & 4 == 0
+
+
+def test_hand_off_under_uneven_load_every_word():
+    """The hand-off of the in-launch surface processes must not depend on what else the device is doing: an N145 LandModel stepped
+    one launch per step on its own stream WHILE a second context streams a 0.93 GB heat + Richards state through the same device on
+    another (the column waves of the LandModel then share CUs, L2 slices and the fabric with a foreign kernel, and the generations of
+    its workgroups interleave with the other launch's) -- every word of every field against the launch pair stepped alone; no wave
+    ever gives up waiting (status bit 4)."""
+    lat, lon = W.columns_from_mask("N145")
+    w = W.make_workload("land", lat, lon, 32)
+    big = W.make_workload("richards", np.tile(lat, 8), np.tile(lon, 8), 32)
+    a, b, hog = W.setup_device(w), W.setup_device(w), W.setup_device(big)
+    a.set_option("surface_in_launch", 1)
+    b.set_option("surface_in_launch", 0)
+    for d in (a, hog):
+        d.set_option("asynchronous", 1)         # (each context has its own stream: the launches of the two overlap on the device)
+    b.step(w["dt"], 36, finalize=False)
+    b.step(w["dt"], 1, finalize=True)
+    hog.step(big["dt"], 2, finalize=False)
+    for n in range(36):
+        if n % 3 == 0:
+            hog.step(big["dt"], 1, finalize=False)      # ~200 us of a foreign streaming kernel under ~7 LandModel launches
+        a.step(w["dt"], 1, finalize=False)
+    a.step(w["dt"], 1, finalize=True)
+    a.synchronize(); hog.synchronize()
+    assert family(a) == PROGRAM_LAND
+    assert_same(a, b, w)
+    assert a.status() & 4 == 0 and hog.status() == 0
