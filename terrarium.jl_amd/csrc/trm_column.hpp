@@ -232,10 +232,12 @@ struct FrontGranules {
     TRM_DEV void load(const unsigned long long* gran, unsigned byte_off_uniform) {     // (adjacent scalar loads: the backend widens them)
         for (int n = 0; n < FRONT_GRANULES; ++n) w[n] = sld_off<unsigned long long>(gran, byte_off_uniform + (unsigned)n * 8u);
     }
-    TRM_DEV bool valid(unsigned epoch) const {
-        bool ok = true;
-        for (int n = 0; n < FRONT_GRANULES; ++n) ok = ok && (unsigned)(w[n] >> 32) == epoch;
-        return ok;
+    // (integer arithmetic on purpose: a chain of `&&` over the six compares was compiled into vector selects, shifts and
+    //  v_readfirstlane -- ~25 vector and ~40 scalar instructions per wave for what is 12 s_xor / s_or)
+    TRM_DEV unsigned mismatch(unsigned epoch) const {
+        unsigned bad = 0;
+        for (int n = 0; n < FRONT_GRANULES; ++n) bad |= (unsigned)(w[n] >> 32) ^ epoch;
+        return bad;
     }
     TRM_DEV double value(int q) const { return __builtin_bit_cast(double, (w[q + 1] << 32) | (w[q] & 0xffffffffull)); }
 };
@@ -417,7 +419,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     NF front_Ut = NF(0), front_St = NF(0);
     bool front_ready = true;
     if constexpr (FRONT) {
-        front_ready = (TRM_FRONT_DIAG & 4) || (fg0.valid(front_epoch) && (CPW == 1 || fg1.valid(front_epoch)));      // (wave-uniform, on the scalar unit)
+        front_ready = (TRM_FRONT_DIAG & 4) || (fg0.mismatch(front_epoch) | (CPW == 1 ? 0u : fg1.mismatch(front_epoch))) == 0u;      // (wave-uniform, on the scalar unit)
         const FrontGranules& g = (CPW == 2 && upper) ? fg1 : fg0;
         front_Ut = g.value(FRONT_GHF); front_St = g.value(FRONT_INFIL); Ts_in = g.value(FRONT_TS);
     }

@@ -206,7 +206,7 @@ struct FrontGranulesF {
     TRM_DEV void load(const unsigned long long* gran, unsigned byte_off_uniform) {
         for (int n = 0; n < 3; ++n) w[n] = sld_off<unsigned long long>(gran, byte_off_uniform + (unsigned)n * 8u);
     }
-    TRM_DEV bool valid(unsigned epoch) const { return (unsigned)(w[0] >> 32) == epoch && (unsigned)(w[1] >> 32) == epoch && (unsigned)(w[2] >> 32) == epoch; }
+    TRM_DEV unsigned mismatch(unsigned epoch) const { return ((unsigned)(w[0] >> 32) ^ epoch) | ((unsigned)(w[1] >> 32) ^ epoch) | ((unsigned)(w[2] >> 32) ^ epoch); }     // (integers: stays on the scalar unit)
     TRM_DEV float value(int q) const { return __builtin_bit_cast(float, (unsigned)w[q]); }
 };
 // FRONT (LandModel, BCSIG_LAND): ground heat flux, infiltration and the new skin temperature come from the surface workgroups of THIS
@@ -314,7 +314,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
             fg[0].load(fa->gran, q0 * GB); fg[1].load(fa->gran, q1 * GB);
             if (CPW == 2) { fg[2].load(fa->gran, q2 * GB); fg[3].load(fa->gran, q3 * GB); }
             const unsigned e = fa->epoch;
-            front_ready = fg[0].valid(e) && fg[1].valid(e) && (CPW == 1 || (fg[2].valid(e) && fg[3].valid(e)));
+            front_ready = (fg[0].mismatch(e) | fg[1].mismatch(e) | (CPW == 1 ? 0u : (fg[2].mismatch(e) | fg[3].mismatch(e)))) == 0u;
             auto pick = [&](int q) { return CPW == 1 ? v2f{fg[0].value(q), fg[1].value(q)} : v2f{upper ? fg[2].value(q) : fg[0].value(q), upper ? fg[3].value(q) : fg[1].value(q)}; };
             in_Ut = pick(0); in_St = pick(1); Ts_in = pick(2);
         }
