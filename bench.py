@@ -384,7 +384,8 @@ def main():
     kernel_name = {"column_land": "k_column_land", "packed_f32": "k_step_pk", "packed_land": "k_step_pk_land", "column_euler": "k_column", "column_heun": "k_column", "column_multi": "k_column",
                    "deep": "k_column_deep", "wide": "k_column_wide", "generic_euler": "k_step_wave", "generic_heun": "k_heun_generic"}.get(program["family"], "unfused sequence")
     assert packed == (program["family"] in ("packed_f32", "packed_land"))
-    pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series and args.steps_per_launch == 1) else None
+    pmc_name = f"pmc_summary_{args.workload}_fused.json" if (args.kernel == "fused" and not heun and not args.series and args.steps_per_launch == 1
+                                                            and not os.environ.get("TRM_BENCH_SHARD_OF")) else None      # (the committed counters are of the full size)
 
     out = {
         "metric": "column-steps/sec",

@@ -34,6 +34,16 @@ for wl in ${WLS:-c3 c3x8 c5 c4 c4vg c5vg c2 c3vg c4vgveg}; do
   run 300 $CMD > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err
   echo trace + bench $wl done
 done
+# BASELINE config 4 as ONE rank of an 8-GPU strong-scaling run holds it (7 119 columns): the kernel trace shows one launch per step
+if [ -z "$WLS" ] || [[ " $WLS " == *" c4 "* ]]; then
+  export TRM_BENCH_SHARD_OF=8
+  CMD="python bench.py --workload c4 --no-cpu-baseline --no-hbm-resident --no-single-process --multistep 0 --steps 50 --warmup 10 --repeats 10"
+  run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_c4_shard8 -- $CMD > $OUT/bench_trace_c4_shard8.json 2> $OUT/trace_c4_shard8.err
+  find $OUT/trace_c4_shard8 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_c4_shard8.csv \;
+  run 300 $CMD > $OUT/bench_c4_shard8.json 2> $OUT/bench_c4_shard8.err
+  unset TRM_BENCH_SHARD_OF
+  echo trace + bench c4 shard done
+fi
 [ -n "$WLS" ] && { rm -rf $OUT/pmc_*/ $OUT/trace_*/; exit 0; }      # (WLS="c3 c4": only those workloads again, the rest of $OUT kept)
 run 300 python bench.py --integrator heun --no-cpu-baseline --no-hbm-resident --multistep 0 > $OUT/bench_c3_heun.json 2>/dev/null
 run 300 python bench.py --kernel unfused --no-cpu-baseline --no-hbm-resident --multistep 0 --repeats 3 > $OUT/bench_c3_unfused.json 2>/dev/null
