@@ -285,7 +285,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     ln.lane = threadIdx.x & 63;
 #if TRM_CUT_MASKS
     // (the wave index and everything that follows from it alone lives on the scalar unit)
-    const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)TRM_STEP_BLOCK + threadIdx.x) >> 6));
     ln.k = ln.lane % LPC;
     const int sub = ln.lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
@@ -305,7 +305,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     ln.act = lane_in(ln.m_act);
     const int ii = i < Nh ? i : Nh - 1;
 #else      // (A/B builds: round 3's lane-wise form)
-    const int wave = (int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int wave = (int)((block * (unsigned)TRM_STEP_BLOCK + threadIdx.x) >> 6);
     ln.k = ln.lane % LPC;
     const int sub = ln.lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
@@ -672,7 +672,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             // wave writes them below, 64 contiguous bytes per array and workgroup in a single instruction, instead of eight
             // stores of two active lanes each -- eight partially written cache lines per wave (profiles/r03/exp17, 19, 20).
             const int cib = (int)(threadIdx.x >> 6) * CPW + sub;      // column within the workgroup
-            const int cpb = (int)(blockDim.x >> 6) * CPW;
+            constexpr int cpb = (TRM_STEP_BLOCK / 64) * CPW;
             NF* st = small_stage<NF>();
             if (write_kf) st[SMALL_KF_TOP * cpb + cib] = Kf_out_top;
             if (RICHARDS) {
@@ -708,7 +708,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         const unsigned enabled = (write_kf ? 1u << SMALL_KF_TOP : 0u) | (RICHARDS ? (1u << SMALL_S) | (1u << SMALL_WT) : 0u) |
                                  ((RICHARDS && finalize) ? 1u << SMALL_G_S : 0u) |
                                  (seb ? (1u << SMALL_TOP_T) | (1u << SMALL_TOP_SAT) | (1u << SMALL_TOP_LIQ) | (1u << SMALL_TS) : 0u);
-        store_small_outputs<NF>(enabled, (int)(blockDim.x >> 6) * CPW, block, Nh);
+        store_small_outputs<NF, (TRM_STEP_BLOCK / 64) * CPW>(enabled, block, Nh);
     }
     // (only real cells report: the clamped copies that tail lanes carry are not repaired and may be out of bounds)
     if (viol && ln.act) atomicOr(v_arg.status, viol);

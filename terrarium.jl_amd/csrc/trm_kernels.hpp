@@ -717,17 +717,20 @@ template <class NF> TRM_DEV NF* small_stage() {
 // After a barrier, lane l of the workgroup's first waves stores entry l of the table: array l / cpb, column l % cpb of the
 // workgroup -- every array receives one contiguous run of cpb values from a single instruction.  The array pointers come from
 // the kernel argument segment (View::small), indexed per lane.  `enabled`: bit per array (wave-uniform).
-template <class NF> TRM_DEV void store_small_outputs(unsigned enabled, int cpb, unsigned block, int Nh) {
-    __syncthreads();
+// CPB (columns per workgroup) is a compile-time constant -- every launch of these programs has TRM_STEP_BLOCK threads -- so the
+// lane's array and column are a shift and a mask (a run-time divisor cost the storing wave a 12-instruction division), and the
+// lane's array pointer is requested BEFORE the barrier: that vector load from the argument segment used to sit, a full trip to
+// memory, between the barrier and the last store of every workgroup.
+template <class NF, int CPB> TRM_DEV void store_small_outputs(unsigned enabled, unsigned block, int Nh) {
+    static_assert((CPB & (CPB - 1)) == 0 && SMALL_COUNT * CPB <= TRM_STEP_BLOCK, "columns per workgroup: a power of two");
     const int l = (int)threadIdx.x;
-    if (l < SMALL_COUNT * cpb) {
-        const int slot = l / cpb, col = l - slot * cpb;
-        const long i = (long)block * cpb + col;
-        if (i < Nh && ((enabled >> slot) & 1u)) {
-            NF* const* tbl = kernarg_reload<View<NF>>(0).small;
-            tbl[slot][i] = small_stage<NF>()[l];
-        }
-    }
+    const int slot = l / CPB, col = l % CPB;
+    const long i = (long)block * CPB + col;
+    const bool mine = l < SMALL_COUNT * CPB && i < Nh && ((enabled >> slot) & 1u);
+    NF* dst = nullptr;
+    if (mine) dst = kernarg_reload<View<NF>>(0).small[slot];
+    __syncthreads();
+    if (mine) dst[i] = small_stage<NF>()[l];
 }
 
 constexpr unsigned round_up_to(unsigned x, unsigned a) { return (x + a - 1) / a * a; }

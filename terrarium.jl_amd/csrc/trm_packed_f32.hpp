@@ -475,7 +475,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         Kf_out = sel(is_bot || is_top, Kc_new, Kmin_new);
         Kf_out_top = Kc_new;
     }
-    const int cpb = (int)(blockDim.x >> 6) * CPW * 2;      // columns per workgroup
+    constexpr int cpb = (TRM_STEP_BLOCK / 64) * CPW * 2;      // columns per workgroup
     auto store = [&](bool act, int cib, unsigned cb_, unsigned ib_, float u, float t, float l, float s, float ps, float kf, float kft, float gu, float gs,
                      float S_new, float GS, float wt, float Ts_old /* already stepped */) {
         if (!act) return;
@@ -534,7 +534,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         const unsigned enabled = (write_kf ? 1u << SMALL_KF_TOP : 0u) | (RICHARDS ? (1u << SMALL_S) | (1u << SMALL_WT) : 0u) |
                                  ((RICHARDS && finalize) ? 1u << SMALL_G_S : 0u) |
                                  (seb ? (1u << SMALL_TOP_T) | (1u << SMALL_TOP_SAT) | (1u << SMALL_TOP_LIQ) | (1u << SMALL_TS) : 0u);
-        store_small_outputs<float>(enabled, cpb, block, Nh);
+        store_small_outputs<float, cpb>(enabled, block, Nh);
     }
     // (a flag raised by the clamped copy of the last column in an odd-sized shard repeats that column's own flag)
     const uint32_t flags = (bad ? 1u : 0u) | ((((viol & 2u) && act0) || ((viol & 4u) && act1)) ? 2u : 0u) | (front_timeout ? 4u : 0u);
