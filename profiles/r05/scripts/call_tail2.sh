@@ -1,17 +1,16 @@
 #!/bin/bash
-# same-box A/B of the working tree against the previous commit (build/libterrarium_hip_prev.so): tests first, then one process per sample, alternating
-# A/B against the committed library (HEAD~) built on the box: one process per sample, alternating
+# same-box A/B of the working tree against the previous commit (build/libterrarium_hip_prev.so): in-launch tests first, then one process per sample
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surface_in_launch.py tests/test_gpu_column_programs.py tests/test_gpu_full_size.py -x -q -m gpu > gpurun_out/tail_tests.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_gpu_surface_in_launch.py tests/test_gpu_program_selection.py tests/test_gpu_full_size.py -x -q -m gpu > gpurun_out/tail_tests.log 2>&1
 rc=$?
-tail -5 gpurun_out/tail_tests.log
+tail -3 gpurun_out/tail_tests.log
 [ $rc -ne 0 ] && exit $rc
-L=gpurun_out/exp16b_isa_junk.log
+L=gpurun_out/exp16c_isa_junk_packed.log
 : > $L
 for rep in 1 2 3; do
   for lib in old new; do
-    for spec in "c4 0" "c4 8" "c4vg 8" "c4vg 0"; do
+    for spec in "c5 64" "c5 32" "c4 8" "c4 0"; do
       set -- $spec
       if [ $lib = old ]; then export TRM_LIBRARY=$PWD/build/libterrarium_hip_prev.so; else unset TRM_LIBRARY; fi
       extra=""; [ $2 != 0 ] && extra="--shard $2"

@@ -39,7 +39,7 @@ enum { PROG_EULER = 0, PROG_HEUN = 1, PROG_MULTI = 2 };
 
 template <class NF> struct Cell { NF U, sat, T, liq, psi; };
 // what one lane knows about its place in the column
-struct LaneInfo { int lane, k; bool is_bot, is_top, act; unsigned long long m_act; };   // m_act: the wave's ballot of act
+struct LaneInfo { int lane, k; bool is_bot, is_top, act; unsigned long long m_act, m_bot, m_top; };   // m_*: the wave's ballots of act, is_bot, is_top
 // boundary inputs of this lane's column (every lane of a column holds the same values)
 template <class NF> struct ColumnBC {
     NF bTb, bTt;            // temperature boundary values (used when the Value condition is set)
@@ -181,7 +181,7 @@ TRM_DEV NF column_advance(const View<NF>& v, const LevelGeom<NF>& L, const LaneI
         if (bc.has_S) gS += bc.flux_S;
         NF snew = sat0 + gS * dt;
         bad = bad || (ln.act && __builtin_isunordered(n.U, snew));   // either one NaN: one compare
-        over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.m_act, ln.is_bot, ln.is_top, L);
+        over = repair_saturation<NF, LPC>(v, snew, ln.k, Nz, ln.m_act, ln.is_bot, ln.is_top, L, ln.m_bot, ln.m_top);
         z0 = water_table<NF, LPC>(snew, ln.m_act, ln.lane, L);
         n.sat = snew;
     }
@@ -237,6 +237,7 @@ struct FrontGranules {
     TRM_DEV unsigned mismatch(unsigned epoch) const {
         unsigned bad = 0;
         for (int n = 0; n < FRONT_GRANULES; ++n) bad |= (unsigned)(w[n] >> 32) ^ epoch;
+        asm volatile("" : "+s"(bad));      // (or else `bad == 0` is folded back into a conjunction of compares, and those into vector selects)
         return bad;
     }
     TRM_DEV double value(int q) const { return __builtin_bit_cast(double, (w[q + 1] << 32) | (w[q] & 0xffffffffull)); }
@@ -291,8 +292,10 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     const int Nz = v.Nz, Nh = (int)v.Nh;
     // which lanes hold the bottom / top cell, a real cell, the wave's second column: wave-uniform masks, no lane-wise compare
     const bool upper = CPW == 2 && lane_in(0xffffffff00000000ull);
-    ln.is_bot = lane_in(level_lanes<LPC>(0));
-    ln.is_top = lane_in(level_lanes<LPC>(Nz - 1));
+    ln.m_bot = level_lanes<LPC>(0);
+    ln.m_top = level_lanes<LPC>(Nz - 1);
+    ln.is_bot = lane_in(ln.m_bot);
+    ln.is_top = lane_in(ln.m_top);
     const NF dt = a.dt;
     const int finalize = a.finalize, write_kf = a.write_kf;
     const bool need_kc = RICHARDS || write_kf;
@@ -312,6 +315,8 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     const bool upper = sub != 0;
     ln.is_bot = ln.k == 0;
     ln.is_top = ln.k == Nz - 1;
+    ln.m_bot = wave_ballot(ln.is_bot);
+    ln.m_top = wave_ballot(ln.is_top);
     const NF dt = a.dt;
     const int finalize = a.finalize, write_kf = a.write_kf;
     const bool need_kc = RICHARDS || write_kf;
@@ -734,14 +739,25 @@ template <class NF, bool RICHARDS, int HYD, int LPC, int DERIVE, bool STAGED, bo
 __global__ void __launch_bounds__(TRM_STEP_BLOCK)
     __attribute__((amdgpu_waves_per_eu(PROG == PROG_HEUN ? 5 : TRM_LAND_WAVES, 8)))
     k_column_land(View<NF> v_arg, DevParams<NF> p_arg, ColumnArgs<NF> a, FrontArgs fa) {
-    if ((int)blockIdx.x < fa.chain_blocks) {
+    // (FrontArgs::chain_blocks, formed here from the column count: the head of the View is what a column wave needs first anyway, so the
+    //  branch costs it no scalar round trip of its own)
+    const int chain_blocks = (int)((v_arg.Nh + (TRM_STEP_BLOCK - 1)) / TRM_STEP_BLOCK);
+    if ((int)blockIdx.x < chain_blocks) {
         // (the surface waves share their SIMDs with up to seven column waves, all of which will wait for them: they issue first)
         __builtin_amdgcn_s_setprio(TRM_FRONT_PRIO);
-        const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i - (long)(threadIdx.x & 63u) < v_arg.Nh && !(TRM_FRONT_DIAG & 1)) surface_front<NF, RICHARDS, HYD>(v_arg, p_arg, fa, i);     // (wave-uniform)
+        const long i = (long)blockIdx.x * TRM_STEP_BLOCK + threadIdx.x;
+        // (the surface workgroups fetch their arguments HERE, through a pointer the optimiser cannot see through: read as `v_arg.x`
+        //  their scalar loads were hoisted in front of the branch, where the COLUMN waves paid for them -- ten v_writelane per wave
+        //  to park them in a vector register, from the disassembly)
+        constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<NF>), (unsigned)alignof(DevParams<NF>));
+        constexpr unsigned off_args = round_up_to(off_p + (unsigned)sizeof(DevParams<NF>), (unsigned)alignof(ColumnArgs<NF>));
+        constexpr unsigned off_front = round_up_to(off_args + (unsigned)sizeof(ColumnArgs<NF>), (unsigned)alignof(FrontArgs));
+        const View<NF>& v = kernarg_reload<View<NF>>(0);
+        if (i - (long)(threadIdx.x & 63u) < v.Nh && !(TRM_FRONT_DIAG & 1))      // (wave-uniform)
+            surface_front<NF, RICHARDS, HYD>(v, kernarg_reload<DevParams<NF>>(off_p), kernarg_reload<FrontArgs>(off_front), i);
         return;
     }
-    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, false, false, STAGED, SCALAR_IN, BCSIG_LAND, true>(v_arg, p_arg, a, blockIdx.x - (unsigned)fa.chain_blocks);
+    column_program<NF, RICHARDS, HYD, LPC, DERIVE, PROG, false, false, STAGED, SCALAR_IN, BCSIG_LAND, true>(v_arg, p_arg, a, blockIdx.x - (unsigned)chain_blocks);
 }
 
 // ---- LandModel, one launch per half step: the soil columns of ONE half of the context and the 0-D surface processes of the
@@ -863,6 +879,7 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) __attribute__((amdgpu_waves_pe
     const bool colok = i < Nh;
     ln.act = colok && ln.k < Nz;
     ln.m_act = wave_ballot(colok) & wave_ballot(ln.k < Nz);
+    ln.m_bot = ln.m_top = 0ull;      // (repair_saturation takes the ballots itself)
     const int ii = colok ? i : Nh - 1;
     const unsigned ib0 = (unsigned)ii * (unsigned)sizeof(NF);
     const unsigned cb0 = ((unsigned)ii * (unsigned)v.Nzp + (unsigned)(ln.k < Nz ? ln.k : Nz - 1)) * (unsigned)sizeof(NF);

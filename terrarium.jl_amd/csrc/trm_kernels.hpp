@@ -557,11 +557,13 @@ template <class NF> TRM_DEV NeighbourDz<NF> neighbour_dz(const View<NF>& v, int 
 // Returns excess * dz_top in the TOP lane (0 elsewhere): the column's overflow into surface_excess_water.
 template <class NF, int LPC>
 TRM_DEV NF repair_saturation(const View<NF>& v, NF& snew, int k, int Nz, unsigned long long m_act, bool is_bot, bool is_top,
-                             const LevelGeom<NF>& L) {
+                             const LevelGeom<NF>& L, unsigned long long m_bot_known = 0ull, unsigned long long m_top_known = 0ull) {
     // (max(s - 1, 0) != 0  <=>  s > 1  and  max(-s, 0) != 0  <=>  s < 0, NaN included: both sides false)
     // Every ballot is taken of ONE compare and the masks are combined on the scalar unit: the ballot of a conjunction goes
     // through a vector register (v_cndmask 0/1 + v_cmp_ne).  m_act: the wave's mask of lanes that hold a cell.
-    const unsigned long long m_top = wave_ballot(is_top), m_bot = wave_ballot(is_bot);
+    // (a caller that formed is_bot / is_top FROM wave-uniform masks hands the masks over: the ballot of such a bool is a round trip
+    //  through a vector register, v_cndmask 0/1 + v_cmp_ne, for a value the scalar unit already holds)
+    const unsigned long long m_top = m_top_known ? m_top_known : wave_ballot(is_top), m_bot = m_bot_known ? m_bot_known : wave_ballot(is_bot);
     const unsigned long long any_over = wave_ballot(snew > NF(1)) & m_act & ~m_top;
     const unsigned long long any_bad = any_over | (wave_ballot(snew < NF(0)) & m_act & ~m_bot);
     // every cell but the bottom one receives `+ carry` / `+ deficit`; with nothing to move that is `+ 0`

@@ -206,7 +206,11 @@ struct FrontGranulesF {
     TRM_DEV void load(const unsigned long long* gran, unsigned byte_off_uniform) {
         for (int n = 0; n < 3; ++n) w[n] = sld_off<unsigned long long>(gran, byte_off_uniform + (unsigned)n * 8u);
     }
-    TRM_DEV unsigned mismatch(unsigned epoch) const { return ((unsigned)(w[0] >> 32) ^ epoch) | ((unsigned)(w[1] >> 32) ^ epoch) | ((unsigned)(w[2] >> 32) ^ epoch); }     // (integers: stays on the scalar unit)
+    TRM_DEV unsigned mismatch(unsigned epoch) const {      // (integers behind a barrier for the optimiser: stays on the scalar unit)
+        unsigned bad = ((unsigned)(w[0] >> 32) ^ epoch) | ((unsigned)(w[1] >> 32) ^ epoch) | ((unsigned)(w[2] >> 32) ^ epoch);
+        asm volatile("" : "+s"(bad));
+        return bad;
+    }
     TRM_DEV float value(int q) const { return __builtin_bit_cast(float, (unsigned)w[q]); }
 };
 // FRONT (LandModel, BCSIG_LAND): ground heat flux, infiltration and the new skin temperature come from the surface workgroups of THIS
@@ -549,13 +553,19 @@ __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk(View<float> v_arg, D
 // temperature from them through granules (k_column_land, trm_column.hpp, in fp64)
 template <int LPC, int HYD, int DERIVE>
 __global__ void __launch_bounds__(TRM_STEP_BLOCK) k_step_pk_land(View<float> v_arg, DevParams<float> p_arg, float dt, int finalize, int write_kf, int staged, FrontArgs fa) {
-    if ((int)blockIdx.x < fa.chain_blocks) {
+    // (as k_column_land: the branch from the head of the View, the surface workgroups' arguments fetched inside their branch -- read as
+    //  `v_arg.x` their scalar loads were hoisted in front of it and parked in vector lanes by every COLUMN wave, 20 v_writelane each)
+    const int chain_blocks = (int)((v_arg.Nh + (TRM_STEP_BLOCK - 1)) / TRM_STEP_BLOCK);
+    if ((int)blockIdx.x < chain_blocks) {
         __builtin_amdgcn_s_setprio(3);
-        const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-        if (i - (long)(threadIdx.x & 63u) < v_arg.Nh) surface_front<float, true, HYD>(v_arg, p_arg, fa, i);      // (wave-uniform)
+        const long i = (long)blockIdx.x * TRM_STEP_BLOCK + threadIdx.x;
+        constexpr unsigned off_p = round_up_to((unsigned)sizeof(View<float>), (unsigned)alignof(DevParams<float>));
+        constexpr unsigned off_fa = round_up_to(off_p + (unsigned)sizeof(DevParams<float>) + 4u * (unsigned)sizeof(int), (unsigned)alignof(FrontArgs));
+        const View<float>& v = kernarg_reload<View<float>>(0);
+        if (i - (long)(threadIdx.x & 63u) < v.Nh) surface_front<float, true, HYD>(v, kernarg_reload<DevParams<float>>(off_p), kernarg_reload<FrontArgs>(off_fa), i);      // (wave-uniform)
         return;
     }
-    step_pk_program<true, LPC, HYD, DERIVE, BCSIG_LAND, true>(v_arg, p_arg, dt, finalize, write_kf, blockIdx.x - (unsigned)fa.chain_blocks, staged, &fa);
+    step_pk_program<true, LPC, HYD, DERIVE, BCSIG_LAND, true>(v_arg, p_arg, dt, finalize, write_kf, blockIdx.x - (unsigned)chain_blocks, staged, &fa);
 }
 // LandModel in fp32: the packed column step of one half of the columns beside the surface processes of the other half in one
 // launch (k_land_euler, trm_column.hpp).  (View, DevParams) first: step_pk_program re-reads them from the kernarg segment.
