@@ -229,11 +229,12 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const int lane = threadIdx.x & 63;
     // (the wave index and what follows from it alone on the scalar unit; lane predicates from wave-uniform masks: lane_in)
 #if TRM_CUT_MASKS
-    const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)blockDim.x + threadIdx.x) >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane((int)((block * (unsigned)TRM_STEP_BLOCK + threadIdx.x) >> 6));
     const int k = lane % LPC, sub = lane / LPC;
     const int Nz = v.Nz, Nh = (int)v.Nh;
     const bool upper = CPW == 2 && lane_in(0xffffffff00000000ull);
-    const bool is_bot = lane_in(level_lanes<LPC>(0)), is_top = lane_in(level_lanes<LPC>(Nz - 1));
+    const unsigned long long m_bot = level_lanes<LPC>(0), m_top = level_lanes<LPC>(Nz - 1);      // (handed to repair_saturation as they are)
+    const bool is_bot = lane_in(m_bot), is_top = lane_in(m_top);
     const LevelGeom<NF> L = level_geom(v, k);
     const bool need_kc = RICHARDS || write_kf;
 
@@ -252,6 +253,7 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
     const int Nz = v.Nz, Nh = (int)v.Nh;
     const bool upper = sub != 0;
     const bool is_bot = k == 0, is_top = k == Nz - 1;
+    const unsigned long long m_bot = 0ull, m_top = 0ull;      // (repair_saturation takes the ballots itself)
     const LevelGeom<NF> L = level_geom(v, k);
     const bool need_kc = RICHARDS || write_kf;
     const int i0 = (wave * CPW + sub) * 2, i1 = i0 + 1;
@@ -457,8 +459,8 @@ TRM_DEV void step_pk_program(const View<float>& v_arg, const DevParams<float>& p
         snew = sat + gS * dt;
         bad = bad || (act0 && is_nan(snew.x)) || (act1 && is_nan(snew.y));
         float sx = snew.x, sy = snew.y;
-        const float over0 = repair_saturation<NF, LPC>(v, sx, k, Nz, m_act0, is_bot, is_top, L);
-        const float over1 = repair_saturation<NF, LPC>(v, sy, k, Nz, m_act1, is_bot, is_top, L);
+        const float over0 = repair_saturation<NF, LPC>(v, sx, k, Nz, m_act0, is_bot, is_top, L, m_bot, m_top);
+        const float over1 = repair_saturation<NF, LPC>(v, sy, k, Nz, m_act1, is_bot, is_top, L, m_bot, m_top);
         snew = v2f{sx, sy};
         z0 = v2f{water_table<NF, LPC>(sx, m_act0, lane, L), water_table<NF, LPC>(sy, m_act1, lane, L)};
         // surface_excess_water: tendency min(0, S) once per column, Euler update, overflow (stored with everything else below)
