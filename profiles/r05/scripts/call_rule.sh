@@ -1,8 +1,8 @@
 #!/bin/bash
-# HEAD: surface processes in the launch vs the launch pair at N145 and half of it, both hydraulics (the size rule)
+# HEAD: surface processes in the launch vs the launch pair at N145, half of it, a third, both hydraulics
 set -o pipefail
 mkdir -p gpurun_out
-L=gpurun_out/exp11_in_launch_rule.log
+L=gpurun_out/exp18_pair_vs_one_launch_head.log
 : > $L
 for rep in 1 2 3; do
   for wl in c4 c4vg; do
