@@ -906,13 +906,14 @@ bool parse_env_int(const char* name, long lo, long hi, long multiple_of, long& o
     return true;
 }
 struct EnvSwitches {
-    long field_skew = 16640, derive_default = -1, debug_placement = 0;
+    long field_skew = 16640, derive_default = -1, debug_placement = 0, handoff_tag_bias = 0;
     std::string error;
     EnvSwitches() {
         long v;
         if (parse_env_int("TRM_FIELD_SKEW", 0, 1 << 20, 256, v, error)) field_skew = v;
         if (error.empty() && parse_env_int("TRM_DERIVE_DEFAULT", 0, 5, 1, v, error)) derive_default = v;
         if (error.empty() && parse_env_int("TRM_DEBUG_PLACEMENT", 0, 1, 1, v, error)) debug_placement = v;   // (prints every field's allocation: profiles/tools/placement_probe.sh)
+        if (error.empty() && parse_env_int("TRM_DEBUG_HANDOFF_TAG_BIAS", 0, 1, 1, v, error)) handoff_tag_bias = v;      // (tests: FrontArgs::tag_bias)
         if (error.empty() && parse_env_int("TRM_STAGED_SMALL", 0, 1, 1, v, error)) { /* read by Policy::staged_now */ }
         if (error.empty() && parse_env_int("TRM_SCALAR_INPUTS", 0, 1, 1, v, error)) { /* read by Policy::scalar_inputs_now */ }
     }
@@ -1419,6 +1420,7 @@ int trm_create(const trm_grid* g, const trm_params* p, trm_ctx** out) {
     // (tests: TRM_DERIVE_DEFAULT = 1 makes small grids take the instances with the derivation, where the staged outputs and the
     // input paths are compiled in -- the value a context starts with for TRM_OPT_DERIVE_CLOSURE_FIELDS)
     if (env_switches().derive_default >= 0) c->opt_derive = (int)env_switches().derive_default;
+    c->debug_handoff_tag_bias = (unsigned)env_switches().handoff_tag_bias;
     if (rc == TRM_OK) hip(hipMemsetAsync(c->d_zero, 0, (size_t)c->Nh * c->esize, c->stream), "hipMemset(zero)");
     if (rc) return bail(rc);
     hip(hipMemsetAsync(c->d_status, 0, sizeof(uint32_t), c->stream), "hipMemset(status)");

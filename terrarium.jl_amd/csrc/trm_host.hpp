@@ -136,6 +136,7 @@ struct trm_ctx {
     int row_stage_next = 0;
     // LandModel, TRM_OPT_SURFACE_IN_LAUNCH: the surface processes run in the first workgroups of the step launch (k_column_land) and
     // hand ground heat flux, infiltration and skin temperature to the column workgroups through granules tagged with the launch's epoch
+    unsigned debug_handoff_tag_bias = 0;        // TRM_DEBUG_HANDOFF_TAG_BIAS (tests of the bounded wait)
     unsigned long long* d_gran = nullptr;   // [Nh][6], zero at allocation (epoch 0 is never used)
     uint32_t front_epoch = 0;               // epoch of the last such launch
     int opt_front = 2;                      // 0 off, 1 whenever legal, 2 the library's rule

@@ -176,6 +176,8 @@ struct FrontArgs {
     unsigned long long* gran;   // fp64 [Nh][6]: {ghf.lo, ghf.hi, infil.lo, infil.hi, Ts.lo, Ts.hi}, fp32 [Nh][3]: {ghf, infil, Ts}; each (epoch << 32) | 32 bits
     unsigned epoch;
     int chain_blocks;           // the first workgroups of the grid evaluate the surface processes, 256 columns each
+    unsigned tag_bias;          // 0; TRM_DEBUG_HANDOFF_TAG_BIAS=1 (tests): the surface workgroups publish under ANOTHER tag, i.e. never for the
+                                // column waves of their launch -- whose bounded wait must then end with TRM_STATUS_HANDOFF_TIMEOUT, not hang
 };
 enum { FRONT_GHF = 0, FRONT_INFIL = 2, FRONT_TS = 4, FRONT_GRANULES = 6, FRONT_SPIN_LIMIT = 1 << 14 };
 // granules per column: one per 32-bit half of the three values -- 6 in fp64 (offsets FRONT_GHF / FRONT_INFIL / FRONT_TS), 3 in fp32
@@ -209,7 +211,7 @@ template <class NF, bool RICHARDS, int HYD> TRM_DEV void surface_front(const Vie
         __shared__ unsigned long long stage[(TRM_STEP_BLOCK / 64) * 64 * FRONT_GRANULES];
         const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
         unsigned long long* st = stage + wv * 64 * G;
-        const unsigned long long tag = (unsigned long long)fa.epoch << 32;
+        const unsigned long long tag = (unsigned long long)(fa.epoch + fa.tag_bias) << 32;
         unsigned long long* mine = st + lane * G;
         const NF vals[3] = {o.ghf, o.infil, o.Ts};
         for (int q = 0; q < 3; ++q) {

@@ -22,6 +22,7 @@ template <int H, int LPC> static int launch_column_land(trm_ctx* c, double dt, i
     FrontArgs fa{};
     fa.gran = c->d_gran;
     fa.epoch = c->front_epoch;
+    fa.tag_bias = c->debug_handoff_tag_bias;
     fa.chain_blocks = (int)((c->Nh + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK);
     dim3 grid = column_grid(c, LPC);
     grid.x += (unsigned)fa.chain_blocks;

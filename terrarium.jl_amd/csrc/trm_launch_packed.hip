@@ -48,6 +48,7 @@ template <int LPC> static int launch_packed_land(trm_ctx* c, double dt, int fina
     FrontArgs fa{};
     fa.gran = c->d_gran;
     fa.epoch = c->front_epoch;
+    fa.tag_bias = c->debug_handoff_tag_bias;
     fa.chain_blocks = (int)((c->Nh + TRM_STEP_BLOCK - 1) / TRM_STEP_BLOCK);
     const int wkf = (c->opt_write_kf || finalize) ? 1 : 0;
     const long pairs = (c->Nh + 1) / 2;

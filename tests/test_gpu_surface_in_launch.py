@@ -295,3 +295,40 @@ def test_hand_off_under_uneven_load_every_word():
     assert family(a) == PROGRAM_LAND
     assert_same(a, b, w)
     assert a.status() & 4 == 0 and hog.status() == 0
+
+
+def test_a_hand_off_that_never_comes_ends_in_a_status_flag_not_in_a_hang():
+    """The column waves' wait for their surface fluxes is bounded: with the surface workgroups publishing under another tag
+    (TRM_DEBUG_HANDOFF_TAG_BIAS=1, a switch of the library for this test) no word ever matches -- every column wave must give up after
+    its spin limit, flag TRM_STATUS_HANDOFF_TIMEOUT (4), leave NaN where the fluxes enter (the top cell's internal energy, the skin temperature), and the
+    launch must RETURN.  In a fresh process: the
+    switch is read once per process."""
+    import subprocess, sys, os, json
+    code = (
+        "import sys, json, time\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "import numpy as np\nimport workloads as W\n"
+        "from test_gpu_surface_in_launch import small_columns, family\n"
+        "out = {}\n"
+        "for dtype in ('float64', 'float32'):\n"
+        "    lat, lon = small_columns(700)\n"
+        "    w = W.make_workload('land', lat, lon, 32, dtype=getattr(np, dtype))\n"
+        "    d = W.setup_device(w)\n"
+        "    d.set_option('surface_in_launch', 1)\n"
+        "    d.step(w['dt'], 1, finalize=False)\n"            # (the launch pair: the fields are read)
+        "    assert d.status() == 0\n"
+        "    t0 = time.time()\n"
+        "    d.step(w['dt'], 1, finalize=False)\n"
+        "    d.synchronize()\n"
+        "    out[dtype] = dict(seconds=time.time() - t0, family=family(d), status=d.status(), nan=bool(np.isnan(d.get('internal_energy')[-1]).all() and np.isnan(d.get('skin_temperature')).all()))\n"
+        "print(json.dumps(out))\n" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    env = dict(os.environ, TRM_DEBUG_HANDOFF_TAG_BIAS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    for dtype, fam in (("float64", PROGRAM_LAND), ("float32", PROGRAM_PACKED_LAND)):
+        o = out[dtype]
+        assert o["family"] == fam, o
+        assert o["status"] & 4, o
+        assert o["nan"], o
+        assert o["seconds"] < 5.0, o
