@@ -428,7 +428,10 @@ def main():
         if hung:
             out["config"]["abi_global_status_note"] = ("trm_comm_init / trm_status_global did not return within 60 s; the ranks leave with exit code 3")
     if world > 1 and not hung and not args.no_strong and args.workload == "c3" and args.scaling == "weak":
-        out["strong"] = strong_leg(W, parallel, args, world, rank, local_rank, configure, sync, barrier, reduce_max, reduce_sum)
+        try:
+            out["strong"] = strong_leg(W, parallel, args, world, rank, local_rank, configure, sync, barrier, reduce_max, reduce_sum)
+        except Exception as e:   # noqa: BLE001 -- a companion leg (the same code on every rank: a failure is a failure on all of them); the headline line is still printed
+            out["strong"] = {"error": f"{type(e).__name__}: {e}"}
 
     if not hung and not args.no_single_process and args.workload == "c3" and args.scaling == "weak" and args.kernel == "fused" and not heun:
         # ONE host thread driving one context per device (the reference's host is one Julia process): rank 0 alone, the other
