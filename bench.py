@@ -286,6 +286,12 @@ def main():
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (see the module docstring)")
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (gloo announces its connections on fd 1): from here on
+    # whatever anything prints to fd 1 goes to stderr, and the line is written to the descriptor saved here.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -461,7 +467,7 @@ def main():
     if single and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=line_out, flush=True)
     if hung or out.get("single_process", {}).get("global_diagnostics", {}).get("timeout"):
         os._exit(3)          # (a collective that did not return: the line says so, and no thread stuck in it keeps the process alive)
     if world > 1:
