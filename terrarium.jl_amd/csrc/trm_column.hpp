@@ -258,6 +258,9 @@ template <class NF> struct ColumnArgs {
 
 
 
+#ifndef TRM_PICK_EXEC
+#define TRM_PICK_EXEC 1
+#endif
 #ifndef TRM_COLUMN_WAVES_EULER
 #define TRM_COLUMN_WAVES_EULER 1
 #endif
@@ -370,7 +373,27 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
         if (DEFER) return ColVal{x0, x1};
         return ColVal{upper ? x1 : x0, NF(0)};
     };
-    auto col_get = [&](const ColVal& q) -> NF { return (DEFER && upper) ? q.x1 : q.x0; };
+    // The select between the wave's two columns, both values wave-uniform: `upper ? x1 : x0` is two v_mov (scalar -> vector, the
+    // select takes one scalar operand: its mask) and a v_cndmask per 32-bit half.  Writing x0 to every lane and then x1 to the upper
+    // half-wave under an execution mask is two v_mov per half (TRM_PICK_EXEC 0: the select, A/B).
+    auto pick_column = [&](NF x0, NF x1) -> NF {
+#if TRM_PICK_EXEC
+        if (__builtin_constant_p(x0 == x1) && x0 == x1) return x0;      // (a condition that is not set: both halves the same constant)
+        if constexpr (sizeof(NF) == 8) {
+            const unsigned long long b0 = __builtin_bit_cast(unsigned long long, x0), b1 = __builtin_bit_cast(unsigned long long, x1);
+            unsigned lo = (unsigned)b0, hi = (unsigned)(b0 >> 32);
+            const unsigned lo1 = (unsigned)b1, hi1 = (unsigned)(b1 >> 32);
+            unsigned long long save;
+            asm("s_mov_b64 %[save], exec\n\ts_and_b64 exec, %[save], %[m]\n\tv_mov_b32 %[lo], %[slo]\n\tv_mov_b32 %[hi], %[shi]\n\ts_mov_b64 exec, %[save]"
+                         : [lo] "+v"(lo), [hi] "+v"(hi), [save] "=&s"(save)
+                         : [slo] "s"(lo1), [shi] "s"(hi1), [m] "s"(0xffffffff00000000ull)
+                         : "scc");
+            return __builtin_bit_cast(NF, ((unsigned long long)hi << 32) | lo);
+        } else
+#endif
+        return upper ? x1 : x0;
+    };
+    auto col_get = [&](const ColVal& q) -> NF { return DEFER ? pick_column(q.x0, q.x1) : q.x0; };
     // ALL of them are requested HERE, behind the field loads and in front of the derivation: the derivation waits for U and sat and
     // branches (the phase-change divide), and a load issued behind it starts its trip to memory only then -- a second full memory
     // latency in every wave's life (round 4: in the round-3 order the boundary values of the HBM-resident step were requested ~110
@@ -425,8 +448,12 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
     bool front_ready = true;
     if constexpr (FRONT) {
         front_ready = (TRM_FRONT_DIAG & 4) || (fg0.mismatch(front_epoch) | (CPW == 1 ? 0u : fg1.mismatch(front_epoch))) == 0u;      // (wave-uniform, on the scalar unit)
-        const FrontGranules& g = (CPW == 2 && upper) ? fg1 : fg0;
-        front_Ut = g.value(FRONT_GHF); front_St = g.value(FRONT_INFIL); Ts_in = g.value(FRONT_TS);
+        if (CPW == 2) {
+            front_Ut = pick_column(fg0.value(FRONT_GHF), fg1.value(FRONT_GHF)); front_St = pick_column(fg0.value(FRONT_INFIL), fg1.value(FRONT_INFIL));
+            Ts_in = pick_column(fg0.value(FRONT_TS), fg1.value(FRONT_TS));
+        } else {
+            front_Ut = fg0.value(FRONT_GHF); front_St = fg0.value(FRONT_INFIL); Ts_in = fg0.value(FRONT_TS);
+        }
     }
     ColumnBC<NF> bc;
     if (FRONT) { in_Ut = front_Ut; in_St = front_St; }
