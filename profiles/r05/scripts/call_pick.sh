@@ -6,4 +6,4 @@ timeout -k 10 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_surfa
 rc=$?
 tail -3 gpurun_out/pick_tests.log
 [ $rc -ne 0 ] && exit $rc
-bash profiles/tools/ab_libs.sh gpurun_out/exp23_pick_exec.log 5 "prev=build/variants/lib_prev.so new=HEAD" "c4 c4vg c3 c4:8 c3x8"
+bash profiles/tools/ab_libs.sh gpurun_out/exp24_flux_selects.log 5 "prev=build/variants/lib_prev.so new=HEAD" "c4 c4vg c4:8"

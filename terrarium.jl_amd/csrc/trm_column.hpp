@@ -477,8 +477,11 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             if (bS) eS_b = flux_term_bottom_nsz(in_Sb, v.g);
             if (tU) eU_t = -flux_term_top_nsz(in_Ut, v.g);
             if (tS) eS_t = -flux_term_top_nsz(seb ? -in_St : in_St, v.g);
-            fU = ln.is_bot ? eU_b : (ln.is_top ? eU_t : NF(0));
-            fS = ln.is_bot ? eS_b : (ln.is_top ? eS_t : NF(0));
+            // (a side whose condition is known at compile time not to be set needs no select of its own: the bottom and the top cell are
+            //  different lanes, Nz >= 2)
+            const NF tU_term = ln.is_top ? eU_t : NF(0), tS_term = ln.is_top ? eS_t : NF(0);
+            fU = (BCSIG >= 0 && !bU) ? tU_term : (ln.is_bot ? eU_b : tU_term);
+            fS = (BCSIG >= 0 && !bS) ? tS_term : (ln.is_bot ? eS_b : tS_term);
         }
 #endif
         bc.flux_U = fU;
@@ -522,7 +525,7 @@ TRM_DEV void column_program(const View<NF>& v_arg, const DevParams<NF>& p_arg, c
             NF ut = value(FRONT_GHF, 0), st = value(FRONT_INFIL, 0), ts = value(FRONT_TS, 0);
             if (CPW == 2) {
                 const NF ut1 = value(FRONT_GHF, LPC), st1 = value(FRONT_INFIL, LPC), ts1 = value(FRONT_TS, LPC);
-                ut = upper ? ut1 : ut; st = upper ? st1 : st; ts = upper ? ts1 : ts;
+                ut = pick_column(ut, ut1); st = pick_column(st, st1); ts = pick_column(ts, ts1);
             }
             if (!ok) {   // gave up: no hang, the columns of the wave are flagged and NaN
                 viol |= 4u;
